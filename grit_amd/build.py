@@ -1,0 +1,75 @@
+"""Build the native pieces in-tree: libgrit_hip.so (hipcc, gfx950 only) and the C oracle (gcc).
+
+`python -m grit_amd.build` or `__graft_entry__.build()`.  hipcc cross-compiles without a GPU.  The
+shared objects stay next to their sources (git-ignored) so they travel with the tree to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "grit_amd", "csrc")
+LIB = os.path.join(CSRC, "libgrit_hip.so")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libmsda_oracle.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def hip_sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def build_hip(force=False, verbose=False):
+    srcs = hip_sources()
+    deps = srcs + [os.path.join(ROOT, "include", "grit_hip.h")] + \
+        [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if not force and _newer(LIB, deps):
+        return LIB
+    # one object per source in parallel, then link
+    objs, procs = [], []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        objs.append(o)
+        if not force and _newer(o, deps):
+            continue
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+               "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (s, out.decode()))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout.decode())
+    return LIB
+
+
+def build_oracle(force=False):
+    """The checker (oracle/*.c).  Building it is not using it: only tests/smoke/bench's cpu leg load it."""
+    src = os.path.join(ORACLE_DIR, "msda_oracle.c")
+    if not force and _newer(ORACLE_LIB, [src]):
+        return ORACLE_LIB
+    cmd = ["gcc", "-O2", "-shared", "-fPIC", "-std=c99", "-o", ORACLE_LIB, src, "-lm"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("gcc failed:\n" + r.stdout.decode())
+    return ORACLE_LIB
+
+
+def build_all(force=False, verbose=False):
+    return build_hip(force, verbose), build_oracle(force)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,367 @@
+// Multi-scale deformable attention for gfx950 (MI355X): forward gather + backward scatter.
+//
+// Semantics follow davidnvq/grit models/ops/src/cuda/ms_deform_im2col_cuda.cuh (forward :237-299 with the
+// bilinear rule of :33-84, backward :406-510 with :87-159); the decomposition is CDNA4's own:
+//
+//   * one 64-lane wavefront owns one output row (b, q, m) -- all L*P sampling points of one head;
+//   * forward fast path (D = 64 / 32): a row's D channels are D/4 lanes x float4, so a wave covers
+//     64/(D/4) sampling points at once and every corner is one 16-byte load per lane (a whole
+//     256-byte pixel-head slice per 16 lanes).  All 4 corners of all points are issued before any
+//     is consumed: 16 independent dwordx4 loads in flight per lane hide the L2 / Infinity-Cache / HBM
+//     latency of the gather.  Out-of-range corners load a clamped (valid) address and are
+//     selected to zero, so there is no divergent branch around a load;
+//   * loc / attn_w of the row are read ONCE by the wave (coalesced) and handed to the lanes by
+//     ds_bpermute -- the reference re-reads them per channel thread;
+//   * the blockIdx -> row map is XCD-aware: workgroups that share an XCD (same blockIdx % 8) walk
+//     one contiguous chunk of rows, i.e. one batch element's value map, so its coarse levels stay
+//     in that XCD's 4 MiB L2;
+//   * backward: lane = channel, so every grad_value update of a corner is ONE wave-wide
+//     global_atomic_add_f32 over 256 contiguous bytes (the full-rate shape of the memory-side
+//     atomic units); grad_loc / grad_attn_w are wave-shuffle reductions -- no LDS tree, no barrier.
+//
+// No hipify, no CUDA dual path: this file only builds for gfx950.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/grit_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kRowsPerBlock = 4;  // 4 waves / workgroup, one row each
+
+// Bijective XCD remap (blocks b and b+8 share an XCD): logical id such that one XCD gets a
+// contiguous range of logical blocks.  Speed only -- any placement gives the same result.
+__device__ __forceinline__ int xcd_logical_block(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// Corner geometry of one sampling point; weights of corners that fall outside are forced to 0 and
+// their indices clamped inside the map, so a load through them is always legal.
+template <typename T>
+struct Corners {
+    int o1, o2, o3, o4;  // pixel offsets (h*W + w) of the 4 corners, clamped
+    T w1, w2, w3, w4;    // bilinear weights (hh*hw, hh*lw, lh*hw, lh*lw)
+    bool k1, k2, k3, k4; // corner inside the map
+    T lh, lw, hh, hw;
+    bool live;           // point passes the (-1, H) x (-1, W) test
+};
+
+template <typename T>
+__device__ __forceinline__ Corners<T> make_corners(T x, T y, int H, int W) {
+    Corners<T> c;
+    const T h_im = y * (T)H - (T)0.5;
+    const T w_im = x * (T)W - (T)0.5;
+    c.live = (h_im > (T)-1) && (w_im > (T)-1) && (h_im < (T)H) && (w_im < (T)W);
+    const T hf = floor(h_im), wf = floor(w_im);
+    // clamp before the int conversion so NaN / huge coordinates cannot produce wild indices
+    const int h_low = (int)fmin(fmax(hf, (T)-2), (T)H);
+    const int w_low = (int)fmin(fmax(wf, (T)-2), (T)W);
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    c.lh = h_im - hf; c.lw = w_im - wf;
+    c.hh = (T)1 - c.lh; c.hw = (T)1 - c.lw;
+    const bool hl = h_low >= 0 && h_low <= H - 1, hhv = h_high >= 0 && h_high <= H - 1;
+    const bool wl = w_low >= 0 && w_low <= W - 1, whv = w_high >= 0 && w_high <= W - 1;
+    c.k1 = c.live && hl && wl;  c.k2 = c.live && hl && whv;
+    c.k3 = c.live && hhv && wl; c.k4 = c.live && hhv && whv;
+    const int hlc = min(max(h_low, 0), H - 1), hhc = min(max(h_high, 0), H - 1);
+    const int wlc = min(max(w_low, 0), W - 1), whc = min(max(w_high, 0), W - 1);
+    c.o1 = hlc * W + wlc; c.o2 = hlc * W + whc; c.o3 = hhc * W + wlc; c.o4 = hhc * W + whc;
+    c.w1 = c.hh * c.hw; c.w2 = c.hh * c.lw; c.w3 = c.lh * c.hw; c.w4 = c.lh * c.lw;
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Forward, fast path: D = 4*LPP floats, NIT = ceil(L*P / (64/LPP)) point rounds per wave.
+// ---------------------------------------------------------------------------------------------------
+template <int LPP, int NIT>
+__global__ __launch_bounds__(kWave * kRowsPerBlock)
+void msda_fwd_vec4(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                   const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+                   const float* __restrict__ aw, int S, int M, int L, int Lq, int P,
+                   float* __restrict__ out, int nrows, int nblk) {
+    constexpr int D = 4 * LPP;
+    constexpr int G = kWave / LPP;  // sampling points handled side by side
+    const int lane = threadIdx.x & (kWave - 1);
+    const int row = xcd_logical_block(blockIdx.x, nblk) * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= nrows) return;  // whole wave leaves together
+    const int LP = L * P;
+    const int m = row % M;
+    const int b = (row / M) / Lq;
+
+    // one coalesced read of the row's 2*LP coordinates and LP weights (LP <= 32 on this path)
+    const float locv = lane < 2 * LP ? loc[(size_t)row * 2 * LP + lane] : 0.f;
+    const float awv = lane < LP ? aw[(size_t)row * LP + lane] : 0.f;
+
+    const int g = lane / LPP, c4 = lane % LPP;
+    const float* vrow = value + (size_t)b * S * M * D + (size_t)m * D + c4 * 4;
+    const size_t pix_stride = (size_t)M * D;
+
+    float4 v[NIT][4];
+    float cw[NIT][4];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * G + g;
+        const bool have = idx < LP;
+        const int idc = have ? idx : LP - 1;
+        const float x = __shfl(locv, 2 * idc, kWave);
+        const float y = __shfl(locv, 2 * idc + 1, kWave);
+        const float wt = have ? __shfl(awv, idc, kWave) : 0.f;
+        const int l = idc / P;
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const float* vl = vrow + (size_t)lsi[l] * pix_stride;
+        const Corners<float> c = make_corners<float>(x, y, H, W);
+        v[it][0] = *reinterpret_cast<const float4*>(vl + (size_t)c.o1 * pix_stride);
+        v[it][1] = *reinterpret_cast<const float4*>(vl + (size_t)c.o2 * pix_stride);
+        v[it][2] = *reinterpret_cast<const float4*>(vl + (size_t)c.o3 * pix_stride);
+        v[it][3] = *reinterpret_cast<const float4*>(vl + (size_t)c.o4 * pix_stride);
+        cw[it][0] = c.k1 ? c.w1 * wt : 0.f;
+        cw[it][1] = c.k2 ? c.w2 * wt : 0.f;
+        cw[it][2] = c.k3 ? c.w3 * wt : 0.f;
+        cw[it][3] = c.k4 ? c.w4 * wt : 0.f;
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // select, not multiply: a non-finite value under a dropped corner must not leak
+            const float w = cw[it][k];
+            const float4 t = v[it][k];
+            acc.x += w != 0.f ? w * t.x : 0.f;
+            acc.y += w != 0.f ? w * t.y : 0.f;
+            acc.z += w != 0.f ? w * t.z : 0.f;
+            acc.w += w != 0.f ? w * t.w : 0.f;
+        }
+    }
+#pragma unroll
+    for (int off = LPP; off < kWave; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off, kWave);
+        acc.y += __shfl_xor(acc.y, off, kWave);
+        acc.z += __shfl_xor(acc.z, off, kWave);
+        acc.w += __shfl_xor(acc.w, off, kWave);
+    }
+    if (lane < LPP) *reinterpret_cast<float4*>(out + (size_t)row * D + lane * 4) = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Forward, any D / L / P, float or double: lanes stride the channels of the wave's row.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kWave * kRowsPerBlock)
+void msda_fwd_generic(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                      const int64_t* __restrict__ lsi, const T* __restrict__ loc,
+                      const T* __restrict__ aw, int S, int M, int D, int L, int Lq, int P,
+                      T* __restrict__ out, int nrows, int nblk) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int row = xcd_logical_block(blockIdx.x, nblk) * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int LP = L * P;
+    const int m = row % M;
+    const int b = (row / M) / Lq;
+    const size_t pix_stride = (size_t)M * D;
+    const T* vhead = value + (size_t)b * S * pix_stride + (size_t)m * D;
+    const T* lrow = loc + (size_t)row * 2 * LP;
+    const T* wrow = aw + (size_t)row * LP;
+    for (int c = lane; c < D; c += kWave) {
+        T acc = 0;
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+            const T* vl = vhead + (size_t)lsi[l] * pix_stride + c;
+            for (int p = 0; p < P; ++p) {
+                const int idx = l * P + p;
+                const Corners<T> k = make_corners<T>(lrow[2 * idx], lrow[2 * idx + 1], H, W);
+                if (!k.live) continue;
+                const T v1 = k.k1 ? vl[(size_t)k.o1 * pix_stride] : (T)0;
+                const T v2 = k.k2 ? vl[(size_t)k.o2 * pix_stride] : (T)0;
+                const T v3 = k.k3 ? vl[(size_t)k.o3 * pix_stride] : (T)0;
+                const T v4 = k.k4 ? vl[(size_t)k.o4 * pix_stride] : (T)0;
+                acc += (k.w1 * v1 + k.w2 * v2 + k.w3 * v3 + k.w4 * v4) * wrow[idx];
+            }
+        }
+        out[(size_t)row * D + c] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward, any D / L / P: lane = channel (strided when D > 64).  PU points are loaded together
+// (4*PU independent loads per lane) before the atomics of any of them are issued.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_add_fast(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add_fast(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+template <typename T, int PU>
+__global__ __launch_bounds__(kWave * kRowsPerBlock)
+void msda_bwd_generic(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                      const int64_t* __restrict__ lsi, const T* __restrict__ loc,
+                      const T* __restrict__ aw, const T* __restrict__ grad_out,
+                      int S, int M, int D, int L, int Lq, int P,
+                      T* __restrict__ grad_value, T* __restrict__ grad_loc, T* __restrict__ grad_aw,
+                      int nrows, int nblk) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int row = xcd_logical_block(blockIdx.x, nblk) * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int LP = L * P;
+    const int m = row % M;
+    const int b = (row / M) / Lq;
+    const size_t pix_stride = (size_t)M * D;
+    const size_t head_off = (size_t)b * S * pix_stride + (size_t)m * D;
+    const T* lrow = loc + (size_t)row * 2 * LP;
+    const T* wrow = aw + (size_t)row * LP;
+
+    for (int i0 = 0; i0 < LP; i0 += PU) {
+        T gx[PU], gy[PU], ga[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) gx[u] = gy[u] = ga[u] = 0;
+        for (int c = lane; c < D; c += kWave) {
+            const T go = grad_out[(size_t)row * D + c];
+            Corners<T> k[PU];
+            size_t base[PU];
+            T wt[PU], v1[PU], v2[PU], v3[PU], v4[PU];
+            int Hs[PU], Ws[PU];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int idx = min(i0 + u, LP - 1);
+                const int l = idx / P;
+                Hs[u] = (int)shapes[2 * l]; Ws[u] = (int)shapes[2 * l + 1];
+                base[u] = head_off + (size_t)lsi[l] * pix_stride + c;
+                k[u] = make_corners<T>(lrow[2 * idx], lrow[2 * idx + 1], Hs[u], Ws[u]);
+                if (i0 + u >= LP) k[u].live = k[u].k1 = k[u].k2 = k[u].k3 = k[u].k4 = false;
+                wt[u] = wrow[idx];
+                v1[u] = value[base[u] + (size_t)k[u].o1 * pix_stride];
+                v2[u] = value[base[u] + (size_t)k[u].o2 * pix_stride];
+                v3[u] = value[base[u] + (size_t)k[u].o3 * pix_stride];
+                v4[u] = value[base[u] + (size_t)k[u].o4 * pix_stride];
+            }
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const Corners<T>& q = k[u];
+                const T tgv = go * wt[u];
+                const T a1 = q.k1 ? v1[u] : (T)0, a2 = q.k2 ? v2[u] : (T)0;
+                const T a3 = q.k3 ? v3[u] : (T)0, a4 = q.k4 ? v4[u] : (T)0;
+                if (q.k1) atomic_add_fast(grad_value + base[u] + (size_t)q.o1 * pix_stride, q.w1 * tgv);
+                if (q.k2) atomic_add_fast(grad_value + base[u] + (size_t)q.o2 * pix_stride, q.w2 * tgv);
+                if (q.k3) atomic_add_fast(grad_value + base[u] + (size_t)q.o3 * pix_stride, q.w3 * tgv);
+                if (q.k4) atomic_add_fast(grad_value + base[u] + (size_t)q.o4 * pix_stride, q.w4 * tgv);
+                // d/dh and d/dw of the bilinear form (dropped corners contribute nothing)
+                const T gh = -q.hw * a1 - q.lw * a2 + q.hw * a3 + q.lw * a4;
+                const T gw = -q.hh * a1 + q.hh * a2 - q.lh * a3 + q.lh * a4;
+                const T val = q.w1 * a1 + q.w2 * a2 + q.w3 * a3 + q.w4 * a4;
+                ga[u] += go * val;
+                gx[u] += (T)Ws[u] * gw * tgv;
+                gy[u] += (T)Hs[u] * gh * tgv;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const T sx = wave_sum(gx[u]), sy = wave_sum(gy[u]), sa = wave_sum(ga[u]);
+            if (lane == 0 && i0 + u < LP) {
+                grad_aw[(size_t)row * LP + i0 + u] = sa;
+                grad_loc[(size_t)row * 2 * LP + 2 * (i0 + u)] = sx;
+                grad_loc[(size_t)row * 2 * LP + 2 * (i0 + u) + 1] = sy;
+            }
+        }
+    }
+}
+
+bool dims_ok(int B, int S, int M, int D, int L, int Lq, int P) {
+    if (B <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return false;
+    const long long rows = (long long)B * Lq * M;
+    return rows < (1LL << 31) - 8 && (long long)L * P < (1 << 20);
+}
+
+template <typename T>
+int launch_fwd(const T* value, const int64_t* shapes, const int64_t* lsi, const T* loc, const T* aw,
+               int B, int S, int M, int D, int L, int Lq, int P, T* out, hipStream_t st) {
+    if (!value || !shapes || !lsi || !loc || !aw || !out) return GRIT_ERR_BAD_ARG;
+    if (!dims_ok(B, S, M, D, L, Lq, P)) return GRIT_ERR_BAD_ARG;
+    const int nrows = B * Lq * M;
+    const int nblk = (nrows + kRowsPerBlock - 1) / kRowsPerBlock;
+    const dim3 grid(nblk), block(kWave * kRowsPerBlock);
+    bool done = false;
+    if constexpr (sizeof(T) == 4) {
+        const int LP = L * P;
+        const bool aligned = ((uintptr_t)value % 16 == 0) && ((uintptr_t)out % 16 == 0);
+#define GRIT_FWD_CASE(LPP_, NIT_)                                                                    \
+    hipLaunchKernelGGL((msda_fwd_vec4<LPP_, NIT_>), grid, block, 0, st, value, shapes, lsi, loc, aw, \
+                       S, M, L, Lq, P, out, nrows, nblk);                                            \
+    done = true
+        if (aligned && D == 64 && LP <= 32) {
+            const int nit = (LP + 3) / 4;
+            if (nit == 1) { GRIT_FWD_CASE(16, 1); } else if (nit == 2) { GRIT_FWD_CASE(16, 2); }
+            else if (nit == 3) { GRIT_FWD_CASE(16, 3); } else if (nit == 4) { GRIT_FWD_CASE(16, 4); }
+            else if (nit == 6) { GRIT_FWD_CASE(16, 6); } else if (nit == 8) { GRIT_FWD_CASE(16, 8); }
+        } else if (aligned && D == 32 && LP <= 32) {
+            const int nit = (LP + 7) / 8;
+            if (nit == 1) { GRIT_FWD_CASE(8, 1); } else if (nit == 2) { GRIT_FWD_CASE(8, 2); }
+            else if (nit == 3) { GRIT_FWD_CASE(8, 3); } else if (nit == 4) { GRIT_FWD_CASE(8, 4); }
+        }
+#undef GRIT_FWD_CASE
+    }
+    if (!done)
+        hipLaunchKernelGGL((msda_fwd_generic<T>), grid, block, 0, st, value, shapes, lsi, loc, aw,
+                           S, M, D, L, Lq, P, out, nrows, nblk);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+template <typename T>
+int launch_bwd(const T* value, const int64_t* shapes, const int64_t* lsi, const T* loc, const T* aw,
+               const T* go, int B, int S, int M, int D, int L, int Lq, int P,
+               T* gv, T* gl, T* gw, hipStream_t st) {
+    if (!value || !shapes || !lsi || !loc || !aw || !go || !gv || !gl || !gw) return GRIT_ERR_BAD_ARG;
+    if (!dims_ok(B, S, M, D, L, Lq, P)) return GRIT_ERR_BAD_ARG;
+    const int nrows = B * Lq * M;
+    const int nblk = (nrows + kRowsPerBlock - 1) / kRowsPerBlock;
+    const dim3 grid(nblk), block(kWave * kRowsPerBlock);
+    if ((L * P) % 4 == 0)
+        hipLaunchKernelGGL((msda_bwd_generic<T, 4>), grid, block, 0, st, value, shapes, lsi, loc, aw, go,
+                           S, M, D, L, Lq, P, gv, gl, gw, nrows, nblk);
+    else
+        hipLaunchKernelGGL((msda_bwd_generic<T, 1>), grid, block, 0, st, value, shapes, lsi, loc, aw, go,
+                           S, M, D, L, Lq, P, gv, gl, gw, nrows, nblk);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int grit_msda_fwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                      const float* loc, const float* attn_w, int B, int S, int M, int D, int L, int Lq,
+                      int P, float* out, void* stream) {
+    return launch_fwd<float>(value, spatial_shapes, level_start, loc, attn_w, B, S, M, D, L, Lq, P, out,
+                             (hipStream_t)stream);
+}
+
+int grit_msda_fwd_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                      const double* loc, const double* attn_w, int B, int S, int M, int D, int L, int Lq,
+                      int P, double* out, void* stream) {
+    return launch_fwd<double>(value, spatial_shapes, level_start, loc, attn_w, B, S, M, D, L, Lq, P, out,
+                              (hipStream_t)stream);
+}
+
+int grit_msda_bwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                      const float* loc, const float* attn_w, const float* grad_out, int B, int S, int M,
+                      int D, int L, int Lq, int P, float* grad_value, float* grad_loc, float* grad_attn_w,
+                      void* stream) {
+    return launch_bwd<float>(value, spatial_shapes, level_start, loc, attn_w, grad_out, B, S, M, D, L, Lq,
+                             P, grad_value, grad_loc, grad_attn_w, (hipStream_t)stream);
+}
+
+int grit_msda_bwd_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                      const double* loc, const double* attn_w, const double* grad_out, int B, int S, int M,
+                      int D, int L, int Lq, int P, double* grad_value, double* grad_loc,
+                      double* grad_attn_w, void* stream) {
+    return launch_bwd<double>(value, spatial_shapes, level_start, loc, attn_w, grad_out, B, S, M, D, L, Lq,
+                              P, grad_value, grad_loc, grad_attn_w, (hipStream_t)stream);
+}
+
+}  // extern "C"

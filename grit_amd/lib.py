@@ -1,0 +1,70 @@
+"""ctypes binding of libgrit_hip.so (C ABI in include/grit_hip.h).
+
+There is no fallback: if the library is missing or a call fails this raises.  Tensors are handed over
+as raw device pointers together with torch's *current* HIP stream, so launches are ordered with the
+surrounding torch ops (same contract as the reference's at::cuda::getCurrentCUDAStream(),
+models/ops/src/cuda/ms_deform_attn_cuda.cu:65).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
+ABI_VERSION = 1
+
+_c = ctypes
+_ptr, _int = _c.c_void_p, _c.c_int
+
+# name -> argument types; mirrors include/grit_hip.h one to one (tests check every symbol resolves)
+SIGNATURES = {
+    "grit_abi_version": [],
+    "grit_status_string": [_int],
+    "grit_msda_fwd_f32": [_ptr] * 5 + [_int] * 7 + [_ptr, _ptr],
+    "grit_msda_fwd_f64": [_ptr] * 5 + [_int] * 7 + [_ptr, _ptr],
+    "grit_msda_bwd_f32": [_ptr] * 6 + [_int] * 7 + [_ptr] * 4,
+    "grit_msda_bwd_f64": [_ptr] * 6 + [_int] * 7 + [_ptr] * 4,
+}
+
+_lib = None
+
+
+class GritHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type the library.  Raises GritHipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GritHipError(
+            "libgrit_hip.so not found at %s -- run `python -m grit_amd.build` (there is no CPU or "
+            "PyTorch fallback for the GRIT kernels)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _c.c_char_p if name == "grit_status_string" else _int
+    if lib.grit_abi_version() != ABI_VERSION:
+        raise GritHipError("libgrit_hip.so ABI %d != binding ABI %d: rebuild" %
+                           (lib.grit_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        raise GritHipError("%s failed: %s" % (what, load().grit_status_string(status).decode()))
+
+
+def current_stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(*tensors):
+    """Reference behaviour: CPU tensors -> error (ms_deform_attn.h:38 'Not implemented on the CPU')."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise GritHipError("Not implemented on the CPU: the GRIT kernels need HIP device tensors")

@@ -1,0 +1,96 @@
+"""Multi-scale deformable attention op: the two functions of the reference's pybind module
+`MultiScaleDeformableAttention` (models/ops/src/vision.cpp:13-16, ms_deform_attn.h:20-62) and the
+autograd Function built on them (models/ops/functions/ms_deform_attn_func.py:21-38), on top of the
+C ABI grit_msda_{fwd,bwd}_{f32,f64}.
+
+Differences from the reference, on purpose:
+  * `im2col_step` is accepted and ignored (no `batch % im2col_step == 0` failure);
+  * bf16/fp16 inputs are computed in float32 and cast back (the reference dispatches float/double only);
+  * launch failures raise (the reference only printf's them, ms_deform_im2col_cuda.cuh:948-952).
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from grit_amd import lib as _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _check_inputs(value, shapes, lsi, loc, aw):
+    _lib.require_device(value, shapes, lsi, loc, aw)
+    if value.dim() != 4 or loc.dim() != 6 or aw.dim() != 5:
+        raise RuntimeError("ms_deform_attn: value [B,S,M,D], sampling_loc [B,Lq,M,L,P,2], attn_weight [B,Lq,M,L,P] expected")
+    for name, t in (("value", value), ("spatial_shapes", shapes), ("level_start_index", lsi),
+                    ("sampling_loc", loc), ("attn_weight", aw)):
+        if not t.is_contiguous():  # reference: AT_ASSERTM(x.is_contiguous()), ms_deform_attn_cuda.cu:28-32
+            raise RuntimeError("%s tensor has to be contiguous" % name)
+    if shapes.dtype != torch.int64 or lsi.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes / level_start_index must be int64")
+    B, S, M, D = value.shape
+    _, Lq, M2, L, P, two = loc.shape
+    if M2 != M or two != 2 or tuple(aw.shape) != (B, Lq, M, L, P) or shapes.shape[0] != L or loc.shape[0] != B:
+        raise RuntimeError("ms_deform_attn: inconsistent shapes")
+    return B, S, M, D, L, Lq, P
+
+
+def _compute_dtype(t):
+    return torch.float64 if t.dtype == torch.float64 else torch.float32
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
+    B, S, M, D, L, Lq, P = _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    cdt = _compute_dtype(value)
+    v, loc, aw = value.to(cdt), sampling_loc.to(cdt), attn_weight.to(cdt)
+    out = torch.empty((B, Lq, M * D), dtype=cdt, device=value.device)
+    fn = _lib.load().grit_msda_fwd_f64 if cdt == torch.float64 else _lib.load().grit_msda_fwd_f32
+    with torch.cuda.device(value.device):
+        st = fn(_ptr(v), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(aw),
+                B, S, M, D, L, Lq, P, _ptr(out), _lib.current_stream_ptr())
+    _lib.check(st, "grit_msda_fwd")
+    return out.to(value.dtype)
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            im2col_step=64):
+    B, S, M, D, L, Lq, P = _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    _lib.require_device(grad_output)
+    cdt = _compute_dtype(value)
+    v, loc, aw = value.to(cdt), sampling_loc.to(cdt), attn_weight.to(cdt)
+    go = grad_output.to(cdt).contiguous()
+    gv = torch.zeros_like(v)  # atomics accumulate into it (ms_deform_attn_cuda.cu:121)
+    gl = torch.empty_like(loc)
+    ga = torch.empty_like(aw)
+    fn = _lib.load().grit_msda_bwd_f64 if cdt == torch.float64 else _lib.load().grit_msda_bwd_f32
+    with torch.cuda.device(value.device):
+        st = fn(_ptr(v), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(aw), _ptr(go),
+                B, S, M, D, L, Lq, P, _ptr(gv), _ptr(gl), _ptr(ga), _lib.current_stream_ptr())
+    _lib.check(st, "grit_msda_bwd")
+    return [gv.to(value.dtype), gl.to(sampling_loc.dtype), ga.to(attn_weight.dtype)]
+
+
+class MSDeformAttnFunction(Function):
+    """Same call signature and gradient tuple as the reference Function."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step=64):
+        ctx.im2col_step = im2col_step
+        value, sampling_locations, attention_weights = (value.contiguous(), sampling_locations.contiguous(),
+                                                        attention_weights.contiguous())
+        output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                        attention_weights, im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                              attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, aw = ctx.saved_tensors
+        gv, gl, ga = ms_deform_attn_backward(value, shapes, lsi, loc, aw, grad_output.contiguous(), ctx.im2col_step)
+        return gv, None, None, gl, ga, None

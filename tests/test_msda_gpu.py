@@ -1,0 +1,166 @@
+"""HIP MSDeformAttn (through the C ABI) against the golden vectors and the C oracle.  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import msda as omsda
+from tests.test_msda_oracle import kink_mask
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def _run(value, shapes, lsi, loc, aw, cot=None):
+    from grit_amd.ops.msda import MSDeformAttnFunction
+    v, l, a = value.clone().requires_grad_(True), loc.clone().requires_grad_(True), aw.clone().requires_grad_(True)
+    out = MSDeformAttnFunction.apply(v, shapes, lsi, l, a, 64)
+    if cot is None:
+        return out.detach()
+    out.backward(cot)
+    return out.detach(), v.grad, l.grad, a.grad
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_reference_forward_checks(golden_dir):
+    """models/ops/test.py:31-60: double with allclose defaults, float with rtol 1e-2 / atol 1e-3 (we hold 1e-6)."""
+    g = _load(golden_dir, "msda_g1.npz")
+    sh, lsi = _t(g["shapes"]), _t(g["lsi"])
+    out = _run(_t(g["dbl_value"], torch.float64), sh, lsi, _t(g["dbl_loc"], torch.float64), _t(g["dbl_aw"], torch.float64))
+    assert torch.allclose(out.cpu(), torch.from_numpy(g["dbl_out"]))
+    out = _run(_t(g["flt_value"]), sh, lsi, _t(g["flt_loc"]), _t(g["flt_aw"]))
+    np.testing.assert_allclose(out.cpu().numpy(), g["flt_out"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("d", [30, 32, 64, 71])
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-4)])
+def test_reference_gradient_cases(golden_dir, d, dtype, tol):
+    """models/ops/test.py:63-86 channel counts (four different backward kernels in the reference)."""
+    g = _load(golden_dir, "msda_g1.npz")
+    sh, lsi = _t(g["shapes"]), _t(g["lsi"])
+    out, gv, gl, ga = _run(_t(g[f"g{d}_value"], dtype), sh, lsi, _t(g[f"g{d}_loc"], dtype), _t(g[f"g{d}_aw"], dtype),
+                           _t(g[f"g{d}_cot"], dtype))
+    rt = tol
+    np.testing.assert_allclose(out.cpu().numpy(), g[f"g{d}_out"], rtol=rt, atol=tol * 1e-2)
+    np.testing.assert_allclose(gv.cpu().numpy(), g[f"g{d}_gv"], rtol=rt, atol=tol)
+    np.testing.assert_allclose(gl.cpu().numpy(), g[f"g{d}_gl"], rtol=rt, atol=tol)
+    np.testing.assert_allclose(ga.cpu().numpy(), g[f"g{d}_ga"], rtol=rt, atol=tol)
+
+
+def test_grit_shape_border_points_fp32(golden_dir):
+    """north_star tolerance: 1e-4 fp32 against the reference op."""
+    g = _load(golden_dir, "msda_g2.npz")
+    out, gv, gl, ga = _run(_t(g["value"]), _t(g["shapes"]), _t(g["lsi"]), _t(g["loc"]), _t(g["aw"]), _t(g["cot"]))
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gv.cpu().numpy(), g["gv"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ga.cpu().numpy(), g["ga"], rtol=1e-4, atol=1e-4)
+    keep = ~kink_mask(g["loc"], g["shapes"])
+    np.testing.assert_allclose(gl.cpu().numpy()[keep], g["gl"][keep], rtol=1e-4, atol=1e-3)
+    # on the kinks the HIP kernel must agree with the CUDA rule, i.e. with the C oracle
+    ogv, ogl, oga = omsda.msda_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["aw"], g["cot"])
+    np.testing.assert_allclose(gl.cpu().numpy(), ogl, rtol=1e-4, atol=1e-3)
+
+
+def _config2(B, seed=0, Lq=150):
+    """SURVEY 8(d) config 2 inputs: levels 80/40/20/10, M=8, D=64, L=P=4."""
+    gen = torch.Generator().manual_seed(seed)
+    shapes = torch.tensor([[80, 80], [40, 40], [20, 20], [10, 10]])
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S, M, D, L, P = int(shapes.prod(1).sum()), 8, 64, 4, 4
+    value = torch.randn(B, S, M, D, generator=gen)
+    ref = torch.rand(B, Lq, 1, 1, 1, 2, generator=gen)
+    loc = (ref + 0.05 * torch.randn(B, Lq, M, L, P, 2, generator=gen)).clamp(-0.05, 1.05)
+    aw = torch.softmax(torch.randn(B, Lq, M, L * P, generator=gen), -1).view(B, Lq, M, L, P)
+    return value, shapes, lsi, loc, aw
+
+
+def test_config2_forward_backward_vs_oracle():
+    value, shapes, lsi, loc, aw = _config2(B=2)
+    cot = torch.randn(2, 150, 512, generator=torch.Generator().manual_seed(5))
+    out, gv, gl, ga = _run(value.to(DEV), shapes.to(DEV), lsi.to(DEV), loc.to(DEV), aw.to(DEV), cot.to(DEV))
+    ref = omsda.msda_forward(value.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy())
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+    ogv, ogl, oga = omsda.msda_backward(value.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy(), cot.numpy())
+    np.testing.assert_allclose(gv.cpu().numpy(), ogv, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ga.cpu().numpy(), oga, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gl.cpu().numpy(), ogl, rtol=1e-3, atol=2e-3)
+
+
+def test_config2_full_size_properties():
+    """BASELINE config 2 at full size (B=8): exact check vs the oracle plus size-independent properties."""
+    value, shapes, lsi, loc, aw = _config2(B=8, seed=1)
+    dv, ds, dl, dloc, daw = (t.to(DEV) for t in (value, shapes, lsi, loc, aw))
+    out = _run(dv, ds, dl, dloc, daw)
+    ref = omsda.msda_forward(value.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy())
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+    # linearity in value
+    v2 = torch.randn_like(dv)
+    lhs = _run(2.5 * dv + v2, ds, dl, dloc, daw)
+    rhs = 2.5 * out + _run(v2, ds, dl, dloc, daw)
+    assert torch.allclose(lhs, rhs, rtol=1e-4, atol=1e-4)
+    # constant map + interior points: out = sum of weights = 1
+    ones = torch.ones_like(dv)
+    inner = dloc.clamp(0.06, 0.94)
+    o1 = _run(ones, ds, dl, inner, daw)
+    assert torch.allclose(o1, torch.ones_like(o1), atol=1e-5)
+    # every point outside the map -> exact zeros
+    assert not _run(dv, ds, dl, dloc + 5.0, daw).any()
+    # sum(grad_value) == sum_q sum(cot * weights-inside): conservation of the scatter
+    cot = torch.ones(8, 150, 512, device=DEV)
+    _, gv, gl, ga = _run(ones, ds, dl, inner, daw, cot)
+    assert abs(gv.sum().item() - cot.numel()) / cot.numel() < 1e-4
+
+
+def test_ragged_and_odd_shapes():
+    """non power-of-two D, L*P not a multiple of 4, 1x1 level, batch not a multiple of anything."""
+    gen = torch.Generator().manual_seed(3)
+    for (B, M, D, Lq, shapes_l, P) in [(3, 3, 7, 5, [(5, 3), (1, 1)], 3), (1, 1, 1, 1, [(1, 1)], 1),
+                                       (2, 4, 32, 9, [(9, 11), (4, 6), (2, 3)], 4), (5, 2, 130, 3, [(3, 3)], 5)]:
+        shapes = torch.tensor(shapes_l)
+        lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+        S, L = int(shapes.prod(1).sum()), len(shapes_l)
+        value = torch.randn(B, S, M, D, generator=gen)
+        loc = torch.rand(B, Lq, M, L, P, 2, generator=gen) * 1.4 - 0.2
+        aw = torch.rand(B, Lq, M, L, P, generator=gen)
+        cot = torch.randn(B, Lq, M * D, generator=gen)
+        out, gv, gl, ga = _run(value.to(DEV), shapes.to(DEV), lsi.to(DEV), loc.to(DEV), aw.to(DEV), cot.to(DEV))
+        ref = omsda.msda_forward(value.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy())
+        ogv, ogl, oga = omsda.msda_backward(value.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy(), cot.numpy())
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(gv.cpu().numpy(), ogv, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(ga.cpu().numpy(), oga, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(gl.cpu().numpy(), ogl, rtol=1e-3, atol=1e-3)
+
+
+def test_bf16_io_and_errors():
+    from grit_amd.ops.msda import ms_deform_attn_forward
+    value, shapes, lsi, loc, aw = _config2(B=1, Lq=10)
+    dv, ds, dl, dloc, daw = (t.to(DEV) for t in (value, shapes, lsi, loc, aw))
+    o32 = ms_deform_attn_forward(dv, ds, dl, dloc, daw, 64)
+    o16 = ms_deform_attn_forward(dv.bfloat16(), ds, dl, dloc, daw, 64)
+    assert o16.dtype == torch.bfloat16
+    assert torch.allclose(o16.float(), o32, rtol=5e-2, atol=5e-2)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ms_deform_attn_forward(dv.transpose(1, 2), ds, dl, dloc, daw, 64)
+    with pytest.raises(RuntimeError, match="CPU"):
+        ms_deform_attn_forward(value, shapes, lsi, loc, aw, 64)
+
+
+def test_shim_module_name():
+    """`import MultiScaleDeformableAttention as MSDA` (ms_deform_attn_func.py:18) resolves to the HIP op."""
+    import MultiScaleDeformableAttention as MSDA
+    value, shapes, lsi, loc, aw = (t.to(DEV) for t in _config2(B=1, Lq=4))
+    out = MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 64)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, aw, torch.ones_like(out), 64)
+    assert out.shape == (1, 4, 512) and gv.shape == value.shape and gl.shape == loc.shape and ga.shape == aw.shape

@@ -1,0 +1,195 @@
+"""Cross-entropy training / evaluation loops of the captioner (reference engine/caption_engine.py).
+
+Kept: build_optimizers :18-73 (two Adams split on 'detector' in the parameter name; the groups carry
+`weight_decay_rate`, which torch.optim.Adam ignores -> effective weight decay 0), gather_result :76-80,
+save_checkpoint :83-103 (same dict layout), evaluate_loss :287-309, train_xe :312-385 (same step order:
+forward -> zero_grad x2 -> NLL on shifted log-probs -> backward -> Adam x2 -> scalar all-reduce -> scheduler, and the
+extra scheduler.step() before each epoch's loop, Q8), evaluate_metrics :144-230 (the beam-search model call; scoring
+is delegated to a caller-supplied scorer because the reference's PTB tokenizer / METEOR are Java programs).
+Out of scope: train_sc (self-critical CIDEr reward), log_epoch, inference_coco_test.
+
+MI355X specifics: Adam runs as torch's fused multi-tensor kernel; the model may be wrapped either in
+torch DDP or in grit_amd.ddp.BucketedDataParallel (gradient buckets all-reduced by RCCL on its side stream while
+backward is still running); tqdm / TensorBoard are optional.
+"""
+import time
+
+import torch
+import torch.distributed as dist
+from torch.nn import NLLLoss
+
+from grit_amd.data import PAD
+from grit_amd.utils.misc import get_rank, get_world_size, is_dist_avail_and_initialized
+
+
+def _unwrap(model):
+    return getattr(model, 'module', model)
+
+
+def build_optimizers(model, config, mode='xe'):
+    model = _unwrap(model)
+    no_decay = ['bias', 'gamma', 'beta']
+
+    def groups(in_detector):
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and (('detector' in n) == in_detector)]
+        return [
+            {'params': [p for n, p in named if any(nd in n for nd in no_decay)], 'weight_decay_rate': 0.0},
+            {'params': [p for n, p in named if not any(nd in n for nd in no_decay)],
+             'weight_decay_rate': config.optimizer.weight_decay},
+        ]
+
+    betas = (config.optimizer.beta_1, config.optimizer.beta_2)
+    fused = all(p.is_cuda for p in model.parameters())
+
+    def adam(param_groups, lr):
+        param_groups = [g for g in param_groups if len(g['params'])] or param_groups
+        return torch.optim.Adam(param_groups, lr=lr, betas=betas, **({'fused': True} if fused else {}))
+
+    return {
+        'model': adam(groups(False), getattr(config.optimizer, f'{mode}_lr', config.optimizer.sc_lr)),
+        'backbone': adam(groups(True), getattr(config.optimizer, f'{mode}_backbone_lr', config.optimizer.sc_backbone_lr)),
+        'mode': mode,
+    }
+
+
+def gather_result(value):
+    """Average a tensor over the ranks (sum all-reduce, then 1/world)."""
+    if isinstance(value, torch.Tensor) and is_dist_avail_and_initialized():
+        dist.all_reduce(value, async_op=False)
+        value.mul_(1.0 / get_world_size())
+    return value
+
+
+def save_checkpoint(model, optimizers, epoch, scores, best_ciders, config=None, filename='checkpoint_last.pth',
+                    scheduler=None):
+    torch.save(
+        {
+            "state_dict": _unwrap(model).state_dict(),
+            "optim_model": optimizers['model'].state_dict(),
+            "optim_backbone": optimizers['backbone'].state_dict(),
+            "scores": scores,
+            "best_ciders": best_ciders,
+            "epoch": epoch,
+            "exp_name": "" if config is None else config.exp.name,
+            "scheduler": [] if scheduler is None else scheduler.state_dict(),
+        }, filename)
+
+
+def _progress(iterable, **kw):
+    try:
+        from tqdm import tqdm
+        return tqdm(iterable, **kw)
+    except Exception:  # pragma: no cover
+        return iterable
+
+
+def _pad_index(text_field):
+    if text_field is None:
+        return PAD
+    return text_field.vocab.stoi['<pad>']
+
+
+def xe_loss(model, batch, loss_fn):
+    """NLL of token t+1 given tokens <= t (log-probs at positions 0..T-2 vs captions 1..T-1)."""
+    out = model(batch['samples'], batch['captions'])
+    target = batch['captions'][:, 1:].contiguous()
+    out = out[:, :-1].contiguous()
+    return loss_fn(out.view(-1, out.shape[-1]), target.view(-1))
+
+
+def evaluate_loss(model, dataloader, loss_fn, text_field, epoch, writer):
+    model.eval()
+    running = .0
+    with torch.no_grad():
+        for it, batch in enumerate(_progress(dataloader, desc='Epoch %d - validation' % epoch, unit='it')):
+            loss = gather_result(xe_loss(model, batch, loss_fn))
+            running += loss.item()
+    val_loss = running / max(1, len(dataloader))
+    if writer is not None and get_rank() == 0:
+        writer.add_scalar('val_loss', val_loss, epoch)
+    return val_loss
+
+
+def train_xe_step(model, batch, optimizers, loss_fn, scheduler=None, autocast_dtype=None):
+    """One optimisation step in the reference's order; returns the (rank-averaged) loss tensor, no host sync."""
+    dev = batch['captions'].device.type
+    with torch.autocast(dev, dtype=autocast_dtype, enabled=autocast_dtype is not None):
+        out = model(batch['samples'], batch['captions'])
+    optimizers['model'].zero_grad(set_to_none=False)
+    optimizers['backbone'].zero_grad(set_to_none=False)
+    target = batch['captions'][:, 1:].contiguous()
+    out = out[:, :-1].contiguous()
+    loss = loss_fn(out.view(-1, out.shape[-1]).float(), target.view(-1))
+    loss.backward()
+    finalize = getattr(model, 'finish_gradient_sync', None)
+    if finalize is not None:
+        finalize()
+    optimizers['model'].step()
+    optimizers['backbone'].step()
+    loss = gather_result(loss.detach())
+    if scheduler is not None:
+        lr = scheduler.step()
+        assert optimizers['model'].param_groups[0]['lr'] == lr, "LR scheduler doesn't work properly."
+    return loss
+
+
+def train_xe(model, dataloaders, optimizers, text_field, epoch, rank=0, config=None, scheduler=None, writer=None,
+             autocast_dtype=None, evaluate=True, checkpoint=True):
+    model.train()
+    loss_fn = NLLLoss(ignore_index=_pad_index(text_field))
+    if scheduler is not None:
+        scheduler.step()
+    running = .0
+    n = len(dataloaders['train'])
+    for it, batch in enumerate(_progress(dataloaders['train'], desc=f'Epoch {epoch} - train', unit='it')):
+        loss = train_xe_step(model, batch, optimizers, loss_fn, scheduler, autocast_dtype)
+        running += loss.item()  # the reference syncs to the host every step as well (:343)
+        if rank == 0 and writer is not None:
+            writer.add_scalar('backbone_lr', optimizers['backbone'].param_groups[0]['lr'], epoch * n + it)
+            writer.add_scalar('model_lr', optimizers['model'].param_groups[0]['lr'], epoch * n + it)
+    val_loss = evaluate_loss(model, dataloaders['valid'], loss_fn, text_field, epoch, writer) \
+        if evaluate and 'valid' in dataloaders else 0.0
+    if rank == 0 and checkpoint:
+        save_checkpoint(model=model, optimizers=optimizers, epoch=epoch, scores=[], best_ciders=(0, 0), config=config,
+                        filename='checkpoint_last.pth', scheduler=scheduler)
+    if is_dist_avail_and_initialized():
+        dist.barrier()
+    return {'loss': running / max(1, n), 'reward': 0, 'reward_baseline': 0, 'val_loss': val_loss}
+
+
+def evaluate_metrics(model, optimizers, dataloader, text_field, epoch=0, split='test', config=None, train_res=None,
+                     writer=None, best_cider=None, which='ft_xe', scheduler=None, log_and_save=True, scorer=None):
+    """Beam-search every batch (reference :165-183) and hand tokens to `scorer(gts, gen) -> dict` if given.
+    Returns (token tensors per batch, seconds per batch) when no scorer is supplied."""
+    model.eval()
+    times, tokens, gen, gts = [], [], {}, {}
+    for it, batch in enumerate(_progress(dataloader, desc=f'Epoch {epoch} - evaluation on {split}', unit='it')):
+        t0 = time.time()
+        with torch.no_grad():
+            out, _ = model(batch['samples'], seq=None, use_beam_search=True, max_len=config.model.beam_len,
+                           eos_idx=config.model.eos_idx, beam_size=config.model.beam_size, out_size=1,
+                           return_probs=False)
+        if out.is_cuda:
+            torch.cuda.synchronize()
+        times.append(time.time() - t0)
+        tokens.append(out)
+        if text_field is not None and scorer is not None:
+            import itertools
+            for i, (gts_i, gen_i) in enumerate(zip(batch['captions'], text_field.decode(out, join_words=False))):
+                gen[f'{it}_{i}'] = [' '.join(k for k, _ in itertools.groupby(gen_i))]
+                gts[f'{it}_{i}'] = gts_i
+    avg = sum(times) / max(1, len(times))
+    if scorer is None:
+        return tokens, avg
+    scores = scorer(gts, gen)
+    if log_and_save and best_cider is not None and scores.get('CIDEr', 0) >= best_cider:
+        best = (scores['CIDEr'], 0) if split == 'valid' else (0, scores['CIDEr'])
+        save_checkpoint(model, optimizers=optimizers, epoch=epoch, scores=scores, best_ciders=best, config=config,
+                        filename=f'checkpoint_best_{split}.pth', scheduler=scheduler)
+        return scores['CIDEr']
+    return scores
+
+
+def train_sc(*args, **kwargs):
+    raise NotImplementedError("self-critical training (CIDEr reward via the Java PTB tokenizer) is outside the "
+                              "MI355X hot path of this build; see DESIGN.md 'next rows' N2")

@@ -1,0 +1,98 @@
+"""Caption decoder: masked self-attention + two *parallel* cross-attentions (grid, region) gated by sigmoids.
+
+Mirror of reference models/caption/cap_generator.py (GeneratorLayer :11-18, ParallelAttentionLayer :20-56,
+CaptionGenerator :90-175).  Reproduced on purpose:
+  * both gates go through `fc_alpha1`; `fc_alpha2` is a dead parameter that stays in the state dict (Q1);
+  * only the 'parallel' layer exists on the reference's reachable path (Q2) -- 'concat' / 'sequential' raise;
+  * stateful decoding grows `running_mask_x` / `running_seq` exactly like the reference (:134-142).
+"""
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from grit_amd.models.caption.containers import Module, ModuleList
+from grit_amd.models.common.attention import MultiHeadAttention
+from grit_amd.models.common.pos_embed import FeedForward, sinusoid_encoding_table
+
+
+class GeneratorLayer(Module):
+
+    def __init__(self, d_model=512, n_heads=8, d_ff=2048, dropout=.1, n_memories=0):
+        super().__init__()
+        self.self_att = MultiHeadAttention(d_model, n_heads, dropout, n_memories=n_memories, can_be_stateful=True)
+        self.pwff = FeedForward(d_model, d_ff, dropout)
+
+
+class ParallelAttentionLayer(GeneratorLayer):
+
+    def __init__(self, d_model=512, n_heads=8, d_ff=2048, dropout=.1, activation='sigmoid', n_memories=0):
+        super().__init__(d_model=d_model, n_heads=n_heads, d_ff=d_ff, dropout=dropout, n_memories=0)
+        self.vis_att1 = MultiHeadAttention(d_model, n_heads, dropout, can_be_stateful=False, n_memories=n_memories)
+        self.vis_att2 = MultiHeadAttention(d_model, n_heads, dropout, can_be_stateful=False, n_memories=n_memories)
+        self.fc_alpha1 = nn.Linear(d_model + d_model, d_model)
+        self.fc_alpha2 = nn.Linear(d_model + d_model, d_model)  # never used in forward (reference quirk)
+        self.activation = activation
+        self.init_weights()
+
+    def init_weights(self):
+        for fc in (self.fc_alpha1, self.fc_alpha2):
+            nn.init.xavier_uniform_(fc.weight)
+            nn.init.constant_(fc.bias, 0)
+
+    def forward(self, x, y1, y2, mask_pad, mask_x, mask_y1, mask_y2):
+        self_att = self.self_att(x, x, x, mask_x) * mask_pad
+        enc1 = self.vis_att1(self_att, y1, y1, mask_y1) * mask_pad  # grid branch
+        enc2 = self.vis_att2(self_att, y2, y2, mask_y2) * mask_pad  # region branch
+        gate1 = torch.sigmoid(self.fc_alpha1(torch.cat([self_att, enc1], -1)))
+        gate2 = torch.sigmoid(self.fc_alpha1(torch.cat([self_att, enc2], -1)))  # fc_alpha1 again, as in the reference
+        fused = (enc1 * gate1 + enc2 * gate2) / np.sqrt(2)
+        return self.pwff(fused * mask_pad) * mask_pad
+
+
+class CaptionGenerator(Module):
+    GENERATOR_LAYER = {'parallel': ParallelAttentionLayer}
+
+    def __init__(self, vocab_size, max_len, n_layers, pad_idx, d_model=512, n_heads=8, d_ff=2048, dropout=.1,
+                 decoder_name='parallel', cfg=None):
+        super().__init__()
+        if decoder_name not in self.GENERATOR_LAYER:
+            raise NotImplementedError("only the 'parallel' decoder is reachable in GRIT (decoder_name is never forwarded)")
+        self.d_model = d_model
+        self.word_emb = nn.Embedding(vocab_size, d_model, padding_idx=pad_idx)
+        self.pos_emb = nn.Embedding.from_pretrained(sinusoid_encoding_table(max_len + 1, d_model, 0), freeze=True)
+        self.cfg, self.decoder_name = cfg, decoder_name
+        layer_cls = self.GENERATOR_LAYER[decoder_name]
+        self.layers = ModuleList([layer_cls(d_model, n_heads, d_ff, dropout) for _ in range(n_layers)])
+        self.fc = nn.Linear(d_model, vocab_size, bias=False)
+        self.max_len, self.pad_idx, self.N = max_len, pad_idx, n_layers
+        self.register_state('running_mask_x', torch.zeros((1, 1, 0)).byte())
+        self.register_state('running_seq', torch.zeros((1,)).long())
+
+    def get_seq_inputs(self, input):
+        """tokens (b, T) -> embeddings (b, T, d), self-attention mask (b, 1, T, T|t) True = masked, pad mask (b, T, 1)."""
+        b_s, seq_len = input.shape[:2]
+        is_pad = input == self.pad_idx
+        mask_pad = (~is_pad).unsqueeze(-1).float()
+        future = torch.triu(torch.ones((seq_len, seq_len), dtype=torch.bool, device=input.device), diagonal=1)
+        mask_x = future[None, None] | is_pad[:, None, None, :]
+        if self._is_stateful:
+            self.running_mask_x = torch.cat([self.running_mask_x.bool(), mask_x], -1)
+            mask_x = self.running_mask_x
+        seq = torch.arange(1, seq_len + 1, device=input.device).view(1, -1).expand(b_s, -1)
+        seq = seq.masked_fill(is_pad, 0)
+        if self._is_stateful:
+            self.running_seq.add_(1)
+            seq = self.running_seq
+        return self.word_emb(input) + self.pos_emb(seq), mask_x, mask_pad
+
+    def forward(self, input, vis_inputs):
+        x, mask_x, mask_pad = self.get_seq_inputs(input)
+        y1, y2 = vis_inputs['gri_feat'], vis_inputs['reg_feat']
+        m1, m2 = vis_inputs['gri_mask'], vis_inputs['reg_mask']
+        for layer in self.layers:
+            x = layer(x, y1, y2, mask_pad, mask_x, m1, m2)
+        # vocabulary projection + log-softmax stay in float32: beam-search token identity depends on them
+        with torch.autocast(x.device.type, enabled=False):
+            logits = F.linear(x.float(), self.fc.weight.float())
+            return F.log_softmax(logits, dim=-1)

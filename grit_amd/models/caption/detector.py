@@ -1,0 +1,58 @@
+"""Caption-side Detector: Swin backbone -> masks -> grid feature (coarsest map) + region features (last decoder
+layer).  Mirror of reference models/caption/detector.py (Detector :11-62, build_detector :65-84)."""
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from grit_amd.models.common.swin_model import swin_base_win7_384
+from grit_amd.models.detection.det_module import build_det_module_with_config
+from grit_amd.utils.misc import NestedTensor, nested_tensor_from_tensor_list
+
+
+class Detector(nn.Module):
+
+    def __init__(self, backbone, det_module=None, use_gri_feat=True, use_reg_feat=True, hidden_dim=256):
+        super().__init__()
+        self.backbone = backbone
+        self.use_gri_feat, self.use_reg_feat = use_gri_feat, use_reg_feat
+        if use_reg_feat:
+            self.det_module = det_module
+            self.input_proj = nn.ModuleList([
+                nn.Sequential(nn.Conv2d(c, hidden_dim, kernel_size=1), nn.GroupNorm(32, hidden_dim))
+                for c in backbone.num_channels
+            ])
+
+    def forward(self, images: NestedTensor):
+        """images.tensors [B,3,H,W], images.mask [B,H,W] (True on padding) ->
+        {gri_feat [B,h*w,1024], gri_mask [B,1,1,h*w], reg_feat [B,150,512], reg_mask [B,1,1,150] (all False)}."""
+        if isinstance(images, (list, tuple, torch.Tensor)):  # the reference's list branch is broken (Q13); fixed here
+            images = nested_tensor_from_tensor_list(list(images))
+        x, mask = images.tensors, images.mask
+        features = self.backbone(x)
+        masks = [F.interpolate(mask[None].float(), size=f.shape[-2:]).to(torch.bool)[0] for f in features]
+        out = {
+            'gri_feat': features[-1].flatten(2).transpose(1, 2),
+            'gri_mask': masks[-1].flatten(1)[:, None, None, :],
+        }
+        if self.use_reg_feat:
+            srcs = [proj(f) for proj, f in zip(self.input_proj, features)]
+            hs, _, _ = self.det_module(srcs, masks)
+            out['reg_feat'] = hs[-1]
+            out['reg_mask'] = hs[-1].new_zeros((hs[-1].shape[0], 1, 1, hs[-1].shape[1])).bool()
+        return out
+
+
+def build_detector(config):
+    pos_dim = getattr(config.model.detector, 'pos_dim', None)
+    backbone, _ = swin_base_win7_384(frozen_stages=config.model.frozen_stages, pos_dim=pos_dim)
+    det_module = build_det_module_with_config(config.model.detector) if config.model.use_reg_feat else None
+    detector = Detector(backbone, det_module=det_module, hidden_dim=config.model.d_model,
+                        use_gri_feat=config.model.use_gri_feat, use_reg_feat=config.model.use_reg_feat)
+    ckpt = config.model.detector.checkpoint
+    if ckpt and os.path.exists(ckpt):
+        state = torch.load(ckpt, map_location='cpu')
+        missing, unexpected = detector.load_state_dict(state['model'], strict=False)
+        print(f"Loading weights for detector: missing: {len(missing)}, unexpected: {len(unexpected)}.")
+    return detector

@@ -1,0 +1,172 @@
+"""GRIT captioner: detector -> grid network -> caption decoder; teacher forcing and beam search.
+
+Mirror of reference models/caption/transformer.py (Transformer.__init__ :14-51, forward :53-132, step :134-169,
+select :184-188, _expand_state :190-202, iter :204-254).  The beam loop keeps the reference's observable
+semantics to the token: always `max_len` steps, candidates = running score + word log-prob,
+a finished beam keeps its score only at vocabulary index 0 (-999 elsewhere), selection = descending torch.sort of
+the flattened [beam*V] candidates, beam = index // V, every registered state is re-gathered per step, final beams
+re-sorted by score.
+"""
+import torch
+from torch import nn
+
+from grit_amd.models.caption.base import BaseCaptioner
+from grit_amd.models.caption.cap_generator import CaptionGenerator
+from grit_amd.models.caption.grid_net import GridFeatureNetwork
+from grit_amd.utils.misc import NestedTensor
+
+
+class Transformer(BaseCaptioner):
+
+    def __init__(self, detector, config=None):
+        super().__init__()
+        m = config.model
+        # d_model 512 / 8 heads / d_ff 2048 are the constructor defaults on purpose: the reference never forwards
+        # config.model.n_heads, grid_net.n_memories or cap_generator.decoder_name
+        self.grid_net = GridFeatureNetwork(n_layers=m.grid_net.n_layers, d_in=m.grid_feat_dim, dropout=m.dropout)
+        self.cap_generator = CaptionGenerator(n_layers=m.cap_generator.n_layers, vocab_size=m.vocab_size,
+                                              max_len=m.max_len, pad_idx=m.pad_idx, dropout=m.dropout,
+                                              cfg=m.cap_generator)
+        self.config = config
+        self.bos_idx = m.bos_idx
+        self.use_reg_feat, self.use_gri_feat = m.use_reg_feat, m.use_gri_feat
+        self.cached_features = False
+        if self.use_gri_feat:
+            self.register_state('gri_feat', None)
+            self.register_state('gri_mask', None)
+        if self.use_reg_feat:
+            self.register_state('reg_feat', None)
+            self.register_state('reg_mask', None)
+        self.init_weights()
+        self.detector = detector  # attached after init_weights: the detector keeps its own initialisation
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    # ------------------------------------------------------------------ visual side
+    def _visual_inputs(self, images):
+        vis = images if self.cached_features else self.detector(images)
+        vis = dict(vis)
+        if self.config.model.use_gri_feat:
+            grid, _ = self.grid_net(vis['gri_feat'], vis['gri_mask'])
+            vis['gri_feat'] = grid[:, -1]
+        return vis
+
+    def forward(self, images, seq, use_beam_search=False, max_len=20, eos_idx=3, beam_size=5, out_size=1,
+                return_probs=False, **kwargs):
+        if not use_beam_search:
+            return self.cap_generator(seq, self._visual_inputs(images))
+        return self.beam_search(images, max_len, eos_idx, beam_size, out_size, return_probs, **kwargs)
+
+    # ------------------------------------------------------------------ beam search
+    def beam_search(self, images, max_len, eos_idx, beam_size, out_size, return_probs, **kwargs):
+        batch_size, device = self.get_bs_device(images)
+        self.seq_mask = torch.ones((batch_size, beam_size, 1), device=device)      # 1 while the beam is alive
+        self.seq_logprob = torch.zeros((batch_size, 1, 1), device=device)          # running score per beam
+        self.log_probs, self.selected_words = [], None
+        if return_probs:
+            self.all_log_probs = []
+        outputs = []
+        with self.statefulness(batch_size):
+            for t in range(max_len):
+                images, outputs = self.iter(timestep=t, samples=images, outputs=outputs, return_probs=return_probs,
+                                            batch_size=batch_size, beam_size=beam_size, eos_idx=eos_idx, **kwargs)
+        _, order = torch.sort(self.seq_logprob, 1, descending=True)
+        idx = order.expand(batch_size, beam_size, max_len)
+        outputs = torch.gather(torch.cat(outputs, -1), 1, idx)
+        log_probs = torch.gather(torch.cat(self.log_probs, -1), 1, idx)
+        outputs, log_probs = outputs.contiguous()[:, :out_size], log_probs.contiguous()[:, :out_size]
+        if out_size == 1:
+            outputs, log_probs = outputs.squeeze(1), log_probs.squeeze(1)
+        if not return_probs:
+            return outputs, log_probs
+        all_lp = torch.cat(self.all_log_probs, 2)
+        all_lp = torch.gather(all_lp, 1, order.unsqueeze(-1).expand(batch_size, beam_size, max_len, all_lp.shape[-1]))
+        return outputs, log_probs, all_lp
+
+    def step(self, timestep, prev_output, samples, seq, mode='teacher_forcing', **kwargs):
+        if mode != 'feedback':
+            raise NotImplementedError
+        if timestep == 0:
+            vis = samples if self.cached_features else self.detector(samples)
+            if self.config.model.use_gri_feat:
+                grid, self.gri_mask = self.grid_net(vis['gri_feat'], vis['gri_mask'])
+                self.gri_feat = grid[:, -1]
+            if self.config.model.use_reg_feat:
+                self.reg_feat, self.reg_mask = vis['reg_feat'], vis['reg_mask']
+            feat = getattr(self, 'gri_feat', self.reg_feat)
+            it = feat.data.new_full((feat.shape[0], 1), self.bos_idx).long()
+        else:
+            it = prev_output
+        vis_inputs = {}
+        if self.config.model.use_gri_feat:
+            vis_inputs.update(gri_feat=self.gri_feat, gri_mask=self.gri_mask)
+        if self.config.model.use_reg_feat:
+            vis_inputs.update(reg_feat=self.reg_feat, reg_mask=self.reg_mask)
+        return self.cap_generator(it, vis_inputs)
+
+    def get_bs_device(self, samples):
+        if isinstance(samples, dict):
+            t = samples['gri_feat' if 'gri_feat' in samples else 'reg_feat']
+        elif isinstance(samples, NestedTensor):
+            t = samples.tensors
+        else:
+            raise TypeError("images must be a NestedTensor or a dict of cached features")
+        return t.shape[0], t.device
+
+    def init_state(self, batch_size, device):
+        return [torch.zeros((batch_size, 0), dtype=torch.long, device=device), None, None]
+
+    def select(self, t, candidate_logprob, beam_size, **kwargs):
+        """[B, Beam, V] -> top `beam_size` of the flattened candidates, in torch.sort's order."""
+        flat = candidate_logprob.reshape(candidate_logprob.shape[0], -1)
+        logprob, idx = torch.sort(flat, -1, descending=True)
+        return idx[:, :beam_size], logprob[:, :beam_size]
+
+    def _expand_state(self, selected_beam, cur_beam_size, batch_size, beam_size):
+        """state [B*cur_beam, ...] -> rows of the surviving beams [B*beam, ...]."""
+
+        def fn(tensor):
+            tail = [int(s) for s in tensor.shape[1:]]
+            index = selected_beam.view(batch_size, beam_size, *([1] * len(tail))).expand(batch_size, beam_size, *tail)
+            picked = torch.gather(tensor.view(batch_size, cur_beam_size, *tail), 1, index)
+            return picked.view(-1, *tail)
+
+        return fn
+
+    def iter(self, timestep, samples, outputs, return_probs, batch_size, beam_size=5, eos_idx=3, **kwargs):
+        cur_beam = 1 if timestep == 0 else beam_size
+        word_logprob = self.step(timestep, self.selected_words, samples, None, mode='feedback', **kwargs)
+        word_logprob = word_logprob.view(batch_size, cur_beam, -1)
+        V = word_logprob.shape[-1]
+        candidates = self.seq_logprob + word_logprob
+        if timestep > 0:
+            alive = (self.selected_words.view(batch_size, cur_beam) != eos_idx).float().unsqueeze(-1)
+            self.seq_mask = self.seq_mask * alive
+            word_logprob = word_logprob * self.seq_mask
+            frozen = self.seq_logprob.expand_as(candidates).contiguous()
+            frozen[:, :, 1:] = -999  # a finished beam survives only through vocabulary index 0
+            candidates = self.seq_mask * candidates + frozen * (1 - self.seq_mask)
+
+        selected_idx, selected_logprob = self.select(timestep, candidates, beam_size, **kwargs)
+        selected_beam = torch.div(selected_idx, V, rounding_mode='floor')
+        selected_words = selected_idx - selected_beam * V
+
+        self.apply_to_states(self._expand_state(selected_beam, cur_beam, batch_size, beam_size))
+
+        beam_col = selected_beam.unsqueeze(-1)
+        self.seq_logprob = selected_logprob.unsqueeze(-1)
+        self.seq_mask = torch.gather(self.seq_mask, 1, beam_col)
+        outputs = [torch.gather(o, 1, beam_col) for o in outputs]
+        outputs.append(selected_words.unsqueeze(-1))
+        if return_probs:
+            lp = word_logprob.expand((batch_size, beam_size, -1)) if timestep == 0 else word_logprob
+            self.all_log_probs.append(lp.unsqueeze(2))
+        picked = torch.gather(word_logprob, 1, beam_col.expand(batch_size, beam_size, V))
+        picked = torch.gather(picked, 2, selected_words.unsqueeze(-1))
+        self.log_probs = [torch.gather(o, 1, beam_col) for o in self.log_probs]
+        self.log_probs.append(picked)
+        self.selected_words = selected_words.view(-1, 1)
+        return samples, outputs

@@ -1,0 +1,80 @@
+"""Caption-side attention blocks on top of the fused gfx950 attention core.
+
+Names / constructor arguments / parameter keys follow the reference models/common/attention.py
+(Attention :25-88, MultiHeadAttention :152-184).  The score / mask / softmax / dropout / P.V chain of
+Attention.forward (:71-84) is one kernel call (grit_amd.ops.attention.attention); the four Linears stay
+plain GEMMs.  Memory slots (n_memories > 0, Meshed-Memory style) are never enabled by GRIT
+(grid_net.n_memories is ignored) and are not implemented.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from grit_amd.models.caption.containers import Module
+from grit_amd.ops.attention import attention as fused_attention
+
+
+def init_params(module):
+    for name, param in module.named_parameters():
+        if 'weight' in name:
+            nn.init.xavier_uniform_(param)
+        elif 'bias' in name:
+            nn.init.constant_(param, 0)
+        elif 'm_' in name:
+            nn.init.normal_(param, mean=0, std=0.01)
+
+
+class Attention(nn.Module):
+    """Scaled dot-product attention with its q/k/v/o projections."""
+
+    def __init__(self, d_model, n_heads, dropout=0.2, n_memories=0):
+        super().__init__()
+        if n_memories > 0:
+            raise NotImplementedError("memory slots are not used by GRIT (n_memories is always 0 on its path)")
+        self.fc_q = nn.Linear(d_model, d_model)
+        self.fc_k = nn.Linear(d_model, d_model)
+        self.fc_v = nn.Linear(d_model, d_model)
+        self.fc_o = nn.Linear(d_model, d_model)
+        self.dropout = nn.Dropout(p=dropout)
+        self.d_model, self.n_heads, self.n_memories = d_model, n_heads, n_memories
+        self.d_k = d_model // n_heads
+        self.apply(init_params)
+
+    def forward(self, q, k, v, attention_mask=None):
+        """q (b, nq, d_model), k/v (b, nk, d_model); attention_mask broadcastable to (b, h, nq, nk), True = masked."""
+        b, nq, nk, h = q.shape[0], q.shape[1], k.shape[1], self.n_heads
+        qh = self.fc_q(q).view(b, nq, h, self.d_k)
+        kh = self.fc_k(k).view(b, nk, h, self.d_k)
+        vh = self.fc_v(v).view(b, nk, h, self.d_k)
+        out = fused_attention(qh, kh, vh, attention_mask, scale=1.0 / np.sqrt(self.d_k), dropout_p=self.dropout.p,
+                              training=self.training)
+        return self.fc_o(out)
+
+
+class MultiHeadAttention(Module):
+    """Attention + dropout + residual LayerNorm; optionally stateful for step-wise decoding.
+
+    Stateful mode reproduces the reference exactly: the *raw* keys/values of every step are
+    appended to running_keys / running_values and re-projected on each call."""
+
+    def __init__(self, d_model, n_heads, dropout=.1, n_memories=0, can_be_stateful=False):
+        super().__init__()
+        self.attention = Attention(d_model=d_model, n_heads=n_heads, dropout=dropout, n_memories=n_memories)
+        self.dropout = nn.Dropout(p=dropout)
+        self.layer_norm = nn.LayerNorm(d_model)
+        self.can_be_stateful = can_be_stateful
+        if can_be_stateful:
+            self.register_state('running_keys', torch.zeros((1, d_model)))
+            self.register_state('running_values', torch.zeros((1, d_model)))
+
+    def forward(self, queries, keys, values, attention_mask=None):
+        if self.can_be_stateful and self._is_stateful:
+            self.running_keys = torch.cat([self.running_keys, keys], 1)
+            self.running_values = torch.cat([self.running_values, values], 1)
+            if self.timestep == 0:  # drop the placeholder row the state was initialised with
+                self.running_keys = self.running_keys[:, 1:]
+                self.running_values = self.running_values[:, 1:]
+            keys, values = self.running_keys, self.running_values
+            self.timestep += 1
+        out = self.dropout(self.attention(queries, keys, values, attention_mask))
+        return self.layer_norm(queries + out)

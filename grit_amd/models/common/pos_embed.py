@@ -1,0 +1,38 @@
+"""Sinusoid position table and the position-wise FeedForward block (reference models/common/pos_embed.py)."""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+
+def position_embedding(input, d_model):
+    """input: positions (any shape) -> (n, d_model): even channels sin(p / 10000^(2i/d)), odd channels cos."""
+    pos = input.view(-1, 1)
+    i = torch.arange(d_model // 2, dtype=torch.float32, device=pos.device).view(1, -1)
+    angle = pos / 10000**(2 * i / d_model)
+    out = torch.zeros((pos.shape[0], d_model), device=pos.device)
+    out[:, 0::2] = torch.sin(angle)
+    out[:, 1::2] = torch.cos(angle)
+    return out
+
+
+def sinusoid_encoding_table(max_len, d_model, padding_idx=None):
+    table = position_embedding(torch.arange(max_len, dtype=torch.float32), d_model)
+    if padding_idx is not None:
+        table[padding_idx] = 0
+    return table
+
+
+class FeedForward(nn.Module):
+    """LayerNorm(x + drop(fc2(drop(relu(fc1(x))))))."""
+
+    def __init__(self, d_model=512, d_ff=2048, dropout=0.1):
+        super().__init__()
+        self.fc1 = nn.Linear(d_model, d_ff)
+        self.fc2 = nn.Linear(d_ff, d_model)
+        self.dropout = nn.Dropout(p=dropout)
+        self.dropout_2 = nn.Dropout(p=dropout)
+        self.layer_norm = nn.LayerNorm(d_model)
+
+    def forward(self, input):
+        hidden = self.dropout_2(F.relu(self.fc1(input)))
+        return self.layer_norm(input + self.dropout(self.fc2(hidden)))

@@ -1,0 +1,361 @@
+"""Swin-B backbone of GRIT, laid out for the fused gfx950 window-attention kernel.
+
+Public names, constructor arguments and state-dict keys are those of the reference
+(models/common/swin_model.py: Mlp :19-37, WindowAttention :108-186, SwinTransformerBlock :189-300,
+PatchMerging :303-349, BasicLayer :352-456, PatchEmbed :459-499, SwinTransformer :502-672,
+swin_base_win7_384 :690-720) so its checkpoints load unchanged.  What differs is the dataflow:
+
+  * the reference pads, rolls and partitions the map, runs qkv/attention/proj per window and reverses all of
+    it again -- five full-map permute copies per block plus a materialised [B_, nH, 144, 144] score tensor.
+    Here `qkv` and `proj` (pointwise Linears) run on the map in its natural token order and the whole
+    pad / roll(-s) / partition / bias / shift-mask / softmax / AV / reverse / roll(+s) / crop chain happens
+    inside ONE kernel through address arithmetic (grit_amd.ops.window_attention).  Padded tokens are
+    zeros *after* norm1 in the reference, hence their q/k/v equal the qkv bias: the kernel is handed
+    that bias as `pad_qkv`;
+  * the relative-position bias is gathered once per forward per block into [nH, N, N] (reference: gathered
+    inside every window-attention call, :168-171) and the shift mask is never materialised;
+  * stochastic depth (timm DropPath in the reference) is a local module with the same semantics.
+"""
+import math
+import os
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.utils.checkpoint as checkpoint
+
+from grit_amd.ops.window_attention import window_attention
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+class DropPath(nn.Module):
+    """Per-sample stochastic depth (timm.models.layers.DropPath semantics: keep w.p. 1-p, rescale by 1/(1-p))."""
+
+    def __init__(self, drop_prob=0.):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob == 0. or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        return x * mask.div_(keep)
+
+    def extra_repr(self):
+        return 'drop_prob=%.3f' % self.drop_prob
+
+
+class Mlp(nn.Module):
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features or in_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+def masked_sin_pos_encoding(x, mask, num_pos_feats, temperature=10000, scale=2 * math.pi):
+    """Sine position code over the un-masked extent of each image (kept for API parity; unused by GRIT's path)."""
+    half = num_pos_feats // 2
+    ok = ~mask
+    y = ok.cumsum(1, dtype=torch.float32)
+    x_ = ok.cumsum(2, dtype=torch.float32)
+    y = y / (y[:, -1:, :] + 1e-6) * scale
+    x_ = x_ / (x_[:, :, -1:] + 1e-6) * scale
+    freq = temperature**(2 * (torch.arange(half, dtype=torch.float32, device=x.device) // 2) / half)
+    px, py = x_[..., None] / freq, y[..., None] / freq
+    px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+    py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((py, px), dim=3)
+
+
+def window_partition(x, window_size):
+    """(B, H, W, C) -> (num_windows*B, ws, ws, C).  Utility only: the block forward never calls it."""
+    B, H, W, C = x.shape
+    x = x.view(B, H // window_size, window_size, W // window_size, window_size, C)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(-1, window_size, window_size, C)
+
+
+def window_reverse(windows, window_size, H, W):
+    """Inverse of window_partition -> (B, H, W, C)."""
+    B = windows.shape[0] // ((H // window_size) * (W // window_size))
+    x = windows.view(B, H // window_size, W // window_size, window_size, window_size, -1)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
+
+
+def _relative_position_index(wh, ww):
+    """[wh*ww, wh*ww] index into the (2wh-1)(2ww-1) bias table: (dy + wh-1)*(2ww-1) + (dx + ww-1)."""
+    ys, xs = torch.meshgrid(torch.arange(wh), torch.arange(ww), indexing='ij')
+    ys, xs = ys.reshape(-1), xs.reshape(-1)
+    dy = ys[:, None] - ys[None, :] + wh - 1
+    dx = xs[:, None] - xs[None, :] + ww - 1
+    return dy * (2 * ww - 1) + dx
+
+
+class WindowAttention(nn.Module):
+    """Window multi-head self-attention with relative position bias; shifted or not."""
+
+    def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.dim = dim
+        self.window_size = window_size  # (Wh, Ww)
+        self.num_heads = num_heads
+        self.scale = qk_scale or (dim // num_heads)**-0.5
+        n_rel = (2 * window_size[0] - 1) * (2 * window_size[1] - 1)
+        self.relative_position_bias_table = nn.Parameter(torch.zeros(n_rel, num_heads))
+        self.register_buffer("relative_position_index", _relative_position_index(*window_size))
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
+        self.softmax = nn.Softmax(dim=-1)
+        if attn_drop > 0:
+            raise NotImplementedError("attention-probability dropout is not fused (GRIT uses attn_drop_rate=0)")
+
+    def relative_position_bias(self):
+        """[nH, N, N] float32, gathered from the table (differentiable w.r.t. the table)."""
+        n = self.window_size[0] * self.window_size[1]
+        bias = self.relative_position_bias_table[self.relative_position_index.view(-1)]
+        return bias.view(n, n, -1).permute(2, 0, 1).contiguous().float()
+
+    def pad_qkv(self, dtype):
+        if self.qkv.bias is None:
+            return torch.zeros(3 * self.dim, dtype=dtype, device=self.qkv.weight.device)
+        return self.qkv.bias.to(dtype)
+
+    def attend_map(self, x, H, W, shift):
+        """x: normalised tokens [B, H*W, C] in map order -> attention output [B, H*W, C] (after proj)."""
+        qkv = self.qkv(x)
+        out = window_attention(qkv, self.relative_position_bias(), self.pad_qkv(qkv.dtype), H, W, self.num_heads,
+                               self.window_size[0], shift, self.scale)
+        return self.proj_drop(self.proj(out))
+
+    def forward(self, x, mask=None):
+        """Reference call form: x (num_windows*B, N, C) already partitioned, mask (nW, N, N) additive or None."""
+        ws = self.window_size[0]
+        qkv = self.qkv(x)
+        out = window_attention(qkv, self.relative_position_bias(), self.pad_qkv(qkv.dtype), ws, ws, self.num_heads, ws,
+                               0, self.scale, mask=mask)
+        return self.proj_drop(self.proj(out))
+
+
+class SwinTransformerBlock(nn.Module):
+
+    def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        assert 0 <= shift_size < window_size, "shift_size must in 0-window_size"
+        self.dim, self.num_heads = dim, num_heads
+        self.window_size, self.shift_size, self.mlp_ratio = window_size, shift_size, mlp_ratio
+        self.norm1 = norm_layer(dim)
+        self.attn = WindowAttention(dim, window_size=to_2tuple(window_size), num_heads=num_heads, qkv_bias=qkv_bias,
+                                    qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.H = None
+        self.W = None
+
+    def forward(self, x, mask_matrix=None):
+        """x (B, H*W, C) with self.H/self.W set by the stage.  `mask_matrix` is accepted for signature parity;
+        the kernel derives the shift mask from (H, W, window, shift) itself."""
+        B, L, C = x.shape
+        H, W = self.H, self.W
+        assert L == H * W, "input feature has wrong size"
+        x = x + self.drop_path(self.attn.attend_map(self.norm1(x), H, W, self.shift_size))
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+class PatchMerging(nn.Module):
+    """2x2 neighbourhood concat (order (0,0),(1,0),(0,1),(1,1)) -> LayerNorm(4C) -> Linear(4C -> 2C | pos_dim)."""
+
+    def __init__(self, dim, norm_layer=nn.LayerNorm, expand=True, pos_dim=768):
+        super().__init__()
+        self.dim = dim
+        out_dim = 2 * dim if expand else pos_dim
+        self.reduction = nn.Linear(4 * dim, out_dim, bias=False)
+        self.norm = norm_layer(4 * dim)
+        # dead parameters of the reference, kept so checkpoints round-trip
+        self.expansion = nn.Linear(dim, out_dim, bias=False)
+        self.norm2 = norm_layer(dim)
+
+    def forward(self, x, H, W):
+        B, L, C = x.shape
+        assert L == H * W, "input feature has wrong size"
+        x = x.view(B, H, W, C)
+        if (H % 2) or (W % 2):
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        Hh, Wh = (H + 1) // 2, (W + 1) // 2
+        # [B, Hh, 2(dy), Wh, 2(dx), C] -> channel blocks ordered (dy,dx) = (0,0),(1,0),(0,1),(1,1)
+        x = x.view(B, Hh, 2, Wh, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, Hh * Wh, 4 * C)
+        return self.reduction(self.norm(x))
+
+
+class BasicLayer(nn.Module):
+    """One Swin stage: `depth` blocks alternating shift 0 / window//2, then the (always present) PatchMerging."""
+
+    def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0.,
+                 attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, downsample=None, last=False,
+                 use_checkpoint=False):
+        super().__init__()
+        self.window_size, self.shift_size = window_size, window_size // 2
+        self.depth, self.dim, self.use_checkpoint = depth, dim, use_checkpoint
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim=dim, num_heads=num_heads, window_size=window_size,
+                                 shift_size=0 if i % 2 == 0 else window_size // 2, mlp_ratio=mlp_ratio,
+                                 qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop, attn_drop=attn_drop,
+                                 drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                                 norm_layer=norm_layer) for i in range(depth)
+        ])
+        self.downsample = None if downsample is None else downsample(dim=dim, norm_layer=norm_layer,
+                                                                     expand=(not last))
+
+    def attention_mask(self, H, W, device=None):
+        """The reference's materialised shift mask [nW, N, N] (0 / -100).  Not used by forward()."""
+        ws, s = self.window_size, self.shift_size
+        Hp, Wp = int(np.ceil(H / ws)) * ws, int(np.ceil(W / ws)) * ws
+        region = torch.zeros(Hp, Wp, device=device)
+        edges_h, edges_w = (0, Hp - ws, Hp - s, Hp), (0, Wp - ws, Wp - s, Wp)
+        for i in range(3):
+            for j in range(3):
+                region[edges_h[i]:edges_h[i + 1], edges_w[j]:edges_w[j + 1]] = 3 * i + j
+        ids = window_partition(region.view(1, Hp, Wp, 1), ws).view(-1, ws * ws)
+        diff = ids[:, None, :] - ids[:, :, None]
+        return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
+
+    def forward(self, x, H, W):
+        for blk in self.blocks:
+            blk.H, blk.W = H, W
+            if self.use_checkpoint and x.requires_grad:
+                x = checkpoint.checkpoint(blk, x, None, use_reentrant=False)
+            else:
+                x = blk(x, None)
+        if self.downsample is None:
+            return x, H, W, x, H, W
+        return x, H, W, self.downsample(x, H, W), (H + 1) // 2, (W + 1) // 2
+
+
+class PatchEmbed(nn.Module):
+    """4x4/4 conv patchify + LayerNorm, output (B, C, H/4, W/4)."""
+
+    def __init__(self, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None):
+        super().__init__()
+        self.patch_size = to_2tuple(patch_size)
+        self.in_chans, self.embed_dim = in_chans, embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+    def forward(self, x):
+        ph, pw = self.patch_size
+        H, W = x.shape[-2:]
+        if W % pw or H % ph:
+            x = F.pad(x, (0, (pw - W % pw) % pw, 0, (ph - H % ph) % ph))
+        x = self.proj(x)
+        if self.norm is not None:
+            B, C, Wh, Ww = x.shape
+            x = self.norm(x.flatten(2).transpose(1, 2)).transpose(1, 2).reshape(B, C, Wh, Ww)
+        return x
+
+
+class SwinTransformer(nn.Module):
+    """Returns 4 maps (NCHW): outputs of stages 1,2,3 and the extra merged H/64 map (pos_dim channels)."""
+
+    def __init__(self, pretrain_img_size=224, patch_size=4, in_chans=3, embed_dim=96, depths=[2, 2, 6, 2],
+                 num_heads=[3, 6, 12, 24], window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0.2, norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
+                 out_indices=[1, 2, 3], frozen_stages=-1, use_checkpoint=False, pos_dim=768):
+        super().__init__()
+        self.pretrain_img_size = pretrain_img_size
+        self.num_layers = len(depths)
+        self.embed_dim, self.ape, self.patch_norm = embed_dim, ape, patch_norm
+        self.out_indices, self.frozen_stages = out_indices, frozen_stages
+        self.patch_embed = PatchEmbed(patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                      norm_layer=norm_layer if patch_norm else None)
+        if ape:
+            size, patch = to_2tuple(pretrain_img_size), to_2tuple(patch_size)
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, embed_dim, size[0] // patch[0], size[1] // patch[1]))
+            nn.init.trunc_normal_(self.absolute_pos_embed, std=.02)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+
+        rates = [r.item() for r in torch.linspace(0, drop_path_rate, sum(depths))]  # stochastic-depth decay
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.layers.append(
+                BasicLayer(dim=int(embed_dim * 2**i), depth=depths[i], num_heads=num_heads[i], window_size=window_size,
+                           mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate,
+                           attn_drop=attn_drop_rate, drop_path=rates[sum(depths[:i]):sum(depths[:i + 1])],
+                           norm_layer=norm_layer,
+                           downsample=partial(PatchMerging, pos_dim=pos_dim),  # after EVERY stage (Q5)
+                           last=None if i < self.num_layers - 1 else True, use_checkpoint=use_checkpoint))
+        self.num_features = [int(embed_dim * 2**i) for i in range(self.num_layers)]
+        for i in out_indices:  # dead LayerNorms of the reference, kept for checkpoint keys
+            self.add_module(f'norm{i}', norm_layer(self.num_features[i]))
+        self._freeze_stages()
+        self.pos_dim = pos_dim
+        self.num_channels = self.num_features[1:] + [pos_dim]
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.patch_embed.eval()
+            for p in self.patch_embed.parameters():
+                p.requires_grad = False
+        if self.frozen_stages >= 1 and self.ape:
+            self.absolute_pos_embed.requires_grad = False
+        if self.frozen_stages >= 2:
+            self.pos_drop.eval()
+            for stage in self.layers[:self.frozen_stages - 1]:
+                stage.eval()
+                for p in stage.parameters():
+                    p.requires_grad = False
+
+    def forward(self, x):
+        B = x.shape[0]
+        x = self.patch_embed(x)
+        Wh, Ww = x.shape[2], x.shape[3]
+        x = self.pos_drop(x.flatten(2).transpose(1, 2))
+        outs = []
+        for i, stage in enumerate(self.layers):
+            x_out, H, W, x, Wh, Ww = stage(x, Wh, Ww)
+            if i > 0:
+                outs.append(x_out.view(B, H, W, -1).permute(0, 3, 1, 2))
+        outs.append(x.view(B, Wh, Ww, -1).permute(0, 3, 1, 2))
+        return outs
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        return self
+
+
+def swin_base_win7_384(pretrained=None, pos_dim=1024, **kwargs):
+    """Name kept from the reference; it builds the window-12 Swin-B (embed 128, depths 2/2/18/2, heads 4/8/16/32)."""
+    model = SwinTransformer(pretrain_img_size=[384, 384], embed_dim=128, depths=[2, 2, 18, 2],
+                            num_heads=[4, 8, 16, 32], window_size=12, drop_path_rate=0.3,
+                            pos_dim=1024 if pos_dim is None else pos_dim, **kwargs)
+    if pretrained not in (None, 'none'):
+        if pretrained == 'imagenet':
+            pretrained = os.path.join(os.environ.get('HOME', '.'), 'checkpoints/eccv',
+                                      'pretrained_weights/swin_base_patch4_window7_384_22k.pth')
+            if not os.path.exists(pretrained):
+                raise FileNotFoundError(f"ImageNet-22K Swin-B weights expected at {pretrained} (no network here)")
+        state = torch.load(pretrained, map_location='cpu')
+        model.load_state_dict(state['model'], strict=False)
+    return model, 1024
+
+
+def build_backbone(backbone_name='swin_base_win7_384_22k', frozen_stages=2, pre_trained='imagenet', pos_dim=None):
+    if backbone_name != 'swin_base_win7_384_22k':
+        raise ValueError(f'backbone {backbone_name} not supported')
+    return swin_base_win7_384(pretrained=pre_trained, frozen_stages=frozen_stages, pos_dim=pos_dim)[0]

@@ -1,0 +1,224 @@
+"""DetectionModule: 150 object queries refined by 6 deformable decoder layers over the 4 backbone levels.
+
+Mirror of reference models/detection/det_module.py (MLP :24-35, DetectionModule :38-213,
+DeformableTransformerDecoderLayer :274-349, build_det_module_with_config :366-381): identical parameter
+names (decoder_layers.N.{cross_attn,self_attn,norm1..3,linear1,linear2}, bbox_embed, class_embed,
+query_embed, reference_points, level_embed), identical arithmetic including the quirks the captioner
+depends on: level_embed is never added, box refinement feeds `.detach()`ed references that are
+4-d from the first layer on, only hs[-1] is consumed downstream.
+
+MI355X specifics: the 150x150 self-attention runs through the fused attention kernel (the
+nn.MultiheadAttention object only owns the parameters, so in_proj_weight/in_proj_bias/out_proj keys are
+unchanged), and the cross-attention samples the value maps with the HIP MSDeformAttn op.
+"""
+import copy
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import normal_
+
+from grit_amd.models.common.swin_model import DropPath
+from grit_amd.models.ops.modules import MSDeformAttn
+from grit_amd.ops.attention import attention as fused_attention
+from grit_amd.utils.misc import inverse_sigmoid
+
+
+class MLP(nn.Module):
+    """Linear-ReLU stack; the last layer is linear."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for layer in self.layers[:-1]:
+            x = F.relu(layer(x))
+        return self.layers[-1](x)
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+def _get_activation_fn(activation):
+    try:
+        return {"relu": F.relu, "gelu": F.gelu, "glu": F.glu}[activation]
+    except KeyError:
+        raise RuntimeError(F"activation should be relu/gelu, not {activation}.")
+
+
+class DeformableTransformerDecoderLayer(nn.Module):
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4,
+                 drop_path=0.):
+        super().__init__()
+        self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)  # parameter container
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_fn(activation)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else None
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward_ffn(self, tgt):
+        tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout4(tgt2))
+
+    def query_self_attention(self, tgt, query_pos):
+        """nn.MultiheadAttention(q = k = tgt + pos, v = tgt) with its own packed weights, batch-first, fused core."""
+        mha = self.self_attn
+        E, h = mha.embed_dim, mha.num_heads
+        B, Lq, _ = tgt.shape
+        qk_in = self.with_pos_embed(tgt, query_pos)
+        qk = F.linear(qk_in, mha.in_proj_weight[:2 * E], mha.in_proj_bias[:2 * E])  # one GEMM for q and k
+        v = F.linear(tgt, mha.in_proj_weight[2 * E:], mha.in_proj_bias[2 * E:])
+        q = qk[..., :E].view(B, Lq, h, E // h)
+        k = qk[..., E:].view(B, Lq, h, E // h)
+        out = fused_attention(q, k, v.view(B, Lq, h, E // h), None, scale=1.0 / math.sqrt(E // h),
+                              dropout_p=mha.dropout, training=self.training)
+        return mha.out_proj(out)
+
+    def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, src_level_start_index,
+                src_valid_ratios, src_padding_mask=None):
+        if reference_points.shape[-1] == 4:
+            ratios = torch.cat([src_valid_ratios, src_valid_ratios], -1)
+        else:
+            assert reference_points.shape[-1] == 2
+            ratios = src_valid_ratios
+        reference_points = reference_points[:, :, None] * ratios[:, None]  # per level
+
+        tgt = self.norm2(tgt + self.dropout2(self.query_self_attention(tgt, query_pos)))
+        tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
+                               src_level_start_index, src_padding_mask)
+        if self.drop_path is None:
+            return self.forward_ffn(self.norm1(tgt + self.dropout1(tgt2)))
+        tgt = tgt + self.drop_path(self.dropout1(tgt2))
+        tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        return self.norm3(tgt + self.drop_path(self.dropout4(tgt2)))
+
+
+class DetectionModule(nn.Module):
+
+    def __init__(self, d_model=256, nhead=8, num_decoder_layers=6, dim_feedforward=1024, dropout=0.1,
+                 activation="relu", return_intermediate_dec=True, num_feature_levels=4, dec_n_points=4, drop_path=0.,
+                 num_classes=81, aux_loss=True, with_box_refine=True, num_queries=100):
+        super().__init__()
+        self.aux_loss, self.with_box_refine = aux_loss, with_box_refine
+        self.d_model, self.nhead = d_model, nhead
+        layer = DeformableTransformerDecoderLayer(d_model, dim_feedforward, dropout, activation, num_feature_levels,
+                                                  nhead, dec_n_points, drop_path=drop_path)
+        self.decoder_layers = _get_clones(layer, num_decoder_layers)
+        self.num_decoder_layers = num_decoder_layers
+        self.return_intermediate = return_intermediate_dec
+        self.reference_points = nn.Linear(d_model, 2)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        self.class_embed = nn.Linear(d_model, num_classes)
+        self.bbox_embed = MLP(d_model, d_model, 4, 3)
+        self.query_embed = nn.Embedding(num_queries, d_model * 2)
+
+        prior = 0.01
+        self.class_embed.bias.data = torch.ones(num_classes) * (-math.log((1 - prior) / prior))
+        nn.init.constant_(self.bbox_embed.layers[-1].weight.data, 0)
+        nn.init.constant_(self.bbox_embed.layers[-1].bias.data, 0)
+        if with_box_refine:
+            self.class_embed = _get_clones(self.class_embed, num_decoder_layers + 1)
+            self.bbox_embed = _get_clones(self.bbox_embed, num_decoder_layers + 1)
+            nn.init.constant_(self.bbox_embed[0].layers[-1].bias.data[2:], -2.0)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        normal_(self.level_embed)
+
+    def bbox_refine(self, bbox_embed, output, reference_points):
+        """Iterative box refinement; the new references are detached (no gradient reaches bbox_embed)."""
+        if bbox_embed is None:
+            return reference_points
+        delta = bbox_embed(output)
+        if reference_points.shape[-1] == 4:
+            new = (delta + inverse_sigmoid(reference_points)).sigmoid()
+        else:
+            assert reference_points.shape[-1] == 2
+            new = torch.cat([delta[..., :2] + inverse_sigmoid(reference_points), delta[..., 2:]], -1).sigmoid()
+        return new.detach()
+
+    def get_valid_ratio(self, mask):
+        _, H, W = mask.shape
+        valid_h = torch.sum(~mask[:, :, 0], 1).float() / H
+        valid_w = torch.sum(~mask[:, 0, :], 1).float() / W
+        return torch.stack([valid_w, valid_h], -1)
+
+    def prepare_od_inputs(self, srcs, masks):
+        B = srcs[0].shape[0]
+        query_pos, query_tgt = torch.split(self.query_embed.weight, self.d_model, dim=1)
+        query_pos = query_pos.unsqueeze(0).expand(B, -1, -1)
+        query_tgt = query_tgt.unsqueeze(0).expand(B, -1, -1)
+        src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)  # [B, S, C]; level_embed NOT added
+        mask_flatten = torch.cat([m.flatten(1) for m in masks], 1)
+        spatial_shapes = torch.as_tensor([tuple(s.shape[-2:]) for s in srcs], dtype=torch.long,
+                                         device=src_flatten.device)
+        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+        reference_points = self.reference_points(query_pos).sigmoid()
+        reference_points = self.bbox_refine(self.bbox_embed[0], query_tgt, reference_points)
+        return {
+            'tgt': query_tgt,
+            'src': src_flatten,
+            'src_spatial_shapes': spatial_shapes,
+            'src_level_start_index': level_start_index,
+            'src_valid_ratios': valid_ratios,
+            'src_padding_mask': mask_flatten,
+            'query_pos': query_pos,
+            'reference_points': reference_points,
+        }
+
+    def forward(self, srcs, masks):
+        od = self.prepare_od_inputs(srcs, masks)
+        init_reference_out = od['reference_points']
+        hs, refs = [od['tgt']], [init_reference_out]
+        for lid, layer in enumerate(self.decoder_layers):
+            od['tgt'] = layer(**od)
+            refine = self.bbox_embed[lid + 1] if self.bbox_embed is not None else None
+            od['reference_points'] = self.bbox_refine(refine, od['tgt'], od['reference_points'])
+            hs.append(od['tgt'])
+            refs.append(od['reference_points'])
+        if self.return_intermediate:
+            return torch.stack(hs), init_reference_out, torch.stack(refs)
+        return od['tgt'], init_reference_out, od['reference_points']
+
+
+def build_det_module_with_config(cfg):
+    return DetectionModule(
+        d_model=cfg.d_model,
+        nhead=cfg.num_heads,
+        num_decoder_layers=cfg.num_layers,
+        dim_feedforward=cfg.dim_feedforward,
+        dropout=cfg.dropout,
+        activation=cfg.activation,
+        num_classes=cfg.num_classes,
+        num_feature_levels=cfg.num_levels,
+        dec_n_points=cfg.num_points,
+        num_queries=cfg.num_queries,
+        return_intermediate_dec=cfg.return_intermediate,
+        aux_loss=getattr(cfg, 'aux_loss', False),
+        with_box_refine=cfg.with_box_refine,
+    )

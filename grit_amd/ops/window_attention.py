@@ -1,0 +1,87 @@
+"""Fused Swin (shifted-)window attention on the token-ordered map (bf16 MFMA, fp32 softmax).
+
+One kernel per direction does what reference models/common/swin_model.py spreads over
+SwinTransformerBlock.forward :257-293 (pad to a multiple of the window, roll(-shift), window_partition,
+window_reverse, roll(+shift), crop), BasicLayer.forward :424-441 (shift mask, value -100) and
+WindowAttention.forward :161-183 (q*scale, q@k^T, + relative-position bias, + mask, softmax, @v):
+grit_winattn_fwd_bf16 / grit_winattn_bwd_bf16 (include/grit_hip.h).
+
+Inputs are what the *pointwise* qkv Linear produced on the un-partitioned map, [B, H*W, 3C]; window
+padding tokens are synthesised in-kernel from `pad_qkv` (= the Linear's bias, since the reference pads
+zeros after norm1).  Gradients: dqkv, d rel_bias (summed over windows, flows on to the bias table through
+the gather in WindowAttention.relative_position_bias) and d pad_qkv.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from grit_amd import lib as _lib
+from grit_amd.ops import backend
+
+WINDOW = 12
+HEAD_DIM = 32
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+class _WindowAttentionFn(Function):
+
+    @staticmethod
+    def forward(ctx, qkv, rel_bias, pad_qkv, mask, H, W, num_heads, window, shift, scale):
+        B, T, C3 = qkv.shape
+        C = C3 // 3
+        nWh, nWw = -(-H // window), -(-W // window)
+        N = window * window
+        out = torch.empty((B, T, C), dtype=torch.bfloat16, device=qkv.device)
+        lse = torch.empty((B * nWh * nWw, num_heads, N), dtype=torch.float32, device=qkv.device)
+        nWm = 0 if mask is None else mask.shape[0]
+        with torch.cuda.device(qkv.device):
+            st = _lib.load().grit_winattn_fwd_bf16(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, B, H, W, C,
+                                                   num_heads, window, shift, scale, _ptr(out), _ptr(lse),
+                                                   _lib.current_stream_ptr())
+        _lib.check(st, "grit_winattn_fwd_bf16")
+        ctx.save_for_backward(qkv, rel_bias, pad_qkv, mask, out, lse)
+        ctx.geom = (H, W, num_heads, window, shift, scale)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        qkv, rel_bias, pad_qkv, mask, out, lse = ctx.saved_tensors
+        H, W, num_heads, window, shift, scale = ctx.geom
+        B, T, C3 = qkv.shape
+        C = C3 // 3
+        dout = dout.contiguous().to(torch.bfloat16)
+        dqkv = torch.empty_like(qkv)
+        dbias = torch.zeros_like(rel_bias)  # accumulated across windows with float atomics
+        dpad = torch.zeros(C3, dtype=torch.float32, device=qkv.device)
+        nWm = 0 if mask is None else mask.shape[0]
+        with torch.cuda.device(qkv.device):
+            st = _lib.load().grit_winattn_bwd_bf16(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, _ptr(out),
+                                                   _ptr(dout), _ptr(lse), B, H, W, C, num_heads, window, shift, scale,
+                                                   _ptr(dqkv), _ptr(dbias), _ptr(dpad), _lib.current_stream_ptr())
+        _lib.check(st, "grit_winattn_bwd_bf16")
+        return dqkv, dbias, dpad.to(pad_qkv.dtype), None, None, None, None, None, None, None
+
+
+def window_attention(qkv, rel_bias, pad_qkv, H, W, num_heads, window, shift, scale, mask=None):
+    """qkv [B, H*W, 3C] (q|k|v, each head-major), rel_bias [nH, N, N] fp32, pad_qkv [3C], optional explicit
+    additive mask [nW_mask, N, N] (replaces the analytic shift mask).  Returns [B, H*W, C] in qkv's dtype."""
+    ov = backend.override()
+    if ov is not None:
+        return ov.window_attention(qkv, rel_bias, pad_qkv, H, W, num_heads, window, shift, scale, mask=mask)
+    _lib.require_device(qkv, rel_bias, pad_qkv, mask)
+    C = qkv.shape[-1] // 3
+    if window != WINDOW or C // num_heads != HEAD_DIM:
+        raise _lib.GritHipError("fused window attention is built for window 12 / head_dim 32 (GRIT's Swin-B); got "
+                                "window %d head_dim %d" % (window, C // num_heads))
+    in_dtype = qkv.dtype
+    out = _WindowAttentionFn.apply(qkv.to(torch.bfloat16).contiguous(), rel_bias.float().contiguous(),
+                                   pad_qkv.to(torch.bfloat16).contiguous(),
+                                   None if mask is None else mask.float().contiguous(), H, W, num_heads, window, shift,
+                                   float(scale))
+    return out.to(in_dtype)

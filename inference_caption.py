@@ -1,0 +1,80 @@
+"""Single-image captioning (reference inference_caption.py:34-69): build detector + Transformer, optional checkpoint
+(`state_dict` key, strict=False), NestedTensor batch of one, beam search, token ids -> words through vocab.json.
+
+    python inference_caption.py --img image.npy|image.png [--checkpoint ckpt.pth] [--vocab data/vocab.json] [--beam 5]
+
+`caption_tokens()` is the plumbing the tests drive (BASELINE config 1: 224x224, beam 1 = greedy, CPU with the
+oracle ops injected)."""
+import argparse
+import json
+import os
+
+import torch
+
+from grit_amd.config import default_config
+from models.caption import Transformer
+from models.caption.detector import build_detector
+from engine.utils import nested_tensor_from_tensor_list
+
+
+def build_model(config, device, checkpoint=''):
+    detector = build_detector(config).to(device)
+    model = Transformer(detector=detector, config=config).to(device)
+    if checkpoint and os.path.exists(checkpoint):
+        state = torch.load(checkpoint, map_location='cpu')
+        missing, unexpected = model.load_state_dict(state['state_dict'], strict=False)
+        print(f"model missing:{len(missing)} model unexpected:{len(unexpected)}")
+    model.cached_features = False
+    return model.eval()
+
+
+@torch.no_grad()
+def caption_tokens(model, image, config, beam_size=None):
+    """image [3,H,W] (already normalised) -> (tokens [1, beam_len] int64, log_probs [1, beam_len])."""
+    device = next(model.parameters()).device
+    images = nested_tensor_from_tensor_list([image]).to(device)
+    return model(images, seq=None, use_beam_search=True, max_len=config.model.beam_len, eos_idx=config.model.eos_idx,
+                 beam_size=beam_size or config.model.beam_size, out_size=1, return_probs=False)
+
+
+def decode(tokens, vocab_path, eos_idx=3):
+    """ids -> words, cut at the first <eos> (reference datasets/caption/field.py:258-283)."""
+    with open(vocab_path) as f:
+        vocab = json.load(f)
+    itos = vocab['itos'] if isinstance(vocab, dict) and 'itos' in vocab else vocab
+    out = []
+    for row in tokens.tolist():
+        words = []
+        for t in row:
+            if t == eos_idx:
+                break
+            words.append(itos[t])
+        out.append(' '.join(words))
+    return out
+
+
+def run_main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--img', required=True)
+    ap.add_argument('--checkpoint', default='')
+    ap.add_argument('--vocab', default=os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'vocab.json'))
+    ap.add_argument('--beam', type=int, default=None)
+    a = ap.parse_args()
+    config = default_config()
+    device = torch.device('cuda:0')  # the kernels need a HIP device; there is no CPU path
+    model = build_model(config, device, a.checkpoint)
+    if a.img.endswith('.npy'):
+        import numpy as np
+        image = torch.from_numpy(np.load(a.img)).float()
+    else:
+        import numpy as np
+        from PIL import Image
+        rgb = np.asarray(Image.open(a.img).convert('RGB'), dtype=np.float32) / 255.0
+        mean, std = np.array([0.485, 0.456, 0.406], np.float32), np.array([0.229, 0.224, 0.225], np.float32)
+        image = torch.from_numpy(((rgb - mean) / std).transpose(2, 0, 1))
+    tokens, _ = caption_tokens(model, image, config, a.beam)
+    print(decode(tokens, a.vocab, config.model.eos_idx)[0] if os.path.exists(a.vocab) else tokens.tolist())
+
+
+if __name__ == "__main__":
+    run_main()

@@ -171,5 +171,222 @@ def main():
         MAKERS[n]()
 
 
+# =====================================================================================================
+# model-level fixtures (g3..g8) -- appended makers; MAKERS is extended at the bottom
+# =====================================================================================================
+def _fill():
+    sys.path.insert(0, HERE)
+    import fill
+    return fill.deterministic_fill_
+
+
+def _cfg(**over):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from grit_amd.config import default_config
+    return default_config(**over)
+
+
+def make_keys():
+    """State-dict surface: key -> shape of the reference model at 3 and 2 decoder layers."""
+    import json
+    import_reference()
+    from models.caption import Transformer
+    from models.caption.detector import build_detector
+    out = {}
+    for n in (3, 2):
+        cfg = _cfg(**{'model.cap_generator.n_layers': n})
+        model = Transformer(build_detector(cfg), cfg)
+        out[str(n)] = {k: list(v.shape) for k, v in model.state_dict().items()}
+        out[f'{n}_trainable'] = sorted(k for k, p in model.named_parameters() if p.requires_grad)
+    with open(os.path.join(HERE, 'state_dict_keys.json'), 'w') as f:
+        json.dump(out, f)
+    print('keys', {k: len(v) for k, v in out.items()})
+
+
+def make_g3():
+    """MSDeformAttn module, 2-d and 4-d reference points, padding mask (ms_deform_attn.py:73-119)."""
+    import_reference()
+    from models.ops.modules import MSDeformAttn
+    g = torch.Generator().manual_seed(33)
+    mod = _fill()(MSDeformAttn(d_model=128, n_levels=3, n_heads=4, n_points=4), 'g3.').double()
+    shapes = torch.as_tensor([(7, 9), (4, 5), (2, 3)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    B, Lq = 2, 11
+    query = torch.randn(B, Lq, 128, generator=g)
+    src = torch.randn(B, S, 128, generator=g)
+    ref2 = torch.rand(B, Lq, 3, 2, generator=g)
+    ref4 = torch.cat([torch.rand(B, Lq, 3, 2, generator=g), 0.1 + 0.4 * torch.rand(B, Lq, 3, 2, generator=g)], -1)
+    pad = torch.zeros(B, S, dtype=torch.bool)
+    pad[1, -9:] = True
+    with torch.no_grad():
+        out2 = mod(query.double(), ref2.double(), src.double(), shapes, _lsi(shapes), None)
+        out4 = mod(query.double(), ref4.double(), src.double(), shapes, _lsi(shapes), pad)
+    np.savez_compressed(os.path.join(HERE, 'msda_module_g3.npz'), shapes=shapes.numpy(), lsi=_lsi(shapes).numpy(),
+                        query=query.numpy(), src=src.numpy(), ref2=ref2.numpy(), ref4=ref4.numpy(), pad=pad.numpy(),
+                        out2=out2.float().numpy(), out4=out4.float().numpy())
+    print('g3', float(out2.abs().mean()), float(out4.abs().mean()))
+
+
+def make_g4():
+    """WindowAttention (dim 128, 4 heads, window 12) without / with the BasicLayer shift mask at H=W=20 (-> 24), and a
+    whole 2-block BasicLayer (no shift + shift, pad + crop, PatchMerging) on the same 20x20 map (covers G5)."""
+    import_reference()
+    from models.common.swin_model import BasicLayer, PatchMerging, WindowAttention, window_partition
+    fill = _fill()
+    g = torch.Generator().manual_seed(44)
+    layer = BasicLayer(dim=128, depth=2, num_heads=4, window_size=12, drop_path=[0.0, 0.1], downsample=PatchMerging)
+    fill(layer, 'g4.')
+    layer.eval()
+    attn = layer.blocks[1].attn
+    xw = torch.randn(4, 144, 128, generator=g)  # 1 image x 4 windows
+    # the mask exactly as BasicLayer.forward builds it (swin_model.py:424-441)
+    Hp = Wp = 24
+    img_mask = torch.zeros((1, Hp, Wp, 1))
+    cnt = 0
+    for h in (slice(0, -12), slice(-12, -6), slice(-6, None)):
+        for w in (slice(0, -12), slice(-12, -6), slice(-6, None)):
+            img_mask[:, h, w, :] = cnt
+            cnt += 1
+    mw = window_partition(img_mask, 12).view(-1, 144)
+    am = mw.unsqueeze(1) - mw.unsqueeze(2)
+    am = am.masked_fill(am != 0, float(-100.0)).masked_fill(am == 0, float(0.0))
+    x = torch.randn(2, 400, 128, generator=g)
+    with torch.no_grad():
+        o_nomask = attn(xw, None)
+        o_mask = attn(xw, am)
+        x_out, H, W, x_down, Wh, Ww = layer(x, 20, 20)
+    np.savez_compressed(os.path.join(HERE, 'win_g4.npz'), xw=xw.numpy(), attn_mask=am.numpy(), o_nomask=o_nomask.numpy(),
+                        o_mask=o_mask.numpy(), x=x.numpy(), x_out=x_out.numpy(), x_down=x_down.numpy(),
+                        dims=np.array([H, W, Wh, Ww]))
+    print('g4', float(o_nomask.abs().mean()), float(x_out.abs().mean()), (H, W, Wh, Ww))
+
+
+def make_g6():
+    """ParallelAttentionLayer with PAD tokens: pins the fc_alpha1-twice quirk (cap_generator.py:40-56) and
+    MultiHeadAttention / FeedForward (attention.py:166-184, pos_embed.py:44-48)."""
+    import_reference()
+    from models.caption.cap_generator import ParallelAttentionLayer
+    g = torch.Generator().manual_seed(66)
+    layer = _fill()(ParallelAttentionLayer(512, 8, 2048, dropout=0.1), 'g6.').eval()
+    B, T, N1, N2 = 2, 7, 9, 12
+    x = torch.randn(B, T, 512, generator=g)
+    y1 = torch.randn(B, N1, 512, generator=g)
+    y2 = torch.randn(B, N2, 512, generator=g)
+    tokens = torch.tensor([[2, 5, 6, 7, 8, 9, 3], [2, 11, 12, 3, 1, 1, 1]])
+    pad = tokens == 1
+    mask_pad = (~pad).unsqueeze(-1).float()
+    mask_x = (torch.triu(torch.ones(T, T, dtype=torch.uint8), diagonal=1)[None, None] + pad[:, None, None].byte()).gt(0)
+    mask_y1 = torch.zeros(B, 1, 1, N1, dtype=torch.bool)
+    mask_y1[1, ..., -3:] = True
+    mask_y2 = torch.zeros(B, 1, 1, N2, dtype=torch.bool)
+    with torch.no_grad():
+        out = layer(x, y1, y2, mask_pad, mask_x, mask_y1, mask_y2)
+    np.savez_compressed(os.path.join(HERE, 'attn_g6.npz'), x=x.numpy(), y1=y1.numpy(), y2=y2.numpy(),
+                        tokens=tokens.numpy(), mask_pad=mask_pad.numpy(), mask_x=mask_x.numpy(),
+                        mask_y1=mask_y1.numpy(), mask_y2=mask_y2.numpy(), out=out.numpy())
+    print('g6', float(out.abs().mean()))
+
+
+def _ref_model(n_layers, **over):
+    import_reference()
+    from models.caption import Transformer
+    from models.caption.detector import build_detector
+    cfg = _cfg(**{'model.cap_generator.n_layers': n_layers, **over})
+    model = Transformer(build_detector(cfg), cfg)
+    _fill()(model)
+    return model, cfg
+
+
+def make_g7():
+    """BASELINE config 1: one 224x224 image, 2-layer decoder, deterministic-fill weights, eval mode, CPU.
+    Teacher-forcing log-probs (top-16 per position), greedy (beam 1) and beam-5 tokens + per-step top-6 candidate
+    scores (margin record), and the detector outputs for decoder-only checks."""
+    import_reference()
+    from engine.utils import NestedTensor
+    model, cfg = _ref_model(2)
+    model.eval()
+    g = torch.Generator().manual_seed(0)
+    image = torch.randn(1, 3, 224, 224, generator=g)
+    samples = NestedTensor(image, torch.zeros(1, 224, 224, dtype=torch.bool))
+    seq = torch.randint(4, 10201, (1, 20), generator=g)
+    seq[:, 0], seq[:, -1] = 2, 3
+    out = {'image': image.numpy(), 'seq': seq.numpy()}
+    with torch.no_grad():
+        vis = model.detector(samples)
+        out.update(gri_feat=vis['gri_feat'].numpy(), reg_feat=vis['reg_feat'].numpy(),
+                   gri_mask=vis['gri_mask'].numpy(), reg_mask=vis['reg_mask'].numpy())
+        lp = model(samples, seq)
+        top = lp.topk(16, -1)
+        out.update(tf_top_val=top.values.numpy(), tf_top_idx=top.indices.numpy(),
+                   tf_target_lp=lp[0, :-1].gather(1, seq[0, 1:, None]).numpy(), tf_row_mean=lp.mean(-1).numpy())
+        for beam in (1, 5):
+            record = []
+            orig = model.select
+
+            def select(t, cand, beam_size, _orig=orig, _rec=record, **kw):
+                flat = cand.reshape(cand.shape[0], -1)
+                _rec.append(torch.sort(flat, -1, descending=True)[0][:, :beam_size + 1].clone())
+                return _orig(t, cand, beam_size, **kw)
+
+            model.select = select
+            toks, lps = model(samples, seq=None, use_beam_search=True, max_len=20, eos_idx=3, beam_size=beam, out_size=1)
+            model.select = orig
+            top6 = torch.stack(record, 1)  # [B, steps, beam+1]
+            margin = (top6[..., :-1] - top6[..., 1:]).abs().min().item()
+            out.update({f'beam{beam}_tokens': toks.numpy(), f'beam{beam}_logprobs': lps.numpy(),
+                        f'beam{beam}_top': top6.numpy()})
+            print(f'g7 beam{beam}', toks.tolist(), 'min margin between consecutive candidates', margin)
+    np.savez_compressed(os.path.join(HERE, 'model_g7.npz'), **out)
+
+
+def make_g8():
+    """One XE step (train mode, every dropout p = 0, DropPath = identity): loss, per-module gradient norms, the set of
+    parameters that receive no gradient (static unused set), ragged batch with PAD tokens and masks."""
+    import json
+    import_reference()
+    from engine.utils import NestedTensor
+    model, cfg = _ref_model(3, **{'model.dropout': 0.0, 'model.detector.dropout': 0.0})
+    model.train()
+    g = torch.Generator().manual_seed(8)
+    B, T = 2, 12
+    images = torch.randn(B, 3, 224, 224, generator=g)
+    mask = torch.zeros(B, 224, 224, dtype=torch.bool)
+    images[1, :, 192:, :] = 0
+    images[1, :, :, 160:] = 0
+    mask[1, 192:, :] = True
+    mask[1, :, 160:] = True
+    caps = torch.randint(4, 10201, (B, T), generator=g)
+    caps[:, 0] = 2
+    caps[0, -1] = 3
+    caps[1, 7] = 3
+    caps[1, 8:] = 1
+    out = model(NestedTensor(images, mask), caps)
+    loss = torch.nn.NLLLoss(ignore_index=1)(out[:, :-1].reshape(-1, out.shape[-1]), caps[:, 1:].reshape(-1))
+    loss.backward()
+    norms, nograd = {}, []
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if p.grad is None:
+            nograd.append(n)
+            continue
+        top = '.'.join(n.split('.')[:2]) if n.startswith('detector') else n.split('.')[0]
+        norms[top] = norms.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+    norms = {k: v**0.5 for k, v in norms.items()}
+    sel = {}
+    for n in ('cap_generator.fc.weight', 'grid_net.fc.weight', 'detector.det_module.decoder_layers.5.cross_attn.value_proj.weight',
+              'detector.backbone.layers.2.blocks.17.attn.relative_position_bias_table',
+              'detector.backbone.layers.1.blocks.1.attn.qkv.bias', 'detector.input_proj.0.0.weight'):
+        p = dict(model.named_parameters())[n]
+        sel[n] = p.grad.flatten()[:64].numpy()
+    np.savez_compressed(os.path.join(HERE, 'step_g8.npz'), images=images.numpy(), mask=mask.numpy(), caps=caps.numpy(),
+                        loss=np.array(loss.item()), **{'grad:' + k: v for k, v in sel.items()})
+    with open(os.path.join(HERE, 'step_g8.json'), 'w') as f:
+        json.dump({'loss': loss.item(), 'grad_norms': norms, 'no_grad': sorted(nograd)}, f, indent=1)
+    print('g8 loss', loss.item(), 'unused', len(nograd), norms)
+
+
+MAKERS.update({'keys': make_keys, 'g3': make_g3, 'g4': make_g4, 'g6': make_g6, 'g7': make_g7, 'g8': make_g8})
+
 if __name__ == "__main__":
     main()

@@ -1,0 +1,90 @@
+"""N>1 path on CPU: two gloo ranks (127.0.0.1) through grit_amd.ddp.BucketedDataParallel -- bucketed all-reduce from
+autograd hooks, static unused-parameter discovery, averaged gradients identical to a single-process run on the
+concatenated batch, and the engine's scalar gather_result."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+class Toy(nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 16)
+        self.b = nn.Linear(16, 4)
+        self.dead = nn.Linear(3, 3)  # never used in forward: static unused set
+        self.frozen = nn.Linear(8, 8)
+        for p in self.frozen.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        return self.b(torch.relu(self.a(self.frozen(x))))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, wire_bf16, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grit_amd.ddp import BucketedDataParallel
+    from grit_amd.engine.caption_engine import gather_result
+    torch.manual_seed(100 + rank)  # different init per rank: the wrapper must broadcast rank 0's parameters
+    model = Toy()
+    ddp = BucketedDataParallel(model, bucket_mb=0.0005, wire_dtype=torch.bfloat16 if wire_bf16 else None)
+    assert len(ddp.buckets) > 1
+    g = torch.Generator().manual_seed(7)
+    data = torch.randn(world * 4, 8, generator=g)
+    target = torch.randn(world * 4, 4, generator=g)
+    xs, ys = data[rank * 4:(rank + 1) * 4], target[rank * 4:(rank + 1) * 4]
+    grads = []
+    for it in range(3):
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        loss = ((ddp(xs) - ys)**2).mean()
+        loss.backward()
+        ddp.finish_gradient_sync()
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    avg = gather_result(loss.detach().clone())
+    if rank == 0:
+        ret["params"] = {n: p.detach().clone() for n, p in model.named_parameters()}
+        ret["grads"] = grads
+        ret["unused"] = [n for n, p in model.named_parameters() if any(p is q for q in ddp.unused_parameters)]
+        ret["avg_loss"] = avg.item()
+        ret["data"], ret["target"] = data, target
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wire_bf16", [False, True])
+def test_bucketed_allreduce_world2(wire_bf16):
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(2, port, wire_bf16, ret), nprocs=2, join=True)
+        ret = dict(ret)
+    # single-process reference on the full batch with rank 0's (broadcast) parameters
+    ref = Toy()
+    ref.load_state_dict(ret["params"])
+    loss = 0.5 * (((ref(ret["data"][:4]) - ret["target"][:4])**2).mean() + ((ref(ret["data"][4:]) - ret["target"][4:])**2).mean())
+    loss.backward()
+    tol = 2e-2 if wire_bf16 else 1e-6
+    for it in range(3):
+        for n, p in ref.named_parameters():
+            if n.startswith(("dead", "frozen")):
+                continue
+            assert torch.allclose(ret["grads"][it][n], p.grad, rtol=tol, atol=tol), (it, n)
+    assert sorted(ret["unused"]) == ["dead.bias", "dead.weight"]
+    assert "dead.weight" not in ret["grads"][1]  # excluded after the first iteration
+    assert abs(ret["avg_loss"] - loss.item()) < 1e-5

@@ -10,10 +10,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c = ctypes
-_ptr, _int = _c.c_void_p, _c.c_int
+_ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
+_ATTN_IN = [_ptr, _i64, _i64] * 3 + [_ptr, _i64, _i64]  # q, k, v (+ row / batch strides), mask (+ strides)
 
 # name -> argument types; mirrors include/grit_hip.h one to one (tests check every symbol resolves)
 SIGNATURES = {
@@ -23,6 +24,10 @@ SIGNATURES = {
     "grit_msda_fwd_f64": [_ptr] * 5 + [_int] * 7 + [_ptr, _ptr],
     "grit_msda_bwd_f32": [_ptr] * 6 + [_int] * 7 + [_ptr] * 4,
     "grit_msda_bwd_f64": [_ptr] * 6 + [_int] * 7 + [_ptr] * 4,
+    "grit_attn_fwd_f32": _ATTN_IN + [_int] * 5 + [_f32, _f32, _u64, _ptr, _ptr, _ptr],
+    "grit_attn_fwd_bf16": _ATTN_IN + [_int] * 5 + [_f32, _f32, _u64, _ptr, _ptr, _ptr],
+    "grit_attn_bwd_f32": _ATTN_IN + [_ptr] * 3 + [_int] * 5 + [_f32, _f32, _u64] + [_ptr] * 4,
+    "grit_attn_bwd_bf16": _ATTN_IN + [_ptr] * 3 + [_int] * 5 + [_f32, _f32, _u64] + [_ptr] * 4,
 }
 
 _lib = None

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 1
+#define GRIT_ABI_VERSION 2
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -77,6 +77,40 @@ int grit_msda_bwd_f64(const double* value, const int64_t* spatial_shapes, const 
                       const double* loc, const double* attn_w, const double* grad_out,
                       int B, int S, int M, int D, int L, int Lq, int P,
                       double* grad_value, double* grad_loc, double* grad_attn_w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Scaled-dot attention core, fp32 arithmetic, head_dim D = 64 (also the 150-query
+ * self-attention of A5).  f32 and bf16 storage variants.
+ *
+ *   q      [B, Tq, H, 64]   row stride ldq, batch stride bsq (elements) -- a slice of a packed projection is fine
+ *   k, v   [B, Nk, H, 64]   row strides ldk / ldv, batch strides bsk / bsv;  Nk <= 256
+ *   mask   uint8, nonzero = masked (-inf before softmax), or NULL.  Element (b, q, j) is read at
+ *          mask[b*mask_sb + q*mask_sq + j]; pass stride 0 to broadcast over batch and/or query
+ *          (reference masks are [B,1,T,T], [B,1,1,Nk]: attention.py:79-80, cap_generator.py:126-136)
+ *   out    [B, Tq, H*64] contiguous;   lse [B, H, Tq] row log-sum-exp of the scaled, masked scores
+ *   P = softmax(scale * q k^T masked);  dropout_p > 0 drops entries of P with a counter hash of `seed`
+ *   (the backward call must pass the same seed);  out = P_drop v.
+ *   A fully masked row yields NaN, as torch.softmax over all -inf does in the reference.
+ * Backward overwrites dq [B,Tq,H,64], dk, dv [B,Nk,H,64] (contiguous); no atomics to global memory.
+ * ------------------------------------------------------------------------------------------------------ */
+int grit_attn_fwd_f32(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk, int64_t bsk,
+                      const void* v, int64_t ldv, int64_t bsv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                      int B, int H, int Tq, int Nk, int D, float scale, float dropout_p, uint64_t seed,
+                      void* out, float* lse, void* stream);
+int grit_attn_fwd_bf16(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk, int64_t bsk,
+                       const void* v, int64_t ldv, int64_t bsv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                       int B, int H, int Tq, int Nk, int D, float scale, float dropout_p, uint64_t seed,
+                       void* out, float* lse, void* stream);
+int grit_attn_bwd_f32(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk, int64_t bsk,
+                      const void* v, int64_t ldv, int64_t bsv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                      const void* out, const void* dout, const float* lse,
+                      int B, int H, int Tq, int Nk, int D, float scale, float dropout_p, uint64_t seed,
+                      void* dq, void* dk, void* dv, void* stream);
+int grit_attn_bwd_bf16(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk, int64_t bsk,
+                       const void* v, int64_t ldv, int64_t bsv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                       const void* out, const void* dout, const float* lse,
+                       int B, int H, int Tq, int Nk, int D, float scale, float dropout_p, uint64_t seed,
+                       void* dq, void* dk, void* dv, void* stream);
 
 #ifdef __cplusplus
 }

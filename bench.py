@@ -1,0 +1,182 @@
+"""Contract benchmark: GRIT cross-entropy training throughput on synthetic 640x640 batches.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric, configs[3] per GPU): full GRIT (Swin-B window 12 + 6 deformable decoder layers +
+3-layer grid net + 3-layer caption decoder, 161 M parameters, random init), 32 images of 3x640x640 per GPU,
+captions of 20 tokens, train mode (dropout / DropPath on), bf16 autocast over fp32 master weights, one step =
+forward + backward + gradient all-reduce (RCCL, bucketed, overlapped with backward) + two fused Adam steps, exactly
+the order of reference engine/caption_engine.py:312-350.  Weak scaling: the per-GPU batch is fixed.
+
+One JSON line on rank 0.  Besides the contract keys:
+  roofline      MSDeformAttn forward kernel (HBM-bound gather): algorithmic bytes per launch / average launch
+                time measured with HIP events on the launch stream inside the timed region, against 8 TB/s.
+  cpu_baseline  (N = 1 only) the same training step on the host CPU: this repo's modules with the oracle ops
+                (oracle/torch_ref.py) injected -- a port, not the reference -- on a bounded sample (batch 1, few steps).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_PEAK_BF16 = 2.5e15
+FLOP_PER_IMAGE_FWD_BWD = 955.8e9  # measured on the reference with torch.utils.flop_counter (640^2, T = 20)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU (metric is defined at 32)")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--caption-len", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--fp32", action="store_true", help="diagnostic: no autocast (not the metric's dtype)")
+    return ap.parse_args()
+
+
+def build(device, config):
+    from grit_amd.models.caption import Transformer
+    from grit_amd.models.caption.detector import build_detector
+    torch.manual_seed(config.exp.seed)
+    model = Transformer(build_detector(config), config).to(device)
+    model.cached_features = False
+    return model
+
+
+def msda_forward_bytes(B, S, M=8, D=64, Lq=150, L=4, P=4):
+    return 4 * (B * S * M * D + 2 * B * Lq * M * L * P + B * Lq * M * L * P + B * Lq * M * D)
+
+
+def cpu_baseline(config, size, caption_len, steps):
+    """Bounded CPU sample of the same step: batch 1, fp32, oracle ops injected (kind = 'port')."""
+    from grit_amd.data import synthetic_batch
+    from grit_amd.engine.caption_engine import build_optimizers, train_xe_step
+    from grit_amd.ops.backend import use_reference_ops
+    from oracle import torch_ref  # checker / CPU baseline only
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    model = build(torch.device("cpu"), config).train()
+    opts = build_optimizers(model, config, mode="xe")
+    loss_fn = torch.nn.NLLLoss(ignore_index=1)
+    batch = synthetic_batch(1, size, size, caption_len, device="cpu", seed=0)
+    times = []
+    with use_reference_ops(torch_ref):
+        for i in range(steps + 1):
+            t0 = time.perf_counter()
+            train_xe_step(model, batch, opts, loss_fn)
+            times.append(time.perf_counter() - t0)
+    timed = times[1:]
+    return {"value": len(timed) / sum(timed), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"batch 1, {size}x{size}, T={caption_len}, fp32, 1 warm-up + {steps} timed steps, "
+                      f"torch {threads} threads on a {cores}-cpu host"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # 'nccl' is RCCL on ROCm
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from grit_amd.config import default_config
+    from grit_amd.data import synthetic_batch
+    from grit_amd.ddp import BucketedDataParallel
+    from grit_amd.engine.caption_engine import build_optimizers, train_xe_step
+    from grit_amd.ops import msda as msda_op
+
+    config = default_config()
+    model = build(device, config).train()
+    wrapped = BucketedDataParallel(model, bucket_mb=64, wire_dtype=torch.bfloat16 if world > 1 else None)
+    optimizers = build_optimizers(wrapped, config, mode="xe")
+    loss_fn = torch.nn.NLLLoss(ignore_index=1)
+    # inputs resident in HBM before the timed region; 4 distinct batches per rank, cycled
+    batches = [synthetic_batch(args.batch, args.size, args.size, args.caption_len, device=device, seed=1000 * rank + i)
+               for i in range(4)]
+    amp = None if args.fp32 else torch.bfloat16
+
+    def step(i):
+        return train_xe_step(wrapped, batches[i % len(batches)], optimizers, loss_fn, autocast_dtype=amp)
+
+    for i in range(args.warmup):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    msda_op.PROFILE_EVENTS = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    events, msda_op.PROFILE_EVENTS = msda_op.PROFILE_EVENTS, None
+    final_loss = float(loss)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+
+    if rank == 0:
+        images = world * args.batch * args.steps
+        value = images / elapsed
+        fwd = [a.elapsed_time(b) * 1e-3 for kind, a, b, _ in events if kind == "fwd"]
+        nbytes = [n for kind, _, _, n in events if kind == "fwd"]
+        roof = None
+        if fwd:
+            avg_t = sum(fwd) / len(fwd)
+            achieved = (sum(nbytes) / len(nbytes)) / avg_t / 1e9
+            roof = {"bound": "hbm", "kernel": "msda_fwd_vec4<16,4> (MSDeformAttn forward, fp32)", "achieved": achieved,
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                    "launches": len(fwd), "avg_launch_us": avg_t * 1e6, "algorithmic_bytes_per_launch": nbytes[0]}
+        out = {
+            "metric": "images/sec (train fwd+bwd) at 640x640 bs=32/GPU",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp32" if args.fp32 else "bf16", "data": "synthetic",
+            "config": {"workload": f"GRIT XE training step (Swin-B w12 + 6 deformable decoder layers + 3-layer grid net + "
+                                   f"3-layer caption decoder, 161M params, random init), {args.size}x{args.size} images, "
+                                   f"caption length {args.caption_len}, Adam x2, dropout on",
+                       "global_batch": world * args.batch, "per_gpu_batch": args.batch,
+                       "parallelism": f"dp{world}", "grad_allreduce": "RCCL bucketed (64 MiB, bf16 wire), overlapped with backward"
+                       if world > 1 else "none (1 GPU)"},
+            "mfma_roofline_frac_bf16": value / world * FLOP_PER_IMAGE_FWD_BWD / MFMA_PEAK_BF16,
+            "final_loss": final_loss,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del wrapped, optimizers, model
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(config, args.size, args.caption_len, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

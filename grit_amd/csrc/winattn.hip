@@ -1,0 +1,475 @@
+// Fused Swin (shifted-)window attention for gfx950 (MI355X): window 12x12 (N = 144 tokens), head_dim 32.
+//
+// Replaces, per Swin block, what davidnvq/grit models/common/swin_model.py does with ~12 full-map ops and a
+// materialised [B_, nH, 144, 144] score tensor:
+//   SwinTransformerBlock.forward :257-293  pad to a multiple of 12, roll(-shift), window_partition,
+//                                          window_reverse, roll(+shift), crop
+//   BasicLayer.forward :424-441            shift mask (0 / -100 between the 9 regions of the rolled map)
+//   WindowAttention.forward :161-183       q*scale @ k^T + relative-position bias + mask, softmax, @ v
+// The kernels read q/k/v where the pointwise qkv Linear left them ([B, H*W, 3C], token order) and write the
+// result back in token order; padding / roll / partition / reverse / crop are address arithmetic, padded
+// tokens are synthesised from `pad_qkv` (= the Linear bias: the reference pads zeros *after* norm1), the shift
+// mask is computed from region ids, and nothing N x N ever reaches HBM.
+//
+// CDNA4 mapping (64-lane waves, MFMA 16x16x32 bf16, fp32 softmax):
+//   * workgroup = 9 waves = one (window, head) at a time; persistent over windows of ONE head, so the
+//     head's relative-position bias lives in registers (36 floats / lane) for the whole launch;
+//   * forward, wave w owns query tile w (16 queries x 144 keys).  S^T = K Q^T is computed with the KEY on the
+//     MFMA row: the accumulator then holds, per lane, one query (lane & 15) and 36 of its keys, so the softmax
+//     row reductions are 36 in-register ops + 2 cross-lane shuffles, and the bf16-packed accumulator is
+//     directly the B operand of O^T = V^T P^T (k-slot order chosen to match; V^T fragments come from the
+//     row-major V tile in LDS through ds_read_b64_tr_b16) -- no LDS round trip for P;
+//   * backward, phase 1 wave w owns KEY tile w: recomputes P from the saved row log-sum-exp, forms dP, dS,
+//     accumulates d(bias) in registers across the windows of the launch, and gets dV^T / dK^T from MFMAs whose
+//     B operand is again the packed accumulator; dS goes once through LDS (transposed) so that phase 2, wave w
+//     = query tile w, produces dQ^T.  dq/dk/dv of a token are written exactly once (every token belongs to one
+//     window): no global atomics except the per-launch flush of d(bias) and of the padded-token gradient.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/grit_hip.h"
+
+namespace {
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s lds_v4s;
+
+constexpr int kWs = 12, kN = 144, kHd = 32, kTiles = 9, kThreads = 576;
+constexpr int kKP = 40;      // pitch (bf16 elements) of row-read tiles: 80 B, spreads ds_read_b128 over banks
+constexpr int kVP = 32;      // pitch of tiles read through ds_read_b64_tr_b16 (64 B rows)
+constexpr int kRows = 160;   // tiles are zero-padded to 5 k-steps of 32
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+struct Geom {
+    int B, H, W, C, nH, shift, nWh, nWw, Hp, Wp, T, nWm;
+    float scale;
+};
+
+// window-local index n of window (wy, wx) -> token index in the H x W map (or -1 for a padding token) and the
+// shift-mask region of the position (swin_model.py:424-436 on the rolled map)
+__device__ __forceinline__ int token_of(int n, int wy, int wx, const Geom& g, int& region) {
+    const int i = n / kWs, j = n - kWs * i;
+    const int ys = wy * kWs + i, xs = wx * kWs + j;
+    const int rh = ys < g.Hp - kWs ? 0 : (ys < g.Hp - g.shift ? 1 : 2);
+    const int rw = xs < g.Wp - kWs ? 0 : (xs < g.Wp - g.shift ? 1 : 2);
+    region = 3 * rh + rw;
+    int y = ys + g.shift, x = xs + g.shift;
+    if (y >= g.Hp) y -= g.Hp;
+    if (x >= g.Wp) x -= g.Wp;
+    return (y < g.H && x < g.W) ? y * g.W + x : -1;
+}
+
+__device__ __forceinline__ uint4 load16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+
+__device__ __forceinline__ v8bf as_v8bf(uint4 u) { return __builtin_bit_cast(v8bf, u); }
+
+__device__ __forceinline__ v8bf tr_pair(const __bf16* lo, const __bf16* hi) {
+    // two transposing reads (4 rows x 16 columns each) -> the 8 k-slots of one A/B fragment
+    const v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)lo);
+    const v4s b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)hi);
+    const v8s r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(v8bf, r);
+}
+
+__device__ __forceinline__ v8bf pack8(const v4f& a, const v4f& b) {
+    v8bf r;
+    r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+    r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+    return r;
+}
+
+__device__ __forceinline__ float xor_max(float v, int o) { return fmaxf(v, __shfl_xor(v, o, 64)); }
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads)
+void winattn_fwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_bias, const __bf16* __restrict__ pad_qkv,
+                 const float* __restrict__ mask, Geom g, __bf16* __restrict__ out, float* __restrict__ lse2) {
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[kN * kKP];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[kRows * kVP];
+    __shared__ __attribute__((aligned(16))) uint8_t rid[kRows];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.x % g.nH, grp = blockIdx.x / g.nH, ngrp = gridDim.x / g.nH;
+    const int NW = g.B * g.nWh * g.nWw;
+    const int C3 = 3 * g.C;
+    const int hoff = h * kHd;
+    const float c2 = g.scale * kLog2e;
+
+    // zero the k-padding rows of V once (rows 144..159 are never written by the window loads)
+    for (int i = tid; i < (kRows - kN) * kVP; i += kThreads) Vs[kN * kVP + i] = (__bf16)0.f;
+    if (tid < kRows - kN) rid[kN + tid] = 0;
+
+    // this wave's slice of the head's relative-position bias, pre-multiplied by log2(e):
+    // b2[kt][r] = bias[h][query 16w + l15][key 16kt + 4lg + r]
+    v4f b2[kTiles];
+    {
+        const float* brow = rel_bias + ((size_t)h * kN + 16 * w + l15) * kN + 4 * lg;
+#pragma unroll
+        for (int kt = 0; kt < kTiles; ++kt) {
+            const float4 t = *reinterpret_cast<const float4*>(brow + 16 * kt);
+            b2[kt] = v4f{t.x * kLog2e, t.y * kLog2e, t.z * kLog2e, t.w * kLog2e};
+        }
+    }
+
+    const int sn = tid >> 2, sc = tid & 3;  // staging role: token sn, 16-byte chunk sc
+    for (int win = grp; win < NW; win += ngrp) {
+        const int b = win / (g.nWh * g.nWw), wrem = win - b * (g.nWh * g.nWw);
+        const int wy = wrem / g.nWw, wx = wrem - wy * g.nWw;
+        const size_t img = (size_t)b * g.T;
+
+        // ---- stage K, V (whole window) and fetch this wave's Q fragment
+        int reg;
+        const int tk = token_of(sn, wy, wx, g, reg);
+        const __bf16* src = tk >= 0 ? qkv + (img + tk) * C3 + hoff + sc * 8 : pad_qkv + hoff + sc * 8;
+        const uint4 kq = load16(src + g.C);
+        const uint4 vq = load16(src + 2 * g.C);
+        int qreg;
+        const int tq = token_of(16 * w + l15, wy, wx, g, qreg);
+        const __bf16* qsrc = tq >= 0 ? qkv + (img + tq) * C3 + hoff + lg * 8 : pad_qkv + hoff + lg * 8;
+        const v8bf qf = as_v8bf(load16(qsrc));
+        __syncthreads();  // previous window's LDS reads are done
+        *reinterpret_cast<uint4*>(&Ks[sn * kKP + sc * 8]) = kq;
+        *reinterpret_cast<uint4*>(&Vs[sn * kVP + sc * 8]) = vq;
+        if (sc == 0) rid[sn] = (uint8_t)reg;
+        __syncthreads();
+
+        // ---- S^T = K Q^T : acc[kt][r] = <q(16w + l15), k(16kt + 4lg + r)>
+        v4f acc[kTiles];
+#pragma unroll
+        for (int kt = 0; kt < kTiles; ++kt) {
+            const v8bf kf = as_v8bf(*reinterpret_cast<const uint4*>(&Ks[(16 * kt + l15) * kKP + lg * 8]));
+            acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+        // ---- logits in the log2 domain: t = s*scale*log2e + bias*log2e (+ mask*log2e)
+        const bool analytic = (mask == nullptr) && g.shift > 0 && (wy == g.nWh - 1 || wx == g.nWw - 1);
+#pragma unroll
+        for (int kt = 0; kt < kTiles; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[kt][r] = fmaf(acc[kt][r], c2, b2[kt][r]);
+        }
+        if (analytic) {
+#pragma unroll
+            for (int kt = 0; kt < kTiles; ++kt) {
+                const uint32_t ids = *reinterpret_cast<const uint32_t*>(&rid[16 * kt + 4 * lg]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((int)((ids >> (8 * r)) & 0xff) != qreg) acc[kt][r] += -100.0f * kLog2e;
+            }
+        } else if (mask != nullptr) {
+            const float* mrow = mask + ((size_t)(win % g.nWm) * kN + 16 * w + l15) * kN + 4 * lg;
+#pragma unroll
+            for (int kt = 0; kt < kTiles; ++kt) {
+                const float4 t = *reinterpret_cast<const float4*>(mrow + 16 * kt);
+                acc[kt][0] = fmaf(t.x, kLog2e, acc[kt][0]);
+                acc[kt][1] = fmaf(t.y, kLog2e, acc[kt][1]);
+                acc[kt][2] = fmaf(t.z, kLog2e, acc[kt][2]);
+                acc[kt][3] = fmaf(t.w, kLog2e, acc[kt][3]);
+            }
+        }
+        // ---- softmax over the 144 keys of this lane's query: 36 registers x 4 lane groups
+        float m = acc[0][0];
+#pragma unroll
+        for (int kt = 0; kt < kTiles; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[kt][r]);
+        m = xor_max(xor_max(m, 16), 32);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < kTiles; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(acc[kt][r] - m);
+                acc[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+
+        // ---- O^T = V^T P^T; k-slot (lg, j<4) = key 32s + 4lg + j, (lg, j>=4) = key 32s + 16 + 4lg + (j-4)
+        v4f o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+        const int trq = l15 >> 2, trp = l15 & 3;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const v8bf pf = s < 4 ? pack8(acc[2 * s], acc[2 * s + 1]) : pack8(acc[8], v4f{0.f, 0.f, 0.f, 0.f});
+            const __bf16* lo = &Vs[(32 * s + 4 * lg + trq) * kVP + 4 * trp];
+            const __bf16* hi = lo + 16 * kVP;
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(lo, hi), pf, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(lo + 16, hi + 16), pf, o1, 0, 0, 0);
+        }
+        // o0[r] = O[query 16w + l15][d = 4lg + r], o1[r] = ... d = 16 + 4lg + r
+        if (tq >= 0) {
+            __bf16* orow = out + (img + tq) * g.C + hoff + 4 * lg;
+            v4bf a, c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = (__bf16)(o0[r] * inv); c[r] = (__bf16)(o1[r] * inv); }
+            *reinterpret_cast<v4bf*>(orow) = a;
+            *reinterpret_cast<v4bf*>(orow + 16) = c;
+        }
+        if (lg == 0) lse2[((size_t)win * g.nH + h) * kN + 16 * w + l15] = m + __builtin_amdgcn_logf(sum);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------
+constexpr int kSP = 152;  // pitch (bf16) of the transposed dS tile: 304-byte rows, 8-byte aligned for tr reads
+
+__global__ __launch_bounds__(kThreads)
+void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_bias, const __bf16* __restrict__ pad_qkv,
+                 const float* __restrict__ mask, Geom g, const __bf16* __restrict__ out, const __bf16* __restrict__ dout,
+                 const float* __restrict__ lse2, __bf16* __restrict__ dqkv, float* __restrict__ dbias,
+                 float* __restrict__ dpad) {
+    __shared__ __attribute__((aligned(16))) __bf16 Qs[kRows * kKP];
+    __shared__ __attribute__((aligned(16))) __bf16 dOs[kRows * kKP];
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[kRows * kKP];
+    __shared__ __attribute__((aligned(16))) __bf16 dSt[kRows * kSP];  // [key][query]
+    __shared__ __attribute__((aligned(16))) float lse_s[kRows];
+    __shared__ __attribute__((aligned(16))) float delta_s[kRows];
+    __shared__ __attribute__((aligned(16))) float pad_s[3 * kHd];
+    __shared__ __attribute__((aligned(16))) uint8_t rid[kRows];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int trq = l15 >> 2, trp = l15 & 3;
+    const int h = blockIdx.x % g.nH, grp = blockIdx.x / g.nH, ngrp = gridDim.x / g.nH;
+    const int NW = g.B * g.nWh * g.nWw;
+    const int C3 = 3 * g.C;
+    const int hoff = h * kHd;
+    const float c2 = g.scale * kLog2e;
+
+    // one-time zero of every k-padding row (rows 144..159) and of the pad-gradient accumulator
+    for (int i = tid; i < (kRows - kN) * kKP; i += kThreads) {
+        Qs[kN * kKP + i] = (__bf16)0.f; dOs[kN * kKP + i] = (__bf16)0.f; Ks[kN * kKP + i] = (__bf16)0.f;
+    }
+    for (int i = tid; i < (kRows - kN) * kSP; i += kThreads) dSt[kN * kSP + i] = (__bf16)0.f;
+    if (tid < kRows - kN) { rid[kN + tid] = 0; lse_s[kN + tid] = 0.f; delta_s[kN + tid] = 0.f; }
+    if (tid < 3 * kHd) pad_s[tid] = 0.f;
+
+    // bias slice of key tile w in the phase-1 layout: b2[qt][r] = bias[h][query 16qt + 4lg + r][key 16w + l15]
+    v4f b2[kTiles], dB[kTiles];
+#pragma unroll
+    for (int qt = 0; qt < kTiles; ++qt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            b2[qt][r] = rel_bias[((size_t)h * kN + 16 * qt + 4 * lg + r) * kN + 16 * w + l15] * kLog2e;
+        dB[qt] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int sn = tid >> 2, sc = tid & 3;
+    for (int win = grp; win < NW; win += ngrp) {
+        const int b = win / (g.nWh * g.nWw), wrem = win - b * (g.nWh * g.nWw);
+        const int wy = wrem / g.nWw, wx = wrem - wy * g.nWw;
+        const size_t img = (size_t)b * g.T;
+
+        // ---- global fetches: staging chunks + this wave's K / V fragments (B operands of phase 1)
+        int reg;
+        const int tk = token_of(sn, wy, wx, g, reg);
+        const __bf16* src = tk >= 0 ? qkv + (img + tk) * C3 + hoff + sc * 8 : pad_qkv + hoff + sc * 8;
+        const uint4 q_c = load16(src);
+        const uint4 k_c = load16(src + g.C);
+        uint4 do_c = make_uint4(0, 0, 0, 0), o_c = make_uint4(0, 0, 0, 0);
+        if (tk >= 0) {
+            do_c = load16(dout + (img + tk) * g.C + hoff + sc * 8);
+            o_c = load16(out + (img + tk) * g.C + hoff + sc * 8);
+        }
+        int kreg;
+        const int tkk = token_of(16 * w + l15, wy, wx, g, kreg);  // this lane's key in phase 1 / query in phase 2
+        const __bf16* ksrc = tkk >= 0 ? qkv + (img + tkk) * C3 + hoff + lg * 8 : pad_qkv + hoff + lg * 8;
+        const v8bf kf = as_v8bf(load16(ksrc + g.C));
+        const v8bf vf = as_v8bf(load16(ksrc + 2 * g.C));
+        float lse_v = 0.f;
+        if (tid < kN) lse_v = lse2[((size_t)win * g.nH + h) * kN + tid];
+        // delta = rowsum(dO * O) over the head's 32 channels: 8 per thread, 4 threads per token
+        float dpart = 0.f;
+        {
+            const v8bf a = as_v8bf(do_c), c = as_v8bf(o_c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dpart = fmaf((float)a[e], (float)c[e], dpart);
+            dpart += __shfl_xor(dpart, 1, 64);
+            dpart += __shfl_xor(dpart, 2, 64);
+        }
+        __syncthreads();  // previous window fully consumed
+        *reinterpret_cast<uint4*>(&Qs[sn * kKP + sc * 8]) = q_c;
+        *reinterpret_cast<uint4*>(&Ks[sn * kKP + sc * 8]) = k_c;
+        *reinterpret_cast<uint4*>(&dOs[sn * kKP + sc * 8]) = do_c;
+        if (sc == 0) { rid[sn] = (uint8_t)reg; delta_s[sn] = dpart; }
+        if (tid < kN) lse_s[tid] = lse_v;
+        __syncthreads();
+
+        // ================= phase 1: wave w = key tile w =================
+        const bool analytic = (mask == nullptr) && g.shift > 0 && (wy == g.nWh - 1 || wx == g.nWw - 1);
+        v4bf Pp[kTiles];  // bf16 P, [query 16qt + 4lg + r][key 16w + l15]; dS goes straight to LDS
+#pragma unroll
+        for (int qt = 0; qt < kTiles; ++qt) {
+            const v8bf qa = as_v8bf(*reinterpret_cast<const uint4*>(&Qs[(16 * qt + l15) * kKP + lg * 8]));
+            const v8bf da = as_v8bf(*reinterpret_cast<const uint4*>(&dOs[(16 * qt + l15) * kKP + lg * 8]));
+            v4f s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const v4f dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const float4 lq = *reinterpret_cast<const float4*>(&lse_s[16 * qt + 4 * lg]);
+            const float4 dq_ = *reinterpret_cast<const float4*>(&delta_s[16 * qt + 4 * lg]);
+            const float lqa[4] = {lq.x, lq.y, lq.z, lq.w}, dla[4] = {dq_.x, dq_.y, dq_.z, dq_.w};
+            uint32_t ids = 0;
+            if (analytic) ids = *reinterpret_cast<const uint32_t*>(&rid[16 * qt + 4 * lg]);
+            v4bf sp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = fmaf(s[r], c2, b2[qt][r]);
+                if (analytic && (int)((ids >> (8 * r)) & 0xff) != kreg) t += -100.0f * kLog2e;
+                if (mask != nullptr)
+                    t = fmaf(mask[((size_t)(win % g.nWm) * kN + 16 * qt + 4 * lg + r) * kN + 16 * w + l15], kLog2e, t);
+                const float p = __builtin_amdgcn_exp2f(t - lqa[r]);
+                const float dsv = p * (dp[r] - dla[r]);
+                dB[qt][r] += dsv;
+                Pp[qt][r] = (__bf16)p;
+                sp[r] = (__bf16)dsv;
+            }
+            *reinterpret_cast<v4bf*>(&dSt[(16 * w + l15) * kSP + 16 * qt + 4 * lg]) = sp;
+            __builtin_amdgcn_sched_barrier(0);  // keep one tile's fragments live at a time (register budget: 168)
+        }
+        // dV^T[d][key] = sum_q dO^T[d][q] P[q][key],  dK^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]
+        v4f dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
+        const v4bf z4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            const v4bf pa = Pp[2 * s5 < kTiles ? 2 * s5 : 0], pb = (2 * s5 + 1 < kTiles) ? Pp[2 * s5 + 1] : z4;
+            // this lane's own dS values, back from the transposed LDS tile (same lane wrote them: program order)
+            const v4bf sa = *reinterpret_cast<const v4bf*>(&dSt[(16 * w + l15) * kSP + 32 * s5 + 4 * lg]);
+            const v4bf sb = (2 * s5 + 1 < kTiles)
+                                ? *reinterpret_cast<const v4bf*>(&dSt[(16 * w + l15) * kSP + 32 * s5 + 16 + 4 * lg]) : z4;
+            const v8bf pf = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3]};
+            const v8bf sf = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
+            const int row = 32 * s5 + 4 * lg + trq;
+            const __bf16* dlo = &dOs[row * kKP + 4 * trp];
+            const __bf16* qlo = &Qs[row * kKP + 4 * trp];
+            dv0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(dlo, dlo + 16 * kKP), pf, dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(dlo + 16, dlo + 16 * kKP + 16), pf, dv1, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(qlo, qlo + 16 * kKP), sf, dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(qlo + 16, qlo + 16 * kKP + 16), sf, dk1, 0, 0, 0);
+        }
+        if (tkk >= 0) {
+            __bf16* base = dqkv + (img + tkk) * C3 + hoff + 4 * lg;
+            v4bf a, c, e, f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a[r] = (__bf16)(dk0[r] * g.scale); c[r] = (__bf16)(dk1[r] * g.scale);
+                e[r] = (__bf16)dv0[r]; f[r] = (__bf16)dv1[r];
+            }
+            *reinterpret_cast<v4bf*>(base + g.C) = a;
+            *reinterpret_cast<v4bf*>(base + g.C + 16) = c;
+            *reinterpret_cast<v4bf*>(base + 2 * g.C) = e;
+            *reinterpret_cast<v4bf*>(base + 2 * g.C + 16) = f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                atomicAdd(&pad_s[kHd + 4 * lg + r], dk0[r] * g.scale);
+                atomicAdd(&pad_s[kHd + 16 + 4 * lg + r], dk1[r] * g.scale);
+                atomicAdd(&pad_s[2 * kHd + 4 * lg + r], dv0[r]);
+                atomicAdd(&pad_s[2 * kHd + 16 + 4 * lg + r], dv1[r]);
+            }
+        }
+        __syncthreads();  // dSt complete
+
+        // ================= phase 2: wave w = query tile w : dQ^T[d][q] = scale * sum_k K^T[d][k] dS^T[k][q]
+        v4f dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            const int row = 32 * s5 + 8 * lg + trq;
+            const __bf16* slo = &dSt[row * kSP + 16 * w + 4 * trp];
+            const v8bf sf = tr_pair(slo, slo + 4 * kSP);
+            const __bf16* klo = &Ks[row * kKP + 4 * trp];
+            dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(klo, klo + 4 * kKP), sf, dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(klo + 16, klo + 4 * kKP + 16), sf, dq1, 0, 0, 0);
+        }
+        if (tkk >= 0) {
+            __bf16* base = dqkv + (img + tkk) * C3 + hoff + 4 * lg;
+            v4bf a, c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = (__bf16)(dq0[r] * g.scale); c[r] = (__bf16)(dq1[r] * g.scale); }
+            *reinterpret_cast<v4bf*>(base) = a;
+            *reinterpret_cast<v4bf*>(base + 16) = c;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                atomicAdd(&pad_s[4 * lg + r], dq0[r] * g.scale);
+                atomicAdd(&pad_s[16 + 4 * lg + r], dq1[r] * g.scale);
+            }
+        }
+    }
+    // ---- flush the register-resident d(bias) of this workgroup's windows and the padded-token gradient
+#pragma unroll
+    for (int qt = 0; qt < kTiles; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            atomicAdd(&dbias[((size_t)h * kN + 16 * qt + 4 * lg + r) * kN + 16 * w + l15], dB[qt][r]);
+    __syncthreads();
+    if (tid < 3 * kHd) {
+        const float v = pad_s[tid];
+        if (v != 0.f) atomicAdd(&dpad[(tid / kHd) * g.C + hoff + (tid % kHd)], v);
+    }
+}
+
+int check_geom(int B, int H, int W, int C, int nH, int window, int shift) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || nH <= 0) return GRIT_ERR_BAD_ARG;
+    if (window != kWs || C != nH * kHd || shift < 0 || shift >= kWs) return GRIT_ERR_UNSUPPORTED;
+    if ((long long)B * H * W * 3 * C >= (1LL << 40)) return GRIT_ERR_BAD_ARG;
+    return GRIT_OK;
+}
+
+Geom make_geom(int B, int H, int W, int C, int nH, int shift, float scale, int nWm) {
+    Geom g;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.nH = nH; g.shift = shift;
+    g.nWh = (H + kWs - 1) / kWs; g.nWw = (W + kWs - 1) / kWs;
+    g.Hp = g.nWh * kWs; g.Wp = g.nWw * kWs; g.T = H * W; g.nWm = nWm > 0 ? nWm : 1; g.scale = scale;
+    return g;
+}
+
+int grid_blocks(const Geom& g) {
+    // persistent: each workgroup serves one head and walks a strided set of windows; aim at ~4 workgroups
+    // per CU in flight so the tail is short, but never more groups than windows
+    const int NW = g.B * g.nWh * g.nWw;
+    int groups = (1024 + g.nH - 1) / g.nH;
+    if (groups > NW) groups = NW;
+    if (groups < 1) groups = 1;
+    return groups * g.nH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int grit_winattn_fwd_bf16(const void* qkv, const float* rel_bias, const void* pad_qkv, const float* mask, int n_mask_windows,
+                          int B, int H, int W, int C, int num_heads, int window, int shift, float scale,
+                          void* out, float* lse, void* stream) {
+    if (!qkv || !rel_bias || !pad_qkv || !out || !lse) return GRIT_ERR_BAD_ARG;
+    const int st = check_geom(B, H, W, C, num_heads, window, shift);
+    if (st != GRIT_OK) return st;
+    if (mask && n_mask_windows <= 0) return GRIT_ERR_BAD_ARG;
+    const Geom g = make_geom(B, H, W, C, num_heads, shift, scale, n_mask_windows);
+    hipLaunchKernelGGL(winattn_fwd, dim3(grid_blocks(g)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (__bf16*)out, lse);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pad_qkv, const float* mask, int n_mask_windows,
+                          const void* out, const void* dout, const float* lse, int B, int H, int W, int C, int num_heads,
+                          int window, int shift, float scale, void* dqkv, float* drel_bias, float* dpad, void* stream) {
+    if (!qkv || !rel_bias || !pad_qkv || !out || !dout || !lse || !dqkv || !drel_bias || !dpad) return GRIT_ERR_BAD_ARG;
+    const int st = check_geom(B, H, W, C, num_heads, window, shift);
+    if (st != GRIT_OK) return st;
+    if (mask && n_mask_windows <= 0) return GRIT_ERR_BAD_ARG;
+    const Geom g = make_geom(B, H, W, C, num_heads, shift, scale, n_mask_windows);
+    hipLaunchKernelGGL(winattn_bwd, dim3(grid_blocks(g)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
+                       (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -17,8 +17,40 @@ from torch.autograd.function import once_differentiable
 from grit_amd import lib as _lib
 
 
+# bench.py sets this to a list to collect (kind, start_event, end_event, algorithmic_bytes) per launch: HIP events
+# recorded on the launch stream right around the kernel, so the roofline figure is measured inside the real step
+PROFILE_EVENTS = None
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
+
+
+def _algorithmic_bytes(kind, B, S, M, D, L, Lq, P, esize):
+    """every tensor once (forward); value-sized traffic x3 + loc/weights read+written (backward)."""
+    pts = B * Lq * M * L * P
+    if kind == "fwd":
+        return esize * (B * S * M * D + 3 * pts + B * Lq * M * D)
+    return esize * (3 * B * S * M * D + 2 * 3 * pts + B * Lq * M * D)
+
+
+class _Timed(object):
+
+    def __init__(self, kind, nbytes):
+        self.kind, self.nbytes = kind, nbytes
+
+    def __enter__(self):
+        self.on = PROFILE_EVENTS is not None
+        if self.on:
+            self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on and PROFILE_EVENTS is not None:
+            self.b.record()
+            PROFILE_EVENTS.append((self.kind, self.a, self.b, self.nbytes))
+        return False
 
 
 def _check_inputs(value, shapes, lsi, loc, aw):
@@ -48,7 +80,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     v, loc, aw = value.to(cdt), sampling_loc.to(cdt), attn_weight.to(cdt)
     out = torch.empty((B, Lq, M * D), dtype=cdt, device=value.device)
     fn = _lib.load().grit_msda_fwd_f64 if cdt == torch.float64 else _lib.load().grit_msda_fwd_f32
-    with torch.cuda.device(value.device):
+    with torch.cuda.device(value.device), _Timed("fwd", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, v.element_size())):
         st = fn(_ptr(v), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(aw),
                 B, S, M, D, L, Lq, P, _ptr(out), _lib.current_stream_ptr())
     _lib.check(st, "grit_msda_fwd")
@@ -66,7 +98,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     gl = torch.empty_like(loc)
     ga = torch.empty_like(aw)
     fn = _lib.load().grit_msda_bwd_f64 if cdt == torch.float64 else _lib.load().grit_msda_bwd_f32
-    with torch.cuda.device(value.device):
+    with torch.cuda.device(value.device), _Timed("bwd", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, v.element_size())):
         st = fn(_ptr(v), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(aw), _ptr(go),
                 B, S, M, D, L, Lq, P, _ptr(gv), _ptr(gl), _ptr(ga), _lib.current_stream_ptr())
     _lib.check(st, "grit_msda_bwd")

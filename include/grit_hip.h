@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 2
+#define GRIT_ABI_VERSION 3
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -111,6 +111,31 @@ int grit_attn_bwd_bf16(const void* q, int64_t ldq, int64_t bsq, const void* k, i
                        const void* out, const void* dout, const float* lse,
                        int B, int H, int Tq, int Nk, int D, float scale, float dropout_p, uint64_t seed,
                        void* dq, void* dk, void* dv, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Swin (shifted-)window attention, window 12 (N = 144), head_dim 32, bf16 storage / MFMA, fp32 softmax
+ * (SURVEY 8 row A6).  Operates on the map in TOKEN ORDER; pad / roll / partition / reverse / crop of
+ * swin_model.py:257-293 and the shift mask of :424-441 are done by address arithmetic inside the kernel.
+ *
+ *   qkv       bf16 [B, H*W, 3*C]   output of the qkv Linear on the un-partitioned map; channel = which*C + head*32 + d
+ *   rel_bias  f32  [nH, 144, 144]  relative_position_bias_table gathered by relative_position_index (:168-171)
+ *   pad_qkv   bf16 [3*C]           q/k/v of a window-padding token (= the qkv Linear bias)
+ *   mask      f32  [n_mask_windows, 144, 144] additive, or NULL.  NULL + shift > 0 -> the kernel derives the
+ *             0 / -100 shift mask from (H, W, shift) itself.  Non-NULL replaces it (WindowAttention.forward(x, mask)
+ *             call form); window i uses mask[i % n_mask_windows].
+ *   out       bf16 [B, H*W, C]     heads concatenated (channel = head*32 + d), padded positions are not written
+ *   lse       f32  [B*nWh*nWw, nH, 144]  per-row log2-sum-exp2 of the logits, consumed by the backward call
+ *   scale     q scaling (head_dim^-0.5);  C = num_heads*32;  0 <= shift < 12;  window must be 12.
+ * Backward: dqkv bf16 like qkv (fully overwritten); drel_bias f32 like rel_bias and dpad f32 [3*C] are
+ * ACCUMULATED with float atomics -- the caller zeroes them.
+ * ------------------------------------------------------------------------------------------------------ */
+int grit_winattn_fwd_bf16(const void* qkv, const float* rel_bias, const void* pad_qkv, const float* mask, int n_mask_windows,
+                          int B, int H, int W, int C, int num_heads, int window, int shift, float scale,
+                          void* out, float* lse, void* stream);
+int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pad_qkv, const float* mask, int n_mask_windows,
+                          const void* out, const void* dout, const float* lse,
+                          int B, int H, int W, int C, int num_heads, int window, int shift, float scale,
+                          void* dqkv, float* drel_bias, float* dpad, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include "../../include/grit_hip.h"
+#include "attn_internal.h"
 
 namespace {
 
@@ -283,8 +284,36 @@ extern "C" {
     }
 
 GRIT_ATTN_FWD(f32, float)
-GRIT_ATTN_FWD(bf16, __hip_bfloat16)
 GRIT_ATTN_BWD(f32, float)
-GRIT_ATTN_BWD(bf16, __hip_bfloat16)
+
+// bf16 storage: matrix-core kernels (attn_mfma.hip) when the shape fits, else the fp32-arithmetic kernels above
+int grit_attn_fwd_bf16(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk, int64_t bsk, const void* v,
+                       int64_t ldv, int64_t bsv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq, int B, int H,
+                       int Tq, int Nk, int D, float scale, float dropout_p, uint64_t seed, void* out, float* lse,
+                       void* stream) {
+    if (!q || !k || !v || !out || !lse || !args_ok(B, H, Tq, Nk, D)) return GRIT_ERR_BAD_ARG;
+    if (dropout_p < 0.f || dropout_p >= 1.f) return GRIT_ERR_UNSUPPORTED;
+    const int st = grit_attn_mfma_fwd(q, ldq, bsq, k, ldk, bsk, v, ldv, bsv, mask, mask_sb, mask_sq, B, H, Tq, Nk, D, scale,
+                                      dropout_p, seed, out, lse, (hipStream_t)stream);
+    if (st != GRIT_ERR_UNSUPPORTED) return st;
+    using T = __hip_bfloat16;
+    return launch_fwd<T>((const T*)q, ldq, bsq, (const T*)k, ldk, bsk, (const T*)v, ldv, bsv, mask, mask_sb, mask_sq, B, H,
+                         Tq, Nk, D, scale, dropout_p, seed, (T*)out, lse, (hipStream_t)stream);
+}
+
+int grit_attn_bwd_bf16(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk, int64_t bsk, const void* v,
+                       int64_t ldv, int64_t bsv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq, const void* out,
+                       const void* dout, const float* lse, int B, int H, int Tq, int Nk, int D, float scale,
+                       float dropout_p, uint64_t seed, void* dq, void* dk, void* dv, void* stream) {
+    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !args_ok(B, H, Tq, Nk, D)) return GRIT_ERR_BAD_ARG;
+    if (dropout_p < 0.f || dropout_p >= 1.f) return GRIT_ERR_UNSUPPORTED;
+    const int st = grit_attn_mfma_bwd(q, ldq, bsq, k, ldk, bsk, v, ldv, bsv, mask, mask_sb, mask_sq, out, dout, lse, B, H, Tq,
+                                      Nk, D, scale, dropout_p, seed, dq, dk, dv, (hipStream_t)stream);
+    if (st != GRIT_ERR_UNSUPPORTED) return st;
+    using T = __hip_bfloat16;
+    return launch_bwd<T>((const T*)q, ldq, bsq, (const T*)k, ldk, bsk, (const T*)v, ldv, bsv, mask, mask_sb, mask_sq,
+                         (const T*)out, (const T*)dout, lse, B, H, Tq, Nk, D, scale, dropout_p, seed, (T*)dq, (T*)dk,
+                         (T*)dv, (hipStream_t)stream);
+}
 
 }  // extern "C"

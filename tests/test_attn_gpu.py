@@ -119,3 +119,50 @@ def test_fully_masked_row_is_nan_like_reference_and_errors():
     big = torch.randn(1, 300, 8, 64, device=DEV)
     with pytest.raises(RuntimeError, match="not supported"):
         attention(q.to(DEV), big, big)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bf16 storage -> matrix-core kernels (attn_mfma.hip); oracle evaluated in fp64 on the same bf16-rounded inputs
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Tq,Nk,mask_kind", [(2, 20, 20, "causal"), (3, 20, 100, "key"), (2, 20, 150, None),
+                                               (2, 150, 150, None), (1, 1, 7, None), (2, 54, 54, "causal"),
+                                               (1, 33, 160, "shared"), (2, 5, 65, "key"), (1, 160, 17, None)])
+def test_bf16_mfma_forward_backward_vs_oracle(B, Tq, Nk, mask_kind):
+    from grit_amd.ops.attention import attention
+    q, k, v, mask = _case(B, Tq, Nk, mask_kind=mask_kind, dtype=torch.bfloat16)
+    cot = torch.randn(B, Tq, 512, generator=torch.Generator().manual_seed(9)).bfloat16()
+    ref = _grads(lambda a, b, c: torch_ref.attention(a, b, c, mask), q.double(), k.double(), v.double(), cot.double())
+    dm = None if mask is None else mask.to(DEV)
+    got = _grads(lambda a, b, c: attention(a, b, c, dm), q.to(DEV), k.to(DEV), v.to(DEV), cot.to(DEV))
+    for name, r, o in zip(("out", "dq", "dk", "dv"), ref, got):
+        assert o.dtype == torch.bfloat16
+        r, o = r.float(), o.float().cpu()
+        scale = r.abs().max().item() + 1e-6
+        assert (o - r).abs().max().item() < 3e-2 * scale, (name, (o - r).abs().max().item(), scale)
+        assert (o - r).abs().mean().item() < 4e-3 * scale, name
+
+
+def test_bf16_mfma_dropout_consistency():
+    """MFMA path: the keep-mask of forward and backward is the same function of the seed."""
+    from grit_amd.ops.attention import _AttentionFn
+    B, Tq, Nk, H, p = 2, 48, 64, 8, 0.2
+    q, k, _, _ = _case(B, Tq, Nk, dtype=torch.bfloat16)
+    v = torch.eye(64).view(1, 64, 1, 64).expand(B, 64, H, 64).contiguous().bfloat16()
+    q, k, v = q.to(DEV), k.to(DEV), v.to(DEV)
+    pd = _AttentionFn.apply(q, k, v, None, 0.125, p, 77).view(B, Tq, H, 64).float()
+    P = torch.softmax(torch.einsum("bqhd,bkhd->bqhk", q.float(), k.float()) * 0.125, -1)
+    kept = pd != 0
+    dropped_frac = 1 - (kept | (P < 1e-3)).float().mean().item()  # tiny P may round to 0 in bf16
+    assert abs(dropped_frac - p) < 0.02
+    big = kept & (P > 1e-2)
+    np.testing.assert_allclose(pd[big].cpu().numpy(), (P / (1 - p))[big].cpu().numpy(), rtol=2e-2)
+    M = kept.float() / (1 - p)
+    cot = torch.randn(B, Tq, 512, device=DEV).bfloat16()
+    gq, gk, gv = (x.clone().requires_grad_(True) for x in (q, k, v))
+    _AttentionFn.apply(gq, gk, gv, None, 0.125, p, 77).backward(cot)
+    rq, rk, rv = (x.float().clone().requires_grad_(True) for x in (q, k, v))
+    Pm = torch.softmax(torch.einsum("bqhd,bkhd->bqhk", rq, rk) * 0.125, -1) * M
+    torch.einsum("bqhk,bkhd->bqhd", Pm, rv).reshape(B, Tq, 512).backward(cot.float())
+    for a, b_ in ((gq.grad, rq.grad), (gk.grad, rk.grad), (gv.grad, rv.grad)):
+        scale = b_.abs().max().item()
+        assert (a.float() - b_).abs().max().item() < 4e-2 * scale

@@ -26,6 +26,7 @@
 //     window): no global atomics except the per-launch flush of d(bias) and of the padded-token gradient.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/grit_hip.h"
 
 namespace {
@@ -220,21 +221,43 @@ void winattn_fwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
 // ---------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------
-constexpr int kSP = 152;  // pitch (bf16) of the transposed dS tile: 304-byte rows, 8-byte aligned for tr reads
+// LDS plan (159 KB, one workgroup per CU): the head's bias slab in fp32, TRANSPOSED [key][query] with a 148-float
+// pitch (conflict-free 16-byte reads, shared by all windows of the launch), Q / dO / K tiles [144][32] bf16, the
+// transposed dS tile [key][query] bf16 (pitch 148) and the per-row statistics.  Registers hold the d(bias)
+// accumulators (36 floats / lane) across the whole launch; everything else is transient, so nothing spills.
+constexpr int kTP = 32;    // tile pitch (bf16) of Q / dO / K: 64-byte rows, 144 rows (k-padding handled by selects)
+constexpr int kSP = 148;   // pitch (bf16) of the transposed dS tile
+constexpr int kBP = 148;   // pitch (float) of the transposed bias slab
 
+// sum over the 16 lanes that share (lane >> 4): the 16 keys / queries of a tile for fixed (channel group, r)
+__device__ __forceinline__ float sum16(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+__device__ __forceinline__ v4s tr_read(const __bf16* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)p); }
+
+__device__ __forceinline__ v8bf join(v4s a, v4s b) {
+    const v8s r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(v8bf, r);
+}
+
+template <bool kExplicitMask>
 __global__ __launch_bounds__(kThreads)
 void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_bias, const __bf16* __restrict__ pad_qkv,
                  const float* __restrict__ mask, Geom g, const __bf16* __restrict__ out, const __bf16* __restrict__ dout,
                  const float* __restrict__ lse2, __bf16* __restrict__ dqkv, float* __restrict__ dbias,
                  float* __restrict__ dpad) {
-    __shared__ __attribute__((aligned(16))) __bf16 Qs[kRows * kKP];
-    __shared__ __attribute__((aligned(16))) __bf16 dOs[kRows * kKP];
-    __shared__ __attribute__((aligned(16))) __bf16 Ks[kRows * kKP];
-    __shared__ __attribute__((aligned(16))) __bf16 dSt[kRows * kSP];  // [key][query]
-    __shared__ __attribute__((aligned(16))) float lse_s[kRows];
-    __shared__ __attribute__((aligned(16))) float delta_s[kRows];
-    __shared__ __attribute__((aligned(16))) float pad_s[3 * kHd];
-    __shared__ __attribute__((aligned(16))) uint8_t rid[kRows];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* bT = reinterpret_cast<float*>(smem_raw);                         // [144][kBP]  bias^T * log2e
+    __bf16* Qs = reinterpret_cast<__bf16*>(bT + kN * kBP);                  // [144][kTP]
+    __bf16* dOs = Qs + kN * kTP;
+    __bf16* Ks = dOs + kN * kTP;
+    __bf16* dSt = Ks + kN * kTP;                                            // [144][kSP]  [key][query]
+    float* lse_s = reinterpret_cast<float*>(dSt + kN * kSP);                // [144]
+    float* delta_s = lse_s + kN;                                            // [144]
+    float* pad_s = delta_s + kN;                                            // [96]
+    uint8_t* rid = reinterpret_cast<uint8_t*>(pad_s + 3 * kHd);             // [144]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -245,24 +268,18 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     const int hoff = h * kHd;
     const float c2 = g.scale * kLog2e;
 
-    // one-time zero of every k-padding row (rows 144..159) and of the pad-gradient accumulator
-    for (int i = tid; i < (kRows - kN) * kKP; i += kThreads) {
-        Qs[kN * kKP + i] = (__bf16)0.f; dOs[kN * kKP + i] = (__bf16)0.f; Ks[kN * kKP + i] = (__bf16)0.f;
+    // one-time: bias slab (transposed, log2 domain) and the pad-gradient accumulator
+    for (int i = tid; i < kN * kN; i += kThreads) {
+        const int qi = i / kN, ki = i - qi * kN;
+        bT[ki * kBP + qi] = rel_bias[(size_t)h * kN * kN + i] * kLog2e;
     }
-    for (int i = tid; i < (kRows - kN) * kSP; i += kThreads) dSt[kN * kSP + i] = (__bf16)0.f;
-    if (tid < kRows - kN) { rid[kN + tid] = 0; lse_s[kN + tid] = 0.f; delta_s[kN + tid] = 0.f; }
     if (tid < 3 * kHd) pad_s[tid] = 0.f;
 
-    // bias slice of key tile w in the phase-1 layout: b2[qt][r] = bias[h][query 16qt + 4lg + r][key 16w + l15]
-    v4f b2[kTiles], dB[kTiles];
+    v4f dB[kTiles];  // d(bias)[query 16qt + 4lg + r][key 16w + l15], summed over this workgroup's windows
 #pragma unroll
-    for (int qt = 0; qt < kTiles; ++qt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            b2[qt][r] = rel_bias[((size_t)h * kN + 16 * qt + 4 * lg + r) * kN + 16 * w + l15] * kLog2e;
-        dB[qt] = v4f{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int qt = 0; qt < kTiles; ++qt) dB[qt] = v4f{0.f, 0.f, 0.f, 0.f};
 
+    const v4s z4s = {0, 0, 0, 0};
     const int sn = tid >> 2, sc = tid & 3;
     for (int win = grp; win < NW; win += ngrp) {
         const int b = win / (g.nWh * g.nWw), wrem = win - b * (g.nWh * g.nWw);
@@ -287,8 +304,7 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
         const v8bf vf = as_v8bf(load16(ksrc + 2 * g.C));
         float lse_v = 0.f;
         if (tid < kN) lse_v = lse2[((size_t)win * g.nH + h) * kN + tid];
-        // delta = rowsum(dO * O) over the head's 32 channels: 8 per thread, 4 threads per token
-        float dpart = 0.f;
+        float dpart = 0.f;  // delta = rowsum(dO * O): 8 channels per thread, 4 threads per token
         {
             const v8bf a = as_v8bf(do_c), c = as_v8bf(o_c);
 #pragma unroll
@@ -296,63 +312,74 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
             dpart += __shfl_xor(dpart, 1, 64);
             dpart += __shfl_xor(dpart, 2, 64);
         }
-        __syncthreads();  // previous window fully consumed
-        *reinterpret_cast<uint4*>(&Qs[sn * kKP + sc * 8]) = q_c;
-        *reinterpret_cast<uint4*>(&Ks[sn * kKP + sc * 8]) = k_c;
-        *reinterpret_cast<uint4*>(&dOs[sn * kKP + sc * 8]) = do_c;
+        __syncthreads();  // previous window fully consumed (and, first time, the bias slab is complete)
+        *reinterpret_cast<uint4*>(&Qs[sn * kTP + sc * 8]) = q_c;
+        *reinterpret_cast<uint4*>(&Ks[sn * kTP + sc * 8]) = k_c;
+        *reinterpret_cast<uint4*>(&dOs[sn * kTP + sc * 8]) = do_c;
         if (sc == 0) { rid[sn] = (uint8_t)reg; delta_s[sn] = dpart; }
         if (tid < kN) lse_s[tid] = lse_v;
         __syncthreads();
 
+        // Per-lane LDS offsets, made opaque once per window: without this hipcc hoists ~90 loop-invariant LDS
+        // addresses out of the window loop, runs out of registers and reloads them from scratch before every read.
+        int oRow = l15 * kTP + lg * 8;                   // row reads of Qs / dOs      (+ 16 qt kTP)
+        int oTr = (4 * lg + trq) * kTP + 4 * trp;        // transposing reads, phase 1 (+ 32 s kTP)
+        int oB = (16 * w + l15) * kBP + 4 * lg;          // bias slab                  (+ 16 qt)
+        int oSt = 4 * lg;                                // lse / delta                (+ 16 qt)
+        int oW = (16 * w + l15) * kSP + 4 * lg;          // dS^T writes                (+ 16 qt)
+        asm volatile("" : "+v"(oRow), "+v"(oTr), "+v"(oB), "+v"(oSt), "+v"(oW));
+
         // ================= phase 1: wave w = key tile w =================
-        const bool analytic = (mask == nullptr) && g.shift > 0 && (wy == g.nWh - 1 || wx == g.nWw - 1);
-        v4bf Pp[kTiles];  // bf16 P, [query 16qt + 4lg + r][key 16w + l15]; dS goes straight to LDS
+        // S[q][k] = Q K^T, dP[q][k] = dO V^T on tiles (qt, w); after each PAIR of query tiles (one 32-deep k-step of
+        // the products that sum over queries) the packed P / dS feed dV^T += dO^T P and dK^T += Q^T dS at once.
+        const bool analytic = !kExplicitMask && g.shift > 0 && (wy == g.nWh - 1 || wx == g.nWw - 1);
+        v4f dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
+        v4bf pprev, sprev;
 #pragma unroll
         for (int qt = 0; qt < kTiles; ++qt) {
-            const v8bf qa = as_v8bf(*reinterpret_cast<const uint4*>(&Qs[(16 * qt + l15) * kKP + lg * 8]));
-            const v8bf da = as_v8bf(*reinterpret_cast<const uint4*>(&dOs[(16 * qt + l15) * kKP + lg * 8]));
-            v4f s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const v8bf qa = as_v8bf(*reinterpret_cast<const uint4*>(&Qs[oRow + 16 * qt * kTP]));
+            const v8bf da = as_v8bf(*reinterpret_cast<const uint4*>(&dOs[oRow + 16 * qt * kTP]));
+            const v4f s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             const v4f dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            const float4 lq = *reinterpret_cast<const float4*>(&lse_s[16 * qt + 4 * lg]);
-            const float4 dq_ = *reinterpret_cast<const float4*>(&delta_s[16 * qt + 4 * lg]);
-            const float lqa[4] = {lq.x, lq.y, lq.z, lq.w}, dla[4] = {dq_.x, dq_.y, dq_.z, dq_.w};
+            const float4 bq = *reinterpret_cast<const float4*>(&bT[oB + 16 * qt]);
+            const float4 lq = *reinterpret_cast<const float4*>(&lse_s[oSt + 16 * qt]);
+            const float4 dl = *reinterpret_cast<const float4*>(&delta_s[oSt + 16 * qt]);
+            const float ba[4] = {bq.x, bq.y, bq.z, bq.w}, lqa[4] = {lq.x, lq.y, lq.z, lq.w};
+            const float dla[4] = {dl.x, dl.y, dl.z, dl.w};
             uint32_t ids = 0;
-            if (analytic) ids = *reinterpret_cast<const uint32_t*>(&rid[16 * qt + 4 * lg]);
-            v4bf sp;
+            if (analytic) ids = *reinterpret_cast<const uint32_t*>(&rid[oSt + 16 * qt]);
+            v4bf pp, sp;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float t = fmaf(s[r], c2, b2[qt][r]);
+                float t = fmaf(s[r], c2, ba[r]);
                 if (analytic && (int)((ids >> (8 * r)) & 0xff) != kreg) t += -100.0f * kLog2e;
-                if (mask != nullptr)
+                if (kExplicitMask)
                     t = fmaf(mask[((size_t)(win % g.nWm) * kN + 16 * qt + 4 * lg + r) * kN + 16 * w + l15], kLog2e, t);
                 const float p = __builtin_amdgcn_exp2f(t - lqa[r]);
                 const float dsv = p * (dp[r] - dla[r]);
                 dB[qt][r] += dsv;
-                Pp[qt][r] = (__bf16)p;
+                pp[r] = (__bf16)p;
                 sp[r] = (__bf16)dsv;
             }
-            *reinterpret_cast<v4bf*>(&dSt[(16 * w + l15) * kSP + 16 * qt + 4 * lg]) = sp;
-            __builtin_amdgcn_sched_barrier(0);  // keep one tile's fragments live at a time (register budget: 168)
-        }
-        // dV^T[d][key] = sum_q dO^T[d][q] P[q][key],  dK^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]
-        v4f dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
-        const v4bf z4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-#pragma unroll
-        for (int s5 = 0; s5 < 5; ++s5) {
-            const v4bf pa = Pp[2 * s5 < kTiles ? 2 * s5 : 0], pb = (2 * s5 + 1 < kTiles) ? Pp[2 * s5 + 1] : z4;
-            // this lane's own dS values, back from the transposed LDS tile (same lane wrote them: program order)
-            const v4bf sa = *reinterpret_cast<const v4bf*>(&dSt[(16 * w + l15) * kSP + 32 * s5 + 4 * lg]);
-            const v4bf sb = (2 * s5 + 1 < kTiles)
-                                ? *reinterpret_cast<const v4bf*>(&dSt[(16 * w + l15) * kSP + 32 * s5 + 16 + 4 * lg]) : z4;
-            const v8bf pf = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3]};
-            const v8bf sf = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
-            const int row = 32 * s5 + 4 * lg + trq;
-            const __bf16* dlo = &dOs[row * kKP + 4 * trp];
-            const __bf16* qlo = &Qs[row * kKP + 4 * trp];
-            dv0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(dlo, dlo + 16 * kKP), pf, dv0, 0, 0, 0);
-            dv1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(dlo + 16, dlo + 16 * kKP + 16), pf, dv1, 0, 0, 0);
-            dk0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(qlo, qlo + 16 * kKP), sf, dk0, 0, 0, 0);
-            dk1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(qlo + 16, qlo + 16 * kKP + 16), sf, dk1, 0, 0, 0);
+            *reinterpret_cast<v4bf*>(&dSt[oW + 16 * qt]) = sp;
+            if ((qt & 1) || qt == kTiles - 1) {
+                const bool single = !(qt & 1);  // last, unpaired tile: upper 16 k-slots are zero
+                const v8bf pf = single ? v8bf{pp[0], pp[1], pp[2], pp[3], 0, 0, 0, 0}
+                                       : v8bf{pprev[0], pprev[1], pprev[2], pprev[3], pp[0], pp[1], pp[2], pp[3]};
+                const v8bf sf = single ? v8bf{sp[0], sp[1], sp[2], sp[3], 0, 0, 0, 0}
+                                       : v8bf{sprev[0], sprev[1], sprev[2], sprev[3], sp[0], sp[1], sp[2], sp[3]};
+                const int r0 = 16 * (single ? qt : qt - 1);  // queries 32s + 4lg + (0..3) | +16
+                const __bf16* dlo = &dOs[oTr + r0 * kTP];
+                const __bf16* qlo = &Qs[oTr + r0 * kTP];
+                const v4s d_hi0 = single ? z4s : tr_read(dlo + 16 * kTP), d_hi1 = single ? z4s : tr_read(dlo + 16 * kTP + 16);
+                const v4s q_hi0 = single ? z4s : tr_read(qlo + 16 * kTP), q_hi1 = single ? z4s : tr_read(qlo + 16 * kTP + 16);
+                dv0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(dlo), d_hi0), pf, dv0, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(dlo + 16), d_hi1), pf, dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(qlo), q_hi0), sf, dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(qlo + 16), q_hi1), sf, dk1, 0, 0, 0);
+            }
+            pprev = pp;
+            sprev = sp;
         }
         if (tkk >= 0) {
             __bf16* base = dqkv + (img + tkk) * C3 + hoff + 4 * lg;
@@ -366,27 +393,38 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
             *reinterpret_cast<v4bf*>(base + g.C + 16) = c;
             *reinterpret_cast<v4bf*>(base + 2 * g.C) = e;
             *reinterpret_cast<v4bf*>(base + 2 * g.C + 16) = f;
-        } else {
+        }
+        if (__any(tkk < 0)) {  // gradient of window-padding tokens flows to pad_qkv: reduce over the tile first
+            const float keep = tkk < 0 ? 1.f : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                atomicAdd(&pad_s[kHd + 4 * lg + r], dk0[r] * g.scale);
-                atomicAdd(&pad_s[kHd + 16 + 4 * lg + r], dk1[r] * g.scale);
-                atomicAdd(&pad_s[2 * kHd + 4 * lg + r], dv0[r]);
-                atomicAdd(&pad_s[2 * kHd + 16 + 4 * lg + r], dv1[r]);
+                const float a = sum16(dk0[r] * keep) * g.scale, c = sum16(dk1[r] * keep) * g.scale;
+                const float e = sum16(dv0[r] * keep), f = sum16(dv1[r] * keep);
+                if (l15 == 0) {
+                    atomicAdd(&pad_s[kHd + 4 * lg + r], a);
+                    atomicAdd(&pad_s[kHd + 16 + 4 * lg + r], c);
+                    atomicAdd(&pad_s[2 * kHd + 4 * lg + r], e);
+                    atomicAdd(&pad_s[2 * kHd + 16 + 4 * lg + r], f);
+                }
             }
         }
         __syncthreads();  // dSt complete
 
         // ================= phase 2: wave w = query tile w : dQ^T[d][q] = scale * sum_k K^T[d][k] dS^T[k][q]
+        // k-slot (lg, j) = key 32s + 8lg + j; the last step covers keys 128..143 only (lanes lg >= 2 contribute zeros)
         v4f dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
+        int oS2 = (8 * lg + trq) * kSP + 16 * w + 4 * trp, oK2 = (8 * lg + trq) * kTP + 4 * trp;
+        int oS2d = trq * kSP + 16 * w + 4 * trp - 128 * kSP, oK2d = trq * kTP + 4 * trp - 128 * kTP;  // dead lanes, s5 = 4
+        asm volatile("" : "+v"(oS2), "+v"(oK2), "+v"(oS2d), "+v"(oK2d));
 #pragma unroll
         for (int s5 = 0; s5 < 5; ++s5) {
-            const int row = 32 * s5 + 8 * lg + trq;
-            const __bf16* slo = &dSt[row * kSP + 16 * w + 4 * trp];
-            const v8bf sf = tr_pair(slo, slo + 4 * kSP);
-            const __bf16* klo = &Ks[row * kKP + 4 * trp];
-            dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(klo, klo + 4 * kKP), sf, dq0, 0, 0, 0);
-            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(klo + 16, klo + 4 * kKP + 16), sf, dq1, 0, 0, 0);
+            const bool live = (s5 < 4) || (lg < 2);  // dead lanes read a valid address (EXEC stays full), then zero
+            const __bf16* slo = &dSt[(live ? oS2 : oS2d) + 32 * s5 * kSP];
+            const __bf16* klo = &Ks[(live ? oK2 : oK2d) + 32 * s5 * kTP];
+            v8bf sf = join(tr_read(slo), tr_read(slo + 4 * kSP));
+            if (!live) sf = v8bf{0, 0, 0, 0, 0, 0, 0, 0};
+            dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(klo), tr_read(klo + 4 * kTP)), sf, dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(klo + 16), tr_read(klo + 4 * kTP + 16)), sf, dq1, 0, 0, 0);
         }
         if (tkk >= 0) {
             __bf16* base = dqkv + (img + tkk) * C3 + hoff + 4 * lg;
@@ -395,11 +433,16 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
             for (int r = 0; r < 4; ++r) { a[r] = (__bf16)(dq0[r] * g.scale); c[r] = (__bf16)(dq1[r] * g.scale); }
             *reinterpret_cast<v4bf*>(base) = a;
             *reinterpret_cast<v4bf*>(base + 16) = c;
-        } else {
+        }
+        if (__any(tkk < 0)) {
+            const float keep = tkk < 0 ? 1.f : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                atomicAdd(&pad_s[4 * lg + r], dq0[r] * g.scale);
-                atomicAdd(&pad_s[16 + 4 * lg + r], dq1[r] * g.scale);
+                const float a = sum16(dq0[r] * keep) * g.scale, c = sum16(dq1[r] * keep) * g.scale;
+                if (l15 == 0) {
+                    atomicAdd(&pad_s[4 * lg + r], a);
+                    atomicAdd(&pad_s[16 + 4 * lg + r], c);
+                }
             }
         }
     }
@@ -416,6 +459,8 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     }
 }
 
+constexpr size_t kBwdLds = (size_t)kN * kBP * 4 + 3 * (size_t)kN * kTP * 2 + (size_t)kN * kSP * 2 + 2 * kN * 4 + 3 * kHd * 4 + kN;
+
 int check_geom(int B, int H, int W, int C, int nH, int window, int shift) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || nH <= 0) return GRIT_ERR_BAD_ARG;
     if (window != kWs || C != nH * kHd || shift < 0 || shift >= kWs) return GRIT_ERR_UNSUPPORTED;
@@ -431,11 +476,13 @@ Geom make_geom(int B, int H, int W, int C, int nH, int shift, float scale, int n
     return g;
 }
 
-int grid_blocks(const Geom& g) {
-    // persistent: each workgroup serves one head and walks a strided set of windows; aim at ~4 workgroups
-    // per CU in flight so the tail is short, but never more groups than windows
+int grid_blocks(const Geom& g, int target) {
+    // persistent: each workgroup serves one head and walks a strided set of windows.  Forward aims at ~4
+    // workgroups per CU in flight so the tail is short; backward at one per CU (it is LDS/register bound to one
+    // anyway) so that the d(bias) flush -- the only contended global atomics -- happens once per CU.
     const int NW = g.B * g.nWh * g.nWw;
-    int groups = (1024 + g.nH - 1) / g.nH;
+    if (const char* e = getenv("GRIT_WINATTN_BLOCKS")) target = atoi(e);  // tuning knob for tools/bench_kernels.py
+    int groups = (target + g.nH - 1) / g.nH;
     if (groups > NW) groups = NW;
     if (groups < 1) groups = 1;
     return groups * g.nH;
@@ -453,7 +500,7 @@ int grit_winattn_fwd_bf16(const void* qkv, const float* rel_bias, const void* pa
     if (st != GRIT_OK) return st;
     if (mask && n_mask_windows <= 0) return GRIT_ERR_BAD_ARG;
     const Geom g = make_geom(B, H, W, C, num_heads, shift, scale, n_mask_windows);
-    hipLaunchKernelGGL(winattn_fwd, dim3(grid_blocks(g)), dim3(kThreads), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(winattn_fwd, dim3(grid_blocks(g, 1024)), dim3(kThreads), 0, (hipStream_t)stream,
                        (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (__bf16*)out, lse);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
@@ -466,9 +513,21 @@ int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pa
     if (st != GRIT_OK) return st;
     if (mask && n_mask_windows <= 0) return GRIT_ERR_BAD_ARG;
     const Geom g = make_geom(B, H, W, C, num_heads, shift, scale, n_mask_windows);
-    hipLaunchKernelGGL(winattn_bwd, dim3(grid_blocks(g)), dim3(kThreads), 0, (hipStream_t)stream,
-                       (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
-                       (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad);
+    static bool lds_attr_set = false;  // idempotent attribute, racing first calls set the same value
+    if (!lds_attr_set) {
+        if (hipFuncSetAttribute((const void*)winattn_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)winattn_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds) != hipSuccess)
+            return GRIT_ERR_LAUNCH;
+        lds_attr_set = true;
+    }
+    if (mask)
+        hipLaunchKernelGGL(winattn_bwd<true>, dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdLds, (hipStream_t)stream,
+                           (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
+                           (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad);
+    else
+        hipLaunchKernelGGL(winattn_bwd<false>, dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdLds, (hipStream_t)stream,
+                           (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
+                           (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 

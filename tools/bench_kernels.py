@@ -64,10 +64,39 @@ def bench_msda(args):
     return res
 
 
+def bench_winattn(args):
+    """Swin stages of the 640x640 benchmark at batch 32: (map side, heads)."""
+    from grit_amd.ops.window_attention import window_attention
+    res = []
+    for (side, nH) in [(160, 4), (80, 8), (40, 16), (20, 32)]:
+        B = args.batch[-1]
+        C = 32 * nH
+        qkv = torch.randn(B, side * side, 3 * C, device="cuda").bfloat16().requires_grad_(True)
+        bias = (torch.randn(nH, 144, 144, device="cuda") * 0.5).requires_grad_(True)
+        pad = torch.randn(3 * C, device="cuda").bfloat16().requires_grad_(True)
+        for shift in (0, 6):
+            f = lambda: window_attention(qkv, bias, pad, side, side, nH, 12, shift, 32**-0.5)
+            tf = time_gpu(f, args.iters)
+            out = f()
+            g = torch.randn_like(out)
+            def fb():
+                qkv.grad = bias.grad = pad.grad = None
+                window_attention(qkv, bias, pad, side, side, nH, 12, shift, 32**-0.5).backward(g)
+            tfb = time_gpu(fb, max(10, args.iters // 4))
+            nwin = B * (-(-side // 12))**2
+            flops_f = nwin * nH * 4 * 144 * 144 * 32
+            io = B * side * side * 4 * C * 2
+            res.append({"side": side, "heads": nH, "shift": shift, "fwd_us": tf * 1e6, "fwd+bwd_us": tfb * 1e6,
+                        "fwd_TFLOPs": flops_f / tf / 1e12, "fwd_io_GBps": io / tf / 1e9,
+                        "ns_per_window_head_fwd": tf * 1e9 / (nwin * nH), "ns_per_window_head_bwd": (tfb - tf) * 1e9 / (nwin * nH)})
+            print(json.dumps(res[-1]))
+    return res
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("which", choices=["msda", "winattn", "attn"])
     ap.add_argument("--batch", type=int, nargs="+", default=[8, 32])
     ap.add_argument("--iters", type=int, default=200)
     a = ap.parse_args()
-    {"msda": bench_msda}[a.which](a)
+    {"msda": bench_msda, "winattn": bench_winattn}[a.which](a)

@@ -6,7 +6,8 @@
 
 Workload (BASELINE.json metric, configs[3] per GPU): full GRIT (Swin-B window 12 + 6 deformable decoder layers +
 3-layer grid net + 3-layer caption decoder, 161 M parameters, random init), 32 images of 3x640x640 per GPU,
-captions of 20 tokens, train mode (dropout / DropPath on), bf16 autocast over fp32 master weights, one step =
+captions of 20 tokens, train mode (dropout / DropPath on), bf16 compute copies over fp32 master weights
+(grit_amd.amp.Bf16Compute; softmax / LayerNorm statistics / sampling locations / logits / loss in fp32), one step =
 forward + backward + gradient all-reduce (RCCL, bucketed, overlapped with backward) + two fused Adam steps, exactly
 the order of reference engine/caption_engine.py:312-350.  Weak scaling: the per-GPU batch is fixed.
 
@@ -102,22 +103,24 @@ def main():
 
     from grit_amd.config import default_config
     from grit_amd.data import synthetic_batch
+    from grit_amd.amp import Bf16Compute
     from grit_amd.ddp import BucketedDataParallel
     from grit_amd.engine.caption_engine import build_optimizers, train_xe_step
     from grit_amd.ops import msda as msda_op
 
     config = default_config()
     model = build(device, config).train()
-    wrapped = BucketedDataParallel(model, bucket_mb=64, wire_dtype=torch.bfloat16 if world > 1 else None)
+    if args.fp32:
+        wrapped = BucketedDataParallel(model, bucket_mb=64)
+    else:  # bf16 compute copies + fp32 master weights; gradients are produced, all-reduced and unscaled in flat bf16 buckets
+        wrapped = Bf16Compute(model, bucket_mb=64)
     optimizers = build_optimizers(wrapped, config, mode="xe")
     loss_fn = torch.nn.NLLLoss(ignore_index=1)
     # inputs resident in HBM before the timed region; 4 distinct batches per rank, cycled
     batches = [synthetic_batch(args.batch, args.size, args.size, args.caption_len, device=device, seed=1000 * rank + i)
                for i in range(4)]
-    amp = None if args.fp32 else torch.bfloat16
-
     def step(i):
-        return train_xe_step(wrapped, batches[i % len(batches)], optimizers, loss_fn, autocast_dtype=amp)
+        return train_xe_step(wrapped, batches[i % len(batches)], optimizers, loss_fn)
 
     for i in range(args.warmup):
         loss = step(i)
@@ -162,7 +165,7 @@ def main():
                                    f"3-layer caption decoder, 161M params, random init), {args.size}x{args.size} images, "
                                    f"caption length {args.caption_len}, Adam x2, dropout on",
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch,
-                       "parallelism": f"dp{world}", "grad_allreduce": "RCCL bucketed (64 MiB, bf16 wire), overlapped with backward"
+                       "parallelism": f"dp{world}", "grad_allreduce": "RCCL bucketed (64 MiB flat bf16 buckets), overlapped with backward"
                        if world > 1 else "none (1 GPU)"},
             "mfma_roofline_frac_bf16": value / world * FLOP_PER_IMAGE_FWD_BWD / MFMA_PEAK_BF16,
             "final_loss": final_loss,

@@ -39,13 +39,15 @@ class _Bucket(object):
 
 class BucketedDataParallel(nn.Module):
 
-    def __init__(self, module, bucket_mb=64, process_group=None, wire_dtype=None, broadcast_parameters=True):
+    def __init__(self, module, bucket_mb=64, process_group=None, wire_dtype=None, broadcast_parameters=True,
+                 repack_unused=True):
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.bucket_bytes = int(bucket_mb * 2**20)
         self.wire_dtype = wire_dtype
+        self.repack_unused = repack_unused  # False: keep the bucket layout (others hold views into it)
         self._seen = set()
         self._static_unused = None  # decided after the first iteration
         self._iteration = 0
@@ -127,7 +129,7 @@ class BucketedDataParallel(nn.Module):
             used = [p for p in self.module.parameters() if p.requires_grad and p in self._seen]
             unused = [p for p in self.module.parameters() if p.requires_grad and p not in self._seen]
             self._static_unused = unused
-            if unused:
+            if unused and self.repack_unused:
                 for p in unused:
                     p.grad = None
                 self._build_buckets(used)

@@ -27,11 +27,14 @@ def _unwrap(model):
 
 
 def build_optimizers(model, config, mode='xe'):
+    # grit_amd.amp.Bf16Compute exposes fp32 masters under the module's parameter names; otherwise the module's own
+    masters = getattr(model, 'named_master_parameters', None)
     model = _unwrap(model)
+    all_named = masters() if masters is not None else list(model.named_parameters())
     no_decay = ['bias', 'gamma', 'beta']
 
     def groups(in_detector):
-        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and (('detector' in n) == in_detector)]
+        named = [(n, p) for n, p in all_named if p.requires_grad and (('detector' in n) == in_detector)]
         return [
             {'params': [p for n, p in named if any(nd in n for nd in no_decay)], 'weight_decay_rate': 0.0},
             {'params': [p for n, p in named if not any(nd in n for nd in no_decay)],
@@ -39,7 +42,7 @@ def build_optimizers(model, config, mode='xe'):
         ]
 
     betas = (config.optimizer.beta_1, config.optimizer.beta_2)
-    fused = all(p.is_cuda for p in model.parameters())
+    fused = all(p.is_cuda for _, p in all_named)
 
     def adam(param_groups, lr):
         param_groups = [g for g in param_groups if len(g['params'])] or param_groups
@@ -64,7 +67,8 @@ def save_checkpoint(model, optimizers, epoch, scores, best_ciders, config=None, 
                     scheduler=None):
     torch.save(
         {
-            "state_dict": _unwrap(model).state_dict(),
+            "state_dict": (model.master_state_dict() if hasattr(model, 'master_state_dict')
+                           else _unwrap(model).state_dict()),
             "optim_model": optimizers['model'].state_dict(),
             "optim_backbone": optimizers['backbone'].state_dict(),
             "scores": scores,
@@ -126,6 +130,9 @@ def train_xe_step(model, batch, optimizers, loss_fn, scheduler=None, autocast_dt
         finalize()
     optimizers['model'].step()
     optimizers['backbone'].step()
+    post = getattr(model, 'after_optimizer_step', None)
+    if post is not None:
+        post()
     loss = gather_result(loss.detach())
     if scheduler is not None:
         lr = scheduler.step()

@@ -88,6 +88,7 @@ class CaptionGenerator(Module):
 
     def forward(self, input, vis_inputs):
         x, mask_x, mask_pad = self.get_seq_inputs(input)
+        mask_pad = mask_pad.to(x.dtype)
         y1, y2 = vis_inputs['gri_feat'], vis_inputs['reg_feat']
         m1, m2 = vis_inputs['gri_mask'], vis_inputs['reg_mask']
         for layer in self.layers:

@@ -322,7 +322,7 @@ class SwinTransformer(nn.Module):
 
     def forward(self, x):
         B = x.shape[0]
-        x = self.patch_embed(x)
+        x = self.patch_embed(x.to(self.patch_embed.proj.weight.dtype))
         Wh, Ww = x.shape[2], x.shape[3]
         x = self.pos_drop(x.flatten(2).transpose(1, 2))
         outs = []

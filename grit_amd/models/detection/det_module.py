@@ -99,7 +99,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         else:
             assert reference_points.shape[-1] == 2
             ratios = src_valid_ratios
-        reference_points = reference_points[:, :, None] * ratios[:, None]  # per level
+        reference_points = reference_points[:, :, None].float() * ratios[:, None]  # per level, fp32
 
         tgt = self.norm2(tgt + self.dropout2(self.query_self_attention(tgt, query_pos)))
         tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
@@ -153,7 +153,9 @@ class DetectionModule(nn.Module):
         """Iterative box refinement; the new references are detached (no gradient reaches bbox_embed)."""
         if bbox_embed is None:
             return reference_points
-        delta = bbox_embed(output)
+        # box arithmetic in fp32 (logit / sigmoid of coordinates), whatever dtype the MLP computes in
+        delta = bbox_embed(output).float()
+        reference_points = reference_points.float()
         if reference_points.shape[-1] == 4:
             new = (delta + inverse_sigmoid(reference_points)).sigmoid()
         else:
@@ -178,7 +180,7 @@ class DetectionModule(nn.Module):
                                          device=src_flatten.device)
         level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
-        reference_points = self.reference_points(query_pos).sigmoid()
+        reference_points = self.reference_points(query_pos).float().sigmoid()
         reference_points = self.bbox_refine(self.bbox_embed[0], query_tgt, reference_points)
         return {
             'tgt': query_tgt,

@@ -63,10 +63,13 @@ class MSDeformAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, M, self.d_model // M)
-        offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
-        weights = F.softmax(self.attention_weights(query).view(N, Len_q, M, L * P), -1).view(N, Len_q, M, L, P)
+        # the (tiny) query-side arithmetic runs in fp32 whatever the projections' dtype: locations need sub-pixel precision
+        cdt = torch.float64 if value.dtype == torch.float64 else torch.float32
+        offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2).to(cdt)
+        weights = F.softmax(self.attention_weights(query).view(N, Len_q, M, L * P).to(cdt), -1).view(N, Len_q, M, L, P)
+        reference_points = reference_points.to(cdt)
         if reference_points.shape[-1] == 2:
-            wh = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+            wh = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1).to(cdt)
             locations = reference_points[:, :, None, :, None, :] + offsets / wh[None, None, None, :, None, :]
         elif reference_points.shape[-1] == 4:
             locations = reference_points[:, :, None, :, None, :2] \
@@ -74,8 +77,6 @@ class MSDeformAttn(nn.Module):
         else:
             raise ValueError('Last dim of reference_points must be 2 or 4, but get {} instead.'.format(
                 reference_points.shape[-1]))
-        # the sampling kernel runs in fp32 whatever the autocast dtype of the projections
-        cdt = torch.float64 if value.dtype == torch.float64 else torch.float32
-        sampled = deformable_sample(value, input_spatial_shapes, input_level_start_index, locations.to(cdt),
-                                    weights.to(cdt), self.im2col_step)
+        sampled = deformable_sample(value, input_spatial_shapes, input_level_start_index, locations, weights,
+                                    self.im2col_step)
         return self.output_proj(sampled.to(value.dtype))

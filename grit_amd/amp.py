@@ -49,7 +49,7 @@ class Bf16Compute(nn.Module):
 
     # ------------------------------------------------------------------ what the engine calls
     def forward(self, *args, **kwargs):
-        return self.module(*args, **kwargs)
+        return self.ddp(*args, **kwargs)  # resets .grad to None first: backward assigns, one packed copy per bucket
 
     def named_master_parameters(self):
         return list(self._masters)
@@ -62,7 +62,6 @@ class Bf16Compute(nn.Module):
     def after_optimizer_step(self):
         for b, compute_flat, master_flat, _ in self._pairs:
             compute_flat.copy_(master_flat)  # fp32 -> bf16
-            b.flat.zero_()
 
     def master_state_dict(self):
         """fp32 state dict under the reference's key names (masters for trainable tensors, upcast copies otherwise)."""

@@ -5,8 +5,10 @@ broadcast_buffers=False) and lets NCCL's ring all-reduce 25 MB buckets.  This is
 
   * gradients live in a few large *flat* buffers (default 64 MiB each; 288 GB of HBM makes big, few
     buckets the right trade on point-to-point xGMI where a collective is per-link bound and each extra
-    launch costs latency).  Every parameter's .grad is a view into its bucket, so there is no gather/
-    scatter copy around the collective and the optimizer reads the reduced values in place;
+    launch costs latency).  Autograd hands every parameter a fresh gradient tensor (.grad is None when
+    backward starts, so no per-parameter accumulate kernel runs); when the last gradient of a bucket has
+    arrived ONE multi-tensor copy packs them into the flat buffer, .grad is re-pointed at the views and the
+    collective starts -- the optimizer then reads the reduced values in place;
   * buckets are filled in reverse registration order (~ reverse of forward = the order backward produces
     gradients); a post-accumulate-grad hook counts arrivals and, when a bucket is complete, launches
     `all_reduce(flat, async_op=True)` -- on the `nccl` (= RCCL) backend that runs on the process group's
@@ -27,14 +29,15 @@ from torch import nn
 
 
 class _Bucket(object):
-    __slots__ = ('params', 'flat', 'pending', 'expected', 'work', 'wire')
+    __slots__ = ('params', 'views', 'flat', 'pending', 'expected', 'work', 'wire', 'packed')
 
-    def __init__(self, params, flat):
-        self.params, self.flat = params, flat
+    def __init__(self, params, views, flat):
+        self.params, self.views, self.flat = params, views, flat
         self.expected = len(params)
         self.pending = self.expected
         self.work = None
         self.wire = None
+        self.packed = False
 
 
 class BucketedDataParallel(nn.Module):
@@ -78,14 +81,15 @@ class BucketedDataParallel(nn.Module):
         for plist in groups:
             total = sum(p.numel() for p in plist)
             flat = torch.zeros(total, dtype=plist[0].dtype, device=plist[0].device)
-            off = 0
+            off, views = 0, []
             for p in plist:
                 view = flat[off:off + p.numel()].view_as(p)
                 if p.grad is not None:
                     view.copy_(p.grad)
-                p.grad = view  # autograd accumulates in place into the bucket from now on
+                    p.grad = view
+                views.append(view)
                 off += p.numel()
-            b = _Bucket(plist, flat)
+            b = _Bucket(plist, views, flat)
             for p in plist:
                 self._where[p] = b
             self.buckets.append(b)
@@ -99,7 +103,24 @@ class BucketedDataParallel(nn.Module):
             self._seen.add(param)
         b.pending -= 1
         if b.pending == 0:
+            self._pack(b)
             self._launch(b)
+
+    def _pack(self, b):
+        """Gradients of the bucket -> flat buffer with one multi-tensor copy; .grad becomes the view."""
+        if b.packed:
+            return
+        src, dst = [], []
+        for p, view in zip(b.params, b.views):
+            if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                src.append(p.grad)
+                dst.append(view)
+        if src:
+            torch._foreach_copy_(dst, src)
+        for p, view in zip(b.params, b.views):
+            if p.grad is not None:
+                p.grad = view
+        b.packed = True
 
     def _launch(self, b):
         if self.world == 1 or b.work is not None:
@@ -114,6 +135,7 @@ class BucketedDataParallel(nn.Module):
         """Launch what is still pending (first iteration / unused params), wait, average."""
         for b in self.buckets:
             if b.work is None:
+                self._pack(b)
                 self._launch(b)
         for b in self.buckets:
             if b.work is not None:
@@ -133,6 +155,10 @@ class BucketedDataParallel(nn.Module):
                 for p in unused:
                     p.grad = None
                 self._build_buckets(used)
+            elif unused:  # keep the layout, but a bucket is complete once its *used* parameters have arrived
+                dead = set(unused)
+                for b in self.buckets:
+                    b.expected = b.pending = sum(1 for p in b.params if p not in dead)
         self._iteration += 1
 
     @property
@@ -140,7 +166,16 @@ class BucketedDataParallel(nn.Module):
         return list(self._static_unused or [])
 
     def forward(self, *args, **kwargs):
+        self.release_gradients()
         return self.module(*args, **kwargs)
+
+    def release_gradients(self):
+        """Start of a step: .grad = None everywhere, so backward assigns instead of accumulating (no add kernels).
+        (Gradient accumulation over several backward passes is therefore not supported by this wrapper.)"""
+        for b in self.buckets:
+            b.packed = False
+            for p in b.params:
+                p.grad = None
 
     def gradient_bytes(self):
         return sum(b.flat.numel() * b.flat.element_size() for b in self.buckets)

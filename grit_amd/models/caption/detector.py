@@ -24,6 +24,17 @@ class Detector(nn.Module):
                 for c in backbone.num_channels
             ])
 
+    def project_level(self, level, feature):
+        """input_proj[level] = Conv2d 1x1 + GroupNorm(32) (reference models/caption/detector.py:28-33,58) on an NCHW map.
+        The 1x1 convolution runs as a GEMM on the token view of the map (the backbone hands out NCHW *views* of
+        token-major tensors, so the view is free); MIOpen's bf16 1x1 conv + weight-gradient kernels cost ~30 ms per
+        training step here, the GEMM ~1 ms.  Same parameters, same result."""
+        conv, gn = self.input_proj[level]
+        B, C, H, W = feature.shape
+        tokens = feature.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        y = F.linear(tokens, conv.weight.view(conv.out_channels, C), conv.bias)
+        return gn(y.transpose(1, 2).reshape(B, conv.out_channels, H, W))
+
     def forward(self, images: NestedTensor):
         """images.tensors [B,3,H,W], images.mask [B,H,W] (True on padding) ->
         {gri_feat [B,h*w,1024], gri_mask [B,1,1,h*w], reg_feat [B,150,512], reg_mask [B,1,1,150] (all False)}."""
@@ -37,7 +48,7 @@ class Detector(nn.Module):
             'gri_mask': masks[-1].flatten(1)[:, None, None, :],
         }
         if self.use_reg_feat:
-            srcs = [proj(f) for proj, f in zip(self.input_proj, features)]
+            srcs = [self.project_level(l, f) for l, f in enumerate(features)]
             hs, _, _ = self.det_module(srcs, masks)
             out['reg_feat'] = hs[-1]
             out['reg_mask'] = hs[-1].new_zeros((hs[-1].shape[0], 1, 1, hs[-1].shape[1])).bool()

@@ -257,16 +257,26 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
         self.norm = norm_layer(embed_dim) if norm_layer is not None else None
 
-    def forward(self, x):
+    def tokens(self, x):
+        """(B, 3, H, W) -> normalised patch tokens (B, H/4 * W/4, C), plus the token-map size.
+        A stride-p p x p convolution is a GEMM on non-overlapping patches: unfold by a view + one permute copy of the
+        (small) input, then F.linear with the conv weight flattened in its own (c, kh, kw) order.  MIOpen's bf16
+        convolution for this shape is two orders of magnitude slower than the GEMM on MI355X."""
         ph, pw = self.patch_size
         H, W = x.shape[-2:]
         if W % pw or H % ph:
             x = F.pad(x, (0, (pw - W % pw) % pw, 0, (ph - H % ph) % ph))
-        x = self.proj(x)
+        B, Cin, H, W = x.shape
+        Wh, Ww = H // ph, W // pw
+        patches = x.view(B, Cin, Wh, ph, Ww, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, Wh * Ww, Cin * ph * pw)
+        t = F.linear(patches, self.proj.weight.view(self.embed_dim, -1), self.proj.bias)
         if self.norm is not None:
-            B, C, Wh, Ww = x.shape
-            x = self.norm(x.flatten(2).transpose(1, 2)).transpose(1, 2).reshape(B, C, Wh, Ww)
-        return x
+            t = self.norm(t)
+        return t, Wh, Ww
+
+    def forward(self, x):
+        t, Wh, Ww = self.tokens(x)
+        return t.transpose(1, 2).reshape(x.shape[0], self.embed_dim, Wh, Ww)
 
 
 class SwinTransformer(nn.Module):
@@ -322,9 +332,11 @@ class SwinTransformer(nn.Module):
 
     def forward(self, x):
         B = x.shape[0]
-        x = self.patch_embed(x.to(self.patch_embed.proj.weight.dtype))
-        Wh, Ww = x.shape[2], x.shape[3]
-        x = self.pos_drop(x.flatten(2).transpose(1, 2))
+        x, Wh, Ww = self.patch_embed.tokens(x.to(self.patch_embed.proj.weight.dtype))
+        if self.ape:
+            pos = F.interpolate(self.absolute_pos_embed, size=(Wh, Ww), mode='bicubic')
+            x = x + pos.flatten(2).transpose(1, 2)
+        x = self.pos_drop(x)
         outs = []
         for i, stage in enumerate(self.layers):
             x_out, H, W, x, Wh, Ww = stage(x, Wh, Ww)

@@ -49,9 +49,6 @@ def _worker(rank, world, port, wire_bf16, ret):
     xs, ys = data[rank * 4:(rank + 1) * 4], target[rank * 4:(rank + 1) * 4]
     grads = []
     for it in range(3):
-        for p in model.parameters():
-            if p.grad is not None:
-                p.grad.zero_()
         loss = ((ddp(xs) - ys)**2).mean()
         loss.backward()
         ddp.finish_gradient_sync()

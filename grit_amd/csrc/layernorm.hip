@@ -1,0 +1,218 @@
+// LayerNorm forward / backward for the Swin token maps on gfx950 (rows = B*H*W tokens, C in {128..4096}).
+//
+// torch's bf16 LayerNorm kernels reach ~0.9 TB/s on these shapes on MI355X (profiles/r01: 18 ms of a 138 ms step);
+// the op is a pure HBM stream (read x, write y; backward read x, dy, write dx).  Here a row is spread over
+// C/8 lanes (<= 64) with one 16-byte load per lane per 512-channel chunk, several rows per wavefront when C < 512,
+// statistics in fp32 registers (two-pass on the register copy), wave-shuffle reductions, and -- backward -- dgamma /
+// dbeta accumulated in registers across a persistent row loop and flushed with one float atomic per channel per
+// workgroup.  Semantics: torch.nn.functional.layer_norm over the last dimension (reference modules use nn.LayerNorm:
+// models/common/swin_model.py:229,233,315).
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include "../../include/grit_hip.h"
+
+namespace {
+
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct Vec8<__hip_bfloat16> {
+    static __device__ __forceinline__ void load(const __hip_bfloat16* p, float (&v)[8]) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(__hip_bfloat16* p, const float (&v)[8]) {
+        typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+        v8bf o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
+        *reinterpret_cast<v8bf*>(p) = o;
+    }
+};
+
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// LPR lanes per row, CH chunks of 8 channels per lane: C = LPR * 8 * CH
+template <typename T, typename WT, int LPR, int CH>
+__global__ __launch_bounds__(256)
+void ln_fwd(const T* __restrict__ x, const WT* __restrict__ w, const WT* __restrict__ b, int rows, float eps,
+            T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+    constexpr int C = LPR * 8 * CH, R = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR;
+    const int row = (blockIdx.x * 4 + wave) * R + lane / LPR;
+    const int rc = min(row, rows - 1);
+    float v[CH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        Vec8<T>::load(x + (size_t)rc * C + (c * LPR + sub) * 8, v[c]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[c][i];
+    }
+    const float mu = row_sum<LPR>(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mu; q = fmaf(d, d, q); }
+    const float rs = rsqrtf(row_sum<LPR>(q) * (1.0f / C) + eps);
+    if (row < rows) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            float wv[8], bv[8], o[8];
+            Vec8<WT>::load(w + (c * LPR + sub) * 8, wv);
+            Vec8<WT>::load(b + (c * LPR + sub) * 8, bv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = fmaf((v[c][i] - mu) * rs, wv[i], bv[i]);
+            Vec8<T>::store(y + (size_t)row * C + (c * LPR + sub) * 8, o);
+        }
+        if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <typename T, typename WT, int LPR, int CH>
+__global__ __launch_bounds__(256)
+void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restrict__ dy, const float* __restrict__ mean,
+            const float* __restrict__ rstd, int rows, T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db) {
+    constexpr int C = LPR * 8 * CH, R = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR;
+    float wv[CH][8], aw[CH][8], ab[CH][8];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        Vec8<WT>::load(w + (c * LPR + sub) * 8, wv[c]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) aw[c][i] = ab[c][i] = 0.f;
+    }
+    const int rows_per_pass = gridDim.x * 4 * R;
+    for (int base = (blockIdx.x * 4 + wave) * R; base < rows; base += rows_per_pass) {  // wave-uniform trip count
+        const int row = base + lane / LPR;
+        const bool live = row < rows;
+        const int rc = live ? row : rows - 1;
+        const float mu = mean[rc], rs = rstd[rc];
+        float xh[CH][8], g[CH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            Vec8<T>::load(x + (size_t)rc * C + (c * LPR + sub) * 8, xh[c]);
+            Vec8<T>::load(dy + (size_t)rc * C + (c * LPR + sub) * 8, g[c]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xh[c][i] = (xh[c][i] - mu) * rs;
+                const float gw = g[c][i] * wv[c][i];
+                s1 += gw;
+                s2 = fmaf(gw, xh[c][i], s2);
+            }
+        }
+        s1 = row_sum<LPR>(s1) * (1.0f / C);
+        s2 = row_sum<LPR>(s2) * (1.0f / C);
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    o[i] = rs * (g[c][i] * wv[c][i] - s1 - xh[c][i] * s2);
+                    aw[c][i] = fmaf(g[c][i], xh[c][i], aw[c][i]);
+                    ab[c][i] += g[c][i];
+                }
+                Vec8<T>::store(dx + (size_t)row * C + (c * LPR + sub) * 8, o);
+            }
+        }
+    }
+    // rows handled side by side in one wave hold the same channels: fold them, fold the 4 waves through LDS, and
+    // write this workgroup's partial sums (no atomics: thousands of waves on <= 4096 addresses serialise badly)
+    __shared__ float part[4][2][512];  // per wave, (dw | db), one 512-channel chunk at a time
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float a = aw[c][i], bsum = ab[c][i];
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); bsum += __shfl_xor(bsum, o, 64); }
+            if (lane < LPR) { part[wave][0][sub * 8 + i] = a; part[wave][1][sub * 8 + i] = bsum; }
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < 2 * LPR * 8; j += 256) {
+            const int which = j / (LPR * 8), ch = j % (LPR * 8);
+            const float v = part[0][which][ch] + part[1][which][ch] + part[2][which][ch] + part[3][which][ch];
+            (which ? db : dw)[(size_t)blockIdx.x * C + c * LPR * 8 + ch] = v;
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int kBwdBlocks = 512;  // persistent backward grid = rows of the partial-sum workspace (GRIT_LN_BWD_PARTIALS)
+
+template <typename T, typename WT>
+int launch(bool fwd, const void* x, const void* w, const void* b_or_dy, const float* mean_in, const float* rstd_in, int rows,
+           int C, float eps, void* out, float* o1, float* o2, hipStream_t st) {
+#define GRIT_LN_CASE(LPR_, CH_)                                                                                        \
+    {                                                                                                                  \
+        constexpr int R = 64 / LPR_;                                                                                   \
+        const int blocks = (rows + 4 * R - 1) / (4 * R);                                                               \
+        if (fwd)                                                                                                       \
+            hipLaunchKernelGGL((ln_fwd<T, WT, LPR_, CH_>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const WT*)w,  \
+                               (const WT*)b_or_dy, rows, eps, (T*)out, o1, o2);                                        \
+        else                                                                                                           \
+            hipLaunchKernelGGL((ln_bwd<T, WT, LPR_, CH_>), dim3(blocks < kBwdBlocks ? blocks : kBwdBlocks), dim3(256), 0, st, \
+                               (const T*)x, (const WT*)w, (const T*)b_or_dy, mean_in, rstd_in, rows, (T*)out, o1, o2); \
+        return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;                                            \
+    }
+    switch (C) {
+        case 128: GRIT_LN_CASE(16, 1)
+        case 256: GRIT_LN_CASE(32, 1)
+        case 512: GRIT_LN_CASE(64, 1)
+        case 1024: GRIT_LN_CASE(64, 2)
+        case 2048: GRIT_LN_CASE(64, 4)
+        case 4096: GRIT_LN_CASE(64, 8)
+        default: return GRIT_ERR_UNSUPPORTED;
+    }
+#undef GRIT_LN_CASE
+}
+
+int dispatch(bool fwd, const void* x, const void* w, const void* b_or_dy, const float* mean_in, const float* rstd_in,
+             int rows, int C, float eps, int x_bf16, int w_bf16, void* out, float* o1, float* o2, hipStream_t st) {
+    if (!x || !w || !b_or_dy || !out || !o1 || !o2 || rows <= 0 || C <= 0) return GRIT_ERR_BAD_ARG;
+    if (x_bf16 && w_bf16) return launch<__hip_bfloat16, __hip_bfloat16>(fwd, x, w, b_or_dy, mean_in, rstd_in, rows, C, eps, out, o1, o2, st);
+    if (x_bf16) return launch<__hip_bfloat16, float>(fwd, x, w, b_or_dy, mean_in, rstd_in, rows, C, eps, out, o1, o2, st);
+    if (!w_bf16) return launch<float, float>(fwd, x, w, b_or_dy, mean_in, rstd_in, rows, C, eps, out, o1, o2, st);
+    return GRIT_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" {
+
+int grit_layernorm_fwd(const void* x, const void* weight, const void* bias, int rows, int C, float eps, int x_is_bf16,
+                       int w_is_bf16, void* y, float* mean, float* rstd, void* stream) {
+    return dispatch(true, x, weight, bias, nullptr, nullptr, rows, C, eps, x_is_bf16, w_is_bf16, y, mean, rstd, (hipStream_t)stream);
+}
+
+int grit_layernorm_bwd(const void* x, const void* weight, const void* dy, const float* mean, const float* rstd, int rows,
+                       int C, int x_is_bf16, int w_is_bf16, void* dx, float* dweight, float* dbias, void* stream) {
+    if (!mean || !rstd) return GRIT_ERR_BAD_ARG;
+    return dispatch(false, x, weight, dy, mean, rstd, rows, C, 0.f, x_is_bf16, w_is_bf16, dx, dweight, dbias, (hipStream_t)stream);
+}
+
+}  // extern "C"

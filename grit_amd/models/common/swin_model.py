@@ -26,6 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
+from grit_amd.ops.layer_norm import LayerNorm
 from grit_amd.ops.window_attention import window_attention
 
 
@@ -154,7 +155,7 @@ class WindowAttention(nn.Module):
 class SwinTransformerBlock(nn.Module):
 
     def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True, qk_scale=None,
-                 drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+                 drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=LayerNorm):
         super().__init__()
         assert 0 <= shift_size < window_size, "shift_size must in 0-window_size"
         self.dim, self.num_heads = dim, num_heads
@@ -181,7 +182,7 @@ class SwinTransformerBlock(nn.Module):
 class PatchMerging(nn.Module):
     """2x2 neighbourhood concat (order (0,0),(1,0),(0,1),(1,1)) -> LayerNorm(4C) -> Linear(4C -> 2C | pos_dim)."""
 
-    def __init__(self, dim, norm_layer=nn.LayerNorm, expand=True, pos_dim=768):
+    def __init__(self, dim, norm_layer=LayerNorm, expand=True, pos_dim=768):
         super().__init__()
         self.dim = dim
         out_dim = 2 * dim if expand else pos_dim
@@ -207,7 +208,7 @@ class BasicLayer(nn.Module):
     """One Swin stage: `depth` blocks alternating shift 0 / window//2, then the (always present) PatchMerging."""
 
     def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0.,
-                 attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, downsample=None, last=False,
+                 attn_drop=0., drop_path=0., norm_layer=LayerNorm, downsample=None, last=False,
                  use_checkpoint=False):
         super().__init__()
         self.window_size, self.shift_size = window_size, window_size // 2
@@ -284,7 +285,7 @@ class SwinTransformer(nn.Module):
 
     def __init__(self, pretrain_img_size=224, patch_size=4, in_chans=3, embed_dim=96, depths=[2, 2, 6, 2],
                  num_heads=[3, 6, 12, 24], window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0.,
-                 attn_drop_rate=0., drop_path_rate=0.2, norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
+                 attn_drop_rate=0., drop_path_rate=0.2, norm_layer=LayerNorm, ape=False, patch_norm=True,
                  out_indices=[1, 2, 3], frozen_stages=-1, use_checkpoint=False, pos_dim=768):
         super().__init__()
         self.pretrain_img_size = pretrain_img_size

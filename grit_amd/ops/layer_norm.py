@@ -1,0 +1,84 @@
+"""LayerNorm over the last dimension on the gfx950 streaming kernels (grit_layernorm_{fwd,bwd}).
+
+Used by the Swin backbone (norm1 / norm2 / patch-merging / patch-embed norms): there LayerNorm is a pure HBM
+stream over maps of up to 819 200 tokens and torch's bf16 kernels run at a fraction of the bandwidth.  Channel
+counts the kernels do not cover fall through to torch.nn.functional.layer_norm (a library op like the GEMMs)."""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from grit_amd import lib as _lib
+from grit_amd.ops import backend
+
+SUPPORTED_C = (128, 256, 512, 1024, 2048, 4096)
+LN_BWD_PARTIALS = 512  # GRIT_LN_BWD_PARTIALS in include/grit_hip.h
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class _LayerNormFn(Function):
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        xb, wb = int(x2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
+        with torch.cuda.device(x.device):
+            st = _lib.load().grit_layernorm_fwd(_ptr(x2), _ptr(weight), _ptr(bias), rows, C, eps, xb, wb, _ptr(y), _ptr(mean),
+                                                _ptr(rstd), _lib.current_stream_ptr())
+        _lib.check(st, "grit_layernorm_fwd")
+        ctx.save_for_backward(x2, weight, mean, rstd)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, weight, mean, rstd = ctx.saved_tensors
+        rows, C = x2.shape
+        dy2 = dy.reshape(rows, C)
+        if not dy2.is_contiguous() or dy2.dtype != x2.dtype:
+            dy2 = dy2.to(x2.dtype).contiguous()
+        dx = torch.empty_like(x2)
+        dwb = torch.zeros(2, LN_BWD_PARTIALS, C, dtype=torch.float32, device=x2.device)  # per-workgroup partial sums
+        xb, wb = int(x2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
+        with torch.cuda.device(x2.device):
+            st = _lib.load().grit_layernorm_bwd(_ptr(x2), _ptr(weight), _ptr(dy2), _ptr(mean), _ptr(rstd), rows, C, xb, wb,
+                                                _ptr(dx), _ptr(dwb[0]), _ptr(dwb[1]), _lib.current_stream_ptr())
+        _lib.check(st, "grit_layernorm_bwd")
+        sums = dwb.sum(1)
+        return dx.view(ctx.shape), sums[0].to(weight.dtype), sums[1].to(weight.dtype), None
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    ov = backend.override()
+    if ov is not None and hasattr(ov, "layer_norm"):
+        return ov.layer_norm(x, weight, bias, eps)
+    C = x.shape[-1]
+    fits = (x.is_cuda and C in SUPPORTED_C and weight is not None and bias is not None
+            and x.dtype in (torch.float32, torch.bfloat16) and weight.dtype == bias.dtype
+            and (weight.dtype == x.dtype or (x.dtype == torch.bfloat16 and weight.dtype == torch.float32)))
+    if not fits:
+        return F.layer_norm(x, (C,), weight, bias, eps)
+    return _LayerNormFn.apply(x, weight.contiguous(), bias.contiguous(), float(eps))
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters / state-dict keys) whose forward runs the streaming HIP kernels."""
+
+    def forward(self, input):
+        if len(self.normalized_shape) != 1 or not self.elementwise_affine:
+            return super().forward(input)
+        return layer_norm(input, self.weight, self.bias, self.eps)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 3
+#define GRIT_ABI_VERSION 4
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -136,6 +136,21 @@ int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pa
                           const void* out, const void* dout, const float* lse,
                           int B, int H, int W, int C, int num_heads, int window, int shift, float scale,
                           void* dqkv, float* drel_bias, float* dpad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension for the Swin token maps (nn.LayerNorm at swin_model.py:229,233,315,495).
+ *   x, y, dy, dx  [rows, C] contiguous, f32 (x_is_bf16 = 0) or bf16 (1);  C in {128, 256, 512, 1024, 2048, 4096}
+ *   weight, bias  [C], f32 or bf16 (w_is_bf16); the combination f32 x with bf16 weight is not provided
+ *   mean, rstd    [rows] f32, written by forward, read by backward
+ *   dweight/dbias [GRIT_LN_BWD_PARTIALS, C] f32 per-workgroup partial sums: rows [0, min(ceil(rows / rows_per_block),
+ *                 GRIT_LN_BWD_PARTIALS)) are overwritten, the caller zero-fills the buffer and sums over dim 0
+ * Statistics and arithmetic are fp32; eps as in torch.nn.functional.layer_norm.
+ * ------------------------------------------------------------------------------------------------------ */
+#define GRIT_LN_BWD_PARTIALS 512
+int grit_layernorm_fwd(const void* x, const void* weight, const void* bias, int rows, int C, float eps, int x_is_bf16,
+                       int w_is_bf16, void* y, float* mean, float* rstd, void* stream);
+int grit_layernorm_bwd(const void* x, const void* weight, const void* dy, const float* mean, const float* rstd, int rows,
+                       int C, int x_is_bf16, int w_is_bf16, void* dx, float* dweight, float* dbias, void* stream);
 
 #ifdef __cplusplus
 }

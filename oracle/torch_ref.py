@@ -124,3 +124,8 @@ def attention(q, k, v, mask=None, scale=None, dropout_p=0.0, training=False):
         p = F.dropout(p, dropout_p, True)
     out = torch.matmul(p, v.permute(0, 2, 1, 3))  # [B,H,Tq,D]
     return out.permute(0, 2, 1, 3).reshape(B, Tq, Hh * D)
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    """torch.nn.functional.layer_norm over the last dimension (what nn.LayerNorm does in the reference)."""
+    return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)

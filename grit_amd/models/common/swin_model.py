@@ -104,6 +104,21 @@ def _relative_position_index(wh, ww):
     return dy * (2 * ww - 1) + dx
 
 
+_ONEHOT_CACHE = {}
+
+
+def _onehot_index(index, n_rel, dtype):
+    """[N*N, n_rel rounded up to 32] one-hot rows of the relative-position index; one copy per (device, dtype)."""
+    key = (index.device, dtype, n_rel, index.numel())
+    hit = _ONEHOT_CACHE.get(key)
+    if hit is None:
+        cols = -(-n_rel // 32) * 32
+        hit = torch.zeros(index.numel(), cols, dtype=dtype, device=index.device)
+        hit.scatter_(1, index.reshape(-1, 1), 1.0)
+        _ONEHOT_CACHE[key] = hit
+    return hit
+
+
 class WindowAttention(nn.Module):
     """Window multi-head self-attention with relative position bias; shifted or not."""
 
@@ -126,9 +141,14 @@ class WindowAttention(nn.Module):
             raise NotImplementedError("attention-probability dropout is not fused (GRIT uses attn_drop_rate=0)")
 
     def relative_position_bias(self):
-        """[nH, N, N] float32, gathered from the table (differentiable w.r.t. the table)."""
+        """[nH, N, N] float32 = table[relative_position_index] (reference :168-171), computed as a one-hot GEMM:
+        exact (one non-zero product per output), and its backward is a plain GEMM instead of torch's sort-based
+        index_put (22 sorts + scatter kernels per step on the 20 736-entry index)."""
         n = self.window_size[0] * self.window_size[1]
-        bias = self.relative_position_bias_table[self.relative_position_index.view(-1)]
+        table = self.relative_position_bias_table
+        onehot = _onehot_index(self.relative_position_index, table.shape[0], table.dtype)
+        pad = onehot.shape[1] - table.shape[0]
+        bias = onehot @ (F.pad(table, (0, 0, 0, pad)) if pad else table)  # [N*N, nH]
         return bias.view(n, n, -1).permute(2, 0, 1).contiguous().float()
 
     def pad_qkv(self, dtype):
@@ -175,8 +195,17 @@ class SwinTransformerBlock(nn.Module):
         B, L, C = x.shape
         H, W = self.H, self.W
         assert L == H * W, "input feature has wrong size"
-        x = x + self.drop_path(self.attn.attend_map(self.norm1(x), H, W, self.shift_size))
-        return x + self.drop_path(self.mlp(self.norm2(x)))
+        x = self._residual(x, self.attn.attend_map(self.norm1(x), H, W, self.shift_size))
+        return self._residual(x, self.mlp(self.norm2(x)))
+
+    def _residual(self, x, branch):
+        """x + drop_path(branch) as ONE elementwise kernel (addcmul with the per-sample keep/scale mask)."""
+        dp = self.drop_path
+        if isinstance(dp, DropPath) and dp.drop_prob > 0. and self.training:
+            keep = 1.0 - dp.drop_prob
+            mask = x.new_empty((x.shape[0], 1, 1)).bernoulli_(keep).div_(keep)
+            return torch.addcmul(x, branch, mask)
+        return x + branch
 
 
 class PatchMerging(nn.Module):

@@ -52,11 +52,16 @@ class _LayerNormFn(Function):
         if not dy2.is_contiguous() or dy2.dtype != x2.dtype:
             dy2 = dy2.to(x2.dtype).contiguous()
         dx = torch.empty_like(x2)
-        dwb = torch.zeros(2, LN_BWD_PARTIALS, C, dtype=torch.float32, device=x2.device)  # per-workgroup partial sums
+        # per-workgroup partial sums; the kernel launches min(ceil(rows / rows_per_block), 512) workgroups and every
+        # one of them writes its row, so the buffer needs no zero fill
+        rows_per_block = 4 * (64 // min(C // 8, 64))
+        nblk = min(-(-rows // rows_per_block), LN_BWD_PARTIALS)
+        dwb = torch.empty(2, LN_BWD_PARTIALS, C, dtype=torch.float32, device=x2.device)[:, :nblk]
         xb, wb = int(x2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
         with torch.cuda.device(x2.device):
+            base = dwb._base if dwb._base is not None else dwb
             st = _lib.load().grit_layernorm_bwd(_ptr(x2), _ptr(weight), _ptr(dy2), _ptr(mean), _ptr(rstd), rows, C, xb, wb,
-                                                _ptr(dx), _ptr(dwb[0]), _ptr(dwb[1]), _lib.current_stream_ptr())
+                                                _ptr(dx), _ptr(base[0]), _ptr(base[1]), _lib.current_stream_ptr())
         _lib.check(st, "grit_layernorm_bwd")
         sums = dwb.sum(1)
         return dx.view(ctx.shape), sums[0].to(weight.dtype), sums[1].to(weight.dtype), None

@@ -21,7 +21,9 @@
 //
 // No hipify, no CUDA dual path: this file only builds for gfx950.
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/grit_hip.h"
 
 namespace {
@@ -272,6 +274,179 @@ void msda_bwd_generic(const T* __restrict__ value, const int64_t* __restrict__ s
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 value maps (training path: value_proj output stays bf16, no fp32 staging copy).  D = 64.
+// Forward: a (pixel, head) slice is 128 bytes = 8 lanes x 16 bytes, so a wave covers 8 sampling points at once.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(w[i] << 16);
+        f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+
+template <int NIT>
+__global__ __launch_bounds__(kWave * kRowsPerBlock)
+void msda_fwd_bf16_d64(const __hip_bfloat16* __restrict__ value, const int64_t* __restrict__ shapes,
+                       const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
+                       int S, int M, int L, int Lq, int P, __hip_bfloat16* __restrict__ out, int nrows, int nblk) {
+    constexpr int D = 64, LPP = 8, G = 8;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int row = xcd_logical_block(blockIdx.x, nblk) * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int LP = L * P;
+    const int m = row % M;
+    const int b = (row / M) / Lq;
+    const float locv = lane < 2 * LP ? loc[(size_t)row * 2 * LP + lane] : 0.f;
+    const float awv = lane < LP ? aw[(size_t)row * LP + lane] : 0.f;
+    const int g = lane / LPP, c8 = lane % LPP;
+    const __hip_bfloat16* vrow = value + (size_t)b * S * M * D + (size_t)m * D + c8 * 8;
+    const size_t pix_stride = (size_t)M * D;
+
+    uint4 v[NIT][4];
+    float cw[NIT][4];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * G + g;
+        const bool have = idx < LP;
+        const int idc = have ? idx : LP - 1;
+        const float x = __shfl(locv, 2 * idc, kWave);
+        const float y = __shfl(locv, 2 * idc + 1, kWave);
+        const float wt = have ? __shfl(awv, idc, kWave) : 0.f;
+        const int l = idc / P;
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const __hip_bfloat16* vl = vrow + (size_t)lsi[l] * pix_stride;
+        const Corners<float> c = make_corners<float>(x, y, H, W);
+        v[it][0] = *reinterpret_cast<const uint4*>(vl + (size_t)c.o1 * pix_stride);
+        v[it][1] = *reinterpret_cast<const uint4*>(vl + (size_t)c.o2 * pix_stride);
+        v[it][2] = *reinterpret_cast<const uint4*>(vl + (size_t)c.o3 * pix_stride);
+        v[it][3] = *reinterpret_cast<const uint4*>(vl + (size_t)c.o4 * pix_stride);
+        cw[it][0] = c.k1 ? c.w1 * wt : 0.f;
+        cw[it][1] = c.k2 ? c.w2 * wt : 0.f;
+        cw[it][2] = c.k3 ? c.w3 * wt : 0.f;
+        cw[it][3] = c.k4 ? c.w4 * wt : 0.f;
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float w = cw[it][k];
+            float f[8];
+            unpack8(v[it][k], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += w != 0.f ? w * f[e] : 0.f;
+        }
+#pragma unroll
+    for (int off = LPP; off < kWave; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], off, kWave);
+    if (lane < LPP) {
+        typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+        v8bf o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[e];
+        *reinterpret_cast<v8bf*>(out + (size_t)row * D + lane * 8) = o;
+    }
+}
+
+__device__ __forceinline__ float ldv(const float* p) { return *p; }
+__device__ __forceinline__ float ldv(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+
+
+// 64-value butterfly: every lane holds v[0..63]; after 6 halving exchanges lane L holds the wave-wide sum of
+// v[bitreverse6(L)].  63 shuffles instead of 64 x 6 for separate reductions.
+template <int N>
+__device__ __forceinline__ void halve_step(float (&v)[64], int lane, int off) {
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+        const bool hi = lane & off;
+        const float keep = hi ? v[2 * i + 1] : v[2 * i];
+        const float send = hi ? v[2 * i] : v[2 * i + 1];
+        v[i] = keep + __shfl_xor(send, off, kWave);
+    }
+}
+
+// Backward for D = 64, L*P <= 16, value / grad_out in f32 or bf16: one wave per (b, q, m) row, lane = channel.
+// (Measured alternatives, see profiles/r01/msda_bwd_ablation.txt: keeping the coarse levels' gradient in LDS with
+//  ds_add_f32 is SLOWER than global float atomics on gfx950 -- ~150 cycles per LDS float-atomic wave instruction --
+//  and software-pipelining rows at 8 waves/CU loses more from the lower occupancy than it hides.)
+template <typename VT>
+__global__ __launch_bounds__(kWave * kRowsPerBlock)
+void msda_bwd_d64(const VT* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                  const float* __restrict__ loc, const float* __restrict__ aw, const VT* __restrict__ grad_out,
+                  int S, int M, int L, int Lq, int P, float* __restrict__ grad_value, float* __restrict__ grad_loc,
+                  float* __restrict__ grad_aw, int nrows, int nblk) {
+    constexpr int D = 64, kMaxLP = 16;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int row = xcd_logical_block(blockIdx.x, nblk) * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int LP = L * P;
+    const int m = row % M;
+    const int b = (row / M) / Lq;
+    const int pix_stride = M * D;
+    const size_t head_off = (size_t)b * S * pix_stride + (size_t)m * D;
+    const VT* vhead = value + head_off + lane;
+    float* ghead = grad_value + head_off + lane;
+
+    // geometry ONCE per row, point p on lane p (the reference and the generic kernel redo it on every channel lane);
+    // the per-point scalars then reach all lanes through v_readlane (SGPRs: scalar branches, scalar addresses)
+    const int pi = min(lane, LP - 1), pl = pi / P;
+    const int pH = (int)shapes[2 * pl], pW = (int)shapes[2 * pl + 1], pst = (int)lsi[pl];
+    const float go = ldv(grad_out + (size_t)row * D + lane);
+    const float px = loc[(size_t)row * 2 * LP + 2 * pi], py = loc[(size_t)row * 2 * LP + 2 * pi + 1];
+    const float pwt = lane < LP ? aw[(size_t)row * LP + pi] : 0.f;
+    const Corners<float> c = make_corners<float>(px, py, pH, pW);
+    const int e1 = pst + c.o1, e2 = pst + c.o2, e3 = pst + c.o3, e4 = pst + c.o4;
+    const int flags = lane < LP ? ((c.k1 ? 1 : 0) | (c.k2 ? 2 : 0) | (c.k3 ? 4 : 0) | (c.k4 ? 8 : 0)) : 0;
+    const float fW = (float)pW * pwt, fH = (float)pH * pwt;
+
+    float part[64];  // [0,16): grad_attn_w per point, [16,48): grad_loc (x, y) per point, rest zero
+#pragma unroll
+    for (int i = 0; i < 64; ++i) part[i] = 0.f;
+#pragma unroll
+    for (int p = 0; p < kMaxLP; ++p) {
+        if (p < LP) {
+            const int f = __builtin_amdgcn_readlane(flags, p);
+            const int s1 = __builtin_amdgcn_readlane(e1, p), s2 = __builtin_amdgcn_readlane(e2, p);
+            const int s3 = __builtin_amdgcn_readlane(e3, p), s4 = __builtin_amdgcn_readlane(e4, p);
+            const float lh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.lh), p));
+            const float lw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.lw), p));
+            const float wt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pwt), p));
+            const float sW = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fW), p));
+            const float sH = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fH), p));
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            // clamped indices are always legal: load all four, select by the validity bits
+            const float r1 = ldv(vhead + (size_t)s1 * pix_stride), r2 = ldv(vhead + (size_t)s2 * pix_stride);
+            const float r3 = ldv(vhead + (size_t)s3 * pix_stride), r4 = ldv(vhead + (size_t)s4 * pix_stride);
+            const float a1 = (f & 1) ? r1 : 0.f, a2 = (f & 2) ? r2 : 0.f, a3 = (f & 4) ? r3 : 0.f, a4 = (f & 8) ? r4 : 0.f;
+            const float tgv = go * wt;
+            if (f & 1) atomic_add_fast(ghead + (size_t)s1 * pix_stride, hh * hw * tgv);
+            if (f & 2) atomic_add_fast(ghead + (size_t)s2 * pix_stride, hh * lw * tgv);
+            if (f & 4) atomic_add_fast(ghead + (size_t)s3 * pix_stride, lh * hw * tgv);
+            if (f & 8) atomic_add_fast(ghead + (size_t)s4 * pix_stride, lh * lw * tgv);
+            const float gh = -hw * a1 - lw * a2 + hw * a3 + lw * a4;
+            const float gw = -hh * a1 + hh * a2 - lh * a3 + lh * a4;
+            const float val = hh * hw * a1 + hh * lw * a2 + lh * hw * a3 + lh * lw * a4;
+            part[p] = go * val;
+            part[16 + 2 * p] = sW * gw * go;
+            part[17 + 2 * p] = sH * gh * go;
+        }
+    }
+    halve_step<64>(part, lane, 32);
+    halve_step<32>(part, lane, 16);
+    halve_step<16>(part, lane, 8);
+    halve_step<8>(part, lane, 4);
+    halve_step<4>(part, lane, 2);
+    halve_step<2>(part, lane, 1);
+    const int j = (int)(__brev((unsigned)lane) >> 26);  // index of the value this lane now owns
+    if (j < LP) grad_aw[(size_t)row * LP + j] = part[0];
+    else if (j >= 16 && j < 16 + 2 * LP) grad_loc[(size_t)row * 2 * LP + (j - 16)] = part[0];
+}
+
 bool dims_ok(int B, int S, int M, int D, int L, int Lq, int P) {
     if (B <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return false;
     const long long rows = (long long)B * Lq * M;
@@ -312,6 +487,17 @@ int launch_fwd(const T* value, const int64_t* shapes, const int64_t* lsi, const 
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 
+template <typename VT>
+int launch_bwd_d64(const VT* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* aw,
+                   const VT* go, int B, int S, int M, int L, int Lq, int P, float* gv, float* gl, float* gw,
+                   hipStream_t st) {
+    const int nrows = B * Lq * M;
+    const int nblk = (nrows + kRowsPerBlock - 1) / kRowsPerBlock;
+    hipLaunchKernelGGL((msda_bwd_d64<VT>), dim3(nblk), dim3(kWave * kRowsPerBlock), 0, st, value, shapes, lsi, loc, aw, go,
+                       S, M, L, Lq, P, gv, gl, gw, nrows, nblk);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
 template <typename T>
 int launch_bwd(const T* value, const int64_t* shapes, const int64_t* lsi, const T* loc, const T* aw,
                const T* go, int B, int S, int M, int D, int L, int Lq, int P,
@@ -321,6 +507,9 @@ int launch_bwd(const T* value, const int64_t* shapes, const int64_t* lsi, const 
     const int nrows = B * Lq * M;
     const int nblk = (nrows + kRowsPerBlock - 1) / kRowsPerBlock;
     const dim3 grid(nblk), block(kWave * kRowsPerBlock);
+    if constexpr (sizeof(T) == 4) {
+        if (D == 64 && L * P <= 16) return launch_bwd_d64<float>(value, shapes, lsi, loc, aw, go, B, S, M, L, Lq, P, gv, gl, gw, st);
+    }
     if ((L * P) % 4 == 0)
         hipLaunchKernelGGL((msda_bwd_generic<T, 4>), grid, block, 0, st, value, shapes, lsi, loc, aw, go,
                            S, M, D, L, Lq, P, gv, gl, gw, nrows, nblk);
@@ -362,6 +551,36 @@ int grit_msda_bwd_f64(const double* value, const int64_t* spatial_shapes, const 
                       double* grad_attn_w, void* stream) {
     return launch_bwd<double>(value, spatial_shapes, level_start, loc, attn_w, grad_out, B, S, M, D, L, Lq,
                               P, grad_value, grad_loc, grad_attn_w, (hipStream_t)stream);
+}
+
+int grit_msda_fwd_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start, const float* loc,
+                       const float* attn_w, int B, int S, int M, int D, int L, int Lq, int P, void* out, void* stream) {
+    if (!value || !spatial_shapes || !level_start || !loc || !attn_w || !out) return GRIT_ERR_BAD_ARG;
+    if (!dims_ok(B, S, M, D, L, Lq, P)) return GRIT_ERR_BAD_ARG;
+    const int LP = L * P;
+    if (D != 64 || LP > 32 || ((uintptr_t)value % 16) || ((uintptr_t)out % 16)) return GRIT_ERR_UNSUPPORTED;
+    const int nrows = B * Lq * M;
+    const int nblk = (nrows + kRowsPerBlock - 1) / kRowsPerBlock;
+    const dim3 grid(nblk), block(kWave * kRowsPerBlock);
+    const int nit = (LP + 7) / 8;
+#define GRIT_FWD16(NIT_)                                                                                          \
+    hipLaunchKernelGGL((msda_fwd_bf16_d64<NIT_>), grid, block, 0, (hipStream_t)stream, (const __hip_bfloat16*)value, \
+                       spatial_shapes, level_start, loc, attn_w, S, M, L, Lq, P, (__hip_bfloat16*)out, nrows, nblk)
+    if (nit == 1) GRIT_FWD16(1); else if (nit == 2) GRIT_FWD16(2); else if (nit == 3) GRIT_FWD16(3); else GRIT_FWD16(4);
+#undef GRIT_FWD16
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+int grit_msda_bwd_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start, const float* loc,
+                       const float* attn_w, const void* grad_out, int B, int S, int M, int D, int L, int Lq, int P,
+                       float* grad_value, float* grad_loc, float* grad_attn_w, void* stream) {
+    if (!value || !spatial_shapes || !level_start || !loc || !attn_w || !grad_out || !grad_value || !grad_loc || !grad_attn_w)
+        return GRIT_ERR_BAD_ARG;
+    if (!dims_ok(B, S, M, D, L, Lq, P)) return GRIT_ERR_BAD_ARG;
+    if (D != 64 || L * P > 16) return GRIT_ERR_UNSUPPORTED;
+    return launch_bwd_d64<__hip_bfloat16>((const __hip_bfloat16*)value, spatial_shapes, level_start, loc, attn_w,
+                                            (const __hip_bfloat16*)grad_out, B, S, M, L, Lq, P, grad_value, grad_loc,
+                                            grad_attn_w, (hipStream_t)stream);
 }
 
 }  // extern "C"

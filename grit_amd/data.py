@@ -34,7 +34,8 @@ def synthetic_batch(batch_size, height=640, width=640, caption_len=20, vocab_siz
             n = max(3, caption_len - (b % 5))
             caps[b, n - 1] = EOS
             caps[b, n:] = PAD
-    return {'samples': NestedTensor(images, mask).to(device), 'captions': caps.to(device)}
+    return {'samples': NestedTensor(images, mask, any_padding=bool(ragged and batch_size > 1)).to(device),
+            'captions': caps.to(device)}
 
 
 class SyntheticLoader(object):

@@ -49,7 +49,7 @@ class Detector(nn.Module):
         }
         if self.use_reg_feat:
             srcs = [self.project_level(l, f) for l, f in enumerate(features)]
-            hs, _, _ = self.det_module(srcs, masks)
+            hs, _, _ = self.det_module(srcs, masks, no_padding=getattr(images, 'any_padding', None) is False)
             out['reg_feat'] = hs[-1]
             out['reg_mask'] = hs[-1].new_zeros((hs[-1].shape[0], 1, 1, hs[-1].shape[1])).bool()
         return out

@@ -193,8 +193,12 @@ class DetectionModule(nn.Module):
             'reference_points': reference_points,
         }
 
-    def forward(self, srcs, masks):
+    def forward(self, srcs, masks, no_padding=False):
+        """no_padding=True (caller knows every mask is all-False) drops the padding mask handed to MSDeformAttn, whose
+        masked_fill would be a full copy of each value map that changes nothing."""
         od = self.prepare_od_inputs(srcs, masks)
+        if no_padding:
+            od['src_padding_mask'] = None
         init_reference_out = od['reference_points']
         hs, refs = [od['tgt']], [init_reference_out]
         for lid, layer in enumerate(self.decoder_layers):

@@ -74,8 +74,20 @@ def _compute_dtype(t):
     return torch.float64 if t.dtype == torch.float64 else torch.float32
 
 
+def _bf16_fast_path(value, D, L, P):
+    return value.dtype == torch.bfloat16 and D == 64 and L * P <= 16
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
     B, S, M, D, L, Lq, P = _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    if _bf16_fast_path(value, D, L, P):  # value map stays bf16: no fp32 staging copy
+        loc, aw = sampling_loc.float(), attn_weight.float()
+        out = torch.empty((B, Lq, M * D), dtype=torch.bfloat16, device=value.device)
+        with torch.cuda.device(value.device), _Timed("fwd", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, 4)):
+            st = _lib.load().grit_msda_fwd_bf16(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc),
+                                                _ptr(aw), B, S, M, D, L, Lq, P, _ptr(out), _lib.current_stream_ptr())
+        _lib.check(st, "grit_msda_fwd_bf16")
+        return out
     cdt = _compute_dtype(value)
     v, loc, aw = value.to(cdt), sampling_loc.to(cdt), attn_weight.to(cdt)
     out = torch.empty((B, Lq, M * D), dtype=cdt, device=value.device)
@@ -91,6 +103,17 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                             im2col_step=64):
     B, S, M, D, L, Lq, P = _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
     _lib.require_device(grad_output)
+    if _bf16_fast_path(value, D, L, P):
+        loc, aw = sampling_loc.float(), attn_weight.float()
+        go = grad_output.to(torch.bfloat16).contiguous()
+        gv = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
+        gl, ga = torch.empty_like(loc), torch.empty_like(aw)
+        with torch.cuda.device(value.device), _Timed("bwd", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 4)):
+            st = _lib.load().grit_msda_bwd_bf16(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc),
+                                                _ptr(aw), _ptr(go), B, S, M, D, L, Lq, P, _ptr(gv), _ptr(gl), _ptr(ga),
+                                                _lib.current_stream_ptr())
+        _lib.check(st, "grit_msda_bwd_bf16")
+        return [gv.to(torch.bfloat16), gl.to(sampling_loc.dtype), ga.to(attn_weight.dtype)]
     cdt = _compute_dtype(value)
     v, loc, aw = value.to(cdt), sampling_loc.to(cdt), attn_weight.to(cdt)
     go = grad_output.to(cdt).contiguous()

@@ -15,13 +15,17 @@ from torch import Tensor
 class NestedTensor(object):
     """A batch of images zero-padded to a common size + a bool mask that is True on the padding."""
 
-    def __init__(self, tensors, mask: Optional[Tensor]):
+    def __init__(self, tensors, mask: Optional[Tensor], any_padding: Optional[bool] = None):
         self.tensors = tensors
         self.mask = mask
+        # host-side knowledge about the mask: False = the builder knows no pixel is padding (all images the same
+        # size), True = some are, None = unknown.  Lets the detector skip the no-op masked_fill of every value map
+        # without a device->host sync; the result is identical either way.
+        self.any_padding = any_padding
 
     def to(self, device, non_blocking=False):
         mask = None if self.mask is None else self.mask.to(device, non_blocking=non_blocking)
-        return NestedTensor(self.tensors.to(device, non_blocking=non_blocking), mask)
+        return NestedTensor(self.tensors.to(device, non_blocking=non_blocking), mask, self.any_padding)
 
     def record_stream(self, *args, **kwargs):
         self.tensors.record_stream(*args, **kwargs)
@@ -48,7 +52,7 @@ def nested_tensor_from_tensor_list(tensor_list: List[Tensor]):
     for i, img in enumerate(tensor_list):
         batch[i, :img.shape[0], :img.shape[1], :img.shape[2]].copy_(img)
         mask[i, :img.shape[1], :img.shape[2]] = False
-    return NestedTensor(batch, mask)
+    return NestedTensor(batch, mask, any_padding=any(int(t.shape[1]) != h or int(t.shape[2]) != w for t in tensor_list))
 
 
 def inverse_sigmoid(x, eps=1e-5):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 4
+#define GRIT_ABI_VERSION 5
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -77,6 +77,15 @@ int grit_msda_bwd_f64(const double* value, const int64_t* spatial_shapes, const 
                       const double* loc, const double* attn_w, const double* grad_out,
                       int B, int S, int M, int D, int L, int Lq, int P,
                       double* grad_value, double* grad_loc, double* grad_attn_w, void* stream);
+
+/* bf16 value maps (D = 64, L*P <= 32): value / out / grad_out are bf16, loc / attn_w and every gradient stay f32.
+ * grad_value is f32 [B,S,M,64], zeroed by the caller, accumulated with float atomics.  Other shapes (L*P > 16 for
+ * backward): GRIT_ERR_UNSUPPORTED (the caller converts to f32 and uses the entry points above). */
+int grit_msda_fwd_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start, const float* loc,
+                       const float* attn_w, int B, int S, int M, int D, int L, int Lq, int P, void* out, void* stream);
+int grit_msda_bwd_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start, const float* loc,
+                       const float* attn_w, const void* grad_out, int B, int S, int M, int D, int L, int Lq, int P,
+                       float* grad_value, float* grad_loc, float* grad_attn_w, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Scaled-dot attention core, fp32 arithmetic, head_dim D = 64 (also the 150-query

@@ -164,3 +164,39 @@ def test_shim_module_name():
     out = MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 64)
     gv, gl, ga = MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, aw, torch.ones_like(out), 64)
     assert out.shape == (1, 4, 512) and gv.shape == value.shape and gl.shape == loc.shape and ga.shape == aw.shape
+
+
+def test_bf16_value_maps_forward_backward():
+    """Training path: value / grad_out in bf16 (grit_msda_{fwd,bwd}_bf16), oracle in fp32 on the same rounded inputs."""
+    value, shapes, lsi, loc, aw = _config2(B=2)
+    v16 = value.bfloat16()
+    cot = torch.randn(2, 150, 512, generator=torch.Generator().manual_seed(5)).bfloat16()
+    out, gv, gl, ga = _run(v16.to(DEV), shapes.to(DEV), lsi.to(DEV), loc.to(DEV), aw.to(DEV), cot.to(DEV))
+    assert out.dtype == torch.bfloat16 and gv.dtype == torch.bfloat16
+    vr, cr = v16.float().numpy(), cot.float().numpy()
+    ref = omsda.msda_forward(vr, shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy())
+    ogv, ogl, oga = omsda.msda_backward(vr, shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy(), cr)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)          # bf16 output rounding
+    np.testing.assert_allclose(gv.float().cpu().numpy(), ogv, rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(ga.cpu().numpy(), oga, rtol=1e-4, atol=1e-4)                       # fp32 accumulations
+    np.testing.assert_allclose(gl.cpu().numpy(), ogl, rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("B", [1, 4, 32])
+def test_owner_backward_query_splits_and_levels(B):
+    """LDS-accumulating backward: 1 workgroup per (b, head) at B = 32, query splits (atomic tile flush) at small B;
+    a level layout where only the last level fits on chip and one where every level does."""
+    gen = torch.Generator().manual_seed(B)
+    for shapes_l in ([(40, 40), (20, 20), (10, 10), (5, 5)], [(9, 7), (5, 4), (3, 2)], [(30, 30), (28, 28)]):
+        shapes = torch.tensor(shapes_l)
+        lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+        S, L, M, D, Lq, P = int(shapes.prod(1).sum()), len(shapes_l), 8, 64, 40, 4
+        value = torch.randn(B, S, M, D, generator=gen)
+        loc = torch.rand(B, Lq, M, L, P, 2, generator=gen) * 1.2 - 0.1
+        aw = torch.rand(B, Lq, M, L, P, generator=gen)
+        cot = torch.randn(B, Lq, M * D, generator=gen)
+        out, gv, gl, ga = _run(value.to(DEV), shapes.to(DEV), lsi.to(DEV), loc.to(DEV), aw.to(DEV), cot.to(DEV))
+        ogv, ogl, oga = omsda.msda_backward(value.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy(), cot.numpy())
+        np.testing.assert_allclose(gv.cpu().numpy(), ogv, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(ga.cpu().numpy(), oga, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(gl.cpu().numpy(), ogl, rtol=1e-3, atol=2e-3)

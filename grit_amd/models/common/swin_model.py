@@ -27,6 +27,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from grit_amd.ops.layer_norm import LayerNorm
+from grit_amd.ops.linear import Linear
 from grit_amd.ops.window_attention import window_attention
 
 
@@ -57,9 +58,9 @@ class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
         super().__init__()
         hidden_features = hidden_features or in_features
-        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc1 = Linear(in_features, hidden_features)
         self.act = act_layer()
-        self.fc2 = nn.Linear(hidden_features, out_features or in_features)
+        self.fc2 = Linear(hidden_features, out_features or in_features)
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
@@ -131,9 +132,9 @@ class WindowAttention(nn.Module):
         n_rel = (2 * window_size[0] - 1) * (2 * window_size[1] - 1)
         self.relative_position_bias_table = nn.Parameter(torch.zeros(n_rel, num_heads))
         self.register_buffer("relative_position_index", _relative_position_index(*window_size))
-        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim)
+        self.proj = Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
         nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
         self.softmax = nn.Softmax(dim=-1)

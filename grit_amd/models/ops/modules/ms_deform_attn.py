@@ -9,6 +9,8 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
+from grit_amd.ops.linear import Linear
+
 from ..functions.ms_deform_attn_func import deformable_sample
 
 
@@ -30,7 +32,7 @@ class MSDeformAttn(nn.Module):
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
         self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
         self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
-        self.value_proj = nn.Linear(d_model, d_model)
+        self.value_proj = Linear(d_model, d_model)  # M = B*S rows: split-K weight gradient
         self.output_proj = nn.Linear(d_model, d_model)
         self._reset_parameters()
 

@@ -1,0 +1,98 @@
+"""nn.Linear with a backward arranged for MI355X on the long token maps of GRIT (M = 51 200 .. 272 000 rows).
+
+The GEMMs stay library GEMMs (hipBLASLt through F.linear / torch.mm / torch.bmm -- plumbing); what changes is how the
+weight gradient is posed.  dW = dY^T X reduces over M: one [N, K] output of at most a few hundred 256x256 tiles with a
+51 200+-deep inner dimension leaves most of the 256 CUs idle or forces the library into slow split kernels (measured,
+tuned: 203 us for 2048x512 @ M = 51 200, 452 us for 256x1024 @ M = 204 800).  Splitting M into S slabs and running ONE
+batched GEMM with fp32 partials (bmm, out_dtype = float32) followed by a sum over the S partials fills the chip:
+132 us and 136 us for the same problems (tools/_dw_bench.py).  The bias gradient db = colsum(dY) uses the streaming
+column-sum kernel (grit_colsum).  Used for the four Linears of every Swin block and MSDeformAttn.value_proj."""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from grit_amd import lib as _lib
+from grit_amd.ops import backend
+
+MIN_ROWS = 4096  # below this the launch overhead dominates: leave it to torch
+
+
+def column_sum(x2d):
+    """[M, N] (bf16 / f32, contiguous, N % 8 == 0) -> f32 [N]."""
+    M, N = x2d.shape
+    slabs = max(1, min(256, (M * N) // (1 << 18), 2048 // max(1, (N + 511) // 512)))
+    partial = torch.empty(slabs, N, dtype=torch.float32, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        st = _lib.load().grit_colsum(ctypes.c_void_p(x2d.data_ptr()), M, N, int(x2d.dtype == torch.bfloat16), slabs,
+                                     ctypes.c_void_p(partial.data_ptr()), _lib.current_stream_ptr())
+    _lib.check(st, "grit_colsum")
+    return partial.sum(0) if slabs > 1 else partial[0]
+
+
+def split_k(M):
+    """Number of row slabs for the weight-gradient GEMM: ~3 200-6 400 rows per slab, at most 64, dividing M."""
+    if M < 25600:
+        return 1
+    s = min(64, M // 3200)
+    while s > 1 and M % s:
+        s -= 1
+    return s
+
+
+def weight_grad(dy2, x2):
+    """dW [N, K] = dy2^T [N, M] @ x2 [M, K], split over M into one batched GEMM with fp32 partial sums."""
+    M, N = dy2.shape
+    S = split_k(M) if (dy2.is_cuda and dy2.dtype == torch.bfloat16) else 1
+    if S == 1:
+        return torch.mm(dy2.t(), x2)
+    part = torch.bmm(dy2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, x2.shape[1]), out_dtype=torch.float32)
+    return part.sum(0).to(dy2.dtype)
+
+
+class _LinearFn(Function):
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dy2, weight).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = weight_grad(dy2, x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = column_sum(dy2).to(weight.dtype)
+        return dx, dw, db
+
+
+def linear(x, weight, bias):
+    fits = (backend.override() is None and x.is_cuda and torch.is_grad_enabled() and bias is not None
+            and (x.requires_grad or weight.requires_grad) and x.dtype == weight.dtype
+            and x.dtype in (torch.bfloat16, torch.float32) and weight.shape[0] % 8 == 0
+            and x.numel() // x.shape[-1] >= MIN_ROWS)
+    if not fits:
+        return F.linear(x, weight, bias)
+    return _LinearFn.apply(x, weight, bias)
+
+
+class Linear(nn.Linear):
+    """Same parameters / state-dict keys as nn.Linear."""
+
+    def forward(self, input):
+        return linear(input, self.weight, self.bias)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 5
+#define GRIT_ABI_VERSION 6
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -160,6 +160,13 @@ int grit_layernorm_fwd(const void* x, const void* weight, const void* bias, int 
                        int w_is_bf16, void* y, float* mean, float* rstd, void* stream);
 int grit_layernorm_bwd(const void* x, const void* weight, const void* dy, const float* mean, const float* rstd, int rows,
                        int C, int x_is_bf16, int w_is_bf16, void* dx, float* dweight, float* dbias, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Column sums (bias gradient of nn.Linear: db = sum over rows of dY).  x [M, N] row-major, f32 or bf16, N % 8 == 0.
+ * partial [slabs, N] f32 is fully overwritten: row s holds the sums over row slab s; the caller adds the slabs.
+ * ------------------------------------------------------------------------------------------------------ */
+#define GRIT_COLSUM_MAX_SLABS 256
+int grit_colsum(const void* x, int M, int N, int x_is_bf16, int slabs, float* partial, void* stream);
 
 #ifdef __cplusplus
 }

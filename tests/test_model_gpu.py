@@ -110,3 +110,28 @@ def test_fp32_training_step_gradients_close_to_reference():
             norms[top] = norms.get(top, 0.0) + float(p.grad.double().pow(2).sum())
     for k, v in ref["grad_norms"].items():
         assert abs(norms[k]**0.5 - v) < 5e-2 * v, (k, norms[k]**0.5, v)
+
+
+def test_beam_search_batched_equals_per_image(g7_model):
+    """BASELINE config 5 property: data-parallel beam decode must give the tokens of a single-image run bit for bit
+    (no cross-image coupling anywhere: per-sample norms, per-row softmax, per-(batch,beam) state gathers)."""
+    model, cfg = g7_model
+    g = load("model_g7.npz")
+    gen = torch.Generator().manual_seed(11)
+    feats = []
+    for i in range(3):  # three different "images": the reference features perturbed
+        feats.append({"gri_feat": t(g["gri_feat"], device=DEV) + 0.3 * i * torch.randn(1, 16, 1024, generator=gen).to(DEV),
+                      "reg_feat": t(g["reg_feat"], device=DEV) + 0.3 * i * torch.randn(1, 150, 512, generator=gen).to(DEV),
+                      "gri_mask": t(g["gri_mask"], device=DEV), "reg_mask": t(g["reg_mask"], device=DEV)})
+    batch = {k: torch.cat([f[k] for f in feats], 0) for k in feats[0]}
+    model.cached_features = True
+    try:
+        with torch.no_grad():
+            tb, lb = model(batch, seq=None, use_beam_search=True, max_len=20, eos_idx=3, beam_size=5, out_size=1)
+            singles = [model(f, seq=None, use_beam_search=True, max_len=20, eos_idx=3, beam_size=5, out_size=1)[0] for f in feats]
+    finally:
+        model.cached_features = False
+    assert tb.shape == (3, 20)
+    for i, s in enumerate(singles):
+        assert torch.equal(tb[i:i + 1], s), i
+    assert not torch.equal(tb[0], tb[2])  # the perturbation actually changes the caption

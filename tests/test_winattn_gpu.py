@@ -125,3 +125,28 @@ def test_layer_norm_kernels_vs_torch(C, dtype, wdtype):
     for got, ref in ((wd.grad, wr.grad), (bd.grad, br.grad)):
         scale = ref.abs().max().item()
         assert (got.float().cpu() - ref.float()).abs().max().item() < (2e-2 if wdtype == torch.bfloat16 else 2e-3) * scale
+
+
+@pytest.mark.parametrize("M,N,dtype", [(51200, 512, torch.bfloat16), (4097, 1536, torch.bfloat16), (5000, 2048, torch.float32),
+                                       (204800, 256, torch.bfloat16), (4096, 8, torch.float32)])
+def test_column_sum_and_linear_backward(M, N, dtype):
+    """grit_colsum (bias gradient of the Swin Linears) against a float64 sum; Linear module grads vs nn.Linear."""
+    from grit_amd.ops.linear import Linear, column_sum
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, N, generator=g).to(dtype).to(DEV)
+    ref = x.double().sum(0)
+    got = column_sum(x)
+    scale = ref.abs().max().item()
+    assert (got.double() - ref).abs().max().item() < 1e-5 * scale + 1e-3
+    if N >= 256:
+        return
+    lin = Linear(N, 16).to(DEV).to(dtype)
+    ref_lin = torch.nn.Linear(N, 16).to(DEV).to(dtype)
+    ref_lin.load_state_dict(lin.state_dict())
+    a = x.clone().requires_grad_(True)
+    b_ = x.clone().requires_grad_(True)
+    cot = torch.randn(M, 16, generator=g).to(dtype).to(DEV)
+    lin(a).backward(cot)
+    ref_lin(b_).backward(cot)
+    for p, q in ((a.grad, b_.grad), (lin.weight.grad, ref_lin.weight.grad), (lin.bias.grad, ref_lin.bias.grad)):
+        assert torch.allclose(p.float(), q.float(), rtol=2e-2, atol=2e-2 * q.float().abs().max().item())

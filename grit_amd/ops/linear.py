@@ -5,7 +5,7 @@ weight gradient is posed.  dW = dY^T X reduces over M: one [N, K] output of at m
 51 200+-deep inner dimension leaves most of the 256 CUs idle or forces the library into slow split kernels (measured,
 tuned: 203 us for 2048x512 @ M = 51 200, 452 us for 256x1024 @ M = 204 800).  Splitting M into S slabs and running ONE
 batched GEMM with fp32 partials (bmm, out_dtype = float32) followed by a sum over the S partials fills the chip:
-132 us and 136 us for the same problems (tools/_dw_bench.py).  The bias gradient db = colsum(dY) uses the streaming
+132 us and 136 us for the same problems (tools/bench_weight_grad.py).  The bias gradient db = colsum(dY) uses the streaming
 column-sum kernel (grit_colsum).  Used for the four Linears of every Swin block and MSDeformAttn.value_proj."""
 import ctypes
 

@@ -1,3 +1,4 @@
+"""Microbenchmark behind grit_amd/ops/linear.py: dW = dY^T X as one torch.mm vs split-M batched GEMMs (fp32 partials)."""
 import torch, time
 def t(fn, it=30):
     for _ in range(5): fn()

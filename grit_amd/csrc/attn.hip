@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256)
 void attn_fwd_kernel(const T* __restrict__ q, long ldq, long bsq, const T* __restrict__ k, long ldk, long bsk,
                      const T* __restrict__ v, long ldv, long bsv, const uint8_t* __restrict__ mask, long msb, long msq,
                      int H, int Tq, int Nk, float scale, float drop_p, unsigned long long seed,
-                     T* __restrict__ out, float* __restrict__ lse) {
+                     const unsigned long long* __restrict__ seed_dev, T* __restrict__ out, float* __restrict__ lse) {
+    if (seed_dev) seed ^= *seed_dev;  // device-resident seed: graph replays draw fresh masks
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                  // [Nk][65]
     float* Vs = smem + (size_t)Nk * 65;  // [Nk][64]
@@ -145,7 +146,9 @@ void attn_bwd_kernel(const T* __restrict__ q, long ldq, long bsq, const T* __res
                      const T* __restrict__ v, long ldv, long bsv, const uint8_t* __restrict__ mask, long msb, long msq,
                      const T* __restrict__ out, const T* __restrict__ dout, const float* __restrict__ lse,
                      int H, int Tq, int Nk, float scale, float drop_p, unsigned long long seed,
-                     T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv) {
+                     const unsigned long long* __restrict__ seed_dev, T* __restrict__ dq, T* __restrict__ dk,
+                     T* __restrict__ dv) {
+    if (seed_dev) seed ^= *seed_dev;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dKs = smem;                          // [Nk][64]
     float* dVs = smem + (size_t)Nk * 64;        // [Nk][64]
@@ -228,7 +231,7 @@ bool args_ok(int B, int H, int Tq, int Nk, int D) { return B > 0 && H > 0 && Tq 
 template <typename T>
 int launch_fwd(const T* q, long ldq, long bsq, const T* k, long ldk, long bsk, const T* v, long ldv, long bsv,
                const uint8_t* mask, long msb, long msq, int B, int H, int Tq, int Nk, int D, float scale, float drop_p,
-               unsigned long long seed, T* out, float* lse, hipStream_t st) {
+               unsigned long long seed, const unsigned long long* seed_dev, T* out, float* lse, hipStream_t st) {
     if (!q || !k || !v || !out || !lse || !args_ok(B, H, Tq, Nk, D)) return GRIT_ERR_BAD_ARG;
     if (D != kD || Nk > kMaxNk || drop_p < 0.f || drop_p >= 1.f) return GRIT_ERR_UNSUPPORTED;
     const size_t lds = (size_t)Nk * (65 + 64) * sizeof(float);
@@ -238,15 +241,15 @@ int launch_fwd(const T* q, long ldq, long bsq, const T* k, long ldk, long bsk, c
         return GRIT_ERR_LAUNCH;
     const dim3 grid(B * H, (Tq + kRowsPerBlockFwd - 1) / kRowsPerBlockFwd), block(256);
     hipLaunchKernelGGL(kern, grid, block, lds, st, q, ldq, bsq, k, ldk, bsk, v, ldv, bsv, mask, msb, msq, H, Tq, Nk,
-                       scale, drop_p, seed, out, lse);
+                       scale, drop_p, seed, seed_dev, out, lse);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 
 template <typename T>
 int launch_bwd(const T* q, long ldq, long bsq, const T* k, long ldk, long bsk, const T* v, long ldv, long bsv,
                const uint8_t* mask, long msb, long msq, const T* out, const T* dout, const float* lse, int B, int H,
-               int Tq, int Nk, int D, float scale, float drop_p, unsigned long long seed, T* dq, T* dk, T* dv,
-               hipStream_t st) {
+               int Tq, int Nk, int D, float scale, float drop_p, unsigned long long seed,
+               const unsigned long long* seed_dev, T* dq, T* dk, T* dv, hipStream_t st) {
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !args_ok(B, H, Tq, Nk, D)) return GRIT_ERR_BAD_ARG;
     if (D != kD || Nk > kMaxNk || drop_p < 0.f || drop_p >= 1.f) return GRIT_ERR_UNSUPPORTED;
     const int threads = 512;
@@ -256,7 +259,7 @@ int launch_bwd(const T* q, long ldq, long bsq, const T* k, long ldk, long bsk, c
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return GRIT_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(B * H), dim3(threads), lds, st, q, ldq, bsq, k, ldk, bsk, v, ldv, bsv, mask, msb, msq,
-                       out, dout, lse, H, Tq, Nk, scale, drop_p, seed, dq, dk, dv);
+                       out, dout, lse, H, Tq, Nk, scale, drop_p, seed, seed_dev, dq, dk, dv);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 
@@ -268,19 +271,20 @@ extern "C" {
     int grit_attn_fwd_##SUF(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk, int64_t bsk,      \
                             const void* v, int64_t ldv, int64_t bsv, const uint8_t* mask, int64_t mask_sb,         \
                             int64_t mask_sq, int B, int H, int Tq, int Nk, int D, float scale, float dropout_p,    \
-                            uint64_t seed, void* out, float* lse, void* stream) {                                  \
+                            uint64_t seed, const uint64_t* seed_dev, void* out, float* lse, void* stream) {        \
         return launch_fwd<T>((const T*)q, ldq, bsq, (const T*)k, ldk, bsk, (const T*)v, ldv, bsv, mask, mask_sb,   \
-                             mask_sq, B, H, Tq, Nk, D, scale, dropout_p, seed, (T*)out, lse, (hipStream_t)stream); \
+                             mask_sq, B, H, Tq, Nk, D, scale, dropout_p, seed,                                      \
+                             (const unsigned long long*)seed_dev, (T*)out, lse, (hipStream_t)stream);              \
     }
 #define GRIT_ATTN_BWD(SUF, T)                                                                                       \
     int grit_attn_bwd_##SUF(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk, int64_t bsk,      \
                             const void* v, int64_t ldv, int64_t bsv, const uint8_t* mask, int64_t mask_sb,         \
                             int64_t mask_sq, const void* out, const void* dout, const float* lse, int B, int H,    \
-                            int Tq, int Nk, int D, float scale, float dropout_p, uint64_t seed, void* dq, void* dk, \
-                            void* dv, void* stream) {                                                              \
+                            int Tq, int Nk, int D, float scale, float dropout_p, uint64_t seed,                    \
+                            const uint64_t* seed_dev, void* dq, void* dk, void* dv, void* stream) {                \
         return launch_bwd<T>((const T*)q, ldq, bsq, (const T*)k, ldk, bsk, (const T*)v, ldv, bsv, mask, mask_sb,   \
                              mask_sq, (const T*)out, (const T*)dout, lse, B, H, Tq, Nk, D, scale, dropout_p, seed, \
-                             (T*)dq, (T*)dk, (T*)dv, (hipStream_t)stream);                                         \
+                             (const unsigned long long*)seed_dev, (T*)dq, (T*)dk, (T*)dv, (hipStream_t)stream);    \
     }
 
 GRIT_ATTN_FWD(f32, float)
@@ -289,31 +293,34 @@ GRIT_ATTN_BWD(f32, float)
 // bf16 storage: matrix-core kernels (attn_mfma.hip) when the shape fits, else the fp32-arithmetic kernels above
 int grit_attn_fwd_bf16(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk, int64_t bsk, const void* v,
                        int64_t ldv, int64_t bsv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq, int B, int H,
-                       int Tq, int Nk, int D, float scale, float dropout_p, uint64_t seed, void* out, float* lse,
-                       void* stream) {
+                       int Tq, int Nk, int D, float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                       void* out, float* lse, void* stream) {
     if (!q || !k || !v || !out || !lse || !args_ok(B, H, Tq, Nk, D)) return GRIT_ERR_BAD_ARG;
     if (dropout_p < 0.f || dropout_p >= 1.f) return GRIT_ERR_UNSUPPORTED;
     const int st = grit_attn_mfma_fwd(q, ldq, bsq, k, ldk, bsk, v, ldv, bsv, mask, mask_sb, mask_sq, B, H, Tq, Nk, D, scale,
-                                      dropout_p, seed, out, lse, (hipStream_t)stream);
+                                      dropout_p, seed, (const unsigned long long*)seed_dev, out, lse, (hipStream_t)stream);
     if (st != GRIT_ERR_UNSUPPORTED) return st;
     using T = __hip_bfloat16;
     return launch_fwd<T>((const T*)q, ldq, bsq, (const T*)k, ldk, bsk, (const T*)v, ldv, bsv, mask, mask_sb, mask_sq, B, H,
-                         Tq, Nk, D, scale, dropout_p, seed, (T*)out, lse, (hipStream_t)stream);
+                         Tq, Nk, D, scale, dropout_p, seed, (const unsigned long long*)seed_dev, (T*)out, lse,
+                         (hipStream_t)stream);
 }
 
 int grit_attn_bwd_bf16(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk, int64_t bsk, const void* v,
                        int64_t ldv, int64_t bsv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq, const void* out,
                        const void* dout, const float* lse, int B, int H, int Tq, int Nk, int D, float scale,
-                       float dropout_p, uint64_t seed, void* dq, void* dk, void* dv, void* stream) {
+                       float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* dq, void* dk, void* dv,
+                       void* stream) {
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !args_ok(B, H, Tq, Nk, D)) return GRIT_ERR_BAD_ARG;
     if (dropout_p < 0.f || dropout_p >= 1.f) return GRIT_ERR_UNSUPPORTED;
     const int st = grit_attn_mfma_bwd(q, ldq, bsq, k, ldk, bsk, v, ldv, bsv, mask, mask_sb, mask_sq, out, dout, lse, B, H, Tq,
-                                      Nk, D, scale, dropout_p, seed, dq, dk, dv, (hipStream_t)stream);
+                                      Nk, D, scale, dropout_p, seed, (const unsigned long long*)seed_dev, dq, dk, dv,
+                                      (hipStream_t)stream);
     if (st != GRIT_ERR_UNSUPPORTED) return st;
     using T = __hip_bfloat16;
     return launch_bwd<T>((const T*)q, ldq, bsq, (const T*)k, ldk, bsk, (const T*)v, ldv, bsv, mask, mask_sb, mask_sq,
-                         (const T*)out, (const T*)dout, lse, B, H, Tq, Nk, D, scale, dropout_p, seed, (T*)dq, (T*)dk,
-                         (T*)dv, (hipStream_t)stream);
+                         (const T*)out, (const T*)dout, lse, B, H, Tq, Nk, D, scale, dropout_p, seed,
+                         (const unsigned long long*)seed_dev, (T*)dq, (T*)dk, (T*)dv, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -8,8 +8,10 @@
 
 int grit_attn_mfma_fwd(const void* q, long ldq, long bsq, const void* k, long ldk, long bsk, const void* v, long ldv,
                        long bsv, const uint8_t* mask, long msb, long msq, int B, int H, int Tq, int Nk, int D, float scale,
-                       float drop_p, unsigned long long seed, void* out, float* lse, hipStream_t st);
+                       float drop_p, unsigned long long seed, const unsigned long long* seed_dev, void* out, float* lse,
+                       hipStream_t st);
 int grit_attn_mfma_bwd(const void* q, long ldq, long bsq, const void* k, long ldk, long bsk, const void* v, long ldv,
                        long bsv, const uint8_t* mask, long msb, long msq, const void* out, const void* dout,
                        const float* lse, int B, int H, int Tq, int Nk, int D, float scale, float drop_p,
-                       unsigned long long seed, void* dq, void* dk, void* dv, hipStream_t st);
+                       unsigned long long seed, const unsigned long long* seed_dev, void* dq, void* dk, void* dv,
+                       hipStream_t st);

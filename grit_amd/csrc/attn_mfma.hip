@@ -65,7 +65,8 @@ __global__ __launch_bounds__(640)
 void attn_mfma_fwd(const __bf16* __restrict__ q, long ldq, long bsq, const __bf16* __restrict__ k, long ldk, long bsk,
                    const __bf16* __restrict__ v, long ldv, long bsv, const uint8_t* __restrict__ mask, long msb, long msq,
                    int H, int Tq, int Nk, float scale, float drop_p, unsigned long long seed,
-                   __bf16* __restrict__ out, float* __restrict__ lse2) {
+                   const unsigned long long* __restrict__ seed_dev, __bf16* __restrict__ out, float* __restrict__ lse2) {
+    if (seed_dev) seed ^= *seed_dev;  // device-resident seed: graph replays draw fresh masks
     __shared__ __attribute__((aligned(16))) __bf16 Ks[kRows * kP];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[kRows * kP];
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
@@ -154,7 +155,9 @@ void attn_mfma_bwd(const __bf16* __restrict__ q, long ldq, long bsq, const __bf1
                    const __bf16* __restrict__ v, long ldv, long bsv, const uint8_t* __restrict__ mask, long msb, long msq,
                    const __bf16* __restrict__ out, const __bf16* __restrict__ dout, const float* __restrict__ lse2,
                    int H, int Tq, int Nk, float scale, float drop_p, unsigned long long seed,
-                   __bf16* __restrict__ dq, __bf16* __restrict__ dk, __bf16* __restrict__ dv) {
+                   const unsigned long long* __restrict__ seed_dev, __bf16* __restrict__ dq, __bf16* __restrict__ dk,
+                   __bf16* __restrict__ dv) {
+    if (seed_dev) seed ^= *seed_dev;
     __shared__ __attribute__((aligned(16))) __bf16 Qs[kRows * kP];
     __shared__ __attribute__((aligned(16))) __bf16 dOs[kRows * kP];
     __shared__ __attribute__((aligned(16))) __bf16 Ks[kRows * kP];
@@ -304,24 +307,26 @@ bool fits(const void* q, long ldq, long bsq, const void* k, long ldk, long bsk, 
 
 int grit_attn_mfma_fwd(const void* q, long ldq, long bsq, const void* k, long ldk, long bsk, const void* v, long ldv,
                        long bsv, const uint8_t* mask, long msb, long msq, int B, int H, int Tq, int Nk, int D, float scale,
-                       float drop_p, unsigned long long seed, void* out, float* lse, hipStream_t st) {
+                       float drop_p, unsigned long long seed, const unsigned long long* seed_dev, void* out, float* lse,
+                       hipStream_t st) {
     if (!fits(q, ldq, bsq, k, ldk, bsk, v, ldv, bsv, Tq, Nk, D) || (uintptr_t)out % 16) return GRIT_ERR_UNSUPPORTED;
     const int waves = (Tq + 15) / 16;
     hipLaunchKernelGGL(attn_mfma_fwd, dim3(B * H), dim3(64 * waves), 0, st, (const __bf16*)q, ldq, bsq, (const __bf16*)k,
-                       ldk, bsk, (const __bf16*)v, ldv, bsv, mask, msb, msq, H, Tq, Nk, scale, drop_p, seed, (__bf16*)out, lse);
+                       ldk, bsk, (const __bf16*)v, ldv, bsv, mask, msb, msq, H, Tq, Nk, scale, drop_p, seed, seed_dev, (__bf16*)out, lse);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 
 int grit_attn_mfma_bwd(const void* q, long ldq, long bsq, const void* k, long ldk, long bsk, const void* v, long ldv,
                        long bsv, const uint8_t* mask, long msb, long msq, const void* out, const void* dout,
                        const float* lse, int B, int H, int Tq, int Nk, int D, float scale, float drop_p,
-                       unsigned long long seed, void* dq, void* dk, void* dv, hipStream_t st) {
+                       unsigned long long seed, const unsigned long long* seed_dev, void* dq, void* dk, void* dv,
+                       hipStream_t st) {
     if (!fits(q, ldq, bsq, k, ldk, bsk, v, ldv, bsv, Tq, Nk, D)) return GRIT_ERR_UNSUPPORTED;
     if ((uintptr_t)out % 16 || (uintptr_t)dout % 16 || (uintptr_t)dq % 16 || (uintptr_t)dk % 16 || (uintptr_t)dv % 16)
         return GRIT_ERR_UNSUPPORTED;
     const int waves = (max(Tq, Nk) + 15) / 16;
     hipLaunchKernelGGL(attn_mfma_bwd, dim3(B * H), dim3(64 * waves), 0, st, (const __bf16*)q, ldq, bsq, (const __bf16*)k,
                        ldk, bsk, (const __bf16*)v, ldv, bsv, mask, msb, msq, (const __bf16*)out, (const __bf16*)dout, lse,
-                       H, Tq, Nk, scale, drop_p, seed, (__bf16*)dq, (__bf16*)dk, (__bf16*)dv);
+                       H, Tq, Nk, scale, drop_p, seed, seed_dev, (__bf16*)dq, (__bf16*)dk, (__bf16*)dv);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }

@@ -49,7 +49,7 @@ def _mask_args(mask, B, Tq, Nk):
 class _AttentionFn(Function):
 
     @staticmethod
-    def forward(ctx, q, k, v, mask, scale, dropout_p, seed):
+    def forward(ctx, q, k, v, mask, scale, dropout_p, seed, seed_dev=None):
         B, Tq, H, D = q.shape
         Nk = k.shape[1]
         q, ldq, bsq = _rows(q)
@@ -62,16 +62,16 @@ class _AttentionFn(Function):
         fn = L.grit_attn_fwd_bf16 if q.dtype == torch.bfloat16 else L.grit_attn_fwd_f32
         with torch.cuda.device(q.device):
             st = fn(_ptr(q), ldq, bsq, _ptr(k), ldk, bsk, _ptr(v), ldv, bsv, _ptr(m), msb, msq, B, H, Tq, Nk, D,
-                    scale, dropout_p, seed, _ptr(out), _ptr(lse), _lib.current_stream_ptr())
+                    scale, dropout_p, seed, _ptr(seed_dev), _ptr(out), _ptr(lse), _lib.current_stream_ptr())
         _lib.check(st, "grit_attn_fwd")
-        ctx.save_for_backward(q, k, v, m, out, lse)
+        ctx.save_for_backward(q, k, v, m, out, lse, seed_dev)
         ctx.args = (scale, dropout_p, seed, msb, msq)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        q, k, v, m, out, lse = ctx.saved_tensors
+        q, k, v, m, out, lse, seed_dev = ctx.saved_tensors
         scale, dropout_p, seed, msb, msq = ctx.args
         B, Tq, H, D = q.shape
         Nk = k.shape[1]
@@ -84,9 +84,9 @@ class _AttentionFn(Function):
         with torch.cuda.device(q.device):
             st = fn(_ptr(q), q.stride(1), q.stride(0), _ptr(k), k.stride(1), k.stride(0), _ptr(v), v.stride(1),
                     v.stride(0), _ptr(m), msb, msq, _ptr(out), _ptr(dout), _ptr(lse), B, H, Tq, Nk, D, scale,
-                    dropout_p, seed, _ptr(dq), _ptr(dk), _ptr(dv), _lib.current_stream_ptr())
+                    dropout_p, seed, _ptr(seed_dev), _ptr(dq), _ptr(dk), _ptr(dv), _lib.current_stream_ptr())
         _lib.check(st, "grit_attn_bwd")
-        return dq, dk, dv, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None
 
 
 def attention(q, k, v, mask=None, scale=None, dropout_p=0.0, training=False):
@@ -103,5 +103,7 @@ def attention(q, k, v, mask=None, scale=None, dropout_p=0.0, training=False):
         q = q.float()
     k, v = k.to(q.dtype), v.to(q.dtype)
     p = float(dropout_p) if training else 0.0
-    seed = int(torch.randint(0, 2**31 - 1, (1,)).item()) if p > 0 else 0
-    return _AttentionFn.apply(q, k, v, mask, float(scale), p, seed)
+    # the dropout seed lives in device memory and is drawn by torch's (graph-safe) device generator: no host sync, and
+    # a captured step (grit_amd/graphs.py) draws a fresh mask on every replay
+    seed_dev = torch.empty(1, dtype=torch.int64, device=q.device).random_() if p > 0 else None
+    return _AttentionFn.apply(q, k, v, mask, float(scale), p, 0, seed_dev)

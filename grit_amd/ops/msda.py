@@ -40,7 +40,7 @@ class _Timed(object):
         self.kind, self.nbytes = kind, nbytes
 
     def __enter__(self):
-        self.on = PROFILE_EVENTS is not None
+        self.on = PROFILE_EVENTS is not None and not torch.cuda.is_current_stream_capturing()
         if self.on:
             self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self.a.record()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 6
+#define GRIT_ABI_VERSION 7
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -98,28 +98,30 @@ int grit_msda_bwd_bf16(const void* value, const int64_t* spatial_shapes, const i
  *          (reference masks are [B,1,T,T], [B,1,1,Nk]: attention.py:79-80, cap_generator.py:126-136)
  *   out    [B, Tq, H*64] contiguous;   lse [B, H, Tq] row log-sum-exp of the scaled, masked scores
  *   P = softmax(scale * q k^T masked);  dropout_p > 0 drops entries of P with a counter hash of `seed`
- *   (the backward call must pass the same seed);  out = P_drop v.
+ *   (the backward call must pass the same seed);  out = P_drop v.  The effective seed is `seed ^ *seed_dev` when
+ *   seed_dev (device uint64, may be NULL) is given: a seed that lives in device memory can be refreshed by a captured
+ *   RNG kernel, so a hipGraph replay of the step draws a new mask each time.
  *   A fully masked row yields NaN, as torch.softmax over all -inf does in the reference.
  * Backward overwrites dq [B,Tq,H,64], dk, dv [B,Nk,H,64] (contiguous); no atomics to global memory.
  * ------------------------------------------------------------------------------------------------------ */
 int grit_attn_fwd_f32(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk, int64_t bsk,
                       const void* v, int64_t ldv, int64_t bsv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
                       int B, int H, int Tq, int Nk, int D, float scale, float dropout_p, uint64_t seed,
-                      void* out, float* lse, void* stream);
+                      const uint64_t* seed_dev, void* out, float* lse, void* stream);
 int grit_attn_fwd_bf16(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk, int64_t bsk,
                        const void* v, int64_t ldv, int64_t bsv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
                        int B, int H, int Tq, int Nk, int D, float scale, float dropout_p, uint64_t seed,
-                       void* out, float* lse, void* stream);
+                       const uint64_t* seed_dev, void* out, float* lse, void* stream);
 int grit_attn_bwd_f32(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk, int64_t bsk,
                       const void* v, int64_t ldv, int64_t bsv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
                       const void* out, const void* dout, const float* lse,
                       int B, int H, int Tq, int Nk, int D, float scale, float dropout_p, uint64_t seed,
-                      void* dq, void* dk, void* dv, void* stream);
+                      const uint64_t* seed_dev, void* dq, void* dk, void* dv, void* stream);
 int grit_attn_bwd_bf16(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk, int64_t bsk,
                        const void* v, int64_t ldv, int64_t bsv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
                        const void* out, const void* dout, const float* lse,
                        int B, int H, int Tq, int Nk, int D, float scale, float dropout_p, uint64_t seed,
-                       void* dq, void* dk, void* dv, void* stream);
+                       const uint64_t* seed_dev, void* dq, void* dk, void* dv, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Swin (shifted-)window attention, window 12 (N = 144), head_dim 32, bf16 storage / MFMA, fp32 softmax

@@ -76,9 +76,9 @@ def test_dropout_is_a_scaled_bernoulli_mask_and_backward_matches():
     v = torch.eye(64).view(1, 64, 1, 64).expand(B, 64, H, 64).contiguous()
     q, k, v = q.to(DEV), k.to(DEV), v.to(DEV)
     scale = 0.125
-    pd = _AttentionFn.apply(q, k, v, None, scale, p, 1234).view(B, Tq, H, 64)
-    pd2 = _AttentionFn.apply(q, k, v, None, scale, p, 1234).view(B, Tq, H, 64)
-    pd3 = _AttentionFn.apply(q, k, v, None, scale, p, 99).view(B, Tq, H, 64)
+    pd = _AttentionFn.apply(q, k, v, None, scale, p, 1234, None).view(B, Tq, H, 64)
+    pd2 = _AttentionFn.apply(q, k, v, None, scale, p, 1234, None).view(B, Tq, H, 64)
+    pd3 = _AttentionFn.apply(q, k, v, None, scale, p, 99, None).view(B, Tq, H, 64)
     assert torch.equal(pd, pd2) and not torch.equal(pd, pd3)
     P = torch.softmax(torch.einsum("bqhd,bkhd->bqhk", q, k) * scale, -1)
     kept = pd != 0
@@ -89,7 +89,7 @@ def test_dropout_is_a_scaled_bernoulli_mask_and_backward_matches():
     M = kept.float() / (1 - p)
     cot = torch.randn(B, Tq, 512, device=DEV)
     gq, gk, gv = (x.clone().requires_grad_(True) for x in (q, k, v))
-    _AttentionFn.apply(gq, gk, gv, None, scale, p, 1234).backward(cot)
+    _AttentionFn.apply(gq, gk, gv, None, scale, p, 1234, None).backward(cot)
     rq, rk, rv = (x.clone().requires_grad_(True) for x in (q, k, v))
     Pm = torch.softmax(torch.einsum("bqhd,bkhd->bqhk", rq, rk) * scale, -1) * M
     torch.einsum("bqhk,bkhd->bqhd", Pm, rv).reshape(B, Tq, 512).backward(cot)
@@ -149,7 +149,7 @@ def test_bf16_mfma_dropout_consistency():
     q, k, _, _ = _case(B, Tq, Nk, dtype=torch.bfloat16)
     v = torch.eye(64).view(1, 64, 1, 64).expand(B, 64, H, 64).contiguous().bfloat16()
     q, k, v = q.to(DEV), k.to(DEV), v.to(DEV)
-    pd = _AttentionFn.apply(q, k, v, None, 0.125, p, 77).view(B, Tq, H, 64).float()
+    pd = _AttentionFn.apply(q, k, v, None, 0.125, p, 0, torch.tensor([77], device=DEV)).view(B, Tq, H, 64).float()
     P = torch.softmax(torch.einsum("bqhd,bkhd->bqhk", q.float(), k.float()) * 0.125, -1)
     kept = pd != 0
     dropped_frac = 1 - (kept | (P < 1e-3)).float().mean().item()  # tiny P may round to 0 in bf16
@@ -159,7 +159,7 @@ def test_bf16_mfma_dropout_consistency():
     M = kept.float() / (1 - p)
     cot = torch.randn(B, Tq, 512, device=DEV).bfloat16()
     gq, gk, gv = (x.clone().requires_grad_(True) for x in (q, k, v))
-    _AttentionFn.apply(gq, gk, gv, None, 0.125, p, 77).backward(cot)
+    _AttentionFn.apply(gq, gk, gv, None, 0.125, p, 0, torch.tensor([77], device=DEV)).backward(cot)
     rq, rk, rv = (x.float().clone().requires_grad_(True) for x in (q, k, v))
     Pm = torch.softmax(torch.einsum("bqhd,bkhd->bqhk", rq, rk) * 0.125, -1) * M
     torch.einsum("bqhk,bkhd->bqhd", Pm, rv).reshape(B, Tq, 512).backward(cot.float())

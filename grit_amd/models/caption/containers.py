@@ -39,7 +39,14 @@ class Module(nn.Module):
 
     def _fresh(self, name):
         default = self._state_defaults[name]
-        return None if default is None else default.clone().detach().to(self._buffers[name].device)
+        if default is None:
+            return None
+        buf = self._buffers[name]
+        # follow the module's device and (for floating states) dtype: .to(bf16) / .cuda() convert the registered buffer
+        # but not this private default
+        if buf is not None and default.is_floating_point() and buf.is_floating_point():
+            return default.clone().detach().to(device=buf.device, dtype=buf.dtype)
+        return default.clone().detach().to(buf.device if buf is not None else default.device)
 
     def _init_states(self, batch_size: int):
         for name in self._state_names:

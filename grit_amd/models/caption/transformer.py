@@ -87,10 +87,17 @@ class Transformer(BaseCaptioner):
         if return_probs:
             self.all_log_probs = []
         outputs = []
-        with self.statefulness(batch_size):
-            for t in range(max_len):
-                images, outputs = self.iter(timestep=t, samples=images, outputs=outputs, return_probs=return_probs,
-                                            batch_size=batch_size, beam_size=beam_size, eos_idx=eos_idx, **kwargs)
+        cross = [m.attention for layer in self.cap_generator.layers for m in (layer.vis_att1, layer.vis_att2)]
+        try:
+            for att in cross:  # N1: project the visual memory once per beam layout instead of once per step
+                att.hoist_kv, att._kv = True, None
+            with self.statefulness(batch_size):
+                for t in range(max_len):
+                    images, outputs = self.iter(timestep=t, samples=images, outputs=outputs, return_probs=return_probs,
+                                                batch_size=batch_size, beam_size=beam_size, eos_idx=eos_idx, **kwargs)
+        finally:
+            for att in cross:
+                att.hoist_kv, att._kv = False, None
         _, order = torch.sort(self.seq_logprob, 1, descending=True)
         idx = order.expand(batch_size, beam_size, max_len)
         outputs = torch.gather(torch.cat(outputs, -1), 1, idx)
@@ -138,10 +145,12 @@ class Transformer(BaseCaptioner):
         return [torch.zeros((batch_size, 0), dtype=torch.long, device=device), None, None]
 
     def select(self, t, candidate_logprob, beam_size, **kwargs):
-        """[B, Beam, V] -> top `beam_size` of the flattened candidates, in torch.sort's order."""
+        """[B, Beam, V] -> the `beam_size` best of the flattened candidates, best first.  The reference takes the head of
+        a full descending torch.sort over beam*V = 51 005 scores per image per step (transformer.py:184-188); top-k
+        returns the same values in the same order (the order among exactly tied scores is unspecified in both)."""
         flat = candidate_logprob.reshape(candidate_logprob.shape[0], -1)
-        logprob, idx = torch.sort(flat, -1, descending=True)
-        return idx[:, :beam_size], logprob[:, :beam_size]
+        logprob, idx = torch.topk(flat, beam_size, dim=-1, largest=True, sorted=True)
+        return idx, logprob
 
     def _expand_state(self, selected_beam, cur_beam_size, batch_size, beam_size):
         """state [B*cur_beam, ...] -> rows of the surviving beams [B*beam, ...]."""
@@ -172,7 +181,15 @@ class Transformer(BaseCaptioner):
         selected_beam = torch.div(selected_idx, V, rounding_mode='floor')
         selected_words = selected_idx - selected_beam * V
 
-        self.apply_to_states(self._expand_state(selected_beam, cur_beam, batch_size, beam_size))
+        expand = self._expand_state(selected_beam, cur_beam, batch_size, beam_size)
+        if timestep > 0:
+            # all beams of an image carry the SAME visual memory: re-gathering it by the surviving beam index
+            # (reference :229) moves nothing.  Leaving those four states untouched also keeps their identity, which is
+            # what the hoisted K/V projections are keyed on.
+            visual = {id(getattr(self, n, None)) for n in ('gri_feat', 'gri_mask', 'reg_feat', 'reg_mask')} - {id(None)}
+            self.apply_to_states(lambda tensor: tensor if id(tensor) in visual else expand(tensor))
+        else:
+            self.apply_to_states(expand)
 
         beam_col = selected_beam.unsqueeze(-1)
         self.seq_logprob = selected_logprob.unsqueeze(-1)

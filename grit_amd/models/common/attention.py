@@ -39,13 +39,24 @@ class Attention(nn.Module):
         self.d_model, self.n_heads, self.n_memories = d_model, n_heads, n_memories
         self.d_k = d_model // n_heads
         self.apply(init_params)
+        # Step-wise decoding re-projects the (unchanging) visual memory on every step in the reference
+        # (attention.py:72-73).  While `hoist_kv` is set (Transformer.beam_search does it for
+        # the two cross-attentions) fc_k / fc_v results are kept for as long as the very same key tensor comes back.
+        self.hoist_kv = False
+        self._kv = None
 
     def forward(self, q, k, v, attention_mask=None):
         """q (b, nq, d_model), k/v (b, nk, d_model); attention_mask broadcastable to (b, h, nq, nk), True = masked."""
         b, nq, nk, h = q.shape[0], q.shape[1], k.shape[1], self.n_heads
         qh = self.fc_q(q).view(b, nq, h, self.d_k)
-        kh = self.fc_k(k).view(b, nk, h, self.d_k)
-        vh = self.fc_v(v).view(b, nk, h, self.d_k)
+        if self.hoist_kv and not self.training and k is v:
+            tag = (k.data_ptr(), tuple(k.shape), k._version)
+            if self._kv is None or self._kv[0] != tag:
+                self._kv = (tag, self.fc_k(k).view(b, nk, h, self.d_k), self.fc_v(v).view(b, nk, h, self.d_k))
+            kh, vh = self._kv[1], self._kv[2]
+        else:
+            kh = self.fc_k(k).view(b, nk, h, self.d_k)
+            vh = self.fc_v(v).view(b, nk, h, self.d_k)
         out = fused_attention(qh, kh, vh, attention_mask, scale=1.0 / np.sqrt(self.d_k), dropout_p=self.dropout.p,
                               training=self.training)
         return self.fc_o(out)

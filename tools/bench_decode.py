@@ -1,0 +1,55 @@
+"""BASELINE config 5 on one GPU: beam-search (beam 5, 20 steps) captions/sec at batch 64 on synthetic 640x640 images.
+
+    python tools/bench_decode.py [--batch 64] [--iters 3] [--bf16]
+
+Reports the detector (backbone + deformable decoder + grid net) and the 20-step decode loop separately."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--bf16", action="store_true", help="bf16 weights (fp32 logits); default fp32 weights")
+    a = ap.parse_args()
+    from grit_amd.config import default_config
+    from grit_amd.data import synthetic_batch
+    from grit_amd.models.caption import Transformer
+    from grit_amd.models.caption.detector import build_detector
+    cfg = default_config()
+    torch.manual_seed(0)
+    model = Transformer(build_detector(cfg), cfg).cuda().eval()
+    if a.bf16:
+        model.to(torch.bfloat16)
+    batch = synthetic_batch(a.batch, 640, 640, device="cuda", seed=1)
+
+    def sync_time(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        return out, time.perf_counter() - t0
+
+    with torch.no_grad():
+        for it in range(a.iters + 1):
+            vis, t_det = sync_time(lambda: model.detector(batch['samples']))
+            model.cached_features = True
+            (tokens, _), t_dec = sync_time(lambda: model(vis, seq=None, use_beam_search=True, max_len=20, eos_idx=3,
+                                                          beam_size=5, out_size=1))
+            model.cached_features = False
+            if it:
+                print(json.dumps({"batch": a.batch, "dtype": "bf16" if a.bf16 else "fp32", "detector_ms": t_det * 1e3,
+                                  "decode_20_steps_ms": t_dec * 1e3, "captions_per_sec": a.batch / (t_det + t_dec)}))
+    assert tokens.shape == (a.batch, 20)
+
+
+if __name__ == "__main__":
+    main()

@@ -120,26 +120,37 @@ void winattn_fwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     }
 
     const int sn = tid >> 2, sc = tid & 3;  // staging role: token sn, 16-byte chunk sc
-    for (int win = grp; win < NW; win += ngrp) {
+    // Software pipeline over windows: the global loads of window i+1 (one K chunk, one V chunk, this lane's Q
+    // fragment) are issued before the math of window i, so their L2 / HBM latency hides under ~3k cycles of MFMA +
+    // softmax instead of stalling the single resident workgroup of the CU at the top of every iteration.
+    struct Fetch { uint4 kq, vq, qf; int reg, tq, qreg, wy, wx; size_t img; };
+    auto fetch = [&](int win) {
+        Fetch f;
         const int b = win / (g.nWh * g.nWw), wrem = win - b * (g.nWh * g.nWw);
-        const int wy = wrem / g.nWw, wx = wrem - wy * g.nWw;
-        const size_t img = (size_t)b * g.T;
-
-        // ---- stage K, V (whole window) and fetch this wave's Q fragment
-        int reg;
-        const int tk = token_of(sn, wy, wx, g, reg);
-        const __bf16* src = tk >= 0 ? qkv + (img + tk) * C3 + hoff + sc * 8 : pad_qkv + hoff + sc * 8;
-        const uint4 kq = load16(src + g.C);
-        const uint4 vq = load16(src + 2 * g.C);
-        int qreg;
-        const int tq = token_of(16 * w + l15, wy, wx, g, qreg);
-        const __bf16* qsrc = tq >= 0 ? qkv + (img + tq) * C3 + hoff + lg * 8 : pad_qkv + hoff + lg * 8;
-        const v8bf qf = as_v8bf(load16(qsrc));
+        f.wy = wrem / g.nWw; f.wx = wrem - f.wy * g.nWw;
+        f.img = (size_t)b * g.T;
+        const int tk = token_of(sn, f.wy, f.wx, g, f.reg);
+        const __bf16* src = tk >= 0 ? qkv + (f.img + tk) * C3 + hoff + sc * 8 : pad_qkv + hoff + sc * 8;
+        f.kq = load16(src + g.C);
+        f.vq = load16(src + 2 * g.C);
+        f.tq = token_of(16 * w + l15, f.wy, f.wx, g, f.qreg);
+        const __bf16* qsrc = f.tq >= 0 ? qkv + (f.img + f.tq) * C3 + hoff + lg * 8 : pad_qkv + hoff + lg * 8;
+        f.qf = load16(qsrc);
+        return f;
+    };
+    Fetch nxt;
+    if (grp < NW) nxt = fetch(grp);
+    for (int win = grp; win < NW; win += ngrp) {
+        const Fetch cur = nxt;
+        const int wy = cur.wy, wx = cur.wx, tq = cur.tq, qreg = cur.qreg;
+        const size_t img = cur.img;
+        const v8bf qf = as_v8bf(cur.qf);
         __syncthreads();  // previous window's LDS reads are done
-        *reinterpret_cast<uint4*>(&Ks[sn * kKP + sc * 8]) = kq;
-        *reinterpret_cast<uint4*>(&Vs[sn * kVP + sc * 8]) = vq;
-        if (sc == 0) rid[sn] = (uint8_t)reg;
+        *reinterpret_cast<uint4*>(&Ks[sn * kKP + sc * 8]) = cur.kq;
+        *reinterpret_cast<uint4*>(&Vs[sn * kVP + sc * 8]) = cur.vq;
+        if (sc == 0) rid[sn] = (uint8_t)cur.reg;
         __syncthreads();
+        if (win + ngrp < NW) nxt = fetch(win + ngrp);  // in flight during this window's compute
 
         // ---- S^T = K Q^T : acc[kt][r] = <q(16w + l15), k(16kt + 4lg + r)>
         v4f acc[kTiles];

@@ -83,6 +83,7 @@ class _LinearFn(Function):
 
 def linear(x, weight, bias):
     fits = (backend.override() is None and x.is_cuda and torch.is_grad_enabled() and bias is not None
+            and not torch.is_autocast_enabled()
             and (x.requires_grad or weight.requires_grad) and x.dtype == weight.dtype
             and x.dtype in (torch.bfloat16, torch.float32) and weight.shape[0] % 8 == 0
             and x.numel() // x.shape[-1] >= MIN_ROWS)

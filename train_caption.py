@@ -19,6 +19,7 @@ import torch.multiprocessing as mp
 
 from grit_amd.config import default_config, load_yaml
 from grit_amd.data import SyntheticLoader
+from grit_amd.amp import Bf16Compute
 from grit_amd.ddp import BucketedDataParallel
 from engine.caption_engine import *  # noqa: F401,F403  (reference does the same star import)
 from engine.caption_engine import build_optimizers, save_checkpoint, train_xe
@@ -51,7 +52,12 @@ def main(gpu, config, dataloaders=None):
             if 'detector' in n:
                 p.requires_grad = False
     model.cached_features = False
-    model = BucketedDataParallel(model, wire_dtype=torch.bfloat16 if getattr(config.exp, 'bf16_grads', False) else None)
+    # precision: bf16 compute copies + fp32 master weights on the GPU (grit_amd/amp.py; gradients are produced and
+    # all-reduced in flat bf16 buckets), plain fp32 with exp.bf16=False or on CPU
+    if getattr(config.exp, 'bf16', use_cuda):
+        model = Bf16Compute(model)
+    else:
+        model = BucketedDataParallel(model)
     optimizers = build_optimizers(model, config, mode='xe')
 
     if dataloaders is None:
@@ -62,17 +68,18 @@ def main(gpu, config, dataloaders=None):
     scheduler = CosineLRScheduler(optimizers['model'], num_epochs=epochs, num_its_per_epoch=len(dataloaders['train']),
                                   init_lr=config.optimizer.xe_lr, min_lr=config.optimizer.min_lr,
                                   warmup_init_lr=config.optimizer.warmup_init_lr)
-    amp = torch.bfloat16 if getattr(config.exp, 'bf16', use_cuda) else None
     results = []
     for epoch in range(getattr(config.exp, 'max_epochs', epochs)):
         print(f"Train: rank={rank}, epoch={epoch}, phase=ft_xe")
         res = train_xe(model, dataloaders, optimizers=optimizers, text_field=None, epoch=epoch, rank=rank, config=config,
-                       scheduler=scheduler, writer=None, autocast_dtype=amp, checkpoint=getattr(config.exp, 'save', False))
+                       scheduler=scheduler, writer=None, checkpoint=getattr(config.exp, 'save', False))
         results.append(res)
         if rank == 0 and getattr(config.exp, 'save', False):
             save_checkpoint(model, optimizers, epoch=epoch, scores=[], best_ciders=[0, 0], config=config,
                             filename='checkpoint_ft_xe.pth', scheduler=scheduler)
         dist.barrier()
+    if dist.is_initialized() and getattr(config.exp, 'destroy_group', True):
+        dist.destroy_process_group()
     return results
 
 

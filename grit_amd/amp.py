@@ -24,10 +24,15 @@ class Bf16Compute(nn.Module):
 
     def __init__(self, module, bucket_mb=64, process_group=None):
         super().__init__()
+        import torch.distributed as dist
         names = {p: n for n, p in module.named_parameters()}
+        if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            for p in module.parameters():  # rank 0's fp32 initialisation is THE model: masters must start from it
+                dist.broadcast(p.data, src=0, group=process_group)
         fp32 = {p: p.detach().clone().float() for p in module.parameters() if p.requires_grad}
         module.to(torch.bfloat16)  # parameters and floating buffers; integer buffers untouched
-        self.ddp = BucketedDataParallel(module, bucket_mb=bucket_mb, process_group=process_group, repack_unused=False)
+        self.ddp = BucketedDataParallel(module, bucket_mb=bucket_mb, process_group=process_group, repack_unused=False,
+                                        broadcast_parameters=False)
         self.module = module
         self._masters, self._pairs = [], []
         for b in self.ddp.buckets:

@@ -85,3 +85,59 @@ def test_bucketed_allreduce_world2(wire_bf16):
     assert sorted(ret["unused"]) == ["dead.bias", "dead.weight"]
     assert "dead.weight" not in ret["grads"][1]  # excluded after the first iteration
     assert abs(ret["avg_loss"] - loss.item()) < 1e-5
+
+
+def _amp_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grit_amd.amp import Bf16Compute
+    from grit_amd.config import default_config
+    from grit_amd.engine.caption_engine import build_optimizers
+    torch.manual_seed(100 + rank)
+    model = Toy()
+    wrapped = Bf16Compute(model, bucket_mb=0.0005)
+    cfg = default_config()
+    # the engine's optimizer builder must pick up the fp32 masters (names of the module's parameters)
+    opts = build_optimizers(wrapped, cfg, mode='xe')
+    n_master = sum(len(g['params']) for g in opts['model'].param_groups)
+    g = torch.Generator().manual_seed(7)
+    data = torch.randn(world * 4, 8, generator=g)
+    target = torch.randn(world * 4, 4, generator=g)
+    xs, ys = data[rank * 4:(rank + 1) * 4].bfloat16(), target[rank * 4:(rank + 1) * 4]
+    losses = []
+    for it in range(4):
+        loss = ((wrapped(xs).float() - ys)**2).mean()
+        loss.backward()
+        wrapped.finish_gradient_sync()
+        opts['model'].step()
+        opts['backbone'].step()
+        wrapped.after_optimizer_step()
+        losses.append(loss.item())
+    sd = wrapped.master_state_dict()
+    flat = torch.cat([v.flatten().float() for v in sd.values()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        ret["same_weights"] = all(torch.equal(gathered[0], t) for t in gathered[1:])
+        ret["dtypes"] = sorted({str(v.dtype) for v in sd.values()})
+        ret["compute_dtype"] = str(next(model.parameters()).dtype)
+        ret["losses"] = losses
+        ret["n_master"] = n_master
+        ret["keys"] = sorted(sd.keys())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_compute_fp32_masters_world2():
+    """grit_amd.amp.Bf16Compute on two gloo ranks: bf16 flat gradient buckets are all-reduced, fp32 masters stepped by
+    Adam stay identical on every rank, compute weights are bf16, the exported state dict is fp32 with module key names."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_amp_worker, args=(2, port, ret), nprocs=2, join=True)
+        ret = dict(ret)
+    assert ret["same_weights"]
+    assert ret["dtypes"] == ["torch.float32"] and ret["compute_dtype"] == "torch.bfloat16"
+    assert ret["n_master"] == 6  # a.*, b.* and the never-used dead.* (trainable; their gradient stays zero)
+    assert ret["keys"] == sorted(Toy().state_dict().keys())
+    assert ret["losses"][-1] < ret["losses"][0]

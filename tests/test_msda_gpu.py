@@ -183,9 +183,9 @@ def test_bf16_value_maps_forward_backward():
 
 
 @pytest.mark.parametrize("B", [1, 4, 32])
-def test_owner_backward_query_splits_and_levels(B):
-    """LDS-accumulating backward: 1 workgroup per (b, head) at B = 32, query splits (atomic tile flush) at small B;
-    a level layout where only the last level fits on chip and one where every level does."""
+def test_d64_backward_batches_and_level_layouts(B):
+    """msda_bwd_d64 (geometry once per row + butterfly reductions) over several batch sizes and level layouts,
+    including 2- and 3-level maps (L*P = 8, 12 < 16 lanes of geometry)."""
     gen = torch.Generator().manual_seed(B)
     for shapes_l in ([(40, 40), (20, 20), (10, 10), (5, 5)], [(9, 7), (5, 4), (3, 2)], [(30, 30), (28, 28)]):
         shapes = torch.tensor(shapes_l)

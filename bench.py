@@ -32,7 +32,11 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_BF16 = 2.5e15
-MSDA_FWD_TRAFFIC_B32 = int((2 * 130045.19 + 9600.0) * 1024)  # bytes / launch, profiles/r01/msda_pmc_b32.txt
+# HBM-side bytes per launch at B = 32 (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes), per kernel, from profiles/r01/
+MSDA_FWD_TRAFFIC_B32 = {"fwd": int((2 * 130045.19 + 9600.0) * 1024), "fwd_bf16": int((2 * 59979.31 + 4800.0) * 1024)}
+MSDA_FWD_TRAFFIC_SOURCE = {"fwd": "profiles/r01/msda_pmc_b32.txt", "fwd_bf16": "profiles/r01/msda_pmc_b32_bf16.txt"}
+MSDA_FWD_KERNEL = {"fwd": "msda_fwd_vec4<16,4> (MSDeformAttn forward, fp32 value map)",
+                   "fwd_bf16": "msda_fwd_bf16_d64<2> (MSDeformAttn forward, bf16 value map, fp32 sampling geometry)"}
 FLOP_PER_IMAGE_FWD_BWD = 955.8e9  # measured on the reference with torch.utils.flop_counter (640^2, T = 20)
 
 
@@ -57,10 +61,6 @@ def build(device, config):
     model = Transformer(build_detector(config), config).to(device)
     model.cached_features = False
     return model
-
-
-def msda_forward_bytes(B, S, M=8, D=64, Lq=150, L=4, P=4):
-    return 4 * (B * S * M * D + 2 * B * Lq * M * L * P + B * Lq * M * L * P + B * Lq * M * D)
 
 
 def cpu_baseline(config, size, caption_len, steps):
@@ -176,20 +176,26 @@ def main():
     if rank == 0:
         images = world * args.batch * args.steps
         value = images / elapsed
-        fwd = [a.elapsed_time(b) * 1e-3 for kind, a, b, _ in events if kind == "fwd"]
-        nbytes = [n for kind, _, _, n in events if kind == "fwd"]
-        roof = None
+        roof, msda_bwd = None, None
+        fwd_kind = "fwd" if args.fp32 else "fwd_bf16"
+        fwd = [(a.elapsed_time(b) * 1e-3, n) for kind, a, b, n in events if kind == fwd_kind]
+        bwd = [(a.elapsed_time(b) * 1e-3, n) for kind, a, b, n in events if kind == fwd_kind.replace("fwd", "bwd")]
         if fwd:
-            avg_t = sum(fwd) / len(fwd)
-            achieved = (sum(nbytes) / len(nbytes)) / avg_t / 1e9
+            avg_t = sum(t for t, _ in fwd) / len(fwd)
+            nbytes = sum(n for _, n in fwd) / len(fwd)
+            achieved = nbytes / avg_t / 1e9
             # HBM-side bytes per launch of this kernel at this shape from the committed PMC profile (separate
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 note); PMC collection
             # cannot run inside the timed benchmark, so the figure is quoted only for the shape it was measured on
-            traffic = MSDA_FWD_TRAFFIC_B32 if (args.batch == 32 and args.size == 640) else None
-            roof = {"bound": "hbm", "kernel": "msda_fwd_vec4<16,4> (MSDeformAttn forward, fp32)", "achieved": achieved,
+            traffic = MSDA_FWD_TRAFFIC_B32[fwd_kind] if (args.batch == 32 and args.size == 640) else None
+            roof = {"bound": "hbm", "kernel": MSDA_FWD_KERNEL[fwd_kind], "achieved": achieved,
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                    "traffic_source": "profiles/r01/msda_pmc_b32.txt" if traffic else None,
-                    "launches": len(fwd), "avg_launch_us": avg_t * 1e6, "algorithmic_bytes_per_launch": nbytes[0]}
+                    "traffic_source": MSDA_FWD_TRAFFIC_SOURCE[fwd_kind] if traffic else None,
+                    "launches": len(fwd), "avg_launch_us": avg_t * 1e6, "algorithmic_bytes_per_launch": int(nbytes)}
+        if bwd:  # informational: the backward is bound by the chip-wide float-atomic rate, not by HBM
+            avg_b = sum(t for t, _ in bwd) / len(bwd)
+            msda_bwd = {"kernel": "msda_bwd_d64", "launches": len(bwd), "avg_launch_us": avg_b * 1e6,
+                        "algorithmic_bytes_per_launch": int(bwd[0][1]), "achieved_GBps": bwd[0][1] / avg_b / 1e9}
         out = {
             "metric": "images/sec (train fwd+bwd) at 640x640 bs=32/GPU",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -204,6 +210,7 @@ def main():
             "mfma_roofline_frac_bf16": value / world * FLOP_PER_IMAGE_FWD_BWD / MFMA_PEAK_BF16,
             "final_loss": final_loss,
             "roofline": roof,
+            "msda_backward": msda_bwd,
         }
         if world == 1 and not args.no_cpu_baseline:
             del wrapped, optimizers, model

@@ -61,7 +61,73 @@ void colsum_kernel(const T* __restrict__ x, int M, int N, int rows_per_slab, flo
     }
 }
 
+// Second stage of every slab-wise reduction in the step (column sums, split-M weight gradients, LayerNorm dgamma/dbeta):
+// out[g][i] = cast(sum_s partial[g][s][i]).  One launch replaces torch's reduce + dtype-cast pair (~350 launches a step).
+// A workgroup covers CW float4 column groups x (256 / CW) interleaved slab lanes, 4 slabs in flight per thread, LDS fold.
+template <typename OT>
+__global__ __launch_bounds__(256)
+void slab_sum_kernel(const float* __restrict__ partial, long group_stride, int slabs, long n, int cw_log2, OT* __restrict__ out) {
+    __shared__ float4 red[256];
+    const int cw = 1 << cw_log2, sg_count = 256 >> cw_log2;
+    const int c = threadIdx.x & (cw - 1), sg = threadIdx.x >> cw_log2;
+    const long col = ((long)blockIdx.x * cw + c) * 4;
+    const float* src = partial + (long)blockIdx.y * group_stride + col;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < n) {
+        int s = sg;
+        for (; s + 3 * sg_count < slabs; s += 4 * sg_count) {
+            const float4 a = *reinterpret_cast<const float4*>(src + (long)s * n);
+            const float4 b = *reinterpret_cast<const float4*>(src + (long)(s + sg_count) * n);
+            const float4 d = *reinterpret_cast<const float4*>(src + (long)(s + 2 * sg_count) * n);
+            const float4 e = *reinterpret_cast<const float4*>(src + (long)(s + 3 * sg_count) * n);
+            acc.x += (a.x + b.x) + (d.x + e.x); acc.y += (a.y + b.y) + (d.y + e.y);
+            acc.z += (a.z + b.z) + (d.z + e.z); acc.w += (a.w + b.w) + (d.w + e.w);
+        }
+        for (; s < slabs; s += sg_count) {
+            const float4 a = *reinterpret_cast<const float4*>(src + (long)s * n);
+            acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (sg == 0 && col < n) {
+        for (int j = 1; j < sg_count; ++j) {
+            const float4 a = red[(j << cw_log2) + c];
+            acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+        }
+        OT* dst = out + (long)blockIdx.y * n + col;
+        if constexpr (sizeof(OT) == 4) {
+            *reinterpret_cast<float4*>(dst) = acc;
+        } else {
+            union { __hip_bfloat16 h[4]; uint2 u; } pk;
+            pk.h[0] = __float2bfloat16(acc.x); pk.h[1] = __float2bfloat16(acc.y);
+            pk.h[2] = __float2bfloat16(acc.z); pk.h[3] = __float2bfloat16(acc.w);
+            *reinterpret_cast<uint2*>(dst) = pk.u;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int grit_slab_sum(const float* partial, int groups, long group_stride, int slabs, long n, void* out,
+                             int out_is_bf16, void* stream) {
+    if (!partial || !out || groups <= 0 || slabs <= 0 || n <= 0 || group_stride < 0) return GRIT_ERR_BAD_ARG;
+    if (n % 4 != 0 || group_stride % 4 != 0 || ((uintptr_t)partial % 16) != 0 || ((uintptr_t)out % 16) != 0 || groups > 65535)
+        return GRIT_ERR_UNSUPPORTED;
+    const long groups4 = n / 4;
+    int cw_log2 = 0;
+    while (cw_log2 < 6 && (1L << cw_log2) < groups4) ++cw_log2;
+    const long blocks = (groups4 + (1L << cw_log2) - 1) >> cw_log2;
+    if (blocks > 0x7fffffffL) return GRIT_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)blocks, groups), block(256);
+    if (out_is_bf16)
+        hipLaunchKernelGGL(slab_sum_kernel<__hip_bfloat16>, grid, block, 0, (hipStream_t)stream, partial, group_stride, slabs, n,
+                           cw_log2, (__hip_bfloat16*)out);
+    else
+        hipLaunchKernelGGL(slab_sum_kernel<float>, grid, block, 0, (hipStream_t)stream, partial, group_stride, slabs, n, cw_log2,
+                           (float*)out);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
 
 extern "C" int grit_colsum(const void* x, int M, int N, int x_is_bf16, int slabs, float* partial, void* stream) {
     if (!x || !partial || M <= 0 || N <= 0 || slabs <= 0 || slabs > GRIT_COLSUM_MAX_SLABS) return GRIT_ERR_BAD_ARG;

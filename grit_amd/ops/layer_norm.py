@@ -13,6 +13,7 @@ from torch.autograd.function import once_differentiable
 
 from grit_amd import lib as _lib
 from grit_amd.ops import backend
+from grit_amd.ops.linear import slab_sum
 
 SUPPORTED_C = (128, 256, 512, 1024, 2048, 4096)
 LN_BWD_PARTIALS = 512  # GRIT_LN_BWD_PARTIALS in include/grit_hip.h
@@ -56,15 +57,14 @@ class _LayerNormFn(Function):
         # one of them writes its row, so the buffer needs no zero fill
         rows_per_block = 4 * (64 // min(C // 8, 64))
         nblk = min(-(-rows // rows_per_block), LN_BWD_PARTIALS)
-        dwb = torch.empty(2, LN_BWD_PARTIALS, C, dtype=torch.float32, device=x2.device)[:, :nblk]
+        base = torch.empty(2, LN_BWD_PARTIALS, C, dtype=torch.float32, device=x2.device)
         xb, wb = int(x2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
         with torch.cuda.device(x2.device):
-            base = dwb._base if dwb._base is not None else dwb
             st = _lib.load().grit_layernorm_bwd(_ptr(x2), _ptr(weight), _ptr(dy2), _ptr(mean), _ptr(rstd), rows, C, xb, wb,
                                                 _ptr(dx), _ptr(base[0]), _ptr(base[1]), _lib.current_stream_ptr())
         _lib.check(st, "grit_layernorm_bwd")
-        sums = dwb.sum(1)
-        return dx.view(ctx.shape), sums[0].to(weight.dtype), sums[1].to(weight.dtype), None
+        sums = slab_sum(base, weight.dtype, slabs=nblk)  # [2, C]: dgamma, dbeta
+        return dx.view(ctx.shape), sums[0], sums[1], None
 
 
 def layer_norm(x, weight, bias, eps=1e-5):

@@ -21,8 +21,24 @@ from grit_amd.ops import backend
 MIN_ROWS = 4096  # below this the launch overhead dominates: leave it to torch
 
 
-def column_sum(x2d):
-    """[M, N] (bf16 / f32, contiguous, N % 8 == 0) -> f32 [N]."""
+def slab_sum(partial, out_dtype, slabs=None):
+    """f32 partial sums [groups, slabs_allocated, n...] (contiguous) -> [groups, n...] in out_dtype: the sum over the first
+    `slabs` slabs of every group and the dtype cast in one launch (grit_slab_sum)."""
+    slabs = partial.shape[1] if slabs is None else slabs
+    tail = partial.shape[2:]
+    n = 1
+    for d in tail:
+        n *= d
+    out = torch.empty((partial.shape[0],) + tuple(tail), dtype=out_dtype, device=partial.device)
+    with torch.cuda.device(partial.device):
+        st = _lib.load().grit_slab_sum(ctypes.c_void_p(partial.data_ptr()), partial.shape[0], partial.stride(0), slabs, n,
+                                       ctypes.c_void_p(out.data_ptr()), int(out_dtype == torch.bfloat16), _lib.current_stream_ptr())
+    _lib.check(st, "grit_slab_sum")
+    return out
+
+
+def column_sum(x2d, out_dtype=torch.float32):
+    """[M, N] (bf16 / f32, contiguous, N % 8 == 0) -> [N] in out_dtype (f32 accumulation)."""
     M, N = x2d.shape
     slabs = max(1, min(256, (M * N) // (1 << 18), 2048 // max(1, (N + 511) // 512)))
     partial = torch.empty(slabs, N, dtype=torch.float32, device=x2d.device)
@@ -30,7 +46,7 @@ def column_sum(x2d):
         st = _lib.load().grit_colsum(ctypes.c_void_p(x2d.data_ptr()), M, N, int(x2d.dtype == torch.bfloat16), slabs,
                                      ctypes.c_void_p(partial.data_ptr()), _lib.current_stream_ptr())
     _lib.check(st, "grit_colsum")
-    return partial.sum(0) if slabs > 1 else partial[0]
+    return slab_sum(partial.unsqueeze(0), out_dtype)[0]
 
 
 def split_k(M):
@@ -50,7 +66,7 @@ def weight_grad(dy2, x2):
     if S == 1:
         return torch.mm(dy2.t(), x2)
     part = torch.bmm(dy2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, x2.shape[1]), out_dtype=torch.float32)
-    return part.sum(0).to(dy2.dtype)
+    return slab_sum(part.unsqueeze(0), dy2.dtype)[0]
 
 
 class _LinearFn(Function):
@@ -77,7 +93,7 @@ class _LinearFn(Function):
         if ctx.needs_input_grad[1]:
             dw = weight_grad(dy2, x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = column_sum(dy2).to(weight.dtype)
+            db = column_sum(dy2, weight.dtype)
         return dx, dw, db
 
 

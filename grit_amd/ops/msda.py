@@ -26,12 +26,17 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def _algorithmic_bytes(kind, B, S, M, D, L, Lq, P, esize):
-    """every tensor once (forward); value-sized traffic x3 + loc/weights read+written (backward)."""
+def _algorithmic_bytes(kind, B, S, M, D, L, Lq, P, esize, geom_esize=None, grad_esize=None):
+    """every tensor once (forward); value-sized traffic x3 + loc/weights read+written (backward).
+    esize: bytes per element of the value map / output rows as the kernel sees them; geom_esize: of sampling
+    locations and weights (fp32 on the bf16 path); grad_esize: of grad_value (fp32 atomics on the bf16 path)."""
+    geom_esize = geom_esize or esize
+    grad_esize = grad_esize or esize
     pts = B * Lq * M * L * P
     if kind == "fwd":
-        return esize * (B * S * M * D + 3 * pts + B * Lq * M * D)
-    return esize * (3 * B * S * M * D + 2 * 3 * pts + B * Lq * M * D)
+        return esize * (B * S * M * D + B * Lq * M * D) + geom_esize * 3 * pts
+    # read value, read-modify-write grad_value, read grad_output; read loc + weights, write their gradients
+    return esize * (B * S * M * D + B * Lq * M * D) + grad_esize * 2 * B * S * M * D + geom_esize * 2 * 3 * pts
 
 
 class _Timed(object):
@@ -83,7 +88,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     if _bf16_fast_path(value, D, L, P):  # value map stays bf16: no fp32 staging copy
         loc, aw = sampling_loc.float(), attn_weight.float()
         out = torch.empty((B, Lq, M * D), dtype=torch.bfloat16, device=value.device)
-        with torch.cuda.device(value.device), _Timed("fwd", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, 4)):
+        with torch.cuda.device(value.device), _Timed("fwd_bf16", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, 2, 4)):
             st = _lib.load().grit_msda_fwd_bf16(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc),
                                                 _ptr(aw), B, S, M, D, L, Lq, P, _ptr(out), _lib.current_stream_ptr())
         _lib.check(st, "grit_msda_fwd_bf16")
@@ -108,7 +113,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         go = grad_output.to(torch.bfloat16).contiguous()
         gv = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
         gl, ga = torch.empty_like(loc), torch.empty_like(aw)
-        with torch.cuda.device(value.device), _Timed("bwd", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 4)):
+        with torch.cuda.device(value.device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 4)):
             st = _lib.load().grit_msda_bwd_bf16(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc),
                                                 _ptr(aw), _ptr(go), B, S, M, D, L, Lq, P, _ptr(gv), _ptr(gl), _ptr(ga),
                                                 _lib.current_stream_ptr())

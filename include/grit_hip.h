@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 7
+#define GRIT_ABI_VERSION 8
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -169,6 +169,16 @@ int grit_layernorm_bwd(const void* x, const void* weight, const void* dy, const 
  * ------------------------------------------------------------------------------------------------------ */
 #define GRIT_COLSUM_MAX_SLABS 256
 int grit_colsum(const void* x, int M, int N, int x_is_bf16, int slabs, float* partial, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Second stage of the slab-wise reductions of the backward pass: out[g][i] = cast(sum_s partial[g][s][i]).
+ * Replaces the `partial.sum(0).to(dtype)` pairs that follow grit_colsum, the split-M weight-gradient GEMM
+ * (dW of nn.Linear, autograd's mm at the sites of swin_model.py:75-76,139,148) and grit_layernorm_bwd.
+ *   partial  f32, group g at partial + g * group_stride, slab s of a group at + s * n      (n % 4 == 0, 16-byte aligned)
+ *   out      [groups, n] f32 (out_is_bf16 = 0) or bf16 (1)
+ * ------------------------------------------------------------------------------------------------------ */
+int grit_slab_sum(const float* partial, int groups, long group_stride, int slabs, long n, void* out, int out_is_bf16,
+                  void* stream);
 
 #ifdef __cplusplus
 }

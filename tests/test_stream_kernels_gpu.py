@@ -1,0 +1,74 @@
+"""Streaming kernels around the library GEMMs: LayerNorm fwd/bwd, column sums (bias gradients), the slab-sum second
+stage, and the Linear module's re-posed backward -- each against torch evaluated in float64 on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("groups,alloc,slabs,n", [(1, 1, 1, 8), (1, 3, 3, 128), (2, 512, 37, 128), (2, 512, 512, 4096),
+                                                   (1, 64, 64, 2048 * 512), (1, 16, 16, 100), (3, 9, 5, 260)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_slab_sum(groups, alloc, slabs, n, out_dtype):
+    """grit_slab_sum: out[g] = cast(sum of the first `slabs` slabs of group g); slabs beyond that are never read."""
+    from grit_amd.ops.linear import slab_sum
+    g = torch.Generator().manual_seed(n + slabs)
+    part = torch.randn(groups, alloc, n, generator=g).to(DEV)
+    part[:, slabs:] = float("nan")
+    got = slab_sum(part, out_dtype, slabs=slabs)
+    ref = part[:, :slabs].double().sum(1)
+    assert got.shape == (groups, n) and got.dtype == out_dtype
+    tol = 1e-5 if out_dtype == torch.float32 else 8e-3
+    np.testing.assert_allclose(got.double().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol * slabs ** 0.5)
+
+
+@pytest.mark.parametrize("C", [128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("dtype,wdtype", [(torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32), (torch.float32, torch.float32)])
+def test_layer_norm_kernels_vs_torch(C, dtype, wdtype):
+    """grit_layernorm_{fwd,bwd} against F.layer_norm evaluated in fp64 on the same (rounded) inputs."""
+    from grit_amd.ops.layer_norm import layer_norm
+    g = torch.Generator().manual_seed(C)
+    rows = 1000 + C // 128  # not a multiple of the rows-per-block
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5).to(dtype)
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(wdtype)
+    b = (0.1 * torch.randn(C, generator=g)).to(wdtype)
+    cot = torch.randn(rows, C, generator=g).to(dtype)
+    xr, wr, br = (z.double().requires_grad_(True) for z in (x, w, b))
+    torch.nn.functional.layer_norm(xr, (C,), wr, br, 1e-5).backward(cot.double())
+    xd, wd, bd = (z.to(DEV).requires_grad_(True) for z in (x, w, b))
+    y = layer_norm(xd.view(4, -1, C) if rows % 4 == 0 else xd, wd, bd, 1e-5)
+    y.backward(cot.to(DEV).view(y.shape))
+    ref_y = torch.nn.functional.layer_norm(x.double(), (C,), w.double(), b.double(), 1e-5)
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    np.testing.assert_allclose(y.detach().float().cpu().numpy().reshape(rows, C), ref_y.float().numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(xd.grad.float().cpu().numpy(), xr.grad.float().numpy(), rtol=tol, atol=tol)
+    for got, ref in ((wd.grad, wr.grad), (bd.grad, br.grad)):
+        scale = ref.abs().max().item()
+        assert (got.float().cpu() - ref.float()).abs().max().item() < (2e-2 if wdtype == torch.bfloat16 else 2e-3) * scale
+
+
+@pytest.mark.parametrize("M,N,dtype", [(51200, 512, torch.bfloat16), (4097, 1536, torch.bfloat16), (5000, 2048, torch.float32),
+                                       (204800, 256, torch.bfloat16), (4096, 8, torch.float32)])
+def test_column_sum_and_linear_backward(M, N, dtype):
+    """grit_colsum (bias gradient of the Swin Linears) against a float64 sum; Linear module grads vs nn.Linear."""
+    from grit_amd.ops.linear import Linear, column_sum
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, N, generator=g).to(dtype).to(DEV)
+    ref = x.double().sum(0)
+    got = column_sum(x)
+    scale = ref.abs().max().item()
+    assert (got.double() - ref).abs().max().item() < 1e-5 * scale + 1e-3
+    if N >= 256:
+        return
+    lin = Linear(N, 16).to(DEV).to(dtype)
+    ref_lin = torch.nn.Linear(N, 16).to(DEV).to(dtype)
+    ref_lin.load_state_dict(lin.state_dict())
+    a = x.clone().requires_grad_(True)
+    b_ = x.clone().requires_grad_(True)
+    cot = torch.randn(M, 16, generator=g).to(dtype).to(DEV)
+    lin(a).backward(cot)
+    ref_lin(b_).backward(cot)
+    for p, q in ((a.grad, b_.grad), (lin.weight.grad, ref_lin.weight.grad), (lin.bias.grad, ref_lin.bias.grad)):
+        assert torch.allclose(p.float(), q.float(), rtol=2e-2, atol=2e-2 * q.float().abs().max().item())

@@ -40,10 +40,10 @@ def time_gpu(fn, iters, warmup=20):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-def msda_bytes(B, S=8500, M=8, D=64, Lq=150, L=4, P=4):
-    fwd = 4 * (B * S * M * D + 2 * B * Lq * M * L * P + B * Lq * M * L * P + B * Lq * M * D)
-    bwd = 4 * (3 * B * S * M * D + 2 * (3 * B * Lq * M * L * P) + B * Lq * M * D)
-    return fwd, bwd
+def msda_bytes(B, bf16=False, S=8500, M=8, D=64, Lq=150, L=4, P=4):
+    from grit_amd.ops.msda import _algorithmic_bytes
+    sizes = (2, 4, 4) if bf16 else (4, 4, 4)  # value/out, locations+weights, grad_value
+    return (_algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, *sizes), _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, *sizes))
 
 
 def bench_msda(args):
@@ -52,12 +52,15 @@ def bench_msda(args):
     for B in args.batch:
         value, shapes, lsi, loc, aw = config2(B)
         go = torch.randn(B, 150, 512, device="cuda")
+        bf16 = args.dtype == "bf16"
+        if bf16:  # the training step's layout: bf16 value map / output rows, fp32 sampling geometry
+            value, go = value.bfloat16(), go.bfloat16()
         tf = time_gpu(lambda: ms_deform_attn_forward(value, shapes, lsi, loc, aw, 64), args.iters)
         tb = time_gpu(lambda: ms_deform_attn_backward(value, shapes, lsi, loc, aw, go, 64), args.iters)
         # backward wrapper also zero-fills grad_value: time the memset separately
         tz = time_gpu(lambda: torch.zeros_like(value), args.iters)
-        fb, bb = msda_bytes(B)
-        res.append({"B": B, "fwd_us": tf * 1e6, "fwd_GBps": fb / tf / 1e9, "fwd_frac_8TBps": fb / tf / 8e12,
+        fb, bb = msda_bytes(B, bf16)
+        res.append({"B": B, "dtype": args.dtype, "fwd_algorithmic_MB": fb / 1e6, "bwd_algorithmic_MB": bb / 1e6, "fwd_us": tf * 1e6, "fwd_GBps": fb / tf / 1e9, "fwd_frac_8TBps": fb / tf / 8e12,
                     "bwd_us(incl zero-fill)": tb * 1e6, "zero_fill_us": tz * 1e6, "bwd_GBps": bb / tb / 1e9,
                     "bwd_frac_8TBps": bb / tb / 8e12})
         print(json.dumps(res[-1]))
@@ -98,5 +101,6 @@ if __name__ == "__main__":
     ap.add_argument("which", choices=["msda", "winattn", "attn"])
     ap.add_argument("--batch", type=int, nargs="+", default=[8, 32])
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="msda: dtype of the value map")
     a = ap.parse_args()
     {"msda": bench_msda, "winattn": bench_winattn}[a.which](a)

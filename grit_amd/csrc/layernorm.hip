@@ -4,8 +4,11 @@
 // the op is a pure HBM stream (read x, write y; backward read x, dy, write dx).  Here a row is spread over
 // C/8 lanes (<= 64) with one 16-byte load per lane per 512-channel chunk, several rows per wavefront when C < 512,
 // statistics in fp32 registers (two-pass on the register copy), wave-shuffle reductions, and -- backward -- dgamma /
-// dbeta accumulated in registers across a persistent row loop and flushed with one float atomic per channel per
-// workgroup.  Semantics: torch.nn.functional.layer_norm over the last dimension (reference modules use nn.LayerNorm:
+// dbeta accumulated in registers across a persistent row loop and written as one partial row per workgroup
+// (grit_slab_sum folds them).  Both directions optionally fuse the residual connection that precedes the norm in a
+// Swin block (x = shortcut + drop_path(branch); y = LN(x)): forward forms, stores and normalises x in one pass, backward
+// adds the gradient arriving at x through the skip path to the LayerNorm input gradient.
+// Semantics: torch.nn.functional.layer_norm over the last dimension (reference modules use nn.LayerNorm:
 // models/common/swin_model.py:229,233,315).
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
@@ -44,6 +47,10 @@ template <> struct Vec8<__hip_bfloat16> {
     }
 };
 
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<__hip_bfloat16>(float v) { return __bfloat162float(__float2bfloat16(v)); }
+
 template <int LPR>
 __device__ __forceinline__ float row_sum(float v) {
 #pragma unroll
@@ -55,7 +62,8 @@ __device__ __forceinline__ float row_sum(float v) {
 template <typename T, typename WT, int LPR, int CH>
 __global__ __launch_bounds__(256)
 void ln_fwd(const T* __restrict__ x, const WT* __restrict__ w, const WT* __restrict__ b, int rows, float eps,
-            T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+            T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+            const T* __restrict__ branch, const float* __restrict__ row_scale, int rows_per_sample, T* __restrict__ sum_out) {
     constexpr int C = LPR * 8 * CH, R = 64 / LPR;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % LPR;
@@ -66,6 +74,14 @@ void ln_fwd(const T* __restrict__ x, const WT* __restrict__ w, const WT* __restr
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         Vec8<T>::load(x + (size_t)rc * C + (c * LPR + sub) * 8, v[c]);
+        if (branch) {  // x <- shortcut + scale * branch, rounded to T exactly as the unfused add / addcmul would store it
+            float br[8];
+            Vec8<T>::load(branch + (size_t)rc * C + (c * LPR + sub) * 8, br);
+            const float sc = row_scale ? row_scale[rc / rows_per_sample] : 1.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[c][i] = round_to<T>(__fadd_rn(v[c][i], __fmul_rn(br[i], sc)));
+            if (row < rows) Vec8<T>::store(sum_out + (size_t)row * C + (c * LPR + sub) * 8, v[c]);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) s += v[c][i];
     }
@@ -93,7 +109,8 @@ void ln_fwd(const T* __restrict__ x, const WT* __restrict__ w, const WT* __restr
 template <typename T, typename WT, int LPR, int CH>
 __global__ __launch_bounds__(256)
 void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restrict__ dy, const float* __restrict__ mean,
-            const float* __restrict__ rstd, int rows, T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db) {
+            const float* __restrict__ rstd, int rows, T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
+            const T* __restrict__ dres) {
     constexpr int C = LPR * 8 * CH, R = 64 / LPR;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % LPR;
@@ -110,12 +127,18 @@ void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restri
         const bool live = row < rows;
         const int rc = live ? row : rows - 1;
         const float mu = mean[rc], rs = rstd[rc];
-        float xh[CH][8], g[CH][8];
+        float xh[CH][8], g[CH][8], skip[CH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             Vec8<T>::load(x + (size_t)rc * C + (c * LPR + sub) * 8, xh[c]);
             Vec8<T>::load(dy + (size_t)rc * C + (c * LPR + sub) * 8, g[c]);
+            if (dres) {
+                Vec8<T>::load(dres + (size_t)rc * C + (c * LPR + sub) * 8, skip[c]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) skip[c][i] = 0.f;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 xh[c][i] = (xh[c][i] - mu) * rs;
@@ -132,7 +155,7 @@ void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restri
                 float o[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    o[i] = rs * (g[c][i] * wv[c][i] - s1 - xh[c][i] * s2);
+                    o[i] = rs * (g[c][i] * wv[c][i] - s1 - xh[c][i] * s2) + skip[c][i];
                     aw[c][i] = fmaf(g[c][i], xh[c][i], aw[c][i]);
                     ab[c][i] += g[c][i];
                 }
@@ -164,19 +187,29 @@ void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restri
 
 constexpr int kBwdBlocks = 512;  // persistent backward grid = rows of the partial-sum workspace (GRIT_LN_BWD_PARTIALS)
 
+struct Fused {  // optional residual operands (all null / 0 for the plain LayerNorm)
+    const void* branch = nullptr;     // forward: drop-path branch added to x
+    const float* row_scale = nullptr; // forward: per-sample drop-path keep / scale factors, or null
+    int rows_per_sample = 1;
+    void* sum_out = nullptr;          // forward: where x + scale * branch is stored
+    const void* dres = nullptr;       // backward: gradient arriving at x through the skip path
+};
+
 template <typename T, typename WT>
 int launch(bool fwd, const void* x, const void* w, const void* b_or_dy, const float* mean_in, const float* rstd_in, int rows,
-           int C, float eps, void* out, float* o1, float* o2, hipStream_t st) {
+           int C, float eps, void* out, float* o1, float* o2, hipStream_t st, const Fused& fu) {
 #define GRIT_LN_CASE(LPR_, CH_)                                                                                        \
     {                                                                                                                  \
         constexpr int R = 64 / LPR_;                                                                                   \
         const int blocks = (rows + 4 * R - 1) / (4 * R);                                                               \
         if (fwd)                                                                                                       \
             hipLaunchKernelGGL((ln_fwd<T, WT, LPR_, CH_>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const WT*)w,  \
-                               (const WT*)b_or_dy, rows, eps, (T*)out, o1, o2);                                        \
+                               (const WT*)b_or_dy, rows, eps, (T*)out, o1, o2, (const T*)fu.branch, fu.row_scale,        \
+                               fu.rows_per_sample, (T*)fu.sum_out);                                                   \
         else                                                                                                           \
             hipLaunchKernelGGL((ln_bwd<T, WT, LPR_, CH_>), dim3(blocks < kBwdBlocks ? blocks : kBwdBlocks), dim3(256), 0, st, \
-                               (const T*)x, (const WT*)w, (const T*)b_or_dy, mean_in, rstd_in, rows, (T*)out, o1, o2); \
+                               (const T*)x, (const WT*)w, (const T*)b_or_dy, mean_in, rstd_in, rows, (T*)out, o1, o2,  \
+                               (const T*)fu.dres);                                                                     \
         return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;                                            \
     }
     switch (C) {
@@ -192,11 +225,12 @@ int launch(bool fwd, const void* x, const void* w, const void* b_or_dy, const fl
 }
 
 int dispatch(bool fwd, const void* x, const void* w, const void* b_or_dy, const float* mean_in, const float* rstd_in,
-             int rows, int C, float eps, int x_bf16, int w_bf16, void* out, float* o1, float* o2, hipStream_t st) {
+             int rows, int C, float eps, int x_bf16, int w_bf16, void* out, float* o1, float* o2, hipStream_t st,
+             const Fused& fu = Fused()) {
     if (!x || !w || !b_or_dy || !out || !o1 || !o2 || rows <= 0 || C <= 0) return GRIT_ERR_BAD_ARG;
-    if (x_bf16 && w_bf16) return launch<__hip_bfloat16, __hip_bfloat16>(fwd, x, w, b_or_dy, mean_in, rstd_in, rows, C, eps, out, o1, o2, st);
-    if (x_bf16) return launch<__hip_bfloat16, float>(fwd, x, w, b_or_dy, mean_in, rstd_in, rows, C, eps, out, o1, o2, st);
-    if (!w_bf16) return launch<float, float>(fwd, x, w, b_or_dy, mean_in, rstd_in, rows, C, eps, out, o1, o2, st);
+    if (x_bf16 && w_bf16) return launch<__hip_bfloat16, __hip_bfloat16>(fwd, x, w, b_or_dy, mean_in, rstd_in, rows, C, eps, out, o1, o2, st, fu);
+    if (x_bf16) return launch<__hip_bfloat16, float>(fwd, x, w, b_or_dy, mean_in, rstd_in, rows, C, eps, out, o1, o2, st, fu);
+    if (!w_bf16) return launch<float, float>(fwd, x, w, b_or_dy, mean_in, rstd_in, rows, C, eps, out, o1, o2, st, fu);
     return GRIT_ERR_UNSUPPORTED;
 }
 
@@ -213,6 +247,26 @@ int grit_layernorm_bwd(const void* x, const void* weight, const void* dy, const 
                        int C, int x_is_bf16, int w_is_bf16, void* dx, float* dweight, float* dbias, void* stream) {
     if (!mean || !rstd) return GRIT_ERR_BAD_ARG;
     return dispatch(false, x, weight, dy, mean, rstd, rows, C, 0.f, x_is_bf16, w_is_bf16, dx, dweight, dbias, (hipStream_t)stream);
+}
+
+int grit_add_layernorm_fwd(const void* shortcut, const void* branch, const float* row_scale, int rows_per_sample,
+                           const void* weight, const void* bias, int rows, int C, float eps, int x_is_bf16, int w_is_bf16,
+                           void* sum_out, void* y, float* mean, float* rstd, void* stream) {
+    if (!branch || !sum_out || rows_per_sample <= 0) return GRIT_ERR_BAD_ARG;
+    Fused fu;
+    fu.branch = branch; fu.row_scale = row_scale; fu.rows_per_sample = rows_per_sample; fu.sum_out = sum_out;
+    return dispatch(true, shortcut, weight, bias, nullptr, nullptr, rows, C, eps, x_is_bf16, w_is_bf16, y, mean, rstd,
+                    (hipStream_t)stream, fu);
+}
+
+int grit_add_layernorm_bwd(const void* x, const void* weight, const void* dy, const void* dres, const float* mean,
+                           const float* rstd, int rows, int C, int x_is_bf16, int w_is_bf16, void* dx, float* dweight,
+                           float* dbias, void* stream) {
+    if (!mean || !rstd) return GRIT_ERR_BAD_ARG;
+    Fused fu;
+    fu.dres = dres;
+    return dispatch(false, x, weight, dy, mean, rstd, rows, C, 0.f, x_is_bf16, w_is_bf16, dx, dweight, dbias,
+                    (hipStream_t)stream, fu);
 }
 
 }  // extern "C"

@@ -353,6 +353,100 @@ void msda_fwd_bf16_d64(const __hip_bfloat16* __restrict__ value, const int64_t* 
     }
 }
 
+// Forward for bf16 maps, D = 64, L*P <= 16 -- the training-step shape -- with the gather latency taken off the
+// critical path.  The wave-per-row kernel above is latency x occupancy bound (two dependent HBM hops per wave:
+// sampling geometry, then the corners; ~5 us of wave lifetime for < 1 us of work).  Here a wave owns FOUR rows:
+//   * geometry: lane j computes point (j & 15) of row r0 + (j >> 4) ONCE (one coalesced float2 + float load for the
+//     4 rows' 64 points) and parks {4 corner offsets, 4 corner weights x attention weight} in a wave-private 2 KB LDS
+//     tile -- no ds_bpermute traffic, no 8x redundant corner arithmetic;
+//   * gather: each 16-lane DPP row serves one output row; its two 8-lane halves walk 8 points each (a 128-byte
+//     pixel-head slice = 8 lanes x 16 B), BATCH points (4*BATCH independent 16-byte loads per lane) in flight at a
+//     time, addresses = uniform base + 32-bit offsets;
+//   * fold: the two halves meet in ONE DPP row_ror:8 add per channel (no LDS shuffles), lanes 0-7 of each row store
+//     the 128-byte output row.
+template <int BATCH>
+__global__ __launch_bounds__(256)
+void msda_fwd_bf16_rows4(const __hip_bfloat16* __restrict__ value, const int64_t* __restrict__ shapes,
+                         const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
+                         int S, int M, int L, int Lq, int P, __hip_bfloat16* __restrict__ out, int nrows, int nblk) {
+    constexpr int D = 64;
+    __shared__ uint4 geo[4][64][2];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = (xcd_logical_block(blockIdx.x, nblk) * 4 + wave) * 4;
+    if (r0 >= nrows) return;
+    const int LP = L * P;
+    {
+        const int row = r0 + (lane >> 4), p = lane & 15;
+        const bool valid = row < nrows && p < LP;
+        const int rc = min(row, nrows - 1), pc = min(p, LP - 1);
+        const float2 xy = *reinterpret_cast<const float2*>(loc + ((size_t)rc * LP + pc) * 2);
+        const float wt = valid ? aw[(size_t)rc * LP + pc] : 0.f;
+        const int l = pc / P;
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const uint32_t m = rc % M, b = (rc / M) / Lq;
+        // byte offsets from `value` (M*D*2 bytes per pixel); the launcher checks that the whole map fits 32 bits
+        const uint32_t base = ((b * (uint32_t)S + (uint32_t)lsi[l]) * (uint32_t)M + m) * (D * 2);
+        const uint32_t pix = (uint32_t)M * (D * 2);
+        const Corners<float> c = make_corners<float>(xy.x, xy.y, H, W);
+        geo[wave][lane][0] = make_uint4(base + c.o1 * pix, base + c.o2 * pix, base + c.o3 * pix, base + c.o4 * pix);
+        geo[wave][lane][1] = make_uint4(__float_as_uint(c.k1 ? c.w1 * wt : 0.f), __float_as_uint(c.k2 ? c.w2 * wt : 0.f),
+                                        __float_as_uint(c.k3 ? c.w3 * wt : 0.f), __float_as_uint(c.k4 ? c.w4 * wt : 0.f));
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int c8 = lane & 7;
+    const uint32_t cb = c8 * 16;
+    const uint4(*g)[2] = &geo[wave][(lane & 48) + (lane & 8)];  // this half's 8 points of this row
+    const char* vb = reinterpret_cast<const char*>(value);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};  // channels (2j, 2j+1): v_pk_fma_f32
+#pragma unroll
+    for (int it0 = 0; it0 < 8; it0 += BATCH) {
+        uint4 v[BATCH][4];
+        float w[BATCH][4];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const uint4 o = g[it0 + i][0], ww = g[it0 + i][1];
+            v[i][0] = *reinterpret_cast<const uint4*>(vb + (o.x + cb));
+            v[i][1] = *reinterpret_cast<const uint4*>(vb + (o.y + cb));
+            v[i][2] = *reinterpret_cast<const uint4*>(vb + (o.z + cb));
+            v[i][3] = *reinterpret_cast<const uint4*>(vb + (o.w + cb));
+            w[i][0] = __uint_as_float(ww.x); w[i][1] = __uint_as_float(ww.y);
+            w[i][2] = __uint_as_float(ww.z); w[i][3] = __uint_as_float(ww.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // every gather of the batch is in flight before the first one is consumed
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // a corner outside the map carries weight 0 and a clamped address: whatever was loaded there (even a
+                // NaN) must contribute exactly nothing, as in the reference, which never reads it
+                const bool dead = w[i][k] == 0.f;
+                const uint32_t d[4] = {dead ? 0u : v[i][k].x, dead ? 0u : v[i][k].y, dead ? 0u : v[i][k].z, dead ? 0u : v[i][k].w};
+                const f2 w2 = {w[i][k], w[i][k]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f2 f = {__uint_as_float(d[j] << 16), __uint_as_float(d[j] & 0xffff0000u)};
+                    acc[j] = __builtin_elementwise_fma(w2, f, acc[j]);
+                }
+            }
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // lanes l and l ^ 8 of a 16-lane row: row_ror:8
+        r[2 * j] = acc[j].x + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc[j].x), 0x128, 0xf, 0xf, true));
+        r[2 * j + 1] = acc[j].y + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc[j].y), 0x128, 0xf, 0xf, true));
+    }
+    const int row = r0 + (lane >> 4);
+    if ((lane & 8) == 0 && row < nrows) {
+        typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+        v8bf o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)r[e];
+        *reinterpret_cast<v8bf*>(out + (size_t)row * D + c8 * 8) = o;
+    }
+}
+
 __device__ __forceinline__ float ldv(const float* p) { return *p; }
 __device__ __forceinline__ float ldv(const __hip_bfloat16* p) { return __bfloat162float(*p); }
 
@@ -560,6 +654,19 @@ int grit_msda_fwd_bf16(const void* value, const int64_t* spatial_shapes, const i
     const int LP = L * P;
     if (D != 64 || LP > 32 || ((uintptr_t)value % 16) || ((uintptr_t)out % 16)) return GRIT_ERR_UNSUPPORTED;
     const int nrows = B * Lq * M;
+    if (LP <= 16 && (uint64_t)B * S * M * D * 2 < (1ull << 32)) {  // 4 rows per wave, 16 rows per workgroup
+        static const int batch = getenv("GRIT_MSDA_FWD_BATCH") ? atoi(getenv("GRIT_MSDA_FWD_BATCH")) : 2;
+        const int nblk16 = (nrows + 15) / 16;
+#define GRIT_ROWS4(BATCH_)                                                                                           \
+    hipLaunchKernelGGL((msda_fwd_bf16_rows4<BATCH_>), dim3(nblk16), dim3(256), 0, (hipStream_t)stream,               \
+                       (const __hip_bfloat16*)value, spatial_shapes, level_start, loc, attn_w, S, M, L, Lq, P,       \
+                       (__hip_bfloat16*)out, nrows, nblk16)
+        if (batch == 0) goto row_per_wave;
+        if (batch == 1) GRIT_ROWS4(1); else if (batch == 4) GRIT_ROWS4(4); else if (batch == 8) GRIT_ROWS4(8); else GRIT_ROWS4(2);
+#undef GRIT_ROWS4
+        return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+    }
+row_per_wave:
     const int nblk = (nrows + kRowsPerBlock - 1) / kRowsPerBlock;
     const dim3 grid(nblk), block(kWave * kRowsPerBlock);
     const int nit = (LP + 7) / 8;

@@ -26,7 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from grit_amd.ops.layer_norm import LayerNorm
+from grit_amd.ops.layer_norm import LayerNorm, add_layer_norm
 from grit_amd.ops.linear import Linear
 from grit_amd.ops.window_attention import window_attention
 
@@ -190,23 +190,43 @@ class SwinTransformerBlock(nn.Module):
         self.H = None
         self.W = None
 
-    def forward(self, x, mask_matrix=None):
+    def forward(self, x, mask_matrix=None, normed=None, next_norm=None):
         """x (B, H*W, C) with self.H/self.W set by the stage.  `mask_matrix` is accepted for signature parity;
-        the kernel derives the shift mask from (H, W, window, shift) itself."""
+        the kernel derives the shift mask from (H, W, window, shift) itself.
+        Each residual connection is fused with the LayerNorm that consumes its result (one pass over the map instead of
+        two): `normed` is norm1(x) when the previous block already produced it, and with `next_norm` (the next block's
+        norm1) the return value is (x, next_norm(x)) instead of x."""
         B, L, C = x.shape
         H, W = self.H, self.W
         assert L == H * W, "input feature has wrong size"
-        x = self._residual(x, self.attn.attend_map(self.norm1(x), H, W, self.shift_size))
-        return self._residual(x, self.mlp(self.norm2(x)))
+        n1 = self.norm1(x) if normed is None else normed
+        x, n2 = self._residual_norm(x, self.attn.attend_map(n1, H, W, self.shift_size), self.norm2)
+        h = self.mlp(n2)
+        if next_norm is None:
+            return self._residual(x, h)
+        return self._residual_norm(x, h, next_norm)
 
-    def _residual(self, x, branch):
-        """x + drop_path(branch) as ONE elementwise kernel (addcmul with the per-sample keep/scale mask)."""
+    def _drop_path_scale(self, x, dtype):
+        """Per-sample stochastic-depth factors (0 or 1/keep) of this call, or None when drop-path is inactive."""
         dp = self.drop_path
         if isinstance(dp, DropPath) and dp.drop_prob > 0. and self.training:
             keep = 1.0 - dp.drop_prob
-            mask = x.new_empty((x.shape[0], 1, 1)).bernoulli_(keep).div_(keep)
-            return torch.addcmul(x, branch, mask)
+            return torch.empty(x.shape[0], dtype=dtype, device=x.device).bernoulli_(keep).div_(keep)
+        return None
+
+    def _residual(self, x, branch):
+        """x + drop_path(branch) as ONE elementwise kernel (addcmul with the per-sample keep/scale mask)."""
+        scale = self._drop_path_scale(x, x.dtype)
+        if scale is not None:
+            return torch.addcmul(x, branch, scale.view(-1, 1, 1))
         return x + branch
+
+    def _residual_norm(self, x, branch, norm):
+        """(x + drop_path(branch), norm(x + drop_path(branch)))."""
+        if isinstance(norm, LayerNorm) and norm.elementwise_affine and len(norm.normalized_shape) == 1:
+            return add_layer_norm(x, branch, self._drop_path_scale(x, torch.float32), norm.weight, norm.bias, norm.eps)
+        x = self._residual(x, branch)
+        return x, norm(x)
 
 
 class PatchMerging(nn.Module):
@@ -267,12 +287,15 @@ class BasicLayer(nn.Module):
         return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
 
     def forward(self, x, H, W):
-        for blk in self.blocks:
+        normed = None  # norm1 of the next block, produced together with the residual sum that feeds it
+        for i, blk in enumerate(self.blocks):
             blk.H, blk.W = H, W
             if self.use_checkpoint and x.requires_grad:
-                x = checkpoint.checkpoint(blk, x, None, use_reentrant=False)
+                x, normed = checkpoint.checkpoint(blk, x, None, use_reentrant=False), None
+            elif i + 1 < len(self.blocks):
+                x, normed = blk(x, None, normed, self.blocks[i + 1].norm1)
             else:
-                x = blk(x, None)
+                x = blk(x, None, normed)
         if self.downsample is None:
             return x, H, W, x, H, W
         return x, H, W, self.downsample(x, H, W), (H + 1) // 2, (W + 1) // 2

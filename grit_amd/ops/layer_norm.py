@@ -80,6 +80,82 @@ def layer_norm(x, weight, bias, eps=1e-5):
     return _LayerNormFn.apply(x, weight.contiguous(), bias.contiguous(), float(eps))
 
 
+class _AddLayerNormFn(Function):
+    """(shortcut, branch, scale) -> (x, LayerNorm(x)) with x = shortcut + scale * branch; scale [B] f32 or None."""
+
+    @staticmethod
+    def forward(ctx, shortcut, branch, scale, weight, bias, eps):
+        C = shortcut.shape[-1]
+        s2, b2 = shortcut.reshape(-1, C), branch.reshape(-1, C)
+        s2 = s2 if s2.is_contiguous() else s2.contiguous()
+        b2 = b2 if b2.is_contiguous() else b2.contiguous()
+        rows = s2.shape[0]
+        x = torch.empty_like(s2)
+        y = torch.empty_like(s2)
+        mean = torch.empty(rows, dtype=torch.float32, device=s2.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=s2.device)
+        xb, wb = int(s2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
+        per_sample = rows // shortcut.shape[0]
+        with torch.cuda.device(s2.device):
+            st = _lib.load().grit_add_layernorm_fwd(_ptr(s2), _ptr(b2), _ptr(scale) if scale is not None else None, per_sample,
+                                                    _ptr(weight), _ptr(bias), rows, C, eps, xb, wb, _ptr(x), _ptr(y), _ptr(mean),
+                                                    _ptr(rstd), _lib.current_stream_ptr())
+        _lib.check(st, "grit_add_layernorm_fwd")
+        ctx.save_for_backward(x, weight, mean, rstd, scale)
+        ctx.shape = shortcut.shape
+        return x.view(shortcut.shape), y.view(shortcut.shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gx, gy):
+        x2, weight, mean, rstd, scale = ctx.saved_tensors
+        rows, C = x2.shape
+        if gy is None:
+            gy = torch.zeros_like(x2)
+        gy2 = gy.reshape(rows, C)
+        if not gy2.is_contiguous() or gy2.dtype != x2.dtype:
+            gy2 = gy2.to(x2.dtype).contiguous()
+        gx2 = None
+        if gx is not None:
+            gx2 = gx.reshape(rows, C)
+            if not gx2.is_contiguous() or gx2.dtype != x2.dtype:
+                gx2 = gx2.to(x2.dtype).contiguous()
+        dx = torch.empty_like(x2)
+        rows_per_block = 4 * (64 // min(C // 8, 64))
+        nblk = min(-(-rows // rows_per_block), LN_BWD_PARTIALS)
+        base = torch.empty(2, LN_BWD_PARTIALS, C, dtype=torch.float32, device=x2.device)
+        xb, wb = int(x2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
+        with torch.cuda.device(x2.device):
+            st = _lib.load().grit_add_layernorm_bwd(_ptr(x2), _ptr(weight), _ptr(gy2), _ptr(gx2) if gx2 is not None else None,
+                                                    _ptr(mean), _ptr(rstd), rows, C, xb, wb, _ptr(dx), _ptr(base[0]),
+                                                    _ptr(base[1]), _lib.current_stream_ptr())
+        _lib.check(st, "grit_add_layernorm_bwd")
+        sums = slab_sum(base, weight.dtype, slabs=nblk)
+        dx = dx.view(ctx.shape)
+        d_branch = dx if scale is None else dx * scale.view(-1, *([1] * (dx.dim() - 1))).to(dx.dtype)
+        return dx, d_branch, None, sums[0], sums[1], None
+
+
+def add_layer_norm(shortcut, branch, scale, weight, bias, eps=1e-5):
+    """x = shortcut + scale[b] * branch (scale None: plain add); returns (x, layer_norm(x)) from one pass over HBM when
+    the streaming kernel covers the shape, otherwise the unfused composition (same values either way)."""
+    C = shortcut.shape[-1]
+    fits = (backend.override() is None and shortcut.is_cuda and C in SUPPORTED_C and shortcut.shape == branch.shape
+            and shortcut.dtype == branch.dtype and shortcut.dtype in (torch.float32, torch.bfloat16)
+            and weight is not None and bias is not None and weight.dtype == bias.dtype and shortcut.dim() >= 2
+            and (weight.dtype == shortcut.dtype or (shortcut.dtype == torch.bfloat16 and weight.dtype == torch.float32))
+            and not torch.is_autocast_enabled())
+    if not fits:
+        if scale is None:
+            x = shortcut + branch
+        else:
+            x = torch.addcmul(shortcut, branch, scale.view(-1, *([1] * (shortcut.dim() - 1))).to(shortcut.dtype))
+        return x, layer_norm(x, weight, bias, eps)
+    if scale is not None:
+        scale = scale.reshape(-1).float().contiguous()
+    return _AddLayerNormFn.apply(shortcut, branch, scale, weight.contiguous(), bias.contiguous(), float(eps))
+
+
 class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm (same parameters / state-dict keys) whose forward runs the streaming HIP kernels."""
 

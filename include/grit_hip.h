@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 8
+#define GRIT_ABI_VERSION 9
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -154,7 +154,7 @@ int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pa
  *   weight, bias  [C], f32 or bf16 (w_is_bf16); the combination f32 x with bf16 weight is not provided
  *   mean, rstd    [rows] f32, written by forward, read by backward
  *   dweight/dbias [GRIT_LN_BWD_PARTIALS, C] f32 per-workgroup partial sums: rows [0, min(ceil(rows / rows_per_block),
- *                 GRIT_LN_BWD_PARTIALS)) are overwritten, the caller zero-fills the buffer and sums over dim 0
+ *                 GRIT_LN_BWD_PARTIALS)) are overwritten and only those may be summed (grit_slab_sum); no zero fill needed
  * Statistics and arithmetic are fp32; eps as in torch.nn.functional.layer_norm.
  * ------------------------------------------------------------------------------------------------------ */
 #define GRIT_LN_BWD_PARTIALS 512
@@ -162,6 +162,21 @@ int grit_layernorm_fwd(const void* x, const void* weight, const void* bias, int 
                        int w_is_bf16, void* y, float* mean, float* rstd, void* stream);
 int grit_layernorm_bwd(const void* x, const void* weight, const void* dy, const float* mean, const float* rstd, int rows,
                        int C, int x_is_bf16, int w_is_bf16, void* dx, float* dweight, float* dbias, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Residual connection + the LayerNorm that follows it, one pass (SwinTransformerBlock.forward, swin_model.py:289-298:
+ * `x = shortcut + self.drop_path(x)` then `self.norm2(x)`; likewise the MLP residual and the next block's norm1):
+ *   sum_out = round(shortcut + row_scale[row / rows_per_sample] * branch)     (row_scale NULL: plain add)
+ *   y       = LayerNorm(sum_out) with the statistics of the rounded sum, i.e. bit-identical to the unfused pair
+ * Backward: dx = dres + dLayerNorm(dy)   (dres = gradient reaching sum_out through the skip path, may be NULL);
+ * the caller scales dx by row_scale for the branch.  Other arguments as in grit_layernorm_{fwd,bwd}.
+ * ------------------------------------------------------------------------------------------------------ */
+int grit_add_layernorm_fwd(const void* shortcut, const void* branch, const float* row_scale, int rows_per_sample,
+                           const void* weight, const void* bias, int rows, int C, float eps, int x_is_bf16, int w_is_bf16,
+                           void* sum_out, void* y, float* mean, float* rstd, void* stream);
+int grit_add_layernorm_bwd(const void* x, const void* weight, const void* dy, const void* dres, const float* mean,
+                           const float* rstd, int rows, int C, int x_is_bf16, int w_is_bf16, void* dx, float* dweight,
+                           float* dbias, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Column sums (bias gradient of nn.Linear: db = sum over rows of dY).  x [M, N] row-major, f32 or bf16, N % 8 == 0.

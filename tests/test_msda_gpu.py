@@ -200,3 +200,35 @@ def test_d64_backward_batches_and_level_layouts(B):
         np.testing.assert_allclose(gv.cpu().numpy(), ogv, rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(ga.cpu().numpy(), oga, rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(gl.cpu().numpy(), ogl, rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("shapes_l,M,Lq,P,B", [
+    ([(40, 40), (20, 20), (10, 10), (5, 5)], 8, 37, 4, 3),   # L*P = 16: four-rows-per-wave kernel, 888 rows (not a multiple of 16)
+    ([(9, 7), (5, 4), (3, 2)], 3, 5, 4, 1),                   # L*P = 12, 15 rows: tail wave with dead rows, M not a power of two
+    ([(30, 30), (28, 28)], 8, 150, 4, 2),                     # L*P = 8: second half-row idle
+    ([(16, 16), (8, 8)], 4, 9, 2, 2),                         # L*P = 4
+    ([(40, 40), (20, 20), (10, 10), (5, 5)], 8, 20, 8, 2),    # L*P = 32: wave-per-row kernel
+])
+def test_bf16_forward_kernels_layouts_and_dead_corners(shapes_l, M, Lq, P, B):
+    """grit_msda_fwd_bf16 across its two kernels.  Pixel (0, 0) of every level is NaN and no live corner touches it:
+    points are either well inside the map or entirely outside it (dead: clamped address = pixel (0, 0)), so any leak of
+    a zero-weight corner into the sum shows up as NaN -- the reference never reads such corners
+    (ms_deform_im2col_cuda.cuh:259-262)."""
+    from grit_amd.ops.msda import ms_deform_attn_forward
+    gen = torch.Generator().manual_seed(len(shapes_l) * 100 + P)
+    shapes = torch.tensor(shapes_l)
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S, L, D = int(shapes.prod(1).sum()), len(shapes_l), 64
+    value = torch.randn(B, S, M, D, generator=gen).bfloat16()
+    value[:, lsi] = float("nan")
+    # inside points: pixel coordinates in [1.6, side - 1.1] never reach row / column 0
+    hw = shapes.flip(1).float().view(1, 1, 1, L, 1, 2)  # (W, H) per level
+    inside = (1.6 + torch.rand(B, Lq, M, L, P, 2, generator=gen) * (hw - 2.7) + 0.5) / hw
+    outside = -(1.5 + torch.rand(B, Lq, M, L, P, 2, generator=gen)) / hw
+    dead = torch.rand(B, Lq, M, L, P, 1, generator=gen) < 0.25
+    loc = torch.where(dead, outside, inside).contiguous()
+    aw = torch.rand(B, Lq, M, L, P, generator=gen)
+    out = ms_deform_attn_forward(value.to(DEV), shapes.to(DEV), lsi.to(DEV), loc.to(DEV), aw.to(DEV), 64)
+    assert out.dtype == torch.bfloat16 and torch.isfinite(out.float()).all()
+    ref = omsda.msda_forward(torch.nan_to_num(value.float()).numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy())
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)

@@ -72,3 +72,38 @@ def test_column_sum_and_linear_backward(M, N, dtype):
     ref_lin(b_).backward(cot)
     for p, q in ((a.grad, b_.grad), (lin.weight.grad, ref_lin.weight.grad), (lin.bias.grad, ref_lin.bias.grad)):
         assert torch.allclose(p.float(), q.float(), rtol=2e-2, atol=2e-2 * q.float().abs().max().item())
+
+
+@pytest.mark.parametrize("C,B,L", [(128, 3, 1601), (256, 2, 400), (512, 4, 100), (1024, 2, 25)])
+@pytest.mark.parametrize("dtype,wdtype", [(torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)])
+@pytest.mark.parametrize("drop_path", [False, True])
+def test_add_layer_norm_fused_vs_composition(C, B, L, dtype, wdtype, drop_path):
+    """grit_add_layernorm_{fwd,bwd}: x = shortcut + scale[b] * branch, y = LN(x) (the residual + norm pairs of a Swin
+    block, swin_model.py:289-298) against the same composition in float64; the stored sum must be BIT-identical to
+    torch's own add / addcmul in the tensor dtype, and both outputs carry gradient (x feeds the next skip path)."""
+    from grit_amd.ops.layer_norm import add_layer_norm
+    g = torch.Generator().manual_seed(C + L)
+    sc, br = (torch.randn(B, L, C, generator=g) * 1.5).to(dtype), torch.randn(B, L, C, generator=g).to(dtype)
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(wdtype)
+    b = (0.1 * torch.randn(C, generator=g)).to(wdtype)
+    scale = (torch.tensor([0.0, 1.25, 1.25, 0.0][:B]) if drop_path else None)
+    cot_x, cot_y = torch.randn(B, L, C, generator=g).to(dtype), torch.randn(B, L, C, generator=g).to(dtype)
+    # float64 reference on the same rounded inputs, with the sum rounded to the tensor dtype like the unfused op
+    s64, b64, w64, bb64 = (z.double().requires_grad_(True) for z in (sc, br, w, b))
+    sum64 = s64 + (b64 if scale is None else b64 * scale.double().view(-1, 1, 1))
+    x_ref = sum64 + (sum64.detach().to(dtype).double() - sum64.detach())  # straight-through rounding
+    y_ref = torch.nn.functional.layer_norm(x_ref, (C,), w64, bb64, 1e-5)
+    (x_ref * cot_x.double()).sum().backward(retain_graph=True)
+    (y_ref * cot_y.double()).sum().backward()
+    sd, bd, wd, bbd = (z.to(DEV).requires_grad_(True) for z in (sc, br, w, b))
+    x, y = add_layer_norm(sd, bd, None if scale is None else scale.to(DEV), wd, bbd, 1e-5)
+    torch.autograd.backward([x, y], [cot_x.to(DEV), cot_y.to(DEV)])
+    unfused = sc.to(DEV) + br.to(DEV) if scale is None else torch.addcmul(sc.to(DEV), br.to(DEV), scale.to(DEV).to(dtype).view(-1, 1, 1))
+    assert torch.equal(x.detach(), unfused)
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), y_ref.detach().float().numpy(), rtol=tol, atol=tol)
+    gtol = 4e-2 if dtype == torch.bfloat16 else 1e-4
+    np.testing.assert_allclose(sd.grad.float().cpu().numpy(), s64.grad.float().numpy(), rtol=gtol, atol=gtol)
+    np.testing.assert_allclose(bd.grad.float().cpu().numpy(), b64.grad.float().numpy(), rtol=gtol, atol=gtol * 1.25)
+    for got, ref in ((wd.grad, w64.grad), (bbd.grad, bb64.grad)):
+        assert (got.float().cpu() - ref.float()).abs().max().item() < (2e-2 if wdtype == torch.bfloat16 else 2e-3) * ref.abs().max().item()

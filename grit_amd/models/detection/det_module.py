@@ -169,6 +169,20 @@ class DetectionModule(nn.Module):
         valid_w = torch.sum(~mask[:, 0, :], 1).float() / W
         return torch.stack([valid_w, valid_h], -1)
 
+    def _level_geometry(self, shapes, device):
+        """(spatial_shapes [L, 2], level_start_index [L]) int64 on `device`, built once per distinct level layout: a
+        host list -> device tensor copy is a *synchronous* pageable H2D transfer that stalls the host until the whole
+        backbone forward has drained, i.e. it throws away the launch lead the small-kernel head depends on."""
+        cache = self.__dict__.setdefault('_geometry_cache', {})
+        key = (shapes, str(device))
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=device)
+            start = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+            cache[key] = (spatial_shapes, start)
+        return cache[key]
+
     def prepare_od_inputs(self, srcs, masks):
         B = srcs[0].shape[0]
         query_pos, query_tgt = torch.split(self.query_embed.weight, self.d_model, dim=1)
@@ -176,9 +190,8 @@ class DetectionModule(nn.Module):
         query_tgt = query_tgt.unsqueeze(0).expand(B, -1, -1)
         src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)  # [B, S, C]; level_embed NOT added
         mask_flatten = torch.cat([m.flatten(1) for m in masks], 1)
-        spatial_shapes = torch.as_tensor([tuple(s.shape[-2:]) for s in srcs], dtype=torch.long,
-                                         device=src_flatten.device)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        spatial_shapes, level_start_index = self._level_geometry(tuple(tuple(s.shape[-2:]) for s in srcs),
+                                                                 src_flatten.device)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
         reference_points = self.reference_points(query_pos).float().sigmoid()
         reference_points = self.bbox_refine(self.bbox_embed[0], query_tgt, reference_points)

@@ -99,7 +99,10 @@ def test_add_layer_norm_fused_vs_composition(C, B, L, dtype, wdtype, drop_path):
     x, y = add_layer_norm(sd, bd, None if scale is None else scale.to(DEV), wd, bbd, 1e-5)
     torch.autograd.backward([x, y], [cot_x.to(DEV), cot_y.to(DEV)])
     unfused = sc.to(DEV) + br.to(DEV) if scale is None else torch.addcmul(sc.to(DEV), br.to(DEV), scale.to(DEV).to(dtype).view(-1, 1, 1))
-    assert torch.equal(x.detach(), unfused)
+    if dtype == torch.bfloat16 or scale is None:
+        assert torch.equal(x.detach(), unfused)
+    else:  # fp32 addcmul contracts a + b*c into one fma inside torch's kernel: 1 ulp
+        np.testing.assert_allclose(x.detach().cpu().numpy(), unfused.cpu().numpy(), rtol=3e-7, atol=5e-7)
     tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
     np.testing.assert_allclose(y.detach().float().cpu().numpy(), y_ref.detach().float().numpy(), rtol=tol, atol=tol)
     gtol = 4e-2 if dtype == torch.bfloat16 else 1e-4

@@ -19,7 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--top", type=int, default=70)
+    ap.add_argument("--top", type=int, default=220)
     args = ap.parse_args()
     import bench
     from grit_amd.amp import Bf16Compute
@@ -50,8 +50,8 @@ def main():
     by_op = collections.defaultdict(lambda: [0.0, 0])
     for e in prof.events():
         t = dev_time(e)
-        if not t:
-            continue
+        if not t or e.name.startswith(("void ", "Cijk", "_ZN", "Custom_Cijk", "__amd", "Memset", "Memcpy")):
+            continue  # kernels are listed by rocprofv3 (tools/steady_profile.py); here only the ops that launch them
         site = "?"
         for fr in (e.stack or []):
             if "/grit_amd/" in fr or "/bench.py" in fr:

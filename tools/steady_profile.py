@@ -35,6 +35,26 @@ def main(out_dir, nwin=2):
           f"GPU busy {tot / 1e6 / nwin:.2f} ms/step, GEMM (hipBLASLt/rocBLAS) {gemm / 1e6 / nwin:.2f} ms/step")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
         print(f"{v[0] / 1e6 / nwin:8.2f} ms/step  calls/step {v[1] / nwin:7.1f}  avg {v[0] / v[1] / 1e3:9.1f} us  {k[:140]}")
+    # where the GPU waits for the host: idle gaps between consecutive kernels inside the window
+    win = [r for r in rows if start <= int(r["Start_Timestamp"]) < end]
+    gaps, busy_until = [], int(win[0]["End_Timestamp"])
+    for prev, cur in zip(win, win[1:]):
+        busy_until = max(busy_until, int(prev["End_Timestamp"]))
+        g = int(cur["Start_Timestamp"]) - busy_until
+        if g > 0:
+            gaps.append((g, int(cur["Start_Timestamp"]) - start, prev["Kernel_Name"][:70], cur["Kernel_Name"][:70]))
+    tot_gap = sum(g[0] for g in gaps)
+    print(f"\nidle: {tot_gap / 1e6 / nwin:.2f} ms/step in {len(gaps) / nwin:.0f} gaps; gaps > 20 us: "
+          f"{sum(g[0] for g in gaps if g[0] > 20e3) / 1e6 / nwin:.2f} ms/step; > 100 us: "
+          f"{sum(g[0] for g in gaps if g[0] > 100e3) / 1e6 / nwin:.2f} ms/step")
+    # idle time per 5-ms slice of the step (position inside the window modulo the step length)
+    step_len = (end - start) / nwin
+    slices = collections.defaultdict(float)
+    for g, pos, _, _ in gaps:
+        slices[int((pos % step_len) / 5e6)] += g
+    print("idle per 5-ms slice of the step [ms/step]: " + " ".join(f"{slices[i] / 1e6 / nwin:.2f}" for i in range(int(step_len / 5e6) + 1)))
+    for g, pos, a, b in sorted(gaps, reverse=True)[:25]:
+        print(f"  gap {g / 1e3:8.1f} us at +{(pos % step_len) / 1e6:6.2f} ms   after {a}   before {b}")
 
 
 if __name__ == "__main__":

@@ -110,7 +110,7 @@ template <typename T, typename WT, int LPR, int CH>
 __global__ __launch_bounds__(256)
 void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restrict__ dy, const float* __restrict__ mean,
             const float* __restrict__ rstd, int rows, T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
-            const T* __restrict__ dres) {
+            const T* __restrict__ dres, const float* __restrict__ row_scale, int rows_per_sample, T* __restrict__ dbranch) {
     constexpr int C = LPR * 8 * CH, R = 64 / LPR;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % LPR;
@@ -160,6 +160,12 @@ void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restri
                     ab[c][i] += g[c][i];
                 }
                 Vec8<T>::store(dx + (size_t)row * C + (c * LPR + sub) * 8, o);
+                if (dbranch) {  // gradient of the drop-path branch: the rounded dx times this sample's keep factor
+                    const float sc = row_scale[row / rows_per_sample];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = round_to<T>(o[i]) * sc;
+                    Vec8<T>::store(dbranch + (size_t)row * C + (c * LPR + sub) * 8, o);
+                }
             }
         }
     }
@@ -193,6 +199,7 @@ struct Fused {  // optional residual operands (all null / 0 for the plain LayerN
     int rows_per_sample = 1;
     void* sum_out = nullptr;          // forward: where x + scale * branch is stored
     const void* dres = nullptr;       // backward: gradient arriving at x through the skip path
+    void* dbranch = nullptr;          // backward: where row_scale * dx (the branch gradient) is stored, or null
 };
 
 template <typename T, typename WT>
@@ -209,7 +216,7 @@ int launch(bool fwd, const void* x, const void* w, const void* b_or_dy, const fl
         else                                                                                                           \
             hipLaunchKernelGGL((ln_bwd<T, WT, LPR_, CH_>), dim3(blocks < kBwdBlocks ? blocks : kBwdBlocks), dim3(256), 0, st, \
                                (const T*)x, (const WT*)w, (const T*)b_or_dy, mean_in, rstd_in, rows, (T*)out, o1, o2,  \
-                               (const T*)fu.dres);                                                                     \
+                               (const T*)fu.dres, fu.row_scale, fu.rows_per_sample, (T*)fu.dbranch);                   \
         return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;                                            \
     }
     switch (C) {
@@ -260,11 +267,12 @@ int grit_add_layernorm_fwd(const void* shortcut, const void* branch, const float
 }
 
 int grit_add_layernorm_bwd(const void* x, const void* weight, const void* dy, const void* dres, const float* mean,
-                           const float* rstd, int rows, int C, int x_is_bf16, int w_is_bf16, void* dx, float* dweight,
-                           float* dbias, void* stream) {
-    if (!mean || !rstd) return GRIT_ERR_BAD_ARG;
+                           const float* rstd, const float* row_scale, int rows_per_sample, int rows, int C, int x_is_bf16,
+                           int w_is_bf16, void* dx, void* dbranch, float* dweight, float* dbias, void* stream) {
+    if (!mean || !rstd || ((row_scale != nullptr) != (dbranch != nullptr)) || (row_scale && rows_per_sample <= 0))
+        return GRIT_ERR_BAD_ARG;
     Fused fu;
-    fu.dres = dres;
+    fu.dres = dres; fu.row_scale = row_scale; fu.rows_per_sample = row_scale ? rows_per_sample : 1; fu.dbranch = dbranch;
     return dispatch(false, x, weight, dy, mean, rstd, rows, C, 0.f, x_is_bf16, w_is_bf16, dx, dweight, dbias,
                     (hipStream_t)stream, fu);
 }

@@ -28,6 +28,7 @@ import torch.utils.checkpoint as checkpoint
 
 from grit_amd.ops.layer_norm import LayerNorm, add_layer_norm
 from grit_amd.ops.linear import Linear
+from grit_amd.ops.rel_bias import relative_position_bias
 from grit_amd.ops.window_attention import window_attention
 
 
@@ -105,21 +106,6 @@ def _relative_position_index(wh, ww):
     return dy * (2 * ww - 1) + dx
 
 
-_ONEHOT_CACHE = {}
-
-
-def _onehot_index(index, n_rel, dtype):
-    """[N*N, n_rel rounded up to 32] one-hot rows of the relative-position index; one copy per (device, dtype)."""
-    key = (index.device, dtype, n_rel, index.numel())
-    hit = _ONEHOT_CACHE.get(key)
-    if hit is None:
-        cols = -(-n_rel // 32) * 32
-        hit = torch.zeros(index.numel(), cols, dtype=dtype, device=index.device)
-        hit.scatter_(1, index.reshape(-1, 1), 1.0)
-        _ONEHOT_CACHE[key] = hit
-    return hit
-
-
 class WindowAttention(nn.Module):
     """Window multi-head self-attention with relative position bias; shifted or not."""
 
@@ -142,15 +128,10 @@ class WindowAttention(nn.Module):
             raise NotImplementedError("attention-probability dropout is not fused (GRIT uses attn_drop_rate=0)")
 
     def relative_position_bias(self):
-        """[nH, N, N] float32 = table[relative_position_index] (reference :168-171), computed as a one-hot GEMM:
-        exact (one non-zero product per output), and its backward is a plain GEMM instead of torch's sort-based
-        index_put (22 sorts + scatter kernels per step on the 20 736-entry index)."""
-        n = self.window_size[0] * self.window_size[1]
-        table = self.relative_position_bias_table
-        onehot = _onehot_index(self.relative_position_index, table.shape[0], table.dtype)
-        pad = onehot.shape[1] - table.shape[0]
-        bias = onehot @ (F.pad(table, (0, 0, 0, pad)) if pad else table)  # [N*N, nH]
-        return bias.view(n, n, -1).permute(2, 0, 1).contiguous().float()
+        """[nH, N, N] float32 = table[relative_position_index] (reference :168-171): one gather kernel forward, a
+        sorted-position segment sum backward (grit_amd/ops/rel_bias.py) instead of torch's gather + permute + cast and
+        its sort-based index_put gradient."""
+        return relative_position_bias(self.relative_position_bias_table, self.relative_position_index)
 
     def pad_qkv(self, dtype):
         if self.qkv.bias is None:

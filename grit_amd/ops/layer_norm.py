@@ -121,19 +121,19 @@ class _AddLayerNormFn(Function):
             if not gx2.is_contiguous() or gx2.dtype != x2.dtype:
                 gx2 = gx2.to(x2.dtype).contiguous()
         dx = torch.empty_like(x2)
+        d_branch = dx if scale is None else torch.empty_like(x2)
         rows_per_block = 4 * (64 // min(C // 8, 64))
         nblk = min(-(-rows // rows_per_block), LN_BWD_PARTIALS)
         base = torch.empty(2, LN_BWD_PARTIALS, C, dtype=torch.float32, device=x2.device)
         xb, wb = int(x2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
         with torch.cuda.device(x2.device):
-            st = _lib.load().grit_add_layernorm_bwd(_ptr(x2), _ptr(weight), _ptr(gy2), _ptr(gx2) if gx2 is not None else None,
-                                                    _ptr(mean), _ptr(rstd), rows, C, xb, wb, _ptr(dx), _ptr(base[0]),
-                                                    _ptr(base[1]), _lib.current_stream_ptr())
+            st = _lib.load().grit_add_layernorm_bwd(
+                _ptr(x2), _ptr(weight), _ptr(gy2), _ptr(gx2) if gx2 is not None else None, _ptr(mean), _ptr(rstd),
+                _ptr(scale) if scale is not None else None, rows // ctx.shape[0], rows, C, xb, wb, _ptr(dx),
+                _ptr(d_branch) if scale is not None else None, _ptr(base[0]), _ptr(base[1]), _lib.current_stream_ptr())
         _lib.check(st, "grit_add_layernorm_bwd")
         sums = slab_sum(base, weight.dtype, slabs=nblk)
-        dx = dx.view(ctx.shape)
-        d_branch = dx if scale is None else dx * scale.view(-1, *([1] * (dx.dim() - 1))).to(dx.dtype)
-        return dx, d_branch, None, sums[0], sums[1], None
+        return dx.view(ctx.shape), d_branch.view(ctx.shape), None, sums[0], sums[1], None
 
 
 def add_layer_norm(shortcut, branch, scale, weight, bias, eps=1e-5):

@@ -1,0 +1,81 @@
+"""Relative-position bias lookup of Swin window attention on the HIP kernels (grit_relbias_{fwd,bwd}).
+
+    bias[h, i, j] = table[index[i, j], h]       (reference models/common/swin_model.py:168-171)
+
+Forward is one small gather kernel writing the [nH, N, N] fp32 slab the attention kernels read; backward sums d(bias)
+over the positions that share a table row, from a host-sorted position list (no atomics, no sort per step)."""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from grit_amd import lib as _lib
+from grit_amd.ops import backend
+
+_SORTED = {}  # (device, n_rows, index data_ptr, numel) -> (order int32 [n_pos], offsets int32 [n_rows + 1])
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _sorted_positions(index, n_rows):
+    key = (str(index.device), n_rows, index.data_ptr(), index.numel())
+    hit = _SORTED.get(key)
+    if hit is None:
+        flat = index.detach().reshape(-1).cpu()  # one-time host round trip per module (the index never changes)
+        if flat.numel() and (int(flat.min()) < 0 or int(flat.max()) >= n_rows):
+            raise RuntimeError("relative_position_index out of range of the bias table")
+        order = torch.argsort(flat, stable=True).to(torch.int32)
+        counts = torch.bincount(flat, minlength=n_rows)
+        offsets = torch.cat((counts.new_zeros(1), counts.cumsum(0))).to(torch.int32)
+        hit = (order.to(index.device), offsets.to(index.device))
+        if len(_SORTED) > 256:
+            _SORTED.clear()
+        _SORTED[key] = hit
+    return hit
+
+
+class _RelBiasFn(Function):
+
+    @staticmethod
+    def forward(ctx, table, index):
+        n_rows, nH = table.shape
+        n_pos = index.numel()
+        out = torch.empty((nH,) + tuple(index.shape), dtype=torch.float32, device=table.device)
+        with torch.cuda.device(table.device):
+            st = _lib.load().grit_relbias_fwd(_ptr(table), _ptr(index), n_rows, nH, n_pos, int(table.dtype == torch.bfloat16),
+                                              _ptr(out), _lib.current_stream_ptr())
+        _lib.check(st, "grit_relbias_fwd")
+        ctx.index, ctx.meta = index, (n_rows, nH, n_pos, table.dtype)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dbias):
+        n_rows, nH, n_pos, dtype = ctx.meta
+        order, offsets = _sorted_positions(ctx.index, n_rows)
+        dbias = dbias.float().contiguous()
+        dtable = torch.empty(n_rows, nH, dtype=dtype, device=dbias.device)
+        with torch.cuda.device(dbias.device):
+            st = _lib.load().grit_relbias_bwd(_ptr(dbias), _ptr(order), _ptr(offsets), n_rows, nH, n_pos,
+                                              int(dtype == torch.bfloat16), _ptr(dtable), _lib.current_stream_ptr())
+        _lib.check(st, "grit_relbias_bwd")
+        return dtable, None
+
+
+def relative_position_bias(table, index):
+    """table [n_rows, nH] (f32 / bf16), index [N, N] int64 -> [nH, N, N] float32."""
+    ov = backend.override()
+    fits = (ov is None and table.is_cuda and index.is_cuda and table.dtype in (torch.float32, torch.bfloat16)
+            and index.dtype == torch.int64 and table.is_contiguous() and index.is_contiguous())
+    if not fits:
+        if not table.is_cuda and ov is None:
+            raise _lib.GritHipError("Not implemented on the CPU: relative_position_bias runs on the HIP kernels "
+                                    "(tests inject oracle ops with grit_amd.ops.backend.use_reference_ops)")
+        n = index.shape[0]
+        return table[index.reshape(-1)].view(n, index.shape[1], -1).permute(2, 0, 1).contiguous().float()
+    if torch.is_grad_enabled() and table.requires_grad:
+        _sorted_positions(index, table.shape[0])  # built outside the autograd thread, before any graph capture
+    return _RelBiasFn.apply(table, index)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 9
+#define GRIT_ABI_VERSION 10
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -164,19 +164,33 @@ int grit_layernorm_bwd(const void* x, const void* weight, const void* dy, const 
                        int C, int x_is_bf16, int w_is_bf16, void* dx, float* dweight, float* dbias, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Relative-position bias of window attention (WindowAttention.forward, swin_model.py:168-171):
+ *   bias[h][p] = (float) table[index[p]][h]          table [n_rows, num_heads] f32 / bf16, index [n_pos] int64
+ * and its gradient  dtable[r][h] = sum over the positions p with index[p] == r of dbias[h][p].  The positions are
+ * passed sorted by table row: order [n_pos] int32 (a permutation of 0..n_pos-1, stable sort of index) and
+ * offsets [n_rows + 1] int32 (row r owns order[offsets[r] .. offsets[r+1])).  dtable is fully overwritten.
+ * ------------------------------------------------------------------------------------------------------ */
+int grit_relbias_fwd(const void* table, const int64_t* index, int n_rows, int num_heads, int n_pos, int table_is_bf16,
+                     float* bias, void* stream);
+int grit_relbias_bwd(const float* dbias, const int32_t* order, const int32_t* offsets, int n_rows, int num_heads, int n_pos,
+                     int table_is_bf16, void* dtable, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Residual connection + the LayerNorm that follows it, one pass (SwinTransformerBlock.forward, swin_model.py:289-298:
  * `x = shortcut + self.drop_path(x)` then `self.norm2(x)`; likewise the MLP residual and the next block's norm1):
  *   sum_out = round(shortcut + row_scale[row / rows_per_sample] * branch)     (row_scale NULL: plain add)
  *   y       = LayerNorm(sum_out) with the statistics of the rounded sum, i.e. bit-identical to the unfused pair
- * Backward: dx = dres + dLayerNorm(dy)   (dres = gradient reaching sum_out through the skip path, may be NULL);
- * the caller scales dx by row_scale for the branch.  Other arguments as in grit_layernorm_{fwd,bwd}.
+ * Backward: dx = dres + dLayerNorm(dy)   (dres = gradient reaching sum_out through the skip path, may be NULL) is the
+ * gradient of `shortcut`; with row_scale the gradient of `branch`, dbranch = row_scale[row / rows_per_sample] * dx, is
+ * written too (row_scale and dbranch are given together or both NULL: the branch gradient is then dx itself).
+ * Other arguments as in grit_layernorm_{fwd,bwd}.
  * ------------------------------------------------------------------------------------------------------ */
 int grit_add_layernorm_fwd(const void* shortcut, const void* branch, const float* row_scale, int rows_per_sample,
                            const void* weight, const void* bias, int rows, int C, float eps, int x_is_bf16, int w_is_bf16,
                            void* sum_out, void* y, float* mean, float* rstd, void* stream);
 int grit_add_layernorm_bwd(const void* x, const void* weight, const void* dy, const void* dres, const float* mean,
-                           const float* rstd, int rows, int C, int x_is_bf16, int w_is_bf16, void* dx, float* dweight,
-                           float* dbias, void* stream);
+                           const float* rstd, const float* row_scale, int rows_per_sample, int rows, int C, int x_is_bf16,
+                           int w_is_bf16, void* dx, void* dbranch, float* dweight, float* dbias, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Column sums (bias gradient of nn.Linear: db = sum over rows of dY).  x [M, N] row-major, f32 or bf16, N % 8 == 0.

@@ -100,3 +100,24 @@ def test_rejects_unsupported_geometry():
         window_attention(qkv.to(DEV), bias.to(DEV), pad.to(DEV), 12, 12, 1, 7, 0, 1.0)
     with pytest.raises(RuntimeError, match="CPU"):
         window_attention(qkv, bias, pad, 12, 12, 1, 12, 0, 1.0)
+
+
+@pytest.mark.parametrize("nH,dtype", [(4, torch.float32), (16, torch.float32), (32, torch.bfloat16), (3, torch.bfloat16)])
+def test_relative_position_bias_kernels(nH, dtype):
+    """grit_relbias_{fwd,bwd} against the reference formulation table[index.view(-1)].view(N, N, nH).permute(2, 0, 1)
+    (swin_model.py:168-171) and its autograd gradient."""
+    from grit_amd.models.common.swin_model import _relative_position_index
+    from grit_amd.ops.rel_bias import relative_position_bias
+    g = torch.Generator().manual_seed(nH)
+    index = _relative_position_index(12, 12).to(DEV)
+    table = torch.randn(529, nH, generator=g).to(dtype).to(DEV).requires_grad_(True)
+    cot = torch.randn(nH, 144, 144, generator=g).to(DEV)
+    out = relative_position_bias(table, index)
+    assert out.dtype == torch.float32 and out.shape == (nH, 144, 144)
+    ref_t = table.detach().clone().requires_grad_(True)
+    ref = ref_t[index.view(-1)].view(144, 144, nH).permute(2, 0, 1).contiguous().float()
+    assert torch.equal(out, ref)
+    out.backward(cot)
+    ref.backward(cot)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(table.grad.float().cpu().numpy(), ref_t.grad.float().cpu().numpy(), rtol=tol, atol=tol * 10)

@@ -141,8 +141,6 @@ def main():
         wrapped = BucketedDataParallel(model, bucket_mb=64)
     else:  # bf16 compute copies + fp32 master weights; gradients are produced, all-reduced and unscaled in flat bf16 buckets
         wrapped = Bf16Compute(model, bucket_mb=64)
-        if os.environ.get("GRIT_GRAPH_HEAD", "0") == "1":
-            model.enable_graphed_head()  # optional hipGraph replay of the post-backbone region (measured: no gain at bs=32)
     optimizers = build_optimizers(wrapped, config, mode="xe")
     loss_fn = torch.nn.NLLLoss(ignore_index=1)
     # inputs resident in HBM before the timed region; 4 distinct batches per rank, cycled

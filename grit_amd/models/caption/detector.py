@@ -8,6 +8,7 @@ import torch.nn.functional as F
 
 from grit_amd.models.common.swin_model import swin_base_win7_384
 from grit_amd.models.detection.det_module import build_det_module_with_config
+from grit_amd.ops.group_norm import group_norm_levels
 from grit_amd.utils.misc import NestedTensor, nested_tensor_from_tensor_list
 
 
@@ -35,6 +36,22 @@ class Detector(nn.Module):
         y = F.linear(tokens, conv.weight.view(conv.out_channels, C), conv.bias)
         return gn(y.transpose(1, 2).reshape(B, conv.out_channels, H, W))
 
+    def project_levels(self, features):
+        """All feature levels through input_proj, as ONE flattened token map [B, sum_l H_l*W_l, hidden] (the layout
+        DetectionModule.prepare_od_inputs builds with flatten + cat, det_module.py:172-175) plus the level shapes.
+        1x1 convolutions run as GEMMs on the token views; the GroupNorms normalise token-major and write straight into
+        the level's slice of the flat map (grit_amd/ops/group_norm.py) -- no NCHW round trip, no concatenation."""
+        tokens, shapes = [], []
+        for (conv, _), feature in zip(self.input_proj, features):
+            B, C, H, W = feature.shape
+            t = feature.permute(0, 2, 3, 1).reshape(B, H * W, C)
+            tokens.append(F.linear(t, conv.weight.view(conv.out_channels, C), conv.bias))
+            shapes.append((H, W))
+        norms = [gn for _, gn in self.input_proj]
+        flat = group_norm_levels(tokens, [gn.weight for gn in norms], [gn.bias for gn in norms], norms[0].num_groups,
+                                 norms[0].eps)
+        return flat, tuple(shapes)
+
     def forward(self, images: NestedTensor):
         """images.tensors [B,3,H,W], images.mask [B,H,W] (True on padding) ->
         {gri_feat [B,h*w,1024], gri_mask [B,1,1,h*w], reg_feat [B,150,512], reg_mask [B,1,1,150] (all False)}."""
@@ -48,8 +65,9 @@ class Detector(nn.Module):
             'gri_mask': masks[-1].flatten(1)[:, None, None, :],
         }
         if self.use_reg_feat:
-            srcs = [self.project_level(l, f) for l, f in enumerate(features)]
-            hs, _, _ = self.det_module(srcs, masks, no_padding=getattr(images, 'any_padding', None) is False)
+            no_padding = getattr(images, 'any_padding', None) is False
+            flat, shapes = self.project_levels(features)
+            hs, _, _ = self.det_module(None, masks, no_padding=no_padding, src_flatten=flat, shapes=shapes)
             out['reg_feat'] = hs[-1]
             out['reg_mask'] = hs[-1].new_zeros((hs[-1].shape[0], 1, 1, hs[-1].shape[1])).bool()
         return out

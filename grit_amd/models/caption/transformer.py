@@ -39,7 +39,6 @@ class Transformer(BaseCaptioner):
             self.register_state('reg_mask', None)
         self.init_weights()
         self.detector = detector  # attached after init_weights: the detector keeps its own initialisation
-        self._graphed_head = None  # grit_amd.graphs.GraphedHead once enable_graphed_head() has been called
 
     def init_weights(self):
         for p in self.parameters():
@@ -55,26 +54,9 @@ class Transformer(BaseCaptioner):
             vis['gri_feat'] = grid[:, -1]
         return vis
 
-    def enable_graphed_head(self, enabled=True):
-        """Capture everything after the backbone (launch-bound: ~900 small kernels each way) in hipGraphs for training
-        steps on un-padded, fixed-size batches (grit_amd/graphs.py).  Same arithmetic; eager whenever a condition fails."""
-        if enabled:
-            from grit_amd.graphs import GraphedHead
-            self._graphed_head = GraphedHead(self)
-        else:
-            self._graphed_head = None
-
-    def _can_graph(self, images):
-        return (self._graphed_head is not None and self.training and torch.is_grad_enabled() and not self.cached_features
-                and isinstance(images, NestedTensor) and images.any_padding is False and images.tensors.is_cuda
-                and self.config.model.use_gri_feat and self.config.model.use_reg_feat
-                and self.cap_generator.fc.weight.dtype == torch.bfloat16)
-
     def forward(self, images, seq, use_beam_search=False, max_len=20, eos_idx=3, beam_size=5, out_size=1,
                 return_probs=False, **kwargs):
         if not use_beam_search:
-            if self._can_graph(images):
-                return self._graphed_head(self.detector.backbone(images.tensors), seq)
             return self.cap_generator(seq, self._visual_inputs(images))
         return self.beam_search(images, max_len, eos_idx, beam_size, out_size, return_probs, **kwargs)
 

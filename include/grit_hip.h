@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 10
+#define GRIT_ABI_VERSION 11
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -191,6 +191,24 @@ int grit_add_layernorm_fwd(const void* shortcut, const void* branch, const float
 int grit_add_layernorm_bwd(const void* x, const void* weight, const void* dy, const void* dres, const float* mean,
                            const float* rstd, const float* row_scale, int rows_per_sample, int rows, int C, int x_is_bf16,
                            int w_is_bf16, void* dx, void* dbranch, float* dweight, float* dbias, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * GroupNorm on token-major maps (nn.GroupNorm(32, hidden_dim) after the 1x1 input projection of every feature level,
+ * reference models/caption/detector.py:28-33,58; statistics over (H*W, C/G) per image and group, biased variance).
+ *   x [B, T, C]: image b at x + b * x_bstride (elements), rows of C channels contiguous; C in {256, 512}, (C/G) % 8 == 0
+ *   y            same geometry with its own batch stride: a level can be written straight into its slice of the flat
+ *                [B, sum_l T_l, C] map that the deformable-attention decoder consumes
+ *   mean, rstd   [B, G] f32, written by forward, read by backward
+ *   workspace    f32, forward: B * GRIT_GN_CHUNKS * 2 * G, backward: B * GRIT_GN_CHUNKS * 2 * C elements (fully overwritten)
+ * Backward: dx [B, T, C] contiguous; dweight / dbias [C] in the weight dtype.  f32 x with bf16 weight is not provided.
+ * ------------------------------------------------------------------------------------------------------ */
+#define GRIT_GN_CHUNKS 16
+int grit_groupnorm_tokens_fwd(const void* x, long x_bstride, const void* weight, const void* bias, int B, int T, int C, int G,
+                              float eps, int x_is_bf16, int w_is_bf16, void* y, long y_bstride, float* mean, float* rstd,
+                              float* workspace, void* stream);
+int grit_groupnorm_tokens_bwd(const void* x, long x_bstride, const void* dy, long dy_bstride, const void* weight,
+                              const float* mean, const float* rstd, int B, int T, int C, int G, int x_is_bf16, int w_is_bf16,
+                              void* dx, void* dweight, void* dbias, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Column sums (bias gradient of nn.Linear: db = sum over rows of dY).  x [M, N] row-major, f32 or bf16, N % 8 == 0.

@@ -110,3 +110,34 @@ def test_add_layer_norm_fused_vs_composition(C, B, L, dtype, wdtype, drop_path):
     np.testing.assert_allclose(bd.grad.float().cpu().numpy(), b64.grad.float().numpy(), rtol=gtol, atol=gtol * 1.25)
     for got, ref in ((wd.grad, w64.grad), (bbd.grad, bb64.grad)):
         assert (got.float().cpu() - ref.float()).abs().max().item() < (2e-2 if wdtype == torch.bfloat16 else 2e-3) * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype,wdtype", [(torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32), (torch.float32, torch.float32)])
+@pytest.mark.parametrize("C,G,Ts,B", [(512, 32, (400, 100, 25, 7), 3), (256, 32, (64, 33), 2), (512, 16, (1601,), 2)])
+def test_group_norm_levels_vs_torch(C, G, Ts, B, dtype, wdtype):
+    """grit_groupnorm_tokens_{fwd,bwd}: per-level GroupNorm on token-major maps written into one flat [B, S, C] map,
+    against torch.nn.functional.group_norm on the channels-first view + cat (detector.py:28-33, det_module.py:172-175)
+    in float64 on the same inputs; gradients of inputs, weights and biases."""
+    from grit_amd.ops.group_norm import group_norm_levels
+    g = torch.Generator().manual_seed(C + len(Ts))
+    xs = [(torch.randn(B, T, C, generator=g) * (1 + l) + 0.3 * l).to(dtype) for l, T in enumerate(Ts)]
+    ws = [(1 + 0.2 * torch.randn(C, generator=g)).to(wdtype) for _ in Ts]
+    bs = [(0.1 * torch.randn(C, generator=g)).to(wdtype) for _ in Ts]
+    cot = torch.randn(B, sum(Ts), C, generator=g).to(dtype)
+    xr, wr, br = ([z.double().requires_grad_(True) for z in zs] for zs in (xs, ws, bs))
+    ref = torch.cat([torch.nn.functional.group_norm(x.transpose(1, 2), G, w, b, 1e-5).transpose(1, 2)
+                     for x, w, b in zip(xr, wr, br)], 1)
+    ref.backward(cot.double())
+    xd, wd, bd = ([z.to(DEV).requires_grad_(True) for z in zs] for zs in (xs, ws, bs))
+    out = group_norm_levels(xd, wd, bd, G, 1e-5)
+    assert out.shape == (B, sum(Ts), C) and out.dtype == dtype and out.is_contiguous()
+    out.backward(cot.to(DEV))
+    tol = 3e-2 if dtype == torch.bfloat16 else 2e-4
+    np.testing.assert_allclose(out.detach().float().cpu().numpy(), ref.detach().float().numpy(), rtol=tol, atol=tol)
+    for got, want in zip(xd, xr):
+        scale = want.grad.abs().max().item()
+        assert (got.grad.double().cpu() - want.grad).abs().max().item() < (3e-2 if dtype == torch.bfloat16 else 2e-4) * scale
+    for gots, wants in ((wd, wr), (bd, br)):
+        for got, want in zip(gots, wants):
+            scale = want.grad.abs().max().item()
+            assert (got.grad.double().cpu() - want.grad).abs().max().item() < (2e-2 if wdtype == torch.bfloat16 else 3e-3) * scale

@@ -36,8 +36,6 @@ def main():
     config = default_config()
     model = bench.build(device, config).train()
     wrapped = Bf16Compute(model, bucket_mb=64)
-    if os.environ.get("GRIT_GRAPH_HEAD", "0") == "1":
-        model.enable_graphed_head()
     opts = build_optimizers(wrapped, config, mode="xe")
     loss_fn = torch.nn.NLLLoss(ignore_index=1)
     batches = [synthetic_batch(args.batch, 640, 640, 20, device=device, seed=i) for i in range(2)]

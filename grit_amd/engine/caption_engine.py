@@ -6,7 +6,8 @@ save_checkpoint :83-103 (same dict layout), evaluate_loss :287-309, train_xe :31
 forward -> zero_grad x2 -> NLL on shifted log-probs -> backward -> Adam x2 -> scalar all-reduce -> scheduler, and the
 extra scheduler.step() before each epoch's loop, Q8), evaluate_metrics :144-230 (the beam-search model call; scoring
 is delegated to a caller-supplied scorer because the reference's PTB tokenizer / METEOR are Java programs).
-Out of scope: train_sc (self-critical CIDEr reward), log_epoch, inference_coco_test.
+train_sc :388-492 (next-row N2): beam search with gradient + reward supplied by the caller (the reference's CIDEr /
+PTB tokenizer are host-side Java).  Out of scope: log_epoch, inference_coco_test.
 
 MI355X specifics: Adam runs as torch's fused multi-tensor kernel; the model may be wrapped either in
 torch DDP or in grit_amd.ddp.BucketedDataParallel (gradient buckets all-reduced by RCCL on its side stream while
@@ -197,6 +198,84 @@ def evaluate_metrics(model, optimizers, dataloader, text_field, epoch=0, split='
     return scores
 
 
-def train_sc(*args, **kwargs):
-    raise NotImplementedError("self-critical training (CIDEr reward via the Java PTB tokenizer) is outside the "
-                              "MI355X hot path of this build; see DESIGN.md 'next rows' N2")
+def sc_loss(log_probs, reward):
+    """Self-critical loss (reference :440-443): -(mean token log-prob of each beam) x (reward - mean reward of the
+    image's beams), averaged.  log_probs [B, beam, T] with grad, reward [B, beam]."""
+    baseline = torch.mean(reward, -1, keepdim=True)
+    return (-torch.mean(log_probs, -1) * (reward - baseline)).mean(), baseline
+
+
+def train_sc_step(model, batch, optimizers, reward_fn, config):
+    """One self-critical step in the reference's order (engine/caption_engine.py:421-449): zero_grad x2 -> beam search
+    WITH gradient (out_size = beam_size) -> host reward -> loss -> backward -> barrier -> Adam x2.
+    reward_fn(tokens [B, beam, T] int64, batch) -> float tensor [B, beam] on the model's device: in the reference it is
+    CIDEr-D of the decoded, PTB-tokenised beams against the ground-truth captions (:433-438), a host-side (Java)
+    component that the caller supplies.  Returns (loss, mean reward, mean baseline) as detached device tensors."""
+    beam_size, seq_len = config.model.beam_size, config.model.beam_len
+    optimizers['model'].zero_grad()
+    optimizers['backbone'].zero_grad()
+    outs, log_probs = model(batch['samples'], seq=None, use_beam_search=True, max_len=seq_len, eos_idx=config.model.eos_idx,
+                            beam_size=beam_size, out_size=beam_size, return_probs=False)
+    reward = reward_fn(outs.detach(), batch).to(log_probs.device, torch.float32).view(outs.shape[0], beam_size)
+    loss, baseline = sc_loss(log_probs, reward)
+    loss.backward()
+    finalize = getattr(model, 'finish_gradient_sync', None)
+    if finalize is not None:
+        finalize()
+    if is_dist_avail_and_initialized():
+        dist.barrier()  # reference :443
+    optimizers['model'].step()
+    optimizers['backbone'].step()
+    post = getattr(model, 'after_optimizer_step', None)
+    if post is not None:
+        post()
+    return gather_result(loss.detach()), gather_result(reward.mean()), gather_result(baseline.mean())
+
+
+def cider_reward_fn(cider, text_field, tokenizer_pool=None, tokenize=None):
+    """The reference's reward (:433-438) from its host objects: text_field.decode -> PTB tokenisation of generated and
+    ground-truth captions (tokenizer_pool.map(tokenize, ...), or tokenize directly) -> cider.compute_score(...)[1]."""
+    import itertools
+
+    import numpy as np
+
+    def reward_fn(tokens, batch):
+        B, beam, T = tokens.shape
+        caps_gen = text_field.decode(tokens.view(-1, T))
+        caps_gt = list(itertools.chain(*([c] * beam for c in batch['captions'])))
+        if tokenize is not None:
+            caps_gen, caps_gt = (tokenizer_pool.map(tokenize, [caps_gen, caps_gt]) if tokenizer_pool is not None
+                                 else (tokenize(caps_gen), tokenize(caps_gt)))
+        reward = cider.compute_score(caps_gt, caps_gen)[1].astype(np.float32)
+        return torch.from_numpy(reward).view(B, beam)
+
+    return reward_fn
+
+
+def train_sc(model, dataloaders, optimizers, cider, text_field, tokenizer_pool, device, epoch, config, rank=0, writer=None,
+             tokenize=None, evaluate=True, checkpoint=True):
+    """Self-critical epoch (reference engine/caption_engine.py:388-492), same signature plus `tokenize` (the reference
+    hard-wires metrics.PTBTokenizer.tokenize, a Java program that is not part of this build)."""
+    model.train()
+    reward_fn = cider_reward_fn(cider, text_field, tokenizer_pool, tokenize)
+    running_loss = running_reward = running_baseline = 0.0
+    n = len(dataloaders['train_dict'])
+    for it, batch in enumerate(_progress(dataloaders['train_dict'], desc=f'Epoch {epoch} - train', unit='it')):
+        loss, reward, baseline = train_sc_step(model, batch, optimizers, reward_fn, config)
+        running_loss += loss.item()
+        running_reward += reward.item()
+        running_baseline += baseline.item()
+        if rank == 0 and writer is not None:
+            writer.add_scalar('backbone_lr', optimizers['backbone'].param_groups[0]['lr'], epoch * n + it)
+            writer.add_scalar('model_lr', optimizers['model'].param_groups[0]['lr'], epoch * n + it)
+    loss_fn = NLLLoss(ignore_index=_pad_index(text_field))
+    val_loss = evaluate_loss(model, dataloaders['valid'], loss_fn, text_field, epoch, writer) \
+        if evaluate and 'valid' in dataloaders else 0.0
+    if rank == 0 and checkpoint:
+        save_checkpoint(model=model, optimizers=optimizers, epoch=epoch, scores=[], best_ciders=(0, 0), config=config,
+                        filename='checkpoint_last.pth', scheduler=None)
+    if is_dist_avail_and_initialized():
+        dist.barrier()
+    n = max(n, 1)
+    return {'loss': running_loss / n, 'reward': running_reward / n, 'reward_baseline': running_baseline / n,
+            'val_loss': val_loss}

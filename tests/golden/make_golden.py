@@ -386,7 +386,45 @@ def make_g8():
     print('g8 loss', loss.item(), 'unused', len(nograd), norms)
 
 
-MAKERS.update({'keys': make_keys, 'g3': make_g3, 'g4': make_g4, 'g6': make_g6, 'g7': make_g7, 'g8': make_g8})
+def make_g9():
+    """One self-critical step (reference engine/caption_engine.py:421-443) on the reference model: train mode, every
+    dropout p = 0, beam search WITH gradient (beam 3, 6 steps, out_size = beam), a fixed reward tensor in place of the
+    host-side CIDEr, loss = mean(-mean_t(log_probs) * (reward - mean_beam(reward))), backward.  Stored: beam tokens,
+    their log-probs, the loss, per-module gradient norms and slices of a few gradients."""
+    import json
+    import_reference()
+    from engine.utils import NestedTensor
+    model, cfg = _ref_model(3, **{'model.dropout': 0.0, 'model.detector.dropout': 0.0})
+    model.train()
+    g = torch.Generator().manual_seed(9)
+    B, beam, T = 2, 3, 6
+    images = torch.randn(B, 3, 224, 224, generator=g)
+    mask = torch.zeros(B, 224, 224, dtype=torch.bool)
+    reward = torch.rand(B, beam, generator=g)
+    outs, log_probs = model(NestedTensor(images, mask), seq=None, use_beam_search=True, max_len=T, eos_idx=3,
+                            beam_size=beam, out_size=beam, return_probs=False)
+    baseline = torch.mean(reward, -1, keepdim=True)
+    loss = (-torch.mean(log_probs, -1) * (reward - baseline)).mean()
+    loss.backward()
+    norms = {}
+    for n, p in model.named_parameters():
+        if p.requires_grad and p.grad is not None:
+            top = '.'.join(n.split('.')[:2]) if n.startswith('detector') else n.split('.')[0]
+            norms[top] = norms.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+    norms = {k: v**0.5 for k, v in norms.items()}
+    sel = {}
+    for n in ('cap_generator.fc.weight', 'grid_net.fc.weight', 'cap_generator.layers.0.vis_att1.attention.fc_k.weight',
+              'detector.det_module.decoder_layers.5.cross_attn.value_proj.weight', 'detector.input_proj.0.0.weight'):
+        sel[n] = dict(model.named_parameters())[n].grad.flatten()[:64].numpy()
+    np.savez_compressed(os.path.join(HERE, 'sc_g9.npz'), images=images.numpy(), reward=reward.numpy(),
+                        tokens=outs.numpy(), log_probs=log_probs.detach().numpy(), loss=np.array(loss.item()),
+                        **{'grad:' + k: v for k, v in sel.items()})
+    with open(os.path.join(HERE, 'sc_g9.json'), 'w') as f:
+        json.dump({'loss': loss.item(), 'grad_norms': norms}, f, indent=1)
+    print('g9 loss', loss.item(), 'tokens', outs.tolist(), norms)
+
+
+MAKERS.update({'keys': make_keys, 'g3': make_g3, 'g4': make_g4, 'g6': make_g6, 'g7': make_g7, 'g8': make_g8, 'g9': make_g9})
 
 if __name__ == "__main__":
     main()

@@ -110,3 +110,47 @@ def test_one_xe_step_loss_grads_and_unused_set():
     assert n_back == sum(1 for n, p in params.items() if p.requires_grad and 'detector' in n)
     assert opts['model'].param_groups[0]['lr'] == 1e-4 and opts['backbone'].param_groups[0]['lr'] == 1e-5
     assert all(gp['weight_decay'] == 0 for gp in opts['model'].param_groups + opts['backbone'].param_groups)
+
+
+def test_one_self_critical_step_matches_reference():
+    """Next-row N2: train_sc_step (reference engine/caption_engine.py:421-449) -- beam search WITH gradient, out_size =
+    beam, reward injected -- against fixture G9 made by the reference model: same beams, same log-probs, same loss, same
+    gradients; the step then updates both optimizers."""
+    from grit_amd.engine.caption_engine import build_optimizers, train_sc_step
+    from grit_amd.utils.misc import NestedTensor
+    g = load("sc_g9.npz")
+    ref = json.load(open(os.path.join(GOLDEN, "sc_g9.json")))
+    model, cfg = build_model(3, **{'model.dropout': 0.0, 'model.detector.dropout': 0.0})
+    model.train()
+    disable_drop_path(model)
+    B, beam, T = g["tokens"].shape
+    cfg.model.beam_size, cfg.model.beam_len = beam, T
+    opts = build_optimizers(model, cfg, mode='sc')
+    seen = {}
+
+    def reward_fn(tokens, batch):
+        seen['tokens'] = tokens.clone()
+        return t(g["reward"])
+
+    before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+    images = t(g["images"])
+    batch = {'samples': NestedTensor(images, torch.zeros(images.shape[0], *images.shape[-2:], dtype=torch.bool))}
+    with oracle_ops():
+        loss, reward, baseline = train_sc_step(model, batch, opts, reward_fn, cfg)
+    assert np.array_equal(seen['tokens'].numpy(), g["tokens"])  # identical beams, all `beam` of them per image
+    assert abs(loss.item() - ref["loss"]) < 2e-4 * abs(ref["loss"]) + 1e-7
+    assert abs(reward.item() - g["reward"].mean()) < 1e-6 and abs(baseline.item() - g["reward"].mean()) < 1e-6
+    params = dict(model.named_parameters())
+    norms = {}
+    for n, p in params.items():
+        if p.requires_grad and p.grad is not None:
+            top = '.'.join(n.split('.')[:2]) if n.startswith('detector') else n.split('.')[0]
+            norms[top] = norms.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+    for k, v in ref["grad_norms"].items():
+        assert abs(norms[k]**0.5 - v) < 3e-3 * v, (k, norms[k]**0.5, v)
+    for key in g.files:
+        if key.startswith("grad:"):
+            got = params[key[5:]].grad.flatten()[:64].numpy()
+            np.testing.assert_allclose(got, g[key], rtol=3e-3, atol=1e-6 + 3e-3 * np.abs(g[key]).max())
+    changed = sum(1 for n, p in params.items() if n in before and p.grad is not None and not torch.equal(p.detach(), before[n]))
+    assert changed > 100  # both Adams stepped

@@ -7,22 +7,96 @@ casts on both sides -- ~20 ms of a 170 ms step on MI355X (profiles/r01).  Here i
   * the module's parameters ARE bf16 tensors, each a view into one flat bf16 buffer per gradient bucket; gradients
     are produced by autograd directly into flat bf16 buckets (grit_amd.ddp.BucketedDataParallel), which is also what
     RCCL all-reduces -- half the bytes on xGMI, no staging copy;
-  * the optimizer owns fp32 master parameters laid out bucket-by-bucket the same way, so "bf16 grads -> fp32 grads"
-    and "fp32 masters -> bf16 compute weights" are ONE copy kernel per bucket per step;
+  * fp32 master parameters and Adam moments are laid out bucket-by-bucket the same way, and the optimizer step is ONE
+    kernel per contiguous run of an optimizer's parameters (FlatAdam / grit_adam_flat): it reads the bf16 gradients as
+    reduced, updates master + moments and rewrites the bf16 compute weights -- 28 B of HBM traffic per parameter, no
+    widening copy of the gradients, no separate refresh of the compute copy;
   * numerically sensitive spots stay fp32 by construction in the modules (softmax / LayerNorm statistics inside the
     HIP kernels, MSDA sampling locations, vocabulary logits + log-softmax, the loss).
 
 State dicts are exported from the masters (fp32) under the reference's key names.
 """
+import ctypes
+import math
+
 import torch
 from torch import nn
 
 from grit_amd.ddp import BucketedDataParallel
 
+SLOT_ALIGN = 8  # elements: every parameter starts 16-byte aligned in the bf16 buffers, 32-byte in the fp32 ones
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam (amsgrad off, weight decay 0) over the flat training state of Bf16Compute: one grit_adam_flat
+    launch per contiguous run of this optimizer's parameters in each bucket reads the bf16 gradients as reduced,
+    updates fp32 master + moments and rewrites the bf16 compute copy.  `state` / `param_groups` / `state_dict()` have
+    torch.optim.Adam's layout (exp_avg / exp_avg_sq are views into the flat moment buffers, `step` one shared tensor)."""
+
+    def __init__(self, owner, params, lr, betas=(0.9, 0.999), eps=1e-8):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                        capturable=False, differentiable=False, fused=None)
+        super().__init__(params, defaults)
+        self._owner = owner
+        mine = {p for g in self.param_groups for p in g['params']}
+        self._runs = owner._runs(mine)
+        self._t = 0
+        self._step_tensor = torch.tensor(0.0)
+        self._link_state()
+
+    def _link_state(self):
+        for g in self.param_groups:
+            for p in g['params']:
+                m, v = self._owner._moment_views[p]
+                self.state[p] = {'step': self._step_tensor, 'exp_avg': m, 'exp_avg_sq': v}
+
+    def zero_grad(self, set_to_none=True):
+        pass  # gradients live in the bf16 buckets, which backward overwrites; the masters never carry .grad
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = []
+        for g in self.param_groups:
+            for p in g['params']:
+                st = self.state.get(p, {})
+                m, v = self._owner._moment_views[p]
+                if 'exp_avg' in st:
+                    m.copy_(st['exp_avg'])
+                    v.copy_(st['exp_avg_sq'])
+                    steps.append(int(float(st['step'])))
+        self._t = max(steps) if steps else 0
+        self._step_tensor.fill_(float(self._t))
+        self._link_state()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from grit_amd import lib as _lib
+        hyper = {(g['lr'], tuple(g['betas']), g['eps'], g['weight_decay'], g['amsgrad'], g['maximize']) for g in self.param_groups}
+        if len(hyper) != 1:
+            raise NotImplementedError("FlatAdam: the parameter groups of one optimizer must share lr / betas / eps "
+                                      "(the reference's groups differ only in the ignored weight_decay_rate)")
+        lr, (b1, b2), eps, wd, amsgrad, maximize = next(iter(hyper))
+        if wd != 0 or amsgrad or maximize:
+            raise NotImplementedError("FlatAdam implements Adam with weight_decay = 0, amsgrad = False, maximize = False")
+        self._t += 1
+        self._step_tensor.fill_(float(self._t))
+        bc1, bc2s = 1.0 - b1 ** self._t, math.sqrt(1.0 - b2 ** self._t)
+        lib = _lib.load()
+        for bucket, compute, master, mom, var, start, end in self._runs:
+            n = end - start
+            with torch.cuda.device(master.device):
+                st = lib.grit_adam_flat(
+                    ctypes.c_void_p(master[start:].data_ptr()), ctypes.c_void_p(bucket.flat[start:].data_ptr()),
+                    int(bucket.flat.dtype == torch.bfloat16), ctypes.c_void_p(mom[start:].data_ptr()),
+                    ctypes.c_void_p(var[start:].data_ptr()), ctypes.c_void_p(compute[start:].data_ptr()), n, float(lr),
+                    float(b1), float(b2), float(eps), bc1, bc2s, 1.0, _lib.current_stream_ptr())
+            _lib.check(st, "grit_adam_flat")
+        return None
+
 
 class Bf16Compute(nn.Module):
 
-    def __init__(self, module, bucket_mb=64, process_group=None):
+    def __init__(self, module, bucket_mb=64, process_group=None, flat_optimizer=None):
         super().__init__()
         import torch.distributed as dist
         names = {p: n for n, p in module.named_parameters()}
@@ -32,25 +106,36 @@ class Bf16Compute(nn.Module):
         fp32 = {p: p.detach().clone().float() for p in module.parameters() if p.requires_grad}
         module.to(torch.bfloat16)  # parameters and floating buffers; integer buffers untouched
         self.ddp = BucketedDataParallel(module, bucket_mb=bucket_mb, process_group=process_group, repack_unused=False,
-                                        broadcast_parameters=False)
+                                        broadcast_parameters=False, slot_align=SLOT_ALIGN)
         self.module = module
-        self._masters, self._pairs = [], []
+        # flat Adam (grit_adam_flat) when the state lives on a GPU; on the CPU (gloo tests) torch's Adam steps the masters
+        # from fp32 copies of the gradients and the compute weights are refreshed by a copy
+        self.flat_optimizer = all(p.is_cuda for p in fp32) if flat_optimizer is None else flat_optimizer
+        self._masters, self._pairs, self._moment_views, self._slots = [], [], {}, []
         for b in self.ddp.buckets:
             n = b.flat.numel()
-            compute_flat = torch.empty(n, dtype=torch.bfloat16, device=b.flat.device)
-            master_flat = torch.empty(n, dtype=torch.float32, device=b.flat.device)
-            master_grad = torch.zeros(n, dtype=torch.float32, device=b.flat.device)
-            off = 0
-            for p in b.params:
+            compute_flat = torch.zeros(n, dtype=torch.bfloat16, device=b.flat.device)
+            master_flat = torch.zeros(n, dtype=torch.float32, device=b.flat.device)
+            if self.flat_optimizer:
+                master_grad = None
+                mom, var = torch.zeros_like(master_flat), torch.zeros_like(master_flat)
+            else:
+                master_grad = torch.zeros(n, dtype=torch.float32, device=b.flat.device)
+                mom = var = None
+            for p, gview in zip(b.params, b.views):
                 k = p.numel()
+                off = gview.storage_offset() - b.flat.storage_offset()
                 m = nn.Parameter(master_flat[off:off + k].view_as(p))
                 m.data.copy_(fp32[p])
-                m.grad = master_grad[off:off + k].view_as(p)
+                if master_grad is not None:
+                    m.grad = master_grad[off:off + k].view_as(p)
+                else:
+                    self._moment_views[m] = (mom[off:off + k].view_as(p), var[off:off + k].view_as(p))
                 compute_flat[off:off + k].view_as(p).copy_(m.data)
                 p.data = compute_flat[off:off + k].view_as(p)  # the module now computes on the flat bf16 copy
                 self._masters.append((names[p], m))
-                off += k
-            self._pairs.append((b, compute_flat, master_flat, master_grad))
+                self._slots.append((m, len(self._pairs), off, off + -(-k // SLOT_ALIGN) * SLOT_ALIGN))
+            self._pairs.append((b, compute_flat, master_flat, master_grad, mom, var))
 
     # ------------------------------------------------------------------ what the engine calls
     def forward(self, *args, **kwargs):
@@ -59,14 +144,42 @@ class Bf16Compute(nn.Module):
     def named_master_parameters(self):
         return list(self._masters)
 
+    def flat_adam(self, params, lr, betas=(0.9, 0.999), eps=1e-8):
+        """Optimizer factory for build_optimizers: Adam over `params` (masters, or Adam-style groups of them)."""
+        return FlatAdam(self, params, lr=lr, betas=betas, eps=eps)
+
+    def _runs(self, masters):
+        """Maximal contiguous slot ranges of each bucket whose parameters all belong to `masters`."""
+        runs, cur = [], None
+        for m, bi, start, end in self._slots:
+            if m in masters:
+                if cur is not None and cur[0] == bi and cur[2] == start:
+                    cur[2] = end
+                else:
+                    if cur is not None:
+                        runs.append(cur)
+                    cur = [bi, start, end]
+            elif cur is not None:
+                runs.append(cur)
+                cur = None
+        if cur is not None:
+            runs.append(cur)
+        out = []
+        for bi, start, end in runs:
+            b, compute, master, _, mom, var = self._pairs[bi]
+            out.append((b, compute, master, mom, var, start, end))
+        return out
+
     def finish_gradient_sync(self):
         self.ddp.finish_gradient_sync()
-        for b, _, _, master_grad in self._pairs:
-            master_grad.copy_(b.flat)  # bf16 -> fp32, one kernel per bucket
+        if not self.flat_optimizer:
+            for b, _, _, master_grad, _, _ in self._pairs:
+                master_grad.copy_(b.flat)  # bf16 -> fp32, one kernel per bucket
 
     def after_optimizer_step(self):
-        for b, compute_flat, master_flat, _ in self._pairs:
-            compute_flat.copy_(master_flat)  # fp32 -> bf16
+        if not self.flat_optimizer:
+            for b, compute_flat, master_flat, _, _, _ in self._pairs:
+                compute_flat.copy_(master_flat)  # fp32 -> bf16
 
     def master_state_dict(self):
         """fp32 state dict under the reference's key names (masters for trainable tensors, upcast copies otherwise)."""

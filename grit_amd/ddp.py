@@ -43,7 +43,7 @@ class _Bucket(object):
 class BucketedDataParallel(nn.Module):
 
     def __init__(self, module, bucket_mb=64, process_group=None, wire_dtype=None, broadcast_parameters=True,
-                 repack_unused=True):
+                 repack_unused=True, slot_align=1):
         super().__init__()
         self.module = module
         self.group = process_group
@@ -51,6 +51,7 @@ class BucketedDataParallel(nn.Module):
         self.bucket_bytes = int(bucket_mb * 2**20)
         self.wire_dtype = wire_dtype
         self.repack_unused = repack_unused  # False: keep the bucket layout (others hold views into it)
+        self.slot_align = slot_align  # every parameter's slot in a flat buffer starts at a multiple of this many elements
         self._seen = set()
         self._static_unused = None  # decided after the first iteration
         self._iteration = 0
@@ -78,8 +79,9 @@ class BucketedDataParallel(nn.Module):
             cur_bytes += nbytes
         if cur:
             groups.append(cur)
+        al = self.slot_align
         for plist in groups:
-            total = sum(p.numel() for p in plist)
+            total = sum(-(-p.numel() // al) * al for p in plist)
             flat = torch.zeros(total, dtype=plist[0].dtype, device=plist[0].device)
             off, views = 0, []
             for p in plist:
@@ -88,7 +90,7 @@ class BucketedDataParallel(nn.Module):
                     view.copy_(p.grad)
                     p.grad = view
                 views.append(view)
-                off += p.numel()
+                off += -(-p.numel() // al) * al  # padding stays zero: it is reduced and optimised as zeros
             b = _Bucket(plist, views, flat)
             for p in plist:
                 self._where[p] = b

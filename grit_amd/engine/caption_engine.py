@@ -30,6 +30,7 @@ def _unwrap(model):
 def build_optimizers(model, config, mode='xe'):
     # grit_amd.amp.Bf16Compute exposes fp32 masters under the module's parameter names; otherwise the module's own
     masters = getattr(model, 'named_master_parameters', None)
+    wrapper = model
     model = _unwrap(model)
     all_named = masters() if masters is not None else list(model.named_parameters())
     no_decay = ['bias', 'gamma', 'beta']
@@ -45,8 +46,12 @@ def build_optimizers(model, config, mode='xe'):
     betas = (config.optimizer.beta_1, config.optimizer.beta_2)
     fused = all(p.is_cuda for _, p in all_named)
 
+    flat = getattr(wrapper, 'flat_adam', None) if getattr(wrapper, 'flat_optimizer', False) else None
+
     def adam(param_groups, lr):
         param_groups = [g for g in param_groups if len(g['params'])] or param_groups
+        if flat is not None:  # grit_amd.amp.FlatAdam: same arithmetic and state layout, one kernel per parameter run
+            return flat(param_groups, lr, betas)
         return torch.optim.Adam(param_groups, lr=lr, betas=betas, **({'fused': True} if fused else {}))
 
     return {

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 11
+#define GRIT_ABI_VERSION 12
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -226,6 +226,18 @@ int grit_colsum(const void* x, int M, int N, int x_is_bf16, int slabs, float* pa
  * ------------------------------------------------------------------------------------------------------ */
 int grit_slab_sum(const float* partial, int groups, long group_stride, int slabs, long n, void* out, int out_is_bf16,
                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Adam step on one flat range of the fp32-master / bf16-compute training state (torch.optim.Adam as configured by the
+ * reference's build_optimizers, engine/caption_engine.py:18-73: amsgrad off, weight decay 0).
+ *   param, exp_avg, exp_avg_sq  f32 [n], updated in place;  grad [n] bf16 (grad_is_bf16) or f32, multiplied by grad_scale
+ *   compute_bf16                bf16 [n] copy of the updated parameters, or NULL
+ *   bias_correction1 = 1 - beta1^t,  bias_correction2_sqrt = sqrt(1 - beta2^t)   (t = 1-based step count)
+ * n % 4 == 0; f32 pointers 16-byte, bf16 pointers 8-byte aligned.
+ * ------------------------------------------------------------------------------------------------------ */
+int grit_adam_flat(float* param, const void* grad, int grad_is_bf16, float* exp_avg, float* exp_avg_sq, void* compute_bf16,
+                   long n, float lr, float beta1, float beta2, float eps, float bias_correction1,
+                   float bias_correction2_sqrt, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -141,3 +141,73 @@ def test_group_norm_levels_vs_torch(C, G, Ts, B, dtype, wdtype):
         for got, want in zip(gots, wants):
             scale = want.grad.abs().max().item()
             assert (got.grad.double().cpu() - want.grad).abs().max().item() < (2e-2 if wdtype == torch.bfloat16 else 3e-3) * scale
+
+
+def test_flat_adam_matches_torch_adam_and_state_dict_roundtrip():
+    """grit_adam_flat through grit_amd.amp.FlatAdam (bf16 gradient buckets -> fp32 masters + moments -> bf16 compute
+    copy, two optimizers splitting the flat space as build_optimizers does) against torch.optim.Adam stepping fp32
+    clones with the same (bf16-rounded) gradients, 6 steps; then state_dict() -> load_state_dict() into a fresh wrapper
+    continues identically."""
+    import copy
+    from grit_amd.amp import Bf16Compute
+
+    def make():
+        torch.manual_seed(3)
+        return torch.nn.Sequential(torch.nn.Linear(24, 50), torch.nn.GELU(), torch.nn.Linear(50, 2), torch.nn.Tanh(),
+                                   torch.nn.Linear(2, 37), torch.nn.LayerNorm(37), torch.nn.Linear(37, 8)).to(DEV)
+
+    def build(module):
+        w = Bf16Compute(module, bucket_mb=0.002)  # several tiny buckets: runs cross bucket boundaries
+        named = w.named_master_parameters()
+        head = [p for n, p in named if n.startswith(("0.", "2."))]
+        tail = [p for n, p in named if not n.startswith(("0.", "2."))]
+        opts = [w.flat_adam([{'params': head[:2]}, {'params': head[2:]}], 1e-2, (0.9, 0.99)), w.flat_adam(tail, 3e-3, (0.9, 0.99))]
+        return w, named, opts
+
+    w, named, opts = build(make())
+    assert w.flat_optimizer and len(w.ddp.buckets) >= 2
+    ref_params = [p.detach().clone().requires_grad_(True) for _, p in named]
+    n_head = sum(len(g['params']) for g in opts[0].param_groups)
+    names = [n for n, _ in named]
+    head_idx = [i for i, n in enumerate(names) if n.startswith(("0.", "2."))]
+    tail_idx = [i for i in range(len(names)) if i not in head_idx]
+    ref_opts = [torch.optim.Adam([ref_params[i] for i in head_idx], lr=1e-2, betas=(0.9, 0.99)),
+                torch.optim.Adam([ref_params[i] for i in tail_idx], lr=3e-3, betas=(0.9, 0.99))]
+    assert n_head == len(head_idx)
+    compute = dict(w.module.named_parameters())
+    gen = torch.Generator(device=DEV).manual_seed(0)
+
+    def one_step(wrapper, optimizers, check=True):
+        x = torch.randn(64, 24, device=DEV, generator=gen).bfloat16()
+        wrapper(x).float().square().mean().backward()
+        wrapper.finish_gradient_sync()
+        if check:
+            for i, n in enumerate(names):
+                ref_params[i].grad = compute[n].grad.detach().float().clone()
+        for o in optimizers:
+            o.step()
+        wrapper.after_optimizer_step()
+        if check:
+            for o in ref_opts:
+                o.step()
+
+    for _ in range(6):
+        one_step(w, opts)
+    for i, (n, m) in enumerate(named):
+        np.testing.assert_allclose(m.detach().cpu().numpy(), ref_params[i].detach().cpu().numpy(), rtol=2e-6, atol=2e-7, err_msg=n)
+        assert torch.equal(compute[n].detach(), m.detach().bfloat16()), n
+    sd = [copy.deepcopy(o.state_dict()) for o in opts]
+    assert sd[0]['state'][0]['exp_avg'].shape == named[head_idx[0]][1].shape and float(sd[0]['state'][0]['step']) == 6.0
+    # resume: fresh wrapper from the exported masters + optimizer state, one more identical step on both
+    state = w.master_state_dict()
+    fresh = make()
+    fresh.load_state_dict(state)
+    w2, named2, opts2 = build(fresh)
+    for o, s in zip(opts2, sd):
+        o.load_state_dict(s)
+    gen_state = gen.get_state()
+    one_step(w, opts, check=False)
+    gen.set_state(gen_state)
+    one_step(w2, opts2, check=False)
+    for (n, a), (_, b) in zip(named, named2):
+        assert torch.equal(a.detach(), b.detach()), n

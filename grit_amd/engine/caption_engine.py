@@ -9,7 +9,8 @@ is delegated to a caller-supplied scorer because the reference's PTB tokenizer /
 train_sc :388-492 (next-row N2): beam search with gradient + reward supplied by the caller (the reference's CIDEr /
 PTB tokenizer are host-side Java).  Out of scope: log_epoch, inference_coco_test.
 
-MI355X specifics: Adam runs as torch's fused multi-tensor kernel; the model may be wrapped either in
+MI355X specifics: with grit_amd.amp.Bf16Compute the two Adams are FlatAdam (one kernel per parameter run over the flat
+bf16-gradient / fp32-master state), otherwise torch's fused multi-tensor Adam; the model may be wrapped either in
 torch DDP or in grit_amd.ddp.BucketedDataParallel (gradient buckets all-reduced by RCCL on its side stream while
 backward is still running); tqdm / TensorBoard are optional.
 """

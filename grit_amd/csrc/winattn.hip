@@ -358,16 +358,27 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
             const float4 dl = *reinterpret_cast<const float4*>(&delta_s[oSt + 16 * qt]);
             const float ba[4] = {bq.x, bq.y, bq.z, bq.w}, lqa[4] = {lq.x, lq.y, lq.z, lq.w};
             const float dla[4] = {dl.x, dl.y, dl.z, dl.w};
-            uint32_t ids = 0;
-            if (analytic) ids = *reinterpret_cast<const uint32_t*>(&rid[oSt + 16 * qt]);
+            float t4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                t4[r] = fmaf(s[r], c2, ba[r]);
+                if (kExplicitMask)
+                    t4[r] = fmaf(mask[((size_t)(win % g.nWm) * kN + 16 * qt + 4 * lg + r) * kN + 16 * w + l15], kLog2e, t4[r]);
+            }
+            if (analytic) {
+                // wave-uniform branch, kept a real branch (the empty asm cannot be speculated): the analytic shift mask is
+                // 3 VALU instructions per element of an instruction-issue-bound loop and only the last window row /
+                // column of shifted blocks needs it
+                asm volatile("" ::: "memory");
+                const uint32_t ids = *reinterpret_cast<const uint32_t*>(&rid[oSt + 16 * qt]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((int)((ids >> (8 * r)) & 0xff) != kreg) t4[r] += -100.0f * kLog2e;
+            }
             v4bf pp, sp;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float t = fmaf(s[r], c2, ba[r]);
-                if (analytic && (int)((ids >> (8 * r)) & 0xff) != kreg) t += -100.0f * kLog2e;
-                if (kExplicitMask)
-                    t = fmaf(mask[((size_t)(win % g.nWm) * kN + 16 * qt + 4 * lg + r) * kN + 16 * w + l15], kLog2e, t);
-                const float p = __builtin_amdgcn_exp2f(t - lqa[r]);
+                const float p = __builtin_amdgcn_exp2f(t4[r] - lqa[r]);
                 const float dsv = p * (dp[r] - dla[r]);
                 dB[qt][r] += dsv;
                 pp[r] = (__bf16)p;

@@ -500,9 +500,10 @@ Geom make_geom(int B, int H, int W, int C, int nH, int shift, float scale, int n
 }
 
 int grid_blocks(const Geom& g, int target) {
-    // persistent: each workgroup serves one head and walks a strided set of windows.  Forward aims at ~4
-    // workgroups per CU in flight so the tail is short; backward at one per CU (it is LDS/register bound to one
-    // anyway) so that the d(bias) flush -- the only contended global atomics -- happens once per CU.
+    // persistent: each workgroup serves one head and walks a strided set of windows, one workgroup per CU (both
+    // kernels are register / LDS bound to one 9-wave workgroup per CU; measured: 256 beats 512 / 1024 / 2048 by 2-8 %
+    // forward and 5-20 % backward, profiles/r01/winattn_bwd_notes.txt), so the bias slice is loaded and the d(bias)
+    // accumulators are flushed -- the only contended global atomics -- once per CU.
     const int NW = g.B * g.nWh * g.nWw;
     if (const char* e = getenv("GRIT_WINATTN_BLOCKS")) target = atoi(e);  // tuning knob for tools/bench_kernels.py
     int groups = (target + g.nH - 1) / g.nH;
@@ -523,7 +524,7 @@ int grit_winattn_fwd_bf16(const void* qkv, const float* rel_bias, const void* pa
     if (st != GRIT_OK) return st;
     if (mask && n_mask_windows <= 0) return GRIT_ERR_BAD_ARG;
     const Geom g = make_geom(B, H, W, C, num_heads, shift, scale, n_mask_windows);
-    hipLaunchKernelGGL(winattn_fwd, dim3(grid_blocks(g, 1024)), dim3(kThreads), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(winattn_fwd, dim3(grid_blocks(g, 256)), dim3(kThreads), 0, (hipStream_t)stream,
                        (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (__bf16*)out, lse);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }

@@ -110,16 +110,24 @@ template <typename T, typename WT, int LPR, int CH>
 __global__ __launch_bounds__(256)
 void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restrict__ dy, const float* __restrict__ mean,
             const float* __restrict__ rstd, int rows, T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
-            const T* __restrict__ dres, const float* __restrict__ row_scale, int rows_per_sample, T* __restrict__ dbranch) {
+            const T* __restrict__ dres, const float* __restrict__ row_scale, int rows_per_sample, T* __restrict__ dbranch,
+            float* __restrict__ dsum) {
     constexpr int C = LPR * 8 * CH, R = 64 / LPR;
+    // column sums of the branch gradient (= bias gradient of the Linear that produced the branch) ride along for the
+    // block widths (C <= 1024); the wide merging norms never fuse a residual and keep their registers
+    constexpr bool kBranchSum = CH <= 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % LPR;
-    float wv[CH][8], aw[CH][8], ab[CH][8];
+    float wv[CH][8], aw[CH][8], ab[CH][8], ad[kBranchSum ? CH : 1][8];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         Vec8<WT>::load(w + (c * LPR + sub) * 8, wv[c]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) aw[c][i] = ab[c][i] = 0.f;
+        if constexpr (kBranchSum) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ad[c][i] = 0.f;
+        }
     }
     const int rows_per_pass = gridDim.x * 4 * R;
     for (int base = (blockIdx.x * 4 + wave) * R; base < rows; base += rows_per_pass) {  // wave-uniform trip count
@@ -166,26 +174,36 @@ void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restri
                     for (int i = 0; i < 8; ++i) o[i] = round_to<T>(o[i]) * sc;
                     Vec8<T>::store(dbranch + (size_t)row * C + (c * LPR + sub) * 8, o);
                 }
+                if constexpr (kBranchSum) {
+                    if (dsum) {  // what the consumer of the branch gradient reads: the stored (rounded) values
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) ad[c][i] += round_to<T>(o[i]);
+                    }
+                }
             }
         }
     }
     // rows handled side by side in one wave hold the same channels: fold them, fold the 4 waves through LDS, and
     // write this workgroup's partial sums (no atomics: thousands of waves on <= 4096 addresses serialise badly)
-    __shared__ float part[4][2][512];  // per wave, (dw | db), one 512-channel chunk at a time
+    __shared__ float part[4][3][512];  // per wave, (dw | db | branch sums), one 512-channel chunk at a time
+    const int nsum = (kBranchSum && dsum) ? 3 : 2;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float a = aw[c][i], bsum = ab[c][i];
+            float a = aw[c][i], bsum = ab[c][i], dsm = kBranchSum ? ad[kBranchSum ? c : 0][i] : 0.f;
 #pragma unroll
-            for (int o = LPR; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); bsum += __shfl_xor(bsum, o, 64); }
-            if (lane < LPR) { part[wave][0][sub * 8 + i] = a; part[wave][1][sub * 8 + i] = bsum; }
+            for (int o = LPR; o < 64; o <<= 1) {
+                a += __shfl_xor(a, o, 64); bsum += __shfl_xor(bsum, o, 64);
+                if (kBranchSum) dsm += __shfl_xor(dsm, o, 64);
+            }
+            if (lane < LPR) { part[wave][0][sub * 8 + i] = a; part[wave][1][sub * 8 + i] = bsum; part[wave][2][sub * 8 + i] = dsm; }
         }
         __syncthreads();
-        for (int j = threadIdx.x; j < 2 * LPR * 8; j += 256) {
+        for (int j = threadIdx.x; j < nsum * LPR * 8; j += 256) {
             const int which = j / (LPR * 8), ch = j % (LPR * 8);
             const float v = part[0][which][ch] + part[1][which][ch] + part[2][which][ch] + part[3][which][ch];
-            (which ? db : dw)[(size_t)blockIdx.x * C + c * LPR * 8 + ch] = v;
+            (which == 0 ? dw : which == 1 ? db : dsum)[(size_t)blockIdx.x * C + c * LPR * 8 + ch] = v;
         }
         __syncthreads();
     }
@@ -200,6 +218,7 @@ struct Fused {  // optional residual operands (all null / 0 for the plain LayerN
     void* sum_out = nullptr;          // forward: where x + scale * branch is stored
     const void* dres = nullptr;       // backward: gradient arriving at x through the skip path
     void* dbranch = nullptr;          // backward: where row_scale * dx (the branch gradient) is stored, or null
+    float* dsum = nullptr;            // backward: per-workgroup partial column sums of the branch gradient, or null
 };
 
 template <typename T, typename WT>
@@ -216,7 +235,7 @@ int launch(bool fwd, const void* x, const void* w, const void* b_or_dy, const fl
         else                                                                                                           \
             hipLaunchKernelGGL((ln_bwd<T, WT, LPR_, CH_>), dim3(blocks < kBwdBlocks ? blocks : kBwdBlocks), dim3(256), 0, st, \
                                (const T*)x, (const WT*)w, (const T*)b_or_dy, mean_in, rstd_in, rows, (T*)out, o1, o2,  \
-                               (const T*)fu.dres, fu.row_scale, fu.rows_per_sample, (T*)fu.dbranch);                   \
+                               (const T*)fu.dres, fu.row_scale, fu.rows_per_sample, (T*)fu.dbranch, fu.dsum);         \
         return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;                                            \
     }
     switch (C) {
@@ -268,11 +287,14 @@ int grit_add_layernorm_fwd(const void* shortcut, const void* branch, const float
 
 int grit_add_layernorm_bwd(const void* x, const void* weight, const void* dy, const void* dres, const float* mean,
                            const float* rstd, const float* row_scale, int rows_per_sample, int rows, int C, int x_is_bf16,
-                           int w_is_bf16, void* dx, void* dbranch, float* dweight, float* dbias, void* stream) {
+                           int w_is_bf16, void* dx, void* dbranch, float* dweight, float* dbias, float* dbranch_colsum,
+                           void* stream) {
     if (!mean || !rstd || ((row_scale != nullptr) != (dbranch != nullptr)) || (row_scale && rows_per_sample <= 0))
         return GRIT_ERR_BAD_ARG;
+    if (dbranch_colsum && C > 1024) return GRIT_ERR_UNSUPPORTED;
     Fused fu;
     fu.dres = dres; fu.row_scale = row_scale; fu.rows_per_sample = row_scale ? rows_per_sample : 1; fu.dbranch = dbranch;
+    fu.dsum = dbranch_colsum;
     return dispatch(false, x, weight, dy, mean, rstd, rows, C, 0.f, x_is_bf16, w_is_bf16, dx, dweight, dbias,
                     (hipStream_t)stream, fu);
 }

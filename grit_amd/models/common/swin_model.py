@@ -26,7 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from grit_amd.ops.layer_norm import LayerNorm, add_layer_norm
+from grit_amd.ops.layer_norm import LayerNorm, add_layer_norm, linear_add_layer_norm
 from grit_amd.ops.linear import Linear
 from grit_amd.ops.rel_bias import relative_position_bias
 from grit_amd.ops.window_attention import window_attention
@@ -64,8 +64,12 @@ class Mlp(nn.Module):
         self.fc2 = Linear(hidden_features, out_features or in_features)
         self.drop = nn.Dropout(drop)
 
+    def hidden(self, x):
+        """fc1 -> act -> drop: everything before fc2."""
+        return self.drop(self.act(self.fc1(x)))
+
     def forward(self, x):
-        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+        return self.drop(self.fc2(self.hidden(x)))
 
 
 def masked_sin_pos_encoding(x, mask, num_pos_feats, temperature=10000, scale=2 * math.pi):
@@ -138,12 +142,15 @@ class WindowAttention(nn.Module):
             return torch.zeros(3 * self.dim, dtype=dtype, device=self.qkv.weight.device)
         return self.qkv.bias.to(dtype)
 
+    def attend_heads(self, x, H, W, shift):
+        """x: normalised tokens [B, H*W, C] in map order -> concatenated head outputs [B, H*W, C] (before proj)."""
+        qkv = self.qkv(x)
+        return window_attention(qkv, self.relative_position_bias(), self.pad_qkv(qkv.dtype), H, W, self.num_heads,
+                                self.window_size[0], shift, self.scale)
+
     def attend_map(self, x, H, W, shift):
         """x: normalised tokens [B, H*W, C] in map order -> attention output [B, H*W, C] (after proj)."""
-        qkv = self.qkv(x)
-        out = window_attention(qkv, self.relative_position_bias(), self.pad_qkv(qkv.dtype), H, W, self.num_heads,
-                               self.window_size[0], shift, self.scale)
-        return self.proj_drop(self.proj(out))
+        return self.proj_drop(self.proj(self.attend_heads(x, H, W, shift)))
 
     def forward(self, x, mask=None):
         """Reference call form: x (num_windows*B, N, C) already partitioned, mask (nW, N, N) additive or None."""
@@ -181,6 +188,14 @@ class SwinTransformerBlock(nn.Module):
         H, W = self.H, self.W
         assert L == H * W, "input feature has wrong size"
         n1 = self.norm1(x) if normed is None else normed
+        if self.attn.proj_drop.p == 0. and self.mlp.drop.p == 0.:
+            # output projection + residual + following LayerNorm as one node (the norm's backward kernel then also
+            # yields the projection's bias gradient): attn.proj -> norm2, mlp.fc2 -> the next block's norm1
+            x, n2 = self._residual_linear_norm(x, self.attn.attend_heads(n1, H, W, self.shift_size), self.attn.proj, self.norm2)
+            h = self.mlp.hidden(n2)
+            if next_norm is None:
+                return self._residual(x, self.mlp.fc2(h))
+            return self._residual_linear_norm(x, h, self.mlp.fc2, next_norm)
         x, n2 = self._residual_norm(x, self.attn.attend_map(n1, H, W, self.shift_size), self.norm2)
         h = self.mlp(n2)
         if next_norm is None:
@@ -201,6 +216,13 @@ class SwinTransformerBlock(nn.Module):
         if scale is not None:
             return torch.addcmul(x, branch, scale.view(-1, 1, 1))
         return x + branch
+
+    def _residual_linear_norm(self, x, inp, linear, norm):
+        """(x + drop_path(linear(inp)), norm(x + drop_path(linear(inp))))."""
+        if isinstance(norm, LayerNorm) and norm.elementwise_affine and len(norm.normalized_shape) == 1:
+            return linear_add_layer_norm(inp, linear, x, self._drop_path_scale(x, torch.float32), norm.weight, norm.bias,
+                                         norm.eps)
+        return self._residual_norm(x, linear(inp), norm)
 
     def _residual_norm(self, x, branch, norm):
         """(x + drop_path(branch), norm(x + drop_path(branch)))."""

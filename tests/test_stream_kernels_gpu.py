@@ -211,3 +211,41 @@ def test_flat_adam_matches_torch_adam_and_state_dict_roundtrip():
     one_step(w2, opts2, check=False)
     for (n, a), (_, b) in zip(named, named2):
         assert torch.equal(a.detach(), b.detach()), n
+
+
+@pytest.mark.parametrize("C,K,B,L,drop_path", [(128, 128, 2, 2500, True), (512, 2048, 3, 1400, False), (256, 1024, 2, 2100, True)])
+def test_linear_add_layer_norm_node(C, K, B, L, drop_path):
+    """linear_add_layer_norm: x = shortcut + scale * (inp @ W^T + b), y = LN(x) as ONE autograd node (attn.proj / mlp.fc2 +
+    residual + the following norm of a Swin block, swin_model.py:289-298) against the float64 composition: outputs and
+    the gradients of inp, W, b (delivered by the LayerNorm backward kernel's extra column sums), shortcut, gamma, beta."""
+    from grit_amd.ops.layer_norm import linear_add_layer_norm
+    from grit_amd.ops.linear import Linear
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(C + K)
+    inp = torch.randn(B, L, K, generator=g).to(dtype)
+    sc = (torch.randn(B, L, C, generator=g) * 1.5).to(dtype)
+    lin = Linear(K, C)
+    lin.weight.data = (torch.randn(C, K, generator=g) / K ** 0.5)
+    lin.bias.data = 0.3 * torch.randn(C, generator=g)
+    lin = lin.to(dtype)
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(dtype)
+    b = (0.1 * torch.randn(C, generator=g)).to(dtype)
+    scale = torch.tensor([1.25, 0.0, 1.25][:B]) if drop_path else None
+    cot_x, cot_y = torch.randn(B, L, C, generator=g).to(dtype), torch.randn(B, L, C, generator=g).to(dtype)
+    i64, s64, W64, B64, w64, b64 = (z.detach().double().requires_grad_(True) for z in (inp, sc, lin.weight, lin.bias, w, b))
+    branch = torch.nn.functional.linear(i64, W64, B64)
+    branch = branch + (branch.detach().to(dtype).double() - branch.detach())  # the GEMM output is stored in bf16
+    x_ref = s64 + (branch if scale is None else branch * scale.double().view(-1, 1, 1))
+    y_ref = torch.nn.functional.layer_norm(x_ref + (x_ref.detach().to(dtype).double() - x_ref.detach()), (C,), w64, b64, 1e-5)
+    torch.autograd.backward([x_ref, y_ref], [cot_x.double(), cot_y.double()])
+    lin_d = lin.to(DEV)
+    i_d, s_d, w_d, b_d = (z.to(DEV).requires_grad_(True) for z in (inp, sc, w, b))
+    x, y = linear_add_layer_norm(i_d, lin_d, s_d, None if scale is None else scale.to(DEV), w_d, b_d, 1e-5)
+    torch.autograd.backward([x, y], [cot_x.to(DEV), cot_y.to(DEV)])
+    np.testing.assert_allclose(x.detach().float().cpu().numpy(), x_ref.detach().float().numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), y_ref.detach().float().numpy(), rtol=3e-2, atol=3e-2)
+    for name, got, want in (("d_inp", i_d.grad, i64.grad), ("d_shortcut", s_d.grad, s64.grad), ("dW", lin_d.weight.grad, W64.grad),
+                            ("db", lin_d.bias.grad, B64.grad), ("dgamma", w_d.grad, w64.grad), ("dbeta", b_d.grad, b64.grad)):
+        scale_ = want.abs().max().item()
+        err = (got.double().cpu() - want).abs().max().item()
+        assert err < 4e-2 * scale_, (name, err, scale_)

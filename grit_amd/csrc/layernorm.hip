@@ -51,6 +51,16 @@ template <typename T> __device__ __forceinline__ float round_to(float v);
 template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
 template <> __device__ __forceinline__ float round_to<__hip_bfloat16>(float v) { return __bfloat162float(__float2bfloat16(v)); }
 
+// counter-based dropout keep factor (same construction as the attention kernels, attn.hip): murmur3 finaliser over
+// (element index + seed mix); forward and backward regenerate the mask from the seed, nothing is stored
+__device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+    unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull;
+    unsigned int x = (unsigned int)(z ^ (z >> 32));
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    const float u = (float)(x >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.0f;
+}
+
 template <int LPR>
 __device__ __forceinline__ float row_sum(float v) {
 #pragma unroll
@@ -63,8 +73,11 @@ template <typename T, typename WT, int LPR, int CH>
 __global__ __launch_bounds__(256)
 void ln_fwd(const T* __restrict__ x, const WT* __restrict__ w, const WT* __restrict__ b, int rows, float eps,
             T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
-            const T* __restrict__ branch, const float* __restrict__ row_scale, int rows_per_sample, T* __restrict__ sum_out) {
+            const T* __restrict__ branch, const float* __restrict__ row_scale, int rows_per_sample, T* __restrict__ sum_out,
+            float drop_p, const unsigned long long* __restrict__ seed_dev) {
     constexpr int C = LPR * 8 * CH, R = 64 / LPR;
+    const unsigned long long seed = (branch && drop_p > 0.f) ? *seed_dev : 0ull;
+    const float inv_keep = 1.0f / (1.0f - drop_p);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % LPR;
     const int row = (blockIdx.x * 4 + wave) * R + lane / LPR;
@@ -78,6 +91,11 @@ void ln_fwd(const T* __restrict__ x, const WT* __restrict__ w, const WT* __restr
             float br[8];
             Vec8<T>::load(branch + (size_t)rc * C + (c * LPR + sub) * 8, br);
             const float sc = row_scale ? row_scale[rc / rows_per_sample] : 1.0f;
+            if (drop_p > 0.f) {  // element dropout of the branch (nn.Dropout between the projection and the residual)
+                const unsigned long long e0 = (unsigned long long)rc * C + (c * LPR + sub) * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) br[i] = round_to<T>(br[i] * keep_scale(seed, e0 + i, drop_p, inv_keep));
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[c][i] = round_to<T>(__fadd_rn(v[c][i], __fmul_rn(br[i], sc)));
             if (row < rows) Vec8<T>::store(sum_out + (size_t)row * C + (c * LPR + sub) * 8, v[c]);
@@ -111,8 +129,10 @@ __global__ __launch_bounds__(256)
 void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restrict__ dy, const float* __restrict__ mean,
             const float* __restrict__ rstd, int rows, T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
             const T* __restrict__ dres, const float* __restrict__ row_scale, int rows_per_sample, T* __restrict__ dbranch,
-            float* __restrict__ dsum) {
+            float* __restrict__ dsum, float drop_p, const unsigned long long* __restrict__ seed_dev) {
     constexpr int C = LPR * 8 * CH, R = 64 / LPR;
+    const unsigned long long seed = (dbranch && drop_p > 0.f) ? *seed_dev : 0ull;
+    const float inv_keep = 1.0f / (1.0f - drop_p);
     // column sums of the branch gradient (= bias gradient of the Linear that produced the branch) ride along for the
     // block widths (C <= 1024); the wide merging norms never fuse a residual and keep their registers
     constexpr bool kBranchSum = CH <= 2;
@@ -168,10 +188,15 @@ void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restri
                     ab[c][i] += g[c][i];
                 }
                 Vec8<T>::store(dx + (size_t)row * C + (c * LPR + sub) * 8, o);
-                if (dbranch) {  // gradient of the drop-path branch: the rounded dx times this sample's keep factor
-                    const float sc = row_scale[row / rows_per_sample];
+                if (dbranch) {  // gradient of the branch: the rounded dx times the sample's drop-path factor and/or the
+                                // element's dropout keep factor
+                    const float sc = row_scale ? row_scale[row / rows_per_sample] : 1.0f;
+                    const unsigned long long e0 = (unsigned long long)row * C + (c * LPR + sub) * 8;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) o[i] = round_to<T>(o[i]) * sc;
+                    for (int i = 0; i < 8; ++i) {
+                        o[i] = round_to<T>(o[i]) * sc;
+                        if (drop_p > 0.f) o[i] *= keep_scale(seed, e0 + i, drop_p, inv_keep);
+                    }
                     Vec8<T>::store(dbranch + (size_t)row * C + (c * LPR + sub) * 8, o);
                 }
                 if constexpr (kBranchSum) {
@@ -219,6 +244,8 @@ struct Fused {  // optional residual operands (all null / 0 for the plain LayerN
     const void* dres = nullptr;       // backward: gradient arriving at x through the skip path
     void* dbranch = nullptr;          // backward: where row_scale * dx (the branch gradient) is stored, or null
     float* dsum = nullptr;            // backward: per-workgroup partial column sums of the branch gradient, or null
+    float drop_p = 0.f;               // element dropout probability applied to the branch (0: none)
+    const unsigned long long* seed_dev = nullptr;  // device-resident dropout seed (read when drop_p > 0)
 };
 
 template <typename T, typename WT>
@@ -231,11 +258,11 @@ int launch(bool fwd, const void* x, const void* w, const void* b_or_dy, const fl
         if (fwd)                                                                                                       \
             hipLaunchKernelGGL((ln_fwd<T, WT, LPR_, CH_>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const WT*)w,  \
                                (const WT*)b_or_dy, rows, eps, (T*)out, o1, o2, (const T*)fu.branch, fu.row_scale,        \
-                               fu.rows_per_sample, (T*)fu.sum_out);                                                   \
+                               fu.rows_per_sample, (T*)fu.sum_out, fu.drop_p, fu.seed_dev);                           \
         else                                                                                                           \
             hipLaunchKernelGGL((ln_bwd<T, WT, LPR_, CH_>), dim3(blocks < kBwdBlocks ? blocks : kBwdBlocks), dim3(256), 0, st, \
                                (const T*)x, (const WT*)w, (const T*)b_or_dy, mean_in, rstd_in, rows, (T*)out, o1, o2,  \
-                               (const T*)fu.dres, fu.row_scale, fu.rows_per_sample, (T*)fu.dbranch, fu.dsum);         \
+                               (const T*)fu.dres, fu.row_scale, fu.rows_per_sample, (T*)fu.dbranch, fu.dsum, fu.drop_p, fu.seed_dev); \
         return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;                                            \
     }
     switch (C) {
@@ -276,25 +303,29 @@ int grit_layernorm_bwd(const void* x, const void* weight, const void* dy, const 
 }
 
 int grit_add_layernorm_fwd(const void* shortcut, const void* branch, const float* row_scale, int rows_per_sample,
-                           const void* weight, const void* bias, int rows, int C, float eps, int x_is_bf16, int w_is_bf16,
-                           void* sum_out, void* y, float* mean, float* rstd, void* stream) {
-    if (!branch || !sum_out || rows_per_sample <= 0) return GRIT_ERR_BAD_ARG;
+                           float drop_p, const uint64_t* seed_dev, const void* weight, const void* bias, int rows, int C,
+                           float eps, int x_is_bf16, int w_is_bf16, void* sum_out, void* y, float* mean, float* rstd,
+                           void* stream) {
+    if (!branch || !sum_out || rows_per_sample <= 0 || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !seed_dev))
+        return GRIT_ERR_BAD_ARG;
     Fused fu;
     fu.branch = branch; fu.row_scale = row_scale; fu.rows_per_sample = rows_per_sample; fu.sum_out = sum_out;
+    fu.drop_p = drop_p; fu.seed_dev = (const unsigned long long*)seed_dev;
     return dispatch(true, shortcut, weight, bias, nullptr, nullptr, rows, C, eps, x_is_bf16, w_is_bf16, y, mean, rstd,
                     (hipStream_t)stream, fu);
 }
 
 int grit_add_layernorm_bwd(const void* x, const void* weight, const void* dy, const void* dres, const float* mean,
-                           const float* rstd, const float* row_scale, int rows_per_sample, int rows, int C, int x_is_bf16,
-                           int w_is_bf16, void* dx, void* dbranch, float* dweight, float* dbias, float* dbranch_colsum,
-                           void* stream) {
-    if (!mean || !rstd || ((row_scale != nullptr) != (dbranch != nullptr)) || (row_scale && rows_per_sample <= 0))
+                           const float* rstd, const float* row_scale, int rows_per_sample, float drop_p,
+                           const uint64_t* seed_dev, int rows, int C, int x_is_bf16, int w_is_bf16, void* dx, void* dbranch,
+                           float* dweight, float* dbias, float* dbranch_colsum, void* stream) {
+    if (!mean || !rstd || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !seed_dev) || (row_scale && rows_per_sample <= 0))
         return GRIT_ERR_BAD_ARG;
+    if (((row_scale != nullptr) || drop_p > 0.f) != (dbranch != nullptr)) return GRIT_ERR_BAD_ARG;
     if (dbranch_colsum && C > 1024) return GRIT_ERR_UNSUPPORTED;
     Fused fu;
     fu.dres = dres; fu.row_scale = row_scale; fu.rows_per_sample = row_scale ? rows_per_sample : 1; fu.dbranch = dbranch;
-    fu.dsum = dbranch_colsum;
+    fu.dsum = dbranch_colsum; fu.drop_p = drop_p; fu.seed_dev = (const unsigned long long*)seed_dev;
     return dispatch(false, x, weight, dy, mean, rstd, rows, C, 0.f, x_is_bf16, w_is_bf16, dx, dweight, dbias,
                     (hipStream_t)stream, fu);
 }

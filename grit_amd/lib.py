@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -32,8 +32,8 @@ SIGNATURES = {
     "grit_layernorm_bwd": [_ptr] * 5 + [_int] * 4 + [_ptr] * 4,
     "grit_relbias_fwd": [_ptr, _ptr, _int, _int, _int, _int, _ptr, _ptr],
     "grit_relbias_bwd": [_ptr, _ptr, _ptr, _int, _int, _int, _int, _ptr, _ptr],
-    "grit_add_layernorm_fwd": [_ptr] * 3 + [_int] + [_ptr] * 2 + [_int, _int, _f32, _int, _int] + [_ptr] * 5,
-    "grit_add_layernorm_bwd": [_ptr] * 7 + [_int] * 5 + [_ptr] * 6,
+    "grit_add_layernorm_fwd": [_ptr] * 3 + [_int, _f32, _ptr] + [_ptr] * 2 + [_int, _int, _f32, _int, _int] + [_ptr] * 5,
+    "grit_add_layernorm_bwd": [_ptr] * 7 + [_int, _f32, _ptr] + [_int] * 4 + [_ptr] * 6,
     "grit_groupnorm_tokens_fwd": [_ptr, _c.c_long, _ptr, _ptr, _int, _int, _int, _int, _f32, _int, _int, _ptr, _c.c_long] + [_ptr] * 4,
     "grit_groupnorm_tokens_bwd": [_ptr, _c.c_long, _ptr, _c.c_long, _ptr, _ptr, _ptr, _int, _int, _int, _int, _int, _int] + [_ptr] * 5,
     "grit_adam_flat": [_ptr, _ptr, _int, _ptr, _ptr, _ptr, _c.c_long] + [_f32] * 7 + [_ptr],

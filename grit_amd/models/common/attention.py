@@ -12,6 +12,7 @@ from torch import nn
 
 from grit_amd.models.caption.containers import Module
 from grit_amd.ops.attention import attention as fused_attention
+from grit_amd.ops.layer_norm import linear_add_layer_norm
 
 
 def init_params(module):
@@ -45,8 +46,9 @@ class Attention(nn.Module):
         self.hoist_kv = False
         self._kv = None
 
-    def forward(self, q, k, v, attention_mask=None):
-        """q (b, nq, d_model), k/v (b, nk, d_model); attention_mask broadcastable to (b, h, nq, nk), True = masked."""
+    def forward(self, q, k, v, attention_mask=None, project=True):
+        """q (b, nq, d_model), k/v (b, nk, d_model); attention_mask broadcastable to (b, h, nq, nk), True = masked.
+        project=False returns the concatenated heads before fc_o (the caller fuses fc_o with what follows)."""
         b, nq, nk, h = q.shape[0], q.shape[1], k.shape[1], self.n_heads
         qh = self.fc_q(q).view(b, nq, h, self.d_k)
         if self.hoist_kv and not self.training and k is v:
@@ -59,7 +61,7 @@ class Attention(nn.Module):
             vh = self.fc_v(v).view(b, nk, h, self.d_k)
         out = fused_attention(qh, kh, vh, attention_mask, scale=1.0 / np.sqrt(self.d_k), dropout_p=self.dropout.p,
                               training=self.training)
-        return self.fc_o(out)
+        return self.fc_o(out) if project else out
 
 
 class MultiHeadAttention(Module):
@@ -87,5 +89,11 @@ class MultiHeadAttention(Module):
                 self.running_values = self.running_values[:, 1:]
             keys, values = self.running_keys, self.running_values
             self.timestep += 1
+        if self.training and torch.is_grad_enabled() and queries.is_cuda:
+            # training step: fc_o + dropout + residual + LayerNorm as one autograd node (grit_amd/ops/layer_norm.py)
+            heads = self.attention(queries, keys, values, attention_mask, project=False)
+            ln = self.layer_norm
+            return linear_add_layer_norm(heads, self.attention.fc_o, queries, None, ln.weight, ln.bias, ln.eps,
+                                         self.dropout.p, True)[1]
         out = self.dropout(self.attention(queries, keys, values, attention_mask))
         return self.layer_norm(queries + out)

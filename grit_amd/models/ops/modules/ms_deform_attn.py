@@ -54,7 +54,7 @@ class MSDeformAttn(nn.Module):
         constant_(self.output_proj.bias.data, 0.)
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
-                input_padding_mask=None):
+                input_padding_mask=None, project=True):
         """query (N, Lq, C); reference_points (N, Lq, L, 2|4) in [0,1]; input_flatten (N, sum H_l*W_l, C);
         input_spatial_shapes (L, 2) int64 (H, W); input_level_start_index (L,) int64; input_padding_mask (N, S) bool
         -> (N, Lq, C)."""
@@ -81,4 +81,5 @@ class MSDeformAttn(nn.Module):
                 reference_points.shape[-1]))
         sampled = deformable_sample(value, input_spatial_shapes, input_level_start_index, locations, weights,
                                     self.im2col_step)
-        return self.output_proj(sampled.to(value.dtype))
+        sampled = sampled.to(value.dtype)
+        return self.output_proj(sampled) if project else sampled

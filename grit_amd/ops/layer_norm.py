@@ -98,8 +98,8 @@ class _AddLayerNormFn(Function):
         per_sample = rows // shortcut.shape[0]
         with torch.cuda.device(s2.device):
             st = _lib.load().grit_add_layernorm_fwd(_ptr(s2), _ptr(b2), _ptr(scale) if scale is not None else None, per_sample,
-                                                    _ptr(weight), _ptr(bias), rows, C, eps, xb, wb, _ptr(x), _ptr(y), _ptr(mean),
-                                                    _ptr(rstd), _lib.current_stream_ptr())
+                                                    0.0, None, _ptr(weight), _ptr(bias), rows, C, eps, xb, wb, _ptr(x), _ptr(y),
+                                                    _ptr(mean), _ptr(rstd), _lib.current_stream_ptr())
         _lib.check(st, "grit_add_layernorm_fwd")
         ctx.save_for_backward(x, weight, mean, rstd, scale)
         ctx.shape = shortcut.shape
@@ -109,11 +109,11 @@ class _AddLayerNormFn(Function):
     @once_differentiable
     def backward(ctx, gx, gy):
         x2, weight, mean, rstd, scale = ctx.saved_tensors
-        dx, d_branch, sums = _add_layer_norm_backward(x2, weight, mean, rstd, scale, gx, gy, ctx.shape[0], False)
+        dx, d_branch, sums = _add_layer_norm_backward(x2, weight, mean, rstd, scale, gx, gy, ctx.shape[0], False, 0.0, None)
         return dx.view(ctx.shape), d_branch.view(ctx.shape), None, sums[0], sums[1], None
 
 
-def _add_layer_norm_backward(x2, weight, mean, rstd, scale, gx, gy, batch, branch_colsum):
+def _add_layer_norm_backward(x2, weight, mean, rstd, scale, gx, gy, batch, branch_colsum, drop_p, seed_dev):
     """(dx, d_branch, sums): sums[0] = dgamma, sums[1] = dbeta, and with branch_colsum sums[2] = column sums of d_branch
     (the bias gradient of the Linear that produced the branch), all from the one grit_add_layernorm_bwd launch."""
     rows, C = x2.shape
@@ -128,7 +128,8 @@ def _add_layer_norm_backward(x2, weight, mean, rstd, scale, gx, gy, batch, branc
         if not gx2.is_contiguous() or gx2.dtype != x2.dtype:
             gx2 = gx2.to(x2.dtype).contiguous()
     dx = torch.empty_like(x2)
-    d_branch = dx if scale is None else torch.empty_like(x2)
+    own_branch = scale is not None or drop_p > 0
+    d_branch = torch.empty_like(x2) if own_branch else dx
     rows_per_block = 4 * (64 // min(C // 8, 64))
     nblk = min(-(-rows // rows_per_block), LN_BWD_PARTIALS)
     n_sums = 3 if branch_colsum else 2
@@ -137,9 +138,9 @@ def _add_layer_norm_backward(x2, weight, mean, rstd, scale, gx, gy, batch, branc
     with torch.cuda.device(x2.device):
         st = _lib.load().grit_add_layernorm_bwd(
             _ptr(x2), _ptr(weight), _ptr(gy2), _ptr(gx2) if gx2 is not None else None, _ptr(mean), _ptr(rstd),
-            _ptr(scale) if scale is not None else None, rows // batch, rows, C, xb, wb, _ptr(dx),
-            _ptr(d_branch) if scale is not None else None, _ptr(base[0]), _ptr(base[1]),
-            _ptr(base[2]) if branch_colsum else None, _lib.current_stream_ptr())
+            _ptr(scale) if scale is not None else None, rows // batch, float(drop_p),
+            _ptr(seed_dev) if drop_p > 0 else None, rows, C, xb, wb, _ptr(dx), _ptr(d_branch) if own_branch else None,
+            _ptr(base[0]), _ptr(base[1]), _ptr(base[2]) if branch_colsum else None, _lib.current_stream_ptr())
     _lib.check(st, "grit_add_layernorm_bwd")
     return dx, d_branch, slab_sum(base, weight.dtype, slabs=nblk)
 
@@ -150,7 +151,7 @@ class _LinearAddLayerNormFn(Function):
     LayerNorm backward kernel, which already streams the branch gradient, also delivers the Linear's bias gradient."""
 
     @staticmethod
-    def forward(ctx, inp, lin_w, lin_b, shortcut, scale, weight, bias, eps):
+    def forward(ctx, inp, lin_w, lin_b, shortcut, scale, weight, bias, eps, drop_p, seed_dev):
         branch = F.linear(inp, lin_w, lin_b)
         C = shortcut.shape[-1]
         s2 = shortcut.reshape(-1, C)
@@ -164,42 +165,55 @@ class _LinearAddLayerNormFn(Function):
         xb, wb = int(s2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
         with torch.cuda.device(s2.device):
             st = _lib.load().grit_add_layernorm_fwd(_ptr(s2), _ptr(b2), _ptr(scale) if scale is not None else None,
-                                                    rows // shortcut.shape[0], _ptr(weight), _ptr(bias), rows, C, eps, xb, wb,
-                                                    _ptr(x), _ptr(y), _ptr(mean), _ptr(rstd), _lib.current_stream_ptr())
+                                                    rows // shortcut.shape[0], float(drop_p),
+                                                    _ptr(seed_dev) if drop_p > 0 else None, _ptr(weight), _ptr(bias), rows, C,
+                                                    eps, xb, wb, _ptr(x), _ptr(y), _ptr(mean), _ptr(rstd),
+                                                    _lib.current_stream_ptr())
         _lib.check(st, "grit_add_layernorm_fwd")
-        ctx.save_for_backward(x, weight, mean, rstd, scale, inp, lin_w)
-        ctx.shape = shortcut.shape
+        ctx.save_for_backward(x, weight, mean, rstd, scale, inp, lin_w, seed_dev)
+        ctx.shape, ctx.drop_p = shortcut.shape, drop_p
         return x.view(shortcut.shape), y.view(shortcut.shape)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gx, gy):
         from grit_amd.ops.linear import weight_grad
-        x2, weight, mean, rstd, scale, inp, lin_w = ctx.saved_tensors
-        dx, d_branch, sums = _add_layer_norm_backward(x2, weight, mean, rstd, scale, gx, gy, ctx.shape[0], True)
+        x2, weight, mean, rstd, scale, inp, lin_w, seed_dev = ctx.saved_tensors
+        dx, d_branch, sums = _add_layer_norm_backward(x2, weight, mean, rstd, scale, gx, gy, ctx.shape[0], True, ctx.drop_p,
+                                                      seed_dev)
         inp2 = inp.reshape(-1, inp.shape[-1])
         if not inp2.is_contiguous():
             inp2 = inp2.contiguous()
         d_inp = torch.mm(d_branch, lin_w).view(inp.shape) if ctx.needs_input_grad[0] else None
         d_lin_w = weight_grad(d_branch, inp2) if ctx.needs_input_grad[1] else None
-        return d_inp, d_lin_w, sums[2].to(lin_w.dtype), dx.view(ctx.shape), None, sums[0], sums[1], None
+        return d_inp, d_lin_w, sums[2].to(lin_w.dtype), dx.view(ctx.shape), None, sums[0], sums[1], None, None, None
 
 
-def linear_add_layer_norm(inp, linear, shortcut, scale, weight, bias, eps=1e-5):
-    """x = shortcut + scale[b] * linear(inp);  returns (x, layer_norm(x)).  `linear` is an nn.Linear-like module with bias."""
+MIN_ROWS_FUSED = 512  # below this torch's own chain is as good
+
+
+def linear_add_layer_norm(inp, linear, shortcut, scale, weight, bias, eps=1e-5, dropout_p=0.0, training=False):
+    """x = shortcut + scale[b] * dropout(linear(inp));  returns (x, layer_norm(x)).  `linear`: an nn.Linear-like module
+    with bias; scale: per-sample stochastic-depth factors or None; dropout_p applies (in training) between the projection
+    and the residual add, as nn.Dropout does in the post-norm decoder layers."""
+    p = float(dropout_p) if training else 0.0
     C = shortcut.shape[-1]
     fits = (backend.override() is None and shortcut.is_cuda and torch.is_grad_enabled() and C in SUPPORTED_C and C <= 1024
             and linear.bias is not None and linear.weight.shape[0] == C and inp.dtype == shortcut.dtype == linear.weight.dtype
             and shortcut.dtype in (torch.float32, torch.bfloat16) and weight is not None and bias is not None
             and weight.dtype == bias.dtype and weight.dtype == linear.weight.dtype and inp.shape[:-1] == shortcut.shape[:-1]
             and (inp.requires_grad or linear.weight.requires_grad) and not torch.is_autocast_enabled()
-            and shortcut.numel() // C >= 4096)
+            and shortcut.numel() // C >= MIN_ROWS_FUSED and 0.0 <= p < 1.0)
     if not fits:
-        return add_layer_norm(shortcut, linear(inp), scale, weight, bias, eps)
+        branch = linear(inp)
+        if p > 0:
+            branch = F.dropout(branch, p, True)
+        return add_layer_norm(shortcut, branch, scale, weight, bias, eps)
     if scale is not None:
         scale = scale.reshape(-1).float().contiguous()
+    seed_dev = torch.empty(1, dtype=torch.int64, device=inp.device).random_() if p > 0 else None
     return _LinearAddLayerNormFn.apply(inp, linear.weight, linear.bias, shortcut, scale, weight.contiguous(), bias.contiguous(),
-                                       float(eps))
+                                       float(eps), p, seed_dev)
 
 
 def add_layer_norm(shortcut, branch, scale, weight, bias, eps=1e-5):

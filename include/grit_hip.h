@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 13
+#define GRIT_ABI_VERSION 14
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -183,17 +183,22 @@ int grit_relbias_bwd(const float* dbias, const int32_t* order, const int32_t* of
  * Backward: dx = dres + dLayerNorm(dy)   (dres = gradient reaching sum_out through the skip path, may be NULL) is the
  * gradient of `shortcut`; with row_scale the gradient of `branch`, dbranch = row_scale[row / rows_per_sample] * dx, is
  * written too (row_scale and dbranch are given together or both NULL: the branch gradient is then dx itself).
+ * drop_p > 0 additionally applies element dropout to the branch before the residual add (the nn.Dropout between a
+ * projection and `LayerNorm(x + dropout(proj))` in the post-norm decoder layers: det_module.py:313-349, attention.py:
+ * 166-184, pos_embed.py:44-48): keep mask = counter hash of (seed read from seed_dev, element index), regenerated in the
+ * backward (same drop_p / seed_dev), which then requires dbranch.
  * dbranch_colsum (optional, C <= 1024): [GRIT_LN_BWD_PARTIALS, C] f32 per-workgroup partial column sums of the branch
  * gradient as stored -- the bias gradient of the Linear that produced `branch` (attn.proj / mlp.fc2), for free.
  * Other arguments as in grit_layernorm_{fwd,bwd}.
  * ------------------------------------------------------------------------------------------------------ */
 int grit_add_layernorm_fwd(const void* shortcut, const void* branch, const float* row_scale, int rows_per_sample,
-                           const void* weight, const void* bias, int rows, int C, float eps, int x_is_bf16, int w_is_bf16,
-                           void* sum_out, void* y, float* mean, float* rstd, void* stream);
-int grit_add_layernorm_bwd(const void* x, const void* weight, const void* dy, const void* dres, const float* mean,
-                           const float* rstd, const float* row_scale, int rows_per_sample, int rows, int C, int x_is_bf16,
-                           int w_is_bf16, void* dx, void* dbranch, float* dweight, float* dbias, float* dbranch_colsum,
+                           float drop_p, const uint64_t* seed_dev, const void* weight, const void* bias, int rows, int C,
+                           float eps, int x_is_bf16, int w_is_bf16, void* sum_out, void* y, float* mean, float* rstd,
                            void* stream);
+int grit_add_layernorm_bwd(const void* x, const void* weight, const void* dy, const void* dres, const float* mean,
+                           const float* rstd, const float* row_scale, int rows_per_sample, float drop_p,
+                           const uint64_t* seed_dev, int rows, int C, int x_is_bf16, int w_is_bf16, void* dx, void* dbranch,
+                           float* dweight, float* dbias, float* dbranch_colsum, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * GroupNorm on token-major maps (nn.GroupNorm(32, hidden_dim) after the 1x1 input projection of every feature level,

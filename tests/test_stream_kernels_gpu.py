@@ -249,3 +249,44 @@ def test_linear_add_layer_norm_node(C, K, B, L, drop_path):
         scale_ = want.abs().max().item()
         err = (got.double().cpu() - want).abs().max().item()
         assert err < 4e-2 * scale_, (name, err, scale_)
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_linear_add_layer_norm_dropout_mask_is_consistent(p):
+    """Element dropout inside the fused tail (nn.Dropout between a projection and LayerNorm(x + .), post-norm decoder
+    layers): the keep mask is regenerated from the device seed in the backward.  fp32, identity projection: the mask is
+    read back from the stored sum, its rate is checked, and outputs / every gradient are compared with the same mask
+    applied through torch ops."""
+    from grit_amd.ops.layer_norm import linear_add_layer_norm
+    C, B, L = 512, 4, 700
+    g = torch.Generator().manual_seed(11)
+    inp = (torch.randn(B, L, C, generator=g) + 3.0).to(DEV).requires_grad_(True)  # away from 0: dropped <=> exactly 0
+    sc = torch.randn(B, L, C, generator=g).to(DEV).requires_grad_(True)
+    lin = torch.nn.Linear(C, C).to(DEV)
+    with torch.no_grad():
+        lin.weight.copy_(torch.eye(C))
+        lin.bias.zero_()
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV).requires_grad_(True)
+    b = (0.1 * torch.randn(C, generator=g)).to(DEV).requires_grad_(True)
+    cot_x, cot_y = torch.randn(B, L, C, generator=g).to(DEV), torch.randn(B, L, C, generator=g).to(DEV)
+    torch.manual_seed(5)
+    x, y = linear_add_layer_norm(inp, lin, sc, None, w, b, 1e-5, dropout_p=p, training=True)
+    torch.autograd.backward([x, y], [cot_x, cot_y])
+    keep = ((x.detach() - sc.detach()).abs() > 1e-6)
+    rate = 1.0 - keep.float().mean().item()
+    assert abs(rate - p) < 0.01, rate
+    got = [t_.grad.clone() for t_ in (inp, sc, lin.weight, lin.bias, w, b)]
+    for t_ in (inp, sc, lin.weight, lin.bias, w, b):
+        t_.grad = None
+    branch = torch.nn.functional.linear(inp, lin.weight, lin.bias) * keep.float() / (1.0 - p)
+    x_ref = sc + branch
+    y_ref = torch.nn.functional.layer_norm(x_ref, (C,), w, b, 1e-5)
+    torch.autograd.backward([x_ref, y_ref], [cot_x, cot_y])
+    np.testing.assert_allclose(x.detach().cpu().numpy(), x_ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    for name, a, t_ in zip(("d_inp", "d_shortcut", "dW", "db", "dgamma", "dbeta"), got, (inp, sc, lin.weight, lin.bias, w, b)):
+        scale_ = t_.grad.abs().max().item()
+        assert (a - t_.grad).abs().max().item() < 2e-3 * scale_, name
+    # a second call draws a different mask
+    x2, _ = linear_add_layer_norm(inp, lin, sc, None, w, b, 1e-5, dropout_p=p, training=True)
+    assert not torch.equal((x2.detach() - sc.detach()).abs() > 1e-6, keep)

@@ -36,6 +36,23 @@ typedef short v8s __attribute__((ext_vector_type(8)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Packed fp32 (two elements per VALU instruction).  hipcc forms v_pk_* from vector expressions only when it feels like
+// it (and unpacks them again next to MFMAs), so the *_asm variants spell the instruction out.  They must never read an
+// MFMA result directly: the compiler's hazard recogniser does not look inside inline asm, and MFMA -> VALU needs
+// software wait states (so does v_exp -> VALU) -- the first consumer of every MFMA accumulator and of every v_exp result
+// below is a plain C++ expression.
+__device__ __forceinline__ v2f pk_add_asm(v2f a, v2f b) {
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f pk_sub_asm(v2f a, v2f b) {  // a - b: negate both halves of the second operand
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 typedef __attribute__((address_space(3))) v4s lds_v4s;
 
 constexpr int kWs = 12, kN = 144, kHd = 32, kTiles = 9, kThreads = 576;
@@ -353,37 +370,44 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
             const v8bf da = as_v8bf(*reinterpret_cast<const uint4*>(&dOs[oRow + 16 * qt * kTP]));
             const v4f s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             const v4f dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            const float4 bq = *reinterpret_cast<const float4*>(&bT[oB + 16 * qt]);
-            const float4 lq = *reinterpret_cast<const float4*>(&lse_s[oSt + 16 * qt]);
-            const float4 dl = *reinterpret_cast<const float4*>(&delta_s[oSt + 16 * qt]);
-            const float ba[4] = {bq.x, bq.y, bq.z, bq.w}, lqa[4] = {lq.x, lq.y, lq.z, lq.w};
-            const float dla[4] = {dl.x, dl.y, dl.z, dl.w};
-            float t4[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                t4[r] = fmaf(s[r], c2, ba[r]);
-                if (kExplicitMask)
-                    t4[r] = fmaf(mask[((size_t)(win % g.nWm) * kN + 16 * qt + 4 * lg + r) * kN + 16 * w + l15], kLog2e, t4[r]);
+            // element-wise part, two score elements per instruction: the loop is instruction-issue bound and hipcc does not
+            // form packed-fp32 operations from this code by itself, so the fma / sub / mul / add pairs are spelled out
+            // (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 on 64-bit register pairs, which the halves of an MFMA result are)
+            const v4f bq = *reinterpret_cast<const v4f*>(&bT[oB + 16 * qt]);
+            const v4f lq = *reinterpret_cast<const v4f*>(&lse_s[oSt + 16 * qt]);
+            const v4f dl = *reinterpret_cast<const v4f*>(&delta_s[oSt + 16 * qt]);
+            const v2f c2v = {c2, c2};
+            // first consumers of the two MFMA results: compiler-visible
+            v2f t_lo = __builtin_elementwise_fma(v2f{s[0], s[1]}, c2v, v2f{bq[0], bq[1]});
+            v2f t_hi = __builtin_elementwise_fma(v2f{s[2], s[3]}, c2v, v2f{bq[2], bq[3]});
+            const v2f d_lo = v2f{dp[0], dp[1]} - v2f{dl[0], dl[1]}, d_hi = v2f{dp[2], dp[3]} - v2f{dl[2], dl[3]};
+            if (kExplicitMask) {
+                const float* mrow = mask + ((size_t)(win % g.nWm) * kN + 16 * qt + 4 * lg) * kN + 16 * w + l15;
+                t_lo[0] = fmaf(mrow[0], kLog2e, t_lo[0]); t_lo[1] = fmaf(mrow[kN], kLog2e, t_lo[1]);
+                t_hi[0] = fmaf(mrow[2 * kN], kLog2e, t_hi[0]); t_hi[1] = fmaf(mrow[3 * kN], kLog2e, t_hi[1]);
             }
             if (analytic) {
                 // wave-uniform branch, kept a real branch (the empty asm cannot be speculated): the analytic shift mask is
-                // 3 VALU instructions per element of an instruction-issue-bound loop and only the last window row /
-                // column of shifted blocks needs it
+                // 3 VALU instructions per element and only the last window row / column of shifted blocks needs it
                 asm volatile("" ::: "memory");
                 const uint32_t ids = *reinterpret_cast<const uint32_t*>(&rid[oSt + 16 * qt]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if ((int)((ids >> (8 * r)) & 0xff) != kreg) t4[r] += -100.0f * kLog2e;
+                if ((int)(ids & 0xff) != kreg) t_lo[0] += -100.0f * kLog2e;
+                if ((int)((ids >> 8) & 0xff) != kreg) t_lo[1] += -100.0f * kLog2e;
+                if ((int)((ids >> 16) & 0xff) != kreg) t_hi[0] += -100.0f * kLog2e;
+                if ((int)((ids >> 24) & 0xff) != kreg) t_hi[1] += -100.0f * kLog2e;
             }
-            v4bf pp, sp;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(t4[r] - lqa[r]);
-                const float dsv = p * (dp[r] - dla[r]);
-                dB[qt][r] += dsv;
-                pp[r] = (__bf16)p;
-                sp[r] = (__bf16)dsv;
+            const v2f e_lo = pk_sub_asm(t_lo, v2f{lq[0], lq[1]}), e_hi = pk_sub_asm(t_hi, v2f{lq[2], lq[3]});
+            const v2f p_lo = {__builtin_amdgcn_exp2f(e_lo[0]), __builtin_amdgcn_exp2f(e_lo[1])};
+            const v2f p_hi = {__builtin_amdgcn_exp2f(e_hi[0]), __builtin_amdgcn_exp2f(e_hi[1])};
+            // p comes out of the transcendental unit (v_exp_f32): TRANS -> VALU is a software hazard as well, so this product
+            // stays a C++ expression too
+            const v2f ds_lo = p_lo * d_lo, ds_hi = p_hi * d_hi;
+            {
+                const v2f a = pk_add_asm(v2f{dB[qt][0], dB[qt][1]}, ds_lo), b = pk_add_asm(v2f{dB[qt][2], dB[qt][3]}, ds_hi);
+                dB[qt] = v4f{a[0], a[1], b[0], b[1]};
             }
+            const v4bf pp = {(__bf16)p_lo[0], (__bf16)p_lo[1], (__bf16)p_hi[0], (__bf16)p_hi[1]};
+            const v4bf sp = {(__bf16)ds_lo[0], (__bf16)ds_lo[1], (__bf16)ds_hi[0], (__bf16)ds_hi[1]};
             *reinterpret_cast<v4bf*>(&dSt[oW + 16 * qt]) = sp;
             if ((qt & 1) || qt == kTiles - 1) {
                 const bool single = !(qt & 1);  // last, unpaired tile: upper 16 k-slots are zero

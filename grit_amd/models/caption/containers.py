@@ -43,10 +43,15 @@ class Module(nn.Module):
             return None
         buf = self._buffers[name]
         # follow the module's device and (for floating states) dtype: .to(bf16) / .cuda() convert the registered buffer
-        # but not this private default
-        if buf is not None and default.is_floating_point() and buf.is_floating_point():
-            return default.clone().detach().to(device=buf.device, dtype=buf.dtype)
-        return default.clone().detach().to(buf.device if buf is not None else default.device)
+        # but not this private default.  The converted default is kept per (device, dtype): a host -> device copy on
+        # every beam search is a synchronising pageable transfer (and illegal while a hipGraph is being captured)
+        device = buf.device if buf is not None else default.device
+        dtype = buf.dtype if (buf is not None and default.is_floating_point() and buf.is_floating_point()) else default.dtype
+        cache = self.__dict__.setdefault('_state_defaults_on', {})
+        key = (name, str(device), dtype)
+        if key not in cache:
+            cache[key] = default.clone().detach().to(device=device, dtype=dtype)
+        return cache[key].clone()
 
     def _init_states(self, batch_size: int):
         for name in self._state_names:

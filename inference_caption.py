@@ -37,6 +37,57 @@ def caption_tokens(model, image, config, beam_size=None):
                  beam_size=beam_size or config.model.beam_size, out_size=1, return_probs=False)
 
 
+@torch.no_grad()
+def caption_stream(model, batches, config, beam_size=None):
+    """Caption a sequence of batches (NestedTensor each), yielding (tokens, log_probs) per batch in order -- the inner loop
+    of evaluate_metrics (reference engine/caption_engine.py:156-175) arranged for the GPU: the detector of batch i+1 is
+    enqueued on its own HIP stream BEFORE the beam search of batch i.  The beam-search loop is launch bound (~60 ms of
+    host time for < 20 ms of GPU work at batch 64) while the detector is GPU bound (~48 ms), so the two overlap almost
+    entirely.  Same kernels on the same data: the results are those of the sequential loop."""
+    beam = beam_size or config.model.beam_size
+    device = next(model.parameters()).device
+    if device.type != 'cuda':
+        for samples in batches:
+            yield model(samples, seq=None, use_beam_search=True, max_len=config.model.beam_len, eos_idx=config.model.eos_idx,
+                        beam_size=beam, out_size=1, return_probs=False)
+        return
+    det_stream, dec_stream = torch.cuda.Stream(device), torch.cuda.Stream(device)
+    caller = torch.cuda.current_stream(device)
+    det_stream.wait_stream(caller)
+    dec_stream.wait_stream(caller)
+
+    def beam_search(vis, ready):
+        was = model.cached_features
+        model.cached_features = True
+        try:
+            with torch.cuda.stream(dec_stream):
+                dec_stream.wait_event(ready)
+                for v in vis.values():
+                    v.record_stream(dec_stream)
+                out = model(vis, seq=None, use_beam_search=True, max_len=config.model.beam_len,
+                            eos_idx=config.model.eos_idx, beam_size=beam, out_size=1, return_probs=False)
+                done = torch.cuda.Event()
+                done.record(dec_stream)
+        finally:
+            model.cached_features = was
+        caller.wait_event(done)
+        for o in out:
+            o.record_stream(caller)
+        return out
+
+    pending = None
+    for samples in batches:
+        with torch.cuda.stream(det_stream):
+            vis = dict(model.detector(samples))
+            ready = torch.cuda.Event()
+            ready.record(det_stream)
+        if pending is not None:
+            yield beam_search(*pending)
+        pending = (vis, ready)
+    if pending is not None:
+        yield beam_search(*pending)
+
+
 def decode(tokens, vocab_path, eos_idx=3):
     """ids -> words, cut at the first <eos> (reference datasets/caption/field.py:258-283)."""
     with open(vocab_path) as f:

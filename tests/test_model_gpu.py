@@ -174,3 +174,25 @@ def test_self_critical_step_on_hip_path_matches_reference():
                 norms[top] = norms.get(top, 0.0) + float(p.grad.double().pow(2).sum())
         for k, v in ref["grad_norms"].items():
             assert abs(norms[k]**0.5 - v) < 8e-2 * v, (k, norms[k]**0.5, v)
+
+
+def test_caption_stream_pipelined_equals_sequential(g7_model):
+    """inference_caption.caption_stream (detector of batch i+1 on its own HIP stream under the beam search of batch i)
+    returns, batch by batch and in order, exactly what the sequential model(...) calls return."""
+    from inference_caption import caption_stream
+    from grit_amd.utils.misc import NestedTensor
+    model, cfg = g7_model
+    gen = torch.Generator().manual_seed(4)
+    batches = []
+    for i in range(3):
+        img = torch.randn(2, 3, 224, 224, generator=gen).to(DEV)
+        batches.append(NestedTensor(img, torch.zeros(2, 224, 224, dtype=torch.bool, device=DEV)))
+    with torch.no_grad():
+        seq = [model(b, seq=None, use_beam_search=True, max_len=cfg.model.beam_len, eos_idx=cfg.model.eos_idx,
+                     beam_size=3, out_size=1) for b in batches]
+        piped = list(caption_stream(model, batches, cfg, beam_size=3))
+    torch.cuda.synchronize()
+    assert len(piped) == 3
+    for (ts, ls), (tp, lp) in zip(seq, piped):
+        assert torch.equal(ts, tp) and torch.equal(ls, lp)
+    assert model.cached_features is False

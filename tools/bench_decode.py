@@ -49,6 +49,19 @@ def main():
                 print(json.dumps({"batch": a.batch, "dtype": "bf16" if a.bf16 else "fp32", "detector_ms": t_det * 1e3,
                                   "decode_20_steps_ms": t_dec * 1e3, "captions_per_sec": a.batch / (t_det + t_dec)}))
     assert tokens.shape == (a.batch, 20)
+    # pipelined: detector of batch i+1 on its own stream under the (launch-bound) beam search of batch i
+    from inference_caption import caption_stream
+    n = 6
+    with torch.no_grad():
+        list(caption_stream(model, [batch['samples']] * 2, cfg, 5))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = list(caption_stream(model, [batch['samples']] * n, cfg, 5))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert all(torch.equal(o[0], tokens) for o in outs)
+    print(json.dumps({"batch": a.batch, "dtype": "bf16" if a.bf16 else "fp32", "pipelined_batches": n,
+                      "ms_per_batch": dt / n * 1e3, "captions_per_sec": a.batch * n / dt}))
 
 
 if __name__ == "__main__":

@@ -25,22 +25,14 @@ class Detector(nn.Module):
                 for c in backbone.num_channels
             ])
 
-    def project_level(self, level, feature):
-        """input_proj[level] = Conv2d 1x1 + GroupNorm(32) (reference models/caption/detector.py:28-33,58) on an NCHW map.
-        The 1x1 convolution runs as a GEMM on the token view of the map (the backbone hands out NCHW *views* of
-        token-major tensors, so the view is free); MIOpen's bf16 1x1 conv + weight-gradient kernels cost ~30 ms per
-        training step here, the GEMM ~1 ms.  Same parameters, same result."""
-        conv, gn = self.input_proj[level]
-        B, C, H, W = feature.shape
-        tokens = feature.permute(0, 2, 3, 1).reshape(B, H * W, C)
-        y = F.linear(tokens, conv.weight.view(conv.out_channels, C), conv.bias)
-        return gn(y.transpose(1, 2).reshape(B, conv.out_channels, H, W))
-
     def project_levels(self, features):
         """All feature levels through input_proj, as ONE flattened token map [B, sum_l H_l*W_l, hidden] (the layout
         DetectionModule.prepare_od_inputs builds with flatten + cat, det_module.py:172-175) plus the level shapes.
-        1x1 convolutions run as GEMMs on the token views; the GroupNorms normalise token-major and write straight into
-        the level's slice of the flat map (grit_amd/ops/group_norm.py) -- no NCHW round trip, no concatenation."""
+        input_proj[l] = Conv2d 1x1 + GroupNorm(32) (reference models/caption/detector.py:28-33,58).  The 1x1 convolutions run
+        as GEMMs on the token views of the maps (the backbone hands out NCHW *views* of token-major tensors, so the view is
+        free; MIOpen's bf16 1x1 conv + weight-gradient kernels cost ~30 ms per training step here, the GEMMs ~1 ms); the
+        GroupNorms normalise token-major and write straight into the level's slice of the flat map
+        (grit_amd/ops/group_norm.py) -- no NCHW round trip, no concatenation.  Same parameters, same result."""
         tokens, shapes = [], []
         for (conv, _), feature in zip(self.input_proj, features):
             B, C, H, W = feature.shape

@@ -103,7 +103,6 @@ def attention(q, k, v, mask=None, scale=None, dropout_p=0.0, training=False):
         q = q.float()
     k, v = k.to(q.dtype), v.to(q.dtype)
     p = float(dropout_p) if training else 0.0
-    # the dropout seed lives in device memory and is drawn by torch's (graph-safe) device generator: no host sync, and
-    # a captured step (grit_amd/graphs.py) draws a fresh mask on every replay
+    # the dropout seed lives in device memory and is drawn by torch's device generator: no host sync
     seed_dev = torch.empty(1, dtype=torch.int64, device=q.device).random_() if p > 0 else None
     return _AttentionFn.apply(q, k, v, mask, float(scale), p, 0, seed_dev)

@@ -424,6 +424,35 @@ def make_g9():
     print('g9 loss', loss.item(), 'tokens', outs.tolist(), norms)
 
 
+def make_g10():
+    """Caption strings (BASELINE config 1 / reference inference_caption.py:66-67): the reference's own TextField.decode
+    (datasets/caption/field.py:258-283) applied to the G7 token ids with the reference's data/vocab.json.  The module
+    is loaded from its file behind a synthetic package (its package __init__ pulls in torchvision / pycocotools) with
+    empty stand-ins for the two imports it never uses while decoding (h5py, spacy).  Committed: the `itos` word list
+    (data) and the expected strings."""
+    import importlib
+    import json
+    pkg = types.ModuleType('refcap')
+    pkg.__path__ = [os.path.join(REF, 'datasets', 'caption')]
+    sys.modules['refcap'] = pkg
+    sys.modules.setdefault('h5py', types.ModuleType('h5py'))
+    sp = types.ModuleType('spacy')
+    sp.load = lambda name: None
+    sys.modules.setdefault('spacy', sp)
+    field = importlib.import_module('refcap.field')
+    tf = field.TextField(vocab_path=os.path.join(REF, 'data', 'vocab.json'))
+    g = np.load(os.path.join(HERE, 'model_g7.npz'))
+    extra = torch.tensor([[2, 4, 5, 3, 7, 7], [3, 9, 9, 9, 9, 9], [10200, 0, 1, 2, 4, 3]])  # eos first / unk / pad / bos
+    out = {'itos': list(tf.vocab.itos), 'eos_token': tf.eos_token,
+           'beam1': tf.decode(torch.from_numpy(g['beam1_tokens']), join_words=True),
+           'beam5': tf.decode(torch.from_numpy(g['beam5_tokens']), join_words=True),
+           'extra_tokens': extra.tolist(), 'extra': tf.decode(extra, join_words=True)}
+    with open(os.path.join(HERE, 'vocab_g10.json'), 'w') as f:
+        json.dump(out, f)
+    print('g10', out['beam1'], out['extra'])
+
+
+MAKERS.update({'g10': make_g10})
 MAKERS.update({'keys': make_keys, 'g3': make_g3, 'g4': make_g4, 'g6': make_g6, 'g7': make_g7, 'g8': make_g8, 'g9': make_g9})
 
 if __name__ == "__main__":

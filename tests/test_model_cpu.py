@@ -154,3 +154,18 @@ def test_one_self_critical_step_matches_reference():
             np.testing.assert_allclose(got, g[key], rtol=3e-3, atol=1e-6 + 3e-3 * np.abs(g[key]).max())
     changed = sum(1 for n, p in params.items() if n in before and p.grad is not None and not torch.equal(p.detach(), before[n]))
     assert changed > 100  # both Adams stepped
+
+
+def test_caption_strings_match_reference_decode(tmp_path):
+    """BASELINE config 1, last hop: token ids -> caption string.  inference_caption.decode (cut at the first <eos>, join
+    with spaces) against the reference's TextField.decode on the G7 beams and on edge rows (eos first, <unk>/<pad>/<bos>
+    inside a caption), with the reference's word list (fixture G10)."""
+    from inference_caption import decode
+    g10 = json.load(open(os.path.join(GOLDEN, "vocab_g10.json")))
+    g7 = load("model_g7.npz")
+    vocab = tmp_path / "vocab.json"
+    vocab.write_text(json.dumps({"itos": g10["itos"]}))
+    assert len(g10["itos"]) == 10201 and g10["itos"][3] == g10["eos_token"] == "<eos>"
+    assert decode(t(g7["beam1_tokens"]), str(vocab)) == g10["beam1"]
+    assert decode(t(g7["beam5_tokens"]), str(vocab)) == g10["beam5"]
+    assert decode(torch.tensor(g10["extra_tokens"]), str(vocab)) == g10["extra"]

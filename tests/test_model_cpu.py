@@ -169,3 +169,37 @@ def test_caption_strings_match_reference_decode(tmp_path):
     assert decode(t(g7["beam1_tokens"]), str(vocab)) == g10["beam1"]
     assert decode(t(g7["beam5_tokens"]), str(vocab)) == g10["beam5"]
     assert decode(torch.tensor(g10["extra_tokens"]), str(vocab)) == g10["extra"]
+
+
+def test_teacher_forcing_and_xe_step_on_cached_features(g7_model):
+    """Next-row N3, model side: the cached-feature ("freezing") training mode (transformer.py:64-67 with
+    model.cached_features = True; features as tools/extract_features.py stores them: gri_feat [N, fh*fw, 1024] f32,
+    gri_mask [N, 1, 1, fh*fw] bool, reg_feat [N, 150, 512], reg_mask [N, 1, 1, 150]).  From the reference's own visual
+    features the decoder reproduces the reference's teacher-forcing log-probs, and an XE step in this mode trains the
+    grid net + caption generator only."""
+    from grit_amd.engine.caption_engine import build_optimizers, train_xe_step
+    model, cfg = g7_model
+    g = load("model_g7.npz")
+    vis = {k: t(g[k]) for k in ("gri_feat", "gri_mask", "reg_feat", "reg_mask")}
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}  # the fixture model is shared: restored below
+    model.cached_features = True
+    try:
+        with oracle_ops(), torch.no_grad():
+            lp = model(vis, t(g["seq"]))
+        top = lp.topk(16, -1)
+        np.testing.assert_array_equal(top.indices[..., :4].numpy(), g["tf_top_idx"][..., :4])
+        np.testing.assert_allclose(top.values.numpy(), g["tf_top_val"], rtol=1e-4, atol=1e-4)
+        model.train()
+        opts = build_optimizers(model, cfg, mode='xe')
+        with oracle_ops():
+            loss = train_xe_step(model, {'samples': vis, 'captions': t(g["seq"])}, opts, torch.nn.NLLLoss(ignore_index=1))
+        assert torch.isfinite(loss)
+        moved = {n for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n])}
+        assert moved and all(not n.startswith('detector.') for n in moved)
+        assert any(n.startswith('grid_net.') for n in moved) and any(n.startswith('cap_generator.') for n in moved)
+    finally:
+        model.cached_features = False
+        model.eval()
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                p.copy_(before[n])

@@ -23,6 +23,34 @@ from grit_amd.ops import backend
 WINDOW = 12
 HEAD_DIM = 32
 
+# bench.py sets this to a list to collect (kind, start_event, end_event, flops) per launch: HIP events recorded on the
+# launch stream right around the kernel (same hook as grit_amd/ops/msda.py)
+PROFILE_EVENTS = None
+
+
+class _Timed(object):
+
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        self.on = PROFILE_EVENTS is not None and not torch.cuda.is_current_stream_capturing()
+        if self.on:
+            self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on and PROFILE_EVENTS is not None:
+            self.b.record()
+            PROFILE_EVENTS.append((self.kind, self.a, self.b, self.flops))
+        return False
+
+
+def _core_flops(B, nWh, nWw, num_heads, N, products):
+    """2*N*N*head_dim flops per product per (window, head): forward QK^T + PV (2), backward S, dP, dV, dK, dQ (5)."""
+    return products * 2 * N * N * HEAD_DIM * B * nWh * nWw * num_heads
+
 
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
@@ -39,7 +67,7 @@ class _WindowAttentionFn(Function):
         out = torch.empty((B, T, C), dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty((B * nWh * nWw, num_heads, N), dtype=torch.float32, device=qkv.device)
         nWm = 0 if mask is None else mask.shape[0]
-        with torch.cuda.device(qkv.device):
+        with torch.cuda.device(qkv.device), _Timed("fwd", _core_flops(B, nWh, nWw, num_heads, N, 2)):
             st = _lib.load().grit_winattn_fwd_bf16(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, B, H, W, C,
                                                    num_heads, window, shift, scale, _ptr(out), _ptr(lse),
                                                    _lib.current_stream_ptr())
@@ -60,7 +88,8 @@ class _WindowAttentionFn(Function):
         dbias = torch.zeros_like(rel_bias)  # accumulated across windows with float atomics
         dpad = torch.zeros(C3, dtype=torch.float32, device=qkv.device)
         nWm = 0 if mask is None else mask.shape[0]
-        with torch.cuda.device(qkv.device):
+        flops = _core_flops(B, -(-H // window), -(-W // window), num_heads, window * window, 5)
+        with torch.cuda.device(qkv.device), _Timed("bwd", flops):
             st = _lib.load().grit_winattn_bwd_bf16(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, _ptr(out),
                                                    _ptr(dout), _ptr(lse), B, H, W, C, num_heads, window, shift, scale,
                                                    _ptr(dqkv), _ptr(dbias), _ptr(dpad), _lib.current_stream_ptr())

@@ -541,6 +541,110 @@ void msda_bwd_d64(const VT* __restrict__ value, const int64_t* __restrict__ shap
     else if (j >= 16 && j < 16 + 2 * LP) grad_loc[(size_t)row * 2 * LP + (j - 16)] = part[0];
 }
 
+// Backward for bf16 maps with the value gradient accumulated IN bf16 by packed atomics (global_atomic_pk_add_bf16: two
+// channels per 32-bit atomic -- measured 655 G channel-adds/s against 323 G for f32 atomics, tools/micro/atomic_rate.hip;
+// the f32 kernel above is bound by exactly that rate).  This is what torch's own bf16 scatter / grid_sample backward do
+// (atomic adds on the bf16 tensor); against f32 accumulation + one final rounding the relative L2 error of grad_value goes
+// from 1.7e-3 to 4.0e-3 on the benchmark geometry (profiles/r01/msda_bwd_bf16_accumulate.txt).  The f32 kernel stays the
+// parity path (f32 maps) and can be forced for bf16 maps (GRIT_MSDA_BWD_F32ACC=1).
+// Lane = channel PAIR: the two 32-lane halves of the wave walk the even / odd points of the row, so one wave instruction
+// gathers or scatters two 128-byte pixel-head rows; grad_loc / grad_w leave through the same 63-shuffle butterfly.
+__global__ __launch_bounds__(kWave * kRowsPerBlock)
+void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __restrict__ shapes,
+                     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
+                     const __hip_bfloat16* __restrict__ grad_out, int S, int M, int L, int Lq, int P,
+                     __hip_bfloat16* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_aw,
+                     int nrows, int nblk) {
+    constexpr int D = 64, kMaxLP = 16;
+    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+    typedef v2bf __attribute__((address_space(1))) * gv2bf_ptr;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int row = xcd_logical_block(blockIdx.x, nblk) * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int LP = L * P;
+    const int m = row % M;
+    const int b = (row / M) / Lq;
+    const int pix_stride = M * D;
+    const bool odd = lane >= 32;            // this half's points: 2i + odd
+    const int cp = lane & 31;               // channels 2cp, 2cp + 1
+    const size_t head_off = (size_t)b * S * pix_stride + (size_t)m * D + 2 * cp;
+    const __hip_bfloat16* vhead = value + head_off;
+    __hip_bfloat16* ghead = grad_value + head_off;
+
+    // geometry once per row, point p on lane p
+    const int pi = min(lane, LP - 1), pl = pi / P;
+    const int pH = (int)shapes[2 * pl], pW = (int)shapes[2 * pl + 1], pst = (int)lsi[pl];
+    const uint32_t gob = *reinterpret_cast<const uint32_t*>(grad_out + (size_t)row * D + 2 * cp);
+    const float go0 = __uint_as_float(gob << 16), go1 = __uint_as_float(gob & 0xffff0000u);
+    const float px = loc[(size_t)row * 2 * LP + 2 * pi], py = loc[(size_t)row * 2 * LP + 2 * pi + 1];
+    const float pwt = lane < LP ? aw[(size_t)row * LP + pi] : 0.f;
+    const Corners<float> c = make_corners<float>(px, py, pH, pW);
+    const int e1 = pst + c.o1, e2 = pst + c.o2, e3 = pst + c.o3, e4 = pst + c.o4;
+    const int flags = lane < LP ? ((c.k1 ? 1 : 0) | (c.k2 ? 2 : 0) | (c.k3 ? 4 : 0) | (c.k4 ? 8 : 0)) : 0;
+    const float fW = (float)pW * pwt, fH = (float)pH * pwt;
+
+    float part[64];  // [0,16): grad_attn_w per point, [16,48): grad_loc (x, y) per point, rest zero
+#pragma unroll
+    for (int i = 0; i < 64; ++i) part[i] = 0.f;
+#define GRIT_PICK_I(x, i) (odd ? __builtin_amdgcn_readlane((x), 2 * (i) + 1) : __builtin_amdgcn_readlane((x), 2 * (i)))
+#define GRIT_PICK_F(x, i) __int_as_float(GRIT_PICK_I(__float_as_int(x), i))
+    // all gathers of the row first (in the training step the value map is cold: one HBM round trip per row instead of
+    // one per point pair), then the arithmetic and the scatters
+    uint32_t rr[kMaxLP / 2][4];
+#pragma unroll
+    for (int i = 0; i < kMaxLP / 2; ++i) {
+        if (2 * i < LP) {
+            const int s1 = GRIT_PICK_I(e1, i), s2 = GRIT_PICK_I(e2, i), s3 = GRIT_PICK_I(e3, i), s4 = GRIT_PICK_I(e4, i);
+            rr[i][0] = *reinterpret_cast<const uint32_t*>(vhead + (size_t)s1 * pix_stride);
+            rr[i][1] = *reinterpret_cast<const uint32_t*>(vhead + (size_t)s2 * pix_stride);
+            rr[i][2] = *reinterpret_cast<const uint32_t*>(vhead + (size_t)s3 * pix_stride);
+            rr[i][3] = *reinterpret_cast<const uint32_t*>(vhead + (size_t)s4 * pix_stride);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxLP / 2; ++i) {
+        if (2 * i < LP) {
+            const int f = (2 * i + 1 < LP || !odd) ? GRIT_PICK_I(flags, i) : 0;
+            const int s1 = GRIT_PICK_I(e1, i), s2 = GRIT_PICK_I(e2, i), s3 = GRIT_PICK_I(e3, i), s4 = GRIT_PICK_I(e4, i);
+            const float lh = GRIT_PICK_F(c.lh, i), lw = GRIT_PICK_F(c.lw, i), wt = GRIT_PICK_F(pwt, i);
+            const float sW = GRIT_PICK_F(fW, i), sH = GRIT_PICK_F(fH, i);
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const float t0 = go0 * wt, t1 = go1 * wt;
+            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+            if (f & 1) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s1 * pix_stride), v2bf{(__bf16)(w1 * t0), (__bf16)(w1 * t1)});
+            if (f & 2) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s2 * pix_stride), v2bf{(__bf16)(w2 * t0), (__bf16)(w2 * t1)});
+            if (f & 4) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s3 * pix_stride), v2bf{(__bf16)(w3 * t0), (__bf16)(w3 * t1)});
+            if (f & 8) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s4 * pix_stride), v2bf{(__bf16)(w4 * t0), (__bf16)(w4 * t1)});
+            // clamped indices are always legal: all four were loaded, select by the validity bits
+            const uint32_t q1 = (f & 1) ? rr[i][0] : 0u, q2 = (f & 2) ? rr[i][1] : 0u, q3 = (f & 4) ? rr[i][2] : 0u, q4 = (f & 8) ? rr[i][3] : 0u;
+            const float a1x = __uint_as_float(q1 << 16), a1y = __uint_as_float(q1 & 0xffff0000u);
+            const float a2x = __uint_as_float(q2 << 16), a2y = __uint_as_float(q2 & 0xffff0000u);
+            const float a3x = __uint_as_float(q3 << 16), a3y = __uint_as_float(q3 & 0xffff0000u);
+            const float a4x = __uint_as_float(q4 << 16), a4y = __uint_as_float(q4 & 0xffff0000u);
+            // the two channels of this lane folded right away: go . (d/dh, d/dw, value) of the bilinear form
+            const float ghx = -hw * a1x - lw * a2x + hw * a3x + lw * a4x, ghy = -hw * a1y - lw * a2y + hw * a3y + lw * a4y;
+            const float gwx = -hh * a1x + hh * a2x - lh * a3x + lh * a4x, gwy = -hh * a1y + hh * a2y - lh * a3y + lh * a4y;
+            const float vx = w1 * a1x + w2 * a2x + w3 * a3x + w4 * a4x, vy = w1 * a1y + w2 * a2y + w3 * a3y + w4 * a4y;
+            const float pa = go0 * vx + go1 * vy;
+            const float plx = sW * (gwx * go0 + gwy * go1), ply = sH * (ghx * go0 + ghy * go1);
+            part[2 * i] = odd ? 0.f : pa;          part[2 * i + 1] = odd ? pa : 0.f;
+            part[16 + 4 * i] = odd ? 0.f : plx;    part[16 + 4 * i + 2] = odd ? plx : 0.f;
+            part[17 + 4 * i] = odd ? 0.f : ply;    part[17 + 4 * i + 2] = odd ? ply : 0.f;
+        }
+    }
+#undef GRIT_PICK_I
+#undef GRIT_PICK_F
+    halve_step<64>(part, lane, 32);
+    halve_step<32>(part, lane, 16);
+    halve_step<16>(part, lane, 8);
+    halve_step<8>(part, lane, 4);
+    halve_step<4>(part, lane, 2);
+    halve_step<2>(part, lane, 1);
+    const int j = (int)(__brev((unsigned)lane) >> 26);  // index of the value this lane now owns
+    if (j < LP) grad_aw[(size_t)row * LP + j] = part[0];
+    else if (j >= 16 && j < 16 + 2 * LP) grad_loc[(size_t)row * 2 * LP + (j - 16)] = part[0];
+}
+
 bool dims_ok(int B, int S, int M, int D, int L, int Lq, int P) {
     if (B <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return false;
     const long long rows = (long long)B * Lq * M;
@@ -688,6 +792,22 @@ int grit_msda_bwd_bf16(const void* value, const int64_t* spatial_shapes, const i
     return launch_bwd_d64<__hip_bfloat16>((const __hip_bfloat16*)value, spatial_shapes, level_start, loc, attn_w,
                                             (const __hip_bfloat16*)grad_out, B, S, M, L, Lq, P, grad_value, grad_loc,
                                             grad_attn_w, (hipStream_t)stream);
+}
+
+int grit_msda_bwd_bf16acc(const void* value, const int64_t* spatial_shapes, const int64_t* level_start, const float* loc,
+                          const float* attn_w, const void* grad_out, int B, int S, int M, int D, int L, int Lq, int P,
+                          void* grad_value, float* grad_loc, float* grad_attn_w, void* stream) {
+    if (!value || !spatial_shapes || !level_start || !loc || !attn_w || !grad_out || !grad_value || !grad_loc || !grad_attn_w)
+        return GRIT_ERR_BAD_ARG;
+    if (!dims_ok(B, S, M, D, L, Lq, P)) return GRIT_ERR_BAD_ARG;
+    if (D != 64 || L * P > 16 || ((uintptr_t)value % 4) || ((uintptr_t)grad_out % 4) || ((uintptr_t)grad_value % 4))
+        return GRIT_ERR_UNSUPPORTED;
+    const int nrows = B * Lq * M;
+    const int nblk = (nrows + kRowsPerBlock - 1) / kRowsPerBlock;
+    hipLaunchKernelGGL(msda_bwd_d64_pk, dim3(nblk), dim3(kWave * kRowsPerBlock), 0, (hipStream_t)stream,
+                       (const __hip_bfloat16*)value, spatial_shapes, level_start, loc, attn_w, (const __hip_bfloat16*)grad_out,
+                       S, M, L, Lq, P, (__hip_bfloat16*)grad_value, grad_loc, grad_attn_w, nrows, nblk);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 
 }  // extern "C"

@@ -9,6 +9,7 @@ Differences from the reference, on purpose:
   * launch failures raise (the reference only printf's them, ms_deform_im2col_cuda.cuh:948-952).
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -20,6 +21,10 @@ from grit_amd import lib as _lib
 # bench.py sets this to a list to collect (kind, start_event, end_event, algorithmic_bytes) per launch: HIP events
 # recorded on the launch stream right around the kernel, so the roofline figure is measured inside the real step
 PROFILE_EVENTS = None
+
+# GRIT_MSDA_BWD_F32ACC=1: bf16 maps keep an f32 staging map for grad_value (f32 atomics + one final rounding) instead of
+# accumulating in bf16 with packed atomics
+F32_ACCUMULATE = os.environ.get("GRIT_MSDA_BWD_F32ACC", "0") == "1"
 
 
 def _ptr(t):
@@ -108,6 +113,19 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                             im2col_step=64):
     B, S, M, D, L, Lq, P = _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
     _lib.require_device(grad_output)
+    if _bf16_fast_path(value, D, L, P) and not F32_ACCUMULATE:
+        # value gradient accumulated in bf16 by packed atomics (two channels per memory-side atomic: the f32-atomic rate
+        # is what bounds this kernel) -- the rounding behaviour of torch's own bf16 scatter / grid_sample backward
+        loc, aw = sampling_loc.float(), attn_weight.float()
+        go = grad_output.to(torch.bfloat16).contiguous()
+        gv = torch.zeros(value.shape, dtype=torch.bfloat16, device=value.device)
+        gl, ga = torch.empty_like(loc), torch.empty_like(aw)
+        with torch.cuda.device(value.device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 2)):
+            st = _lib.load().grit_msda_bwd_bf16acc(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc),
+                                                   _ptr(aw), _ptr(go), B, S, M, D, L, Lq, P, _ptr(gv), _ptr(gl), _ptr(ga),
+                                                   _lib.current_stream_ptr())
+        _lib.check(st, "grit_msda_bwd_bf16acc")
+        return [gv, gl.to(sampling_loc.dtype), ga.to(attn_weight.dtype)]
     if _bf16_fast_path(value, D, L, P):
         loc, aw = sampling_loc.float(), attn_weight.float()
         go = grad_output.to(torch.bfloat16).contiguous()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 14
+#define GRIT_ABI_VERSION 15
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -86,6 +86,13 @@ int grit_msda_fwd_bf16(const void* value, const int64_t* spatial_shapes, const i
 int grit_msda_bwd_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start, const float* loc,
                        const float* attn_w, const void* grad_out, int B, int S, int M, int D, int L, int Lq, int P,
                        float* grad_value, float* grad_loc, float* grad_attn_w, void* stream);
+/* Same backward with grad_value ACCUMULATED IN bf16 by packed atomics (two channels per 32-bit memory-side atomic: twice
+ * the rate of the f32 atomics that bound grit_msda_bwd_bf16, no f32 staging map, no cast).  grad_value [B, S, M, D] bf16,
+ * zeroed by the caller.  Accumulation order and rounding are those of torch's own bf16 scatter / grid_sample backward;
+ * use grit_msda_bwd_bf16 when f32 accumulation of the value gradient is required.  D = 64, L*P <= 16. */
+int grit_msda_bwd_bf16acc(const void* value, const int64_t* spatial_shapes, const int64_t* level_start, const float* loc,
+                          const float* attn_w, const void* grad_out, int B, int S, int M, int D, int L, int Lq, int P,
+                          void* grad_value, float* grad_loc, float* grad_attn_w, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Scaled-dot attention core, fp32 arithmetic, head_dim D = 64 (also the 150-query

@@ -554,12 +554,20 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
                      const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
                      const __hip_bfloat16* __restrict__ grad_out, int S, int M, int L, int Lq, int P,
                      __hip_bfloat16* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_aw,
-                     int nrows, int nblk) {
+                     int nrows, int nblk, int images_interleaved) {
     constexpr int D = 64, kMaxLP = 16;
     typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
     typedef v2bf __attribute__((address_space(1))) * gv2bf_ptr;
     const int lane = threadIdx.x & (kWave - 1);
-    const int row = xcd_logical_block(blockIdx.x, nblk) * kRowsPerBlock + (threadIdx.x >> 6);
+    int blk = xcd_logical_block(blockIdx.x, nblk);
+    if (images_interleaved > 1) {
+        // consecutive workgroups take the same query block of DIFFERENT images: workgroups in flight together then
+        // scatter into different value maps.  A freshly initialised GRIT puts every query's reference point near the
+        // image centre, so neighbouring queries of one image pile their atomics onto the same few hundred pixels.
+        const int per_image = nblk / images_interleaved;
+        blk = (blk % images_interleaved) * per_image + blk / images_interleaved;
+    }
+    const int row = blk * kRowsPerBlock + (threadIdx.x >> 6);
     if (row >= nrows) return;
     const int LP = L * P;
     const int m = row % M;
@@ -804,9 +812,12 @@ int grit_msda_bwd_bf16acc(const void* value, const int64_t* spatial_shapes, cons
         return GRIT_ERR_UNSUPPORTED;
     const int nrows = B * Lq * M;
     const int nblk = (nrows + kRowsPerBlock - 1) / kRowsPerBlock;
+    // image-interleaved workgroup order when the rows of an image fill whole workgroups (GRIT_MSDA_BWD_INTERLEAVE=0: off)
+    static const bool interleave = !(getenv("GRIT_MSDA_BWD_INTERLEAVE") && atoi(getenv("GRIT_MSDA_BWD_INTERLEAVE")) == 0);
+    const int images = (interleave && B > 1 && (Lq * M) % kRowsPerBlock == 0) ? B : 1;
     hipLaunchKernelGGL(msda_bwd_d64_pk, dim3(nblk), dim3(kWave * kRowsPerBlock), 0, (hipStream_t)stream,
                        (const __hip_bfloat16*)value, spatial_shapes, level_start, loc, attn_w, (const __hip_bfloat16*)grad_out,
-                       S, M, L, Lq, P, (__hip_bfloat16*)grad_value, grad_loc, grad_attn_w, nrows, nblk);
+                       S, M, L, Lq, P, (__hip_bfloat16*)grad_value, grad_loc, grad_attn_w, nrows, nblk, images);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 

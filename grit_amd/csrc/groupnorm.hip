@@ -226,21 +226,33 @@ template <typename WT>
 __global__ __launch_bounds__(256)
 void gn_bwd_params(const float* __restrict__ partial, const float* __restrict__ mean, const float* __restrict__ rstd, int B,
                    int C, int G, WT* __restrict__ dgamma, WT* __restrict__ dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const int g = c / (C / G);
+    // 64 channels per workgroup, the images spread over the 4 waves (a single thread walking B x chunks partials is a
+    // 1 000-deep dependent-latency chain)
+    __shared__ float red[4][2][64];
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float dg = 0.f, dbv = 0.f;
-    for (int b = 0; b < B; ++b) {
-        float A = 0.f, Bv = 0.f;
-        for (int k = 0; k < kChunks; ++k) {
-            A += partial[(((size_t)b * kChunks + k) * 2 + 0) * C + c];
-            Bv += partial[(((size_t)b * kChunks + k) * 2 + 1) * C + c];
+    if (c < C) {
+        const int g = c / (C / G);
+        for (int b = part; b < B; b += 4) {
+            float A = 0.f, Bv = 0.f;
+#pragma unroll
+            for (int k = 0; k < kChunks; ++k) {
+                A += partial[(((size_t)b * kChunks + k) * 2 + 0) * C + c];
+                Bv += partial[(((size_t)b * kChunks + k) * 2 + 1) * C + c];
+            }
+            dg = fmaf(rstd[b * G + g], A - mean[b * G + g] * Bv, dg);
+            dbv += Bv;
         }
-        dg = fmaf(rstd[b * G + g], A - mean[b * G + g] * Bv, dg);
-        dbv += Bv;
     }
-    if constexpr (sizeof(WT) == 4) { dgamma[c] = dg; dbeta[c] = dbv; }
-    else { dgamma[c] = __float2bfloat16(dg); dbeta[c] = __float2bfloat16(dbv); }
+    red[part][0][cl] = dg; red[part][1][cl] = dbv;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        dg = red[0][0][cl] + red[1][0][cl] + red[2][0][cl] + red[3][0][cl];
+        dbv = red[0][1][cl] + red[1][1][cl] + red[2][1][cl] + red[3][1][cl];
+        if constexpr (sizeof(WT) == 4) { dgamma[c] = dg; dbeta[c] = dbv; }
+        else { dgamma[c] = __float2bfloat16(dg); dbeta[c] = __float2bfloat16(dbv); }
+    }
 }
 
 bool shape_ok(int B, int T, int C, int G) {
@@ -290,7 +302,7 @@ int grit_groupnorm_tokens_bwd(const void* x, long x_bstride, const void* dy, lon
                            T, workspace);                                                                                   \
         hipLaunchKernelGGL((gn_bwd_apply<T_, WT_, LPR_>), grid, block, 0, st, (const T_*)x, x_bstride, (const T_*)dy,       \
                            dy_bstride, (const WT_*)weight, mean, rstd, T, G, workspace, (T_*)dx);                           \
-        hipLaunchKernelGGL((gn_bwd_params<WT_>), dim3((C + 255) / 256), block, 0, st, workspace, mean, rstd, B, C, G,      \
+        hipLaunchKernelGGL((gn_bwd_params<WT_>), dim3((C + 63) / 64), block, 0, st, workspace, mean, rstd, B, C, G,      \
                            (WT_*)dweight, (WT_*)dbias);                                                                     \
     }
     if (x_is_bf16 && w_is_bf16) { if (C == 512) GRIT_GN_BWD(__hip_bfloat16, __hip_bfloat16, 64) else GRIT_GN_BWD(__hip_bfloat16, __hip_bfloat16, 32) }

@@ -234,7 +234,7 @@ void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restri
     }
 }
 
-constexpr int kBwdBlocks = 512;  // persistent backward grid = rows of the partial-sum workspace (GRIT_LN_BWD_PARTIALS)
+constexpr int kBwdBlocks = GRIT_LN_BWD_PARTIALS;  // persistent backward grid = rows of the partial-sum workspace (GRIT_LN_BWD_PARTIALS)
 
 struct Fused {  // optional residual operands (all null / 0 for the plain LayerNorm)
     const void* branch = nullptr;     // forward: drop-path branch added to x

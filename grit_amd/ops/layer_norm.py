@@ -16,7 +16,7 @@ from grit_amd.ops import backend
 from grit_amd.ops.linear import slab_sum
 
 SUPPORTED_C = (128, 256, 512, 1024, 2048, 4096)
-LN_BWD_PARTIALS = 512  # GRIT_LN_BWD_PARTIALS in include/grit_hip.h
+LN_BWD_PARTIALS = 1024  # GRIT_LN_BWD_PARTIALS in include/grit_hip.h
 
 
 def _ptr(t):
@@ -53,7 +53,7 @@ class _LayerNormFn(Function):
         if not dy2.is_contiguous() or dy2.dtype != x2.dtype:
             dy2 = dy2.to(x2.dtype).contiguous()
         dx = torch.empty_like(x2)
-        # per-workgroup partial sums; the kernel launches min(ceil(rows / rows_per_block), 512) workgroups and every
+        # per-workgroup partial sums; the kernel launches min(ceil(rows / rows_per_block), LN_BWD_PARTIALS) workgroups and every
         # one of them writes its row, so the buffer needs no zero fill
         rows_per_block = 4 * (64 // min(C // 8, 64))
         nblk = min(-(-rows // rows_per_block), LN_BWD_PARTIALS)

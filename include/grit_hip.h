@@ -164,7 +164,7 @@ int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pa
  *                 GRIT_LN_BWD_PARTIALS)) are overwritten and only those may be summed (grit_slab_sum); no zero fill needed
  * Statistics and arithmetic are fp32; eps as in torch.nn.functional.layer_norm.
  * ------------------------------------------------------------------------------------------------------ */
-#define GRIT_LN_BWD_PARTIALS 512
+#define GRIT_LN_BWD_PARTIALS 1024
 int grit_layernorm_fwd(const void* x, const void* weight, const void* bias, int rows, int C, float eps, int x_is_bf16,
                        int w_is_bf16, void* y, float* mean, float* rstd, void* stream);
 int grit_layernorm_bwd(const void* x, const void* weight, const void* dy, const float* mean, const float* rstd, int rows,

@@ -52,7 +52,8 @@ class Attention(nn.Module):
         b, nq, nk, h = q.shape[0], q.shape[1], k.shape[1], self.n_heads
         qh = self.fc_q(q).view(b, nq, h, self.d_k)
         if self.hoist_kv and not self.training and k is v:
-            tag = (k.data_ptr(), tuple(k.shape), k._version)
+            # inference tensors carry no version counter; beam search never writes the visual memory in place
+            tag = (k.data_ptr(), tuple(k.shape), 0 if k.is_inference() else k._version)
             if self._kv is None or self._kv[0] != tag:
                 self._kv = (tag, self.fc_k(k).view(b, nk, h, self.d_k), self.fc_v(v).view(b, nk, h, self.d_k))
             kh, vh = self._kv[1], self._kv[2]

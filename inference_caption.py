@@ -28,7 +28,7 @@ def build_model(config, device, checkpoint=''):
     return model.eval()
 
 
-@torch.no_grad()
+@torch.inference_mode()
 def caption_tokens(model, image, config, beam_size=None):
     """image [3,H,W] (already normalised) -> (tokens [1, beam_len] int64, log_probs [1, beam_len])."""
     device = next(model.parameters()).device
@@ -37,7 +37,7 @@ def caption_tokens(model, image, config, beam_size=None):
                  beam_size=beam_size or config.model.beam_size, out_size=1, return_probs=False)
 
 
-@torch.no_grad()
+@torch.inference_mode()
 def caption_stream(model, batches, config, beam_size=None):
     """Caption a sequence of batches (NestedTensor each), yielding (tokens, log_probs) per batch in order -- the inner loop
     of evaluate_metrics (reference engine/caption_engine.py:156-175) arranged for the GPU: the detector of batch i+1 is

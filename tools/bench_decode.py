@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--bf16", action="store_true", help="bf16 weights (fp32 logits); default fp32 weights")
+    ap.add_argument("--inference-mode", action="store_true", help="torch.inference_mode instead of torch.no_grad")
     a = ap.parse_args()
     from grit_amd.config import default_config
     from grit_amd.data import synthetic_batch
@@ -38,7 +39,8 @@ def main():
         torch.cuda.synchronize()
         return out, time.perf_counter() - t0
 
-    with torch.no_grad():
+    mode = torch.inference_mode if a.inference_mode else torch.no_grad
+    with mode():
         for it in range(a.iters + 1):
             vis, t_det = sync_time(lambda: model.detector(batch['samples']))
             model.cached_features = True

@@ -6,20 +6,19 @@ from grit_amd.ops.layer_norm import linear_add_layer_norm
 
 
 def position_embedding(input, d_model):
-    """input: positions (any shape) -> (n, d_model): even channels sin(p / 10000^(2i/d)), odd channels cos."""
-    pos = input.view(-1, 1)
-    i = torch.arange(d_model // 2, dtype=torch.float32, device=pos.device).view(1, -1)
-    angle = pos / 10000**(2 * i / d_model)
-    out = torch.zeros((pos.shape[0], d_model), device=pos.device)
-    out[:, 0::2] = torch.sin(angle)
-    out[:, 1::2] = torch.cos(angle)
-    return out
+    """positions (any shape) -> [n, d_model]; channel 2i = sin(p / 10000^(2i/d)), channel 2i+1 = cos(same angle)."""
+    positions = input.reshape(-1, 1)
+    exponent = 2 * torch.arange(d_model // 2, dtype=torch.float32, device=positions.device).view(1, -1) / d_model
+    angle = positions / 10000**exponent
+    # interleave (sin, cos) pairs along the channel axis
+    return torch.stack((torch.sin(angle), torch.cos(angle)), dim=-1).flatten(1)
 
 
 def sinusoid_encoding_table(max_len, d_model, padding_idx=None):
+    """[max_len, d_model] table for positions 0..max_len-1 (row `padding_idx` zeroed)."""
     table = position_embedding(torch.arange(max_len, dtype=torch.float32), d_model)
     if padding_idx is not None:
-        table[padding_idx] = 0
+        table[padding_idx].zero_()
     return table
 
 

@@ -1,7 +1,7 @@
 """Type aliases used by the stateful containers (reference: utils/typing.py)."""
-from typing import Sequence, Union
+from typing import Optional, Sequence, Union
 
-import torch
+from torch import Tensor
 
-TensorOrSequence = Union[Sequence[torch.Tensor], torch.Tensor]
-TensorOrNone = Union[torch.Tensor, None]
+TensorOrNone = Optional[Tensor]
+TensorOrSequence = Union[Tensor, Sequence[Tensor]]

@@ -43,8 +43,8 @@ FLOP_PER_IMAGE_FWD_BWD = 955.8e9  # measured on the reference with to
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (metric is defined at 32)")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--caption-len", type=int, default=20)

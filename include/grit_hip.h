@@ -18,6 +18,16 @@
  *   grit_attn_*          <- Attention.forward core (QK^T/sqrt(d_k), masked_fill(-inf), softmax, .V),
  *                           models/common/attention.py:51-88 (no native ancestor); also serves
  *                           nn.MultiheadAttention inside models/detection/det_module.py:330-333
+ *   grit_layernorm_*, grit_add_layernorm_*
+ *                        <- nn.LayerNorm of the Swin blocks (models/common/swin_model.py:229,233,315,495) and the
+ *                           "projection -> dropout / drop-path -> residual -> LayerNorm" tails around it
+ *                           (swin_model.py:289-298, det_module.py:313-349, attention.py:166-184, pos_embed.py:44-48)
+ *   grit_relbias_*       <- relative_position_bias_table[relative_position_index] gather, swin_model.py:168-171
+ *   grit_groupnorm_tokens_* <- input_proj's GroupNorm(32, 512) + flatten/cat, models/caption/detector.py:28-33,58,
+ *                           models/detection/det_module.py:172-175
+ *   grit_colsum, grit_slab_sum <- bias / weight gradient reductions of nn.Linear's backward on the long token maps
+ *   grit_adam_flat       <- the two torch.optim.Adam of build_optimizers, engine/caption_engine.py:18-73
+ * (none of the last five groups has a native ancestor in the reference: they replace chains of torch ops)
  */
 #ifndef GRIT_HIP_H
 #define GRIT_HIP_H

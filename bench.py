@@ -174,6 +174,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
 
+    # what an event pair reads with NOTHING between its two markers: the part of every per-launch figure below that is
+    # marker / dispatch latency, not kernel time (reported, not subtracted: the roofline figures stay conservative)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    for a, b in pairs:
+        a.record()
+        b.record()
+    torch.cuda.synchronize()
+    empty_pair_us = sorted(a.elapsed_time(b) * 1e3 for a, b in pairs)[len(pairs) // 2]
+
     if rank == 0:
         images = world * args.batch * args.steps
         value = images / elapsed
@@ -195,7 +204,8 @@ def main():
                     # the algorithmic convention charges the whole value map; the gather touches ~45 % of it, so frac can
                     # exceed 1 -- traffic_frac prices the measured HBM-side bytes instead
                     "traffic_frac": (traffic / avg_t / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                    "launches": len(fwd), "avg_launch_us": avg_t * 1e6, "algorithmic_bytes_per_launch": int(nbytes)}
+                    "launches": len(fwd), "avg_launch_us": avg_t * 1e6, "algorithmic_bytes_per_launch": int(nbytes),
+                    "empty_event_pair_us": empty_pair_us}
         if bwd:  # informational: the backward is bound by the chip-wide float-atomic rate, not by HBM
             avg_b = sum(t for t, _ in bwd) / len(bwd)
             msda_bwd = {"kernel": "msda_bwd_d64", "launches": len(bwd), "avg_launch_us": avg_b * 1e6,

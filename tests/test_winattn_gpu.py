@@ -121,3 +121,26 @@ def test_relative_position_bias_kernels(nH, dtype):
     ref.backward(cot)
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     np.testing.assert_allclose(table.grad.float().cpu().numpy(), ref_t.grad.float().cpu().numpy(), rtol=tol, atol=tol * 10)
+
+
+def test_backward_conservation_at_benchmark_size():
+    """Stage-0 geometry of the 640x640 benchmark (160x160 map padded to 14x14 windows, 4 heads, shift 6), B = 4 -- too big
+    for the oracle, checked through a size-independent property of the backward: softmax rows sum to one, so
+    sum_j dV_j = sum_i dO_i per head channel, where j runs over the real tokens AND the window-padding tokens (whose share
+    lands in d(pad_qkv)); dO of padded queries is zero (they are cropped), and d(bias) sums to zero over keys for every
+    query row (d softmax is orthogonal to the all-ones direction)."""
+    from grit_amd.ops.window_attention import window_attention
+    B, H, W, nH = 4, 160, 160, 4
+    C = 32 * nH
+    qkv, bias, pad = _inputs(B, H, W, nH, seed=11)
+    cot = torch.randn(B, H * W, C, generator=torch.Generator().manual_seed(12)).bfloat16()
+    x, y, z = qkv.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True), pad.to(DEV).requires_grad_(True)
+    window_attention(x, y, z, H, W, nH, 12, 6, 32**-0.5).backward(cot.to(DEV))
+    dv_real = x.grad[..., 2 * C:].float().sum((0, 1))                 # [C]
+    dv_pad = z.grad[2 * C:].float()                                   # [C]
+    do_sum = cot.float().sum((0, 1)).to(DEV)
+    scale = do_sum.abs().max().item() + cot.float().abs().sum().item() * 2e-3 / C
+    assert (dv_real + dv_pad - do_sum).abs().max().item() < 2e-2 * scale + 0.5
+    row = y.grad.sum(-1)                                              # [nH, 144]: sum over keys of d(bias)
+    assert row.abs().max().item() < 2e-2 * y.grad.abs().sum(-1).max().item() + 1e-3
+    assert torch.isfinite(x.grad.float()).all() and torch.isfinite(y.grad).all()

@@ -87,15 +87,16 @@ def test_bucketed_allreduce_world2(wire_bf16):
     assert abs(ret["avg_loss"] - loss.item()) < 1e-5
 
 
-def _amp_worker(rank, world, port, ret):
+def _amp_worker(rank, world, port, ret, device="cpu"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from grit_amd.amp import Bf16Compute
     from grit_amd.config import default_config
     from grit_amd.engine.caption_engine import build_optimizers
     torch.manual_seed(100 + rank)
-    model = Toy()
+    model = Toy().to(device)
     wrapped = Bf16Compute(model, bucket_mb=0.0005)
+    ret["flat_%d" % rank] = bool(wrapped.flat_optimizer)
     cfg = default_config()
     # the engine's optimizer builder must pick up the fp32 masters (names of the module's parameters)
     opts = build_optimizers(wrapped, cfg, mode='xe')
@@ -103,7 +104,7 @@ def _amp_worker(rank, world, port, ret):
     g = torch.Generator().manual_seed(7)
     data = torch.randn(world * 4, 8, generator=g)
     target = torch.randn(world * 4, 4, generator=g)
-    xs, ys = data[rank * 4:(rank + 1) * 4].bfloat16(), target[rank * 4:(rank + 1) * 4]
+    xs, ys = data[rank * 4:(rank + 1) * 4].bfloat16().to(device), target[rank * 4:(rank + 1) * 4].to(device)
     losses = []
     for it in range(4):
         loss = ((wrapped(xs).float() - ys)**2).mean()
@@ -113,7 +114,7 @@ def _amp_worker(rank, world, port, ret):
         opts['backbone'].step()
         wrapped.after_optimizer_step()
         losses.append(loss.item())
-    sd = wrapped.master_state_dict()
+    sd = {k: v.cpu() for k, v in wrapped.master_state_dict().items()}
     flat = torch.cat([v.flatten().float() for v in sd.values()])
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
@@ -140,4 +141,19 @@ def test_bf16_compute_fp32_masters_world2():
     assert ret["dtypes"] == ["torch.float32"] and ret["compute_dtype"] == "torch.bfloat16"
     assert ret["n_master"] == 6  # a.*, b.* and the never-used dead.* (trainable; their gradient stays zero)
     assert ret["keys"] == sorted(Toy().state_dict().keys())
+    assert ret["losses"][-1] < ret["losses"][0]
+
+
+@pytest.mark.gpu
+def test_bf16_compute_flat_adam_world2_on_gpu():
+    """The same two-rank step on the GPU (both gloo ranks share cuda:0): here Bf16Compute takes the FlatAdam path
+    (grit_adam_flat reading the all-reduced bf16 buckets); masters must stay identical across the ranks."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_amp_worker, args=(2, port, ret, "cuda"), nprocs=2, join=True)
+        ret = dict(ret)
+    assert ret["flat_0"] and ret["flat_1"]
+    assert ret["same_weights"]
+    assert ret["dtypes"] == ["torch.float32"] and ret["compute_dtype"] == "torch.bfloat16"
     assert ret["losses"][-1] < ret["losses"][0]

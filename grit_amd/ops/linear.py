@@ -8,6 +8,7 @@ batched GEMM with fp32 partials (bmm, out_dtype = float32) followed by a sum ove
 132 us and 136 us for the same problems (tools/bench_weight_grad.py).  The bias gradient db = colsum(dY) uses the streaming
 column-sum kernel (grit_colsum).  Used for the four Linears of every Swin block and MSDeformAttn.value_proj."""
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -49,11 +50,14 @@ def column_sum(x2d, out_dtype=torch.float32):
     return slab_sum(partial.unsqueeze(0), out_dtype)[0]
 
 
+_SLAB_ROWS = int(os.environ.get("GRIT_WGRAD_SLAB_ROWS", "3200"))  # tuning knob (tools/bench_weight_grad.py)
+
+
 def split_k(M):
     """Number of row slabs for the weight-gradient GEMM: ~3 200-6 400 rows per slab, at most 64, dividing M."""
     if M < 25600:
         return 1
-    s = min(64, M // 3200)
+    s = min(64, M // _SLAB_ROWS)
     while s > 1 and M % s:
         s -= 1
     return s

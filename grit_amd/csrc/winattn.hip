@@ -364,12 +364,24 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
         const bool analytic = !kExplicitMask && g.shift > 0 && (wy == g.nWh - 1 || wx == g.nWw - 1);
         v4f dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
         v4bf pprev, sprev;
-#pragma unroll
-        for (int qt = 0; qt < kTiles; ++qt) {
+        // software pipeline by one query tile: the S / dP MFMAs of tile qt+1 (and the LDS reads feeding them) are issued
+        // before the element-wise work of tile qt, so their latency hides under ~60 VALU instructions instead of parking the
+        // wave (PMC: 52 % of the wave cycles were s_waitcnt / barrier waits, 26 % issue stalls on MFMA results)
+        auto score_tiles = [&](int qt, v4f& s_out, v4f& dp_out) {
             const v8bf qa = as_v8bf(*reinterpret_cast<const uint4*>(&Qs[oRow + 16 * qt * kTP]));
             const v8bf da = as_v8bf(*reinterpret_cast<const uint4*>(&dOs[oRow + 16 * qt * kTP]));
-            const v4f s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            const v4f dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            s_out = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            dp_out = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        };
+        v4f s_cur, dp_cur;
+        score_tiles(0, s_cur, dp_cur);
+#pragma unroll
+        for (int qt = 0; qt < kTiles; ++qt) {
+            const v4f s = s_cur, dp = dp_cur;
+            if (qt + 1 < kTiles) {  // next tile's MFMAs and LDS reads fly under this tile's element-wise work
+                score_tiles(qt + 1, s_cur, dp_cur);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // element-wise part, two score elements per instruction: the loop is instruction-issue bound and hipcc does not
             // form packed-fp32 operations from this code by itself, so the fma / sub / mul / add pairs are spelled out
             // (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 on 64-bit register pairs, which the halves of an MFMA result are)

@@ -57,13 +57,15 @@ def build_hip(force=False, verbose=False):
 
 def build_oracle(force=False):
     """The checker (oracle/*.c).  Building it is not using it: only tests/smoke/bench's cpu leg load it."""
-    src = os.path.join(ORACLE_DIR, "msda_oracle.c")
-    if not force and _newer(ORACLE_LIB, [src]):
-        return ORACLE_LIB
-    cmd = ["gcc", "-O2", "-shared", "-fPIC", "-std=c99", "-o", ORACLE_LIB, src, "-lm"]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    if r.returncode != 0:
-        raise RuntimeError("gcc failed:\n" + r.stdout.decode())
+    for name in ("msda", "image"):
+        src = os.path.join(ORACLE_DIR, name + "_oracle.c")
+        lib = os.path.join(ORACLE_DIR, "lib%s_oracle.so" % name)
+        if not force and _newer(lib, [src]):
+            continue
+        cmd = ["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-std=c99", "-o", lib, src, "-lm"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("gcc failed:\n" + r.stdout.decode())
     return ORACLE_LIB
 
 

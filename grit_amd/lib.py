@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -38,6 +38,8 @@ SIGNATURES = {
     "grit_groupnorm_tokens_fwd": [_ptr, _c.c_long, _ptr, _ptr, _int, _int, _int, _int, _f32, _int, _int, _ptr, _c.c_long] + [_ptr] * 4,
     "grit_groupnorm_tokens_bwd": [_ptr, _c.c_long, _ptr, _c.c_long, _ptr, _ptr, _ptr, _int, _int, _int, _int, _int, _int] + [_ptr] * 5,
     "grit_adam_flat": [_ptr, _ptr, _int, _ptr, _ptr, _ptr, _c.c_long] + [_f32] * 7 + [_ptr],
+    "grit_resample_taps_bicubic": [_int, _int, _ptr, _ptr, _c.c_long],
+    "grit_image_batch_fwd": [_ptr] * 5 + [_int] * 6 + [_ptr] * 3,
     "grit_colsum": [_ptr, _int, _int, _int, _int, _ptr, _ptr],
     "grit_slab_sum": [_ptr, _int, _c.c_long, _int, _c.c_long, _ptr, _int, _ptr],
     "grit_attn_fwd_f32": _ATTN_IN + [_int] * 5 + [_f32, _f32, _u64, _ptr, _ptr, _ptr, _ptr],

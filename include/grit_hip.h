@@ -27,7 +27,12 @@
  *                           models/detection/det_module.py:172-175
  *   grit_colsum, grit_slab_sum <- bias / weight gradient reductions of nn.Linear's backward on the long token maps
  *   grit_adam_flat       <- the two torch.optim.Adam of build_optimizers, engine/caption_engine.py:18-73
- * (none of the last five groups has a native ancestor in the reference: they replace chains of torch ops)
+ *   grit_resample_taps_bicubic, grit_image_batch_fwd
+ *                        <- the image side of the batch contract: PIL resize(BICUBIC) of MaxWHResize / MinMaxResize
+ *                           (datasets/caption/transforms/utils.py:4-45), ToTensor + Normalize
+ *                           (datasets/caption/transforms/__init__.py:6-32), zero padding + mask of
+ *                           nested_tensor_from_tensor_list (engine/utils.py:278-295)
+ * (none of the last six groups has a native ancestor in the reference: they replace chains of torch / PIL ops)
  */
 #ifndef GRIT_HIP_H
 #define GRIT_HIP_H
@@ -38,7 +43,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 15
+#define GRIT_ABI_VERSION 16
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -263,6 +268,35 @@ int grit_slab_sum(const float* partial, int groups, long group_stride, int slabs
 int grit_adam_flat(float* param, const void* grad, int grad_is_bf16, float* exp_avg, float* exp_avg_sq, void* compute_bf16,
                    long n, float lr, float beta1, float beta2, float eps, float bias_correction1,
                    float bias_correction2_sqrt, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Decoded RGB images -> the model's input batch: bicubic resize with Pillow's 8-bit arithmetic
+ * (bit-identical to Image.resize(size, Image.BICUBIC) on an RGB image), x/255, (x - mean)/std, zero padding to the
+ * batch maximum and the padding mask -- transforms/utils.py:4-45, transforms/__init__.py:6-32, engine/utils.py:278-295.
+ *
+ * grit_resample_taps_bicubic (host code, no GPU work): the tap table of one axis.
+ *   bounds [out_size][2] = (first source index, tap count);  taps [out_size][ksize] 22-bit fixed point, zero past the count
+ *   returns ksize (> 0); with bounds == taps == NULL only ksize is computed; -GRIT_ERR_BAD_ARG on bad sizes / capacity
+ *
+ * grit_image_batch_fwd (two launches):
+ *   src     uint8 blob holding the images, each [src_h, src_w, 3] contiguous at byte offset src_off; 4-byte aligned and
+ *           readable for GRIT_IMAGE_SRC_PAD bytes past the last image (the row pass fetches whole dwords)
+ *   desc    [batch][GRIT_IMAGE_DESC_FIELDS] int64 (device): src_off, src_h, src_w, dst_h, dst_w, kx, ky, xb_off, xt_off,
+ *           yb_off, yt_off, tmp_off -- k* = ksize of the x / y table, *b_off / *t_off = offsets (in int32 elements) of the
+ *           bounds / taps of that axis inside `tables` (even), tmp_off = byte offset (multiple of 4) of this image's slot
+ *           in tmp: src_h rows of GRIT_IMAGE_TMP_PITCH(dst_w) bytes
+ *   tables  int32 blob (device) of the tap tables;  tmp uint8 scratch, 4-byte aligned, sum of the slots
+ *   lut     [3][256] f32: lut[c][v] = (v / 255 - mean[c]) / std[c], computed by the caller
+ *   out     [batch, 3, out_h, out_w] f32 and mask [batch, out_h, out_w] uint8 (1 on padding), both fully overwritten
+ *   max_src_h = max src_h, max_dst_w = max dst_w (<= out_w), max_kx = max kx over the batch; grid extents <= 65535
+ * ------------------------------------------------------------------------------------------------------ */
+#define GRIT_IMAGE_DESC_FIELDS 12
+#define GRIT_IMAGE_SRC_PAD 64
+#define GRIT_IMAGE_TMP_PITCH(dst_w) ((3 * (dst_w) + 3) & ~3)
+int grit_resample_taps_bicubic(int in_size, int out_size, int32_t* bounds, int32_t* taps, long taps_capacity);
+int grit_image_batch_fwd(const uint8_t* src, const int64_t* desc, const int32_t* tables, uint8_t* tmp, const float* lut,
+                         int batch, int max_src_h, int max_dst_w, int max_kx, int out_h, int out_w, float* out,
+                         uint8_t* mask, void* stream);
 
 #ifdef __cplusplus
 }

@@ -452,7 +452,47 @@ def make_g10():
     print('g10', out['beam1'], out['extra'])
 
 
-MAKERS.update({'g10': make_g10})
+def make_g11():
+    """Image side of the batch contract.  The reference's own resize classes
+    (datasets/caption/transforms/utils.py, loaded from the file: the package __init__ needs torchvision, absent here) are
+    applied to seeded PIL images; ToTensor / Normalize are torchvision's published definitions restated with torch ops
+    (`uint8 HWC -> CHW float32 .div(255)`, `.sub_(mean).div_(std)`, constants of transforms/__init__.py:6-7), and the
+    padding + mask come from the reference's nested_tensor_from_tensor_list (engine/utils.py:278-295)."""
+    import importlib.util
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location('ref_transform_utils', os.path.join(REF, 'datasets/caption/transforms/utils.py'))
+    tu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tu)
+    import_reference()
+    from engine.utils import nested_tensor_from_tensor_list
+    mean = torch.as_tensor([0.485, 0.456, 0.406], dtype=torch.float32)[:, None, None]
+    std = torch.as_tensor([0.229, 0.224, 0.225], dtype=torch.float32)[:, None, None]
+    rng = np.random.default_rng(11)
+    shapes = [(60, 80), (75, 50), (64, 64), (31, 97), (120, 160)]
+    out = {}
+    for name, policy in (('maxwh', tu.MaxWHResize((48, 64))), ('minmax', tu.MinMaxResize((64, 128)))):
+        tensors, sizes = [], []
+        for i, (h, w) in enumerate(shapes):
+            if i % 2 == 0:  # noise
+                img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            else:  # smooth ramps with a sharp edge (overshoot -> exercises the clamp)
+                y, x = np.mgrid[0:h, 0:w]
+                img = np.stack([x * 255 // (w - 1), y * 255 // (h - 1), np.where(x > w // 2, 255, 0)], -1).astype(np.uint8)
+            out['%s_in%d' % (name, i)] = img
+            small = policy(Image.fromarray(img, 'RGB'))
+            u8 = torch.from_numpy(np.asarray(small).copy())
+            out['%s_u8_%d' % (name, i)] = u8.numpy()
+            sizes.append(u8.shape[:2])
+            tensors.append(u8.permute(2, 0, 1).to(torch.float32).div(255).sub_(mean).div_(std))
+        nt = nested_tensor_from_tensor_list(tensors)
+        out[name + '_sizes'] = np.asarray(sizes, np.int64)
+        out[name + '_tensors'] = nt.tensors.numpy()
+        out[name + '_mask'] = nt.mask.numpy()
+        print('g11', name, sizes, tuple(nt.tensors.shape))
+    np.savez_compressed(os.path.join(HERE, 'image_g11.npz'), **out)
+
+
+MAKERS.update({'g10': make_g10, 'g11': make_g11})
 MAKERS.update({'keys': make_keys, 'g3': make_g3, 'g4': make_g4, 'g6': make_g6, 'g7': make_g7, 'g8': make_g8, 'g9': make_g9})
 
 if __name__ == "__main__":

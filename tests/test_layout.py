@@ -28,7 +28,8 @@ def test_product_never_imports_oracle_or_reads_reference():
 
 
 def test_oracle_headers_say_test_infrastructure():
-    for f in ("oracle/__init__.py", "oracle/msda.py", "oracle/torch_ref.py", "oracle/msda_oracle.c"):
+    for f in ("oracle/__init__.py", "oracle/msda.py", "oracle/torch_ref.py", "oracle/msda_oracle.c", "oracle/image.py",
+              "oracle/image_oracle.c"):
         assert "TEST INFRASTRUCTURE" in open(os.path.join(ROOT, f)).read(), f
 
 

@@ -18,12 +18,13 @@ def get_transform(cfg):
     return {'train': resize, 'valid': resize}
 
 
-def collate_images(items, device=None):
+def collate_images(items, device=None, pad_to=None):
     """List of `Deferred` (what the transforms return) -> NestedTensor on the device; the device counterpart of
     Compose([resize, ToTensor(), normalize()]) per image + nested_tensor_from_tensor_list(imgs).to(device)."""
     for it in items:
         if not isinstance(it, Deferred):
             raise TypeError("collate_images expects the Deferred images returned by get_transform()'s transforms")
     sizes = [it.size for it in items]
-    tensors, mask = image_batch([it.pixels for it in items], sizes, MEAN, STD, device)
-    return NestedTensor(tensors, mask, any_padding=len(set(sizes)) > 1)
+    tensors, mask = image_batch([it.pixels for it in items], sizes, MEAN, STD, device, pad_to)
+    padded = len(set(sizes)) > 1 or (pad_to is not None and tuple(pad_to) != tuple(sizes[0]))
+    return NestedTensor(tensors, mask, any_padding=padded)

@@ -66,7 +66,8 @@ class _Staging(object):
         if slot[1] is not None:
             slot[1].synchronize()
         if slot[0] is None or slot[0].numel() < nbytes:
-            slot[0] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
+            with torch.inference_mode(False):  # the buffer outlives the caller's inference_mode block
+                slot[0] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
         return slot
 
     def upload(self, slot, nbytes, device):
@@ -119,10 +120,12 @@ def plan(shapes, sizes):
     return desc, np.concatenate(parts), tmp_off, src_off
 
 
-def image_batch(images, sizes, mean=MEAN, std=STD, device=None):
+def image_batch(images, sizes, mean=MEAN, std=STD, device=None, pad_to=None):
     """images: list of [h, w, 3] uint8 (torch / numpy / PIL, host or device); sizes: list of (oh, ow).
 
-    -> (tensors [B, 3, H, W] f32, mask [B, H, W] bool) on `device`, H = max oh, W = max ow."""
+    -> (tensors [B, 3, H, W] f32, mask [B, H, W] bool) on `device`, H = max oh, W = max ow -- or `pad_to` = (H, W), the
+    fixed canvas the feature extractor needs (the reference gets it by appending a dummy H x W image to every batch,
+    tools/extract_features.py:103)."""
     imgs = [_as_u8(im) for im in images]
     if len(imgs) == 0 or len(imgs) != len(sizes):
         raise ValueError("need one target size per image and at least one image")
@@ -134,6 +137,11 @@ def image_batch(images, sizes, mean=MEAN, std=STD, device=None):
     lib = _lib.load()
     desc, tables, tmp_bytes, src_bytes = plan([tuple(im.shape[:2]) for im in imgs], [tuple(s) for s in sizes])
     H, W = int(desc[:, 3].max()), int(desc[:, 4].max())
+    max_dst_w = W
+    if pad_to is not None:
+        if pad_to[0] < H or pad_to[1] < W:
+            raise ValueError("pad_to %s is smaller than the largest resized image (%d, %d)" % (tuple(pad_to), H, W))
+        H, W = int(pad_to[0]), int(pad_to[1])
     B = len(imgs)
     with torch.cuda.device(device):
         if all(im.is_cuda for im in imgs):
@@ -159,6 +167,6 @@ def image_batch(images, sizes, mean=MEAN, std=STD, device=None):
         mask = torch.empty(B, H, W, dtype=torch.bool, device=device)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         st = lib.grit_image_batch_fwd(p(src), p(d_desc), p(d_tables), p(tmp), p(_lut(tuple(mean), tuple(std), device)),
-                                      B, int(desc[:, 1].max()), W, int(desc[:, 5].max()), H, W, p(out), p(mask), _lib.current_stream_ptr())
+                                      B, int(desc[:, 1].max()), max_dst_w, int(desc[:, 5].max()), H, W, p(out), p(mask), _lib.current_stream_ptr())
         _lib.check(st, "grit_image_batch_fwd")
     return out, mask

@@ -117,6 +117,10 @@ extern "C" int grit_slab_sum(const float* partial, int groups, long group_stride
     const long groups4 = n / 4;
     int cw_log2 = 0;
     while (cw_log2 < 6 && (1L << cw_log2) < groups4) ++cw_log2;
+    // tall, narrow partials (LayerNorm: 1024 slabs x 512 columns) would leave the chip to a handful of workgroups that
+    // each walk hundreds of slabs: trade column width (>= 128 contiguous bytes per slab row) for slab lanes
+    while (cw_log2 > 3 && (((groups4 + (1L << cw_log2) - 1) >> cw_log2) * groups) < 256 && slabs >= 8 * (256 >> (cw_log2 - 1)))
+        --cw_log2;
     const long blocks = (groups4 + (1L << cw_log2) - 1) >> cw_log2;
     if (blocks > 0x7fffffffL) return GRIT_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)blocks, groups), block(256);

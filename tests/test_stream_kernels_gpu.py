@@ -9,7 +9,8 @@ DEV = "cuda"
 
 
 @pytest.mark.parametrize("groups,alloc,slabs,n", [(1, 1, 1, 8), (1, 3, 3, 128), (2, 512, 37, 128), (2, 512, 512, 4096),
-                                                   (1, 64, 64, 2048 * 512), (1, 16, 16, 100), (3, 9, 5, 260)])
+                                                   (1, 64, 64, 2048 * 512), (1, 16, 16, 100), (3, 9, 5, 260), (3, 1024, 1024, 512),
+                                                   (2, 1024, 700, 128), (1, 256, 256, 1536)])
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
 def test_slab_sum(groups, alloc, slabs, n, out_dtype):
     """grit_slab_sum: out[g] = cast(sum of the first `slabs` slabs of group g); slabs beyond that are never read."""

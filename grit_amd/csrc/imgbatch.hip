@@ -122,9 +122,13 @@ void resample_cols_normalize(const uint8_t* __restrict__ tmp, const ImageDesc* _
     for (int i = threadIdx.x; i < 3 * 256; i += 256) table[i] = lut[i];
     __syncthreads();
     const ImageDesc d = desc[blockIdx.z];
-    const int yy = blockIdx.y;
+    // Workgroups go to the 8 XCDs round-robin in launch order and every XCD has its own L2.  Neighbouring output rows
+    // share most of their source rows, so each XCD gets one contiguous band of rows (gridDim.y is a multiple of 8 when
+    // the grid is one workgroup wide) instead of every eighth row -- otherwise each L2 fetches the whole intermediate.
+    int yy = blockIdx.y;
+    if (gridDim.x == 1) yy = (yy & 7) * (gridDim.y >> 3) + (yy >> 3);
     const int px0 = 4 * (blockIdx.x * 256 + threadIdx.x);
-    if (px0 >= out_w) return;
+    if (yy >= out_h || px0 >= out_w) return;
     const int ow = (int)d.dst_w, pitch = tmp_pitch(ow);
     int s[12];
 #pragma unroll
@@ -241,7 +245,8 @@ extern "C" int grit_image_batch_fwd(const uint8_t* src, const int64_t* desc, con
     else
         hipLaunchKernelGGL(resample_rows_any, dim3((max_dst_w * 3 + 255) / 256, max_src_h, batch), dim3(256), 0, s,
                            src, d, tables, tmp);
-    hipLaunchKernelGGL(resample_cols_normalize, dim3((out_w + 1023) / 1024, out_h, batch), dim3(256), 0, s,
+    const int wide = (out_w + 1023) / 1024;
+    hipLaunchKernelGGL(resample_cols_normalize, dim3(wide, wide == 1 ? (out_h + 7) / 8 * 8 : out_h, batch), dim3(256), 0, s,
                        tmp, d, tables, lut, out_h, out_w, out, mask);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }

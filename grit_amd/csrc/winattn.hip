@@ -65,7 +65,21 @@ constexpr float kLn2 = 0.6931471805599453f;
 struct Geom {
     int B, H, W, C, nH, shift, nWh, nWw, Hp, Wp, T, nWm;
     float scale;
+    int xcd_pairs;  // 1: workgroup id -> (head, window group) keeps heads 2j / 2j+1 on one XCD (head_and_group)
 };
+
+// Workgroups are dealt to the 8 XCDs round-robin by id and every XCD has its own L2.  A head's q / k / v slice of a token
+// is 64 bytes, so heads 2j and 2j+1 share each 128-byte line: with head = id % nH the two always sit on different XCDs
+// and every line of qkv / out / dout is filled into two L2s.  This mapping gives each XCD whole pairs of heads (for 4 and
+// 8 heads, two XCDs share a pair and split the window groups).
+__device__ __forceinline__ void head_and_group(const Geom& g, int& h, int& grp) {
+    const int id = blockIdx.x;
+    if (!g.xcd_pairs) { h = id % g.nH; grp = id / g.nH; return; }
+    const int x = id & 7, r = id >> 3;
+    if (g.nH >= 16) { const int hp = g.nH >> 3; h = x * hp + r % hp; grp = r / hp; }
+    else if (g.nH == 8) { h = (x & ~1) + (r & 1); grp = (r >> 1) * 2 + (x & 1); }
+    else { h = 2 * ((x >> 1) & 1) + (r & 1); grp = (r >> 1) * 4 + (x & 1) + 2 * (x >> 2); }  // 4 heads
+}
 
 // window-local index n of window (wy, wx) -> token index in the H x W map (or -1 for a padding token) and the
 // shift-mask region of the position (swin_model.py:424-436 on the rolled map)
@@ -114,7 +128,9 @@ void winattn_fwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int h = blockIdx.x % g.nH, grp = blockIdx.x / g.nH, ngrp = gridDim.x / g.nH;
+    int h, grp;
+    head_and_group(g, h, grp);
+    const int ngrp = gridDim.x / g.nH;
     const int NW = g.B * g.nWh * g.nWw;
     const int C3 = 3 * g.C;
     const int hoff = h * kHd;
@@ -290,7 +306,9 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int trq = l15 >> 2, trp = l15 & 3;
-    const int h = blockIdx.x % g.nH, grp = blockIdx.x / g.nH, ngrp = gridDim.x / g.nH;
+    int h, grp;
+    head_and_group(g, h, grp);
+    const int ngrp = gridDim.x / g.nH;
     const int NW = g.B * g.nWh * g.nWw;
     const int C3 = 3 * g.C;
     const int hoff = h * kHd;
@@ -532,6 +550,7 @@ Geom make_geom(int B, int H, int W, int C, int nH, int shift, float scale, int n
     g.B = B; g.H = H; g.W = W; g.C = C; g.nH = nH; g.shift = shift;
     g.nWh = (H + kWs - 1) / kWs; g.nWw = (W + kWs - 1) / kWs;
     g.Hp = g.nWh * kWs; g.Wp = g.nWw * kWs; g.T = H * W; g.nWm = nWm > 0 ? nWm : 1; g.scale = scale;
+    g.xcd_pairs = 0;
     return g;
 }
 
@@ -548,6 +567,13 @@ int grid_blocks(const Geom& g, int target) {
     return groups * g.nH;
 }
 
+Geom with_xcd_mapping(Geom g, int blocks) {
+    const int groups = blocks / g.nH;
+    g.xcd_pairs = (g.nH % 8 == 0 && g.nH >= 16) || (g.nH == 8 && groups % 2 == 0) || (g.nH == 4 && groups % 4 == 0);
+    if (getenv("GRIT_WINATTN_PLAIN_MAP")) g.xcd_pairs = 0;  // A/B knob for tools/bench_kernels.py
+    return g;
+}
+
 }  // namespace
 
 extern "C" {
@@ -559,7 +585,8 @@ int grit_winattn_fwd_bf16(const void* qkv, const float* rel_bias, const void* pa
     const int st = check_geom(B, H, W, C, num_heads, window, shift);
     if (st != GRIT_OK) return st;
     if (mask && n_mask_windows <= 0) return GRIT_ERR_BAD_ARG;
-    const Geom g = make_geom(B, H, W, C, num_heads, shift, scale, n_mask_windows);
+    const Geom g0 = make_geom(B, H, W, C, num_heads, shift, scale, n_mask_windows);
+    const Geom g = with_xcd_mapping(g0, grid_blocks(g0, 256));
     hipLaunchKernelGGL(winattn_fwd, dim3(grid_blocks(g, 256)), dim3(kThreads), 0, (hipStream_t)stream,
                        (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (__bf16*)out, lse);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
@@ -572,7 +599,8 @@ int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pa
     const int st = check_geom(B, H, W, C, num_heads, window, shift);
     if (st != GRIT_OK) return st;
     if (mask && n_mask_windows <= 0) return GRIT_ERR_BAD_ARG;
-    const Geom g = make_geom(B, H, W, C, num_heads, shift, scale, n_mask_windows);
+    const Geom g0 = make_geom(B, H, W, C, num_heads, shift, scale, n_mask_windows);
+    const Geom g = with_xcd_mapping(g0, grid_blocks(g0, 256));
     static bool lds_attr_set = false;  // idempotent attribute, racing first calls set the same value
     if (!lds_attr_set) {
         if (hipFuncSetAttribute((const void*)winattn_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds) != hipSuccess ||

@@ -554,7 +554,7 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
                      const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
                      const __hip_bfloat16* __restrict__ grad_out, int S, int M, int L, int Lq, int P,
                      __hip_bfloat16* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_aw,
-                     int nrows, int nblk, int images_interleaved) {
+                     int nrows, int nblk, int images_interleaved, int merge_disabled) {
     constexpr int D = 64, kMaxLP = 16;
     typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
     typedef v2bf __attribute__((address_space(1))) * gv2bf_ptr;
@@ -609,9 +609,49 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
             rr[i][3] = *reinterpret_cast<const uint32_t*>(vhead + (size_t)s4 * pix_stride);
         }
     }
+    // A freshly initialised model (and any query whose offsets are still small) puts the P points of a level into ONE
+    // pixel cell: the four corner updates of the four points then hit the same four addresses.  That case is detected
+    // per level with wave-uniform compares and the bilinear weights are summed first -- 4 half-wave atomics per level
+    // instead of 8 full-wave ones, and a quarter of the same-address traffic.  Levels whose points differ take the
+    // per-point path unchanged.
+    const bool mergeable = P == 4 && LP == kMaxLP && !merge_disabled;
+    bool merged = false;
 #pragma unroll
     for (int i = 0; i < kMaxLP / 2; ++i) {
         if (2 * i < LP) {
+            if ((i & 1) == 0) {
+                merged = mergeable;
+                const int p0 = 2 * i;
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    merged = merged && __builtin_amdgcn_readlane(e1, p0) == __builtin_amdgcn_readlane(e1, p0 + k) &&
+                             __builtin_amdgcn_readlane(e2, p0) == __builtin_amdgcn_readlane(e2, p0 + k) &&
+                             __builtin_amdgcn_readlane(e3, p0) == __builtin_amdgcn_readlane(e3, p0 + k) &&
+                             __builtin_amdgcn_readlane(e4, p0) == __builtin_amdgcn_readlane(e4, p0 + k) &&
+                             __builtin_amdgcn_readlane(flags, p0) == __builtin_amdgcn_readlane(flags, p0 + k);
+                if (merged) {
+                    float W1 = 0.f, W2 = 0.f, W3 = 0.f, W4 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float lh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.lh), p0 + k));
+                        const float lw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.lw), p0 + k));
+                        const float wt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pwt), p0 + k));
+                        const float hh = (1.f - lh) * wt, lhw = lh * wt;
+                        W1 += hh * (1.f - lw); W2 += hh * lw; W3 += lhw * (1.f - lw); W4 += lhw * lw;
+                    }
+                    const int f = __builtin_amdgcn_readlane(flags, p0);
+                    if (!odd) {
+                        __hip_bfloat16* g1 = ghead + (size_t)__builtin_amdgcn_readlane(e1, p0) * pix_stride;
+                        __hip_bfloat16* g2 = ghead + (size_t)__builtin_amdgcn_readlane(e2, p0) * pix_stride;
+                        __hip_bfloat16* g3 = ghead + (size_t)__builtin_amdgcn_readlane(e3, p0) * pix_stride;
+                        __hip_bfloat16* g4 = ghead + (size_t)__builtin_amdgcn_readlane(e4, p0) * pix_stride;
+                        if (f & 1) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)g1, v2bf{(__bf16)(W1 * go0), (__bf16)(W1 * go1)});
+                        if (f & 2) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)g2, v2bf{(__bf16)(W2 * go0), (__bf16)(W2 * go1)});
+                        if (f & 4) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)g3, v2bf{(__bf16)(W3 * go0), (__bf16)(W3 * go1)});
+                        if (f & 8) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)g4, v2bf{(__bf16)(W4 * go0), (__bf16)(W4 * go1)});
+                    }
+                }
+            }
             const int f = (2 * i + 1 < LP || !odd) ? GRIT_PICK_I(flags, i) : 0;
             const int s1 = GRIT_PICK_I(e1, i), s2 = GRIT_PICK_I(e2, i), s3 = GRIT_PICK_I(e3, i), s4 = GRIT_PICK_I(e4, i);
             const float lh = GRIT_PICK_F(c.lh, i), lw = GRIT_PICK_F(c.lw, i), wt = GRIT_PICK_F(pwt, i);
@@ -619,10 +659,12 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
             const float hh = 1.f - lh, hw = 1.f - lw;
             const float t0 = go0 * wt, t1 = go1 * wt;
             const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-            if (f & 1) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s1 * pix_stride), v2bf{(__bf16)(w1 * t0), (__bf16)(w1 * t1)});
-            if (f & 2) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s2 * pix_stride), v2bf{(__bf16)(w2 * t0), (__bf16)(w2 * t1)});
-            if (f & 4) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s3 * pix_stride), v2bf{(__bf16)(w3 * t0), (__bf16)(w3 * t1)});
-            if (f & 8) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s4 * pix_stride), v2bf{(__bf16)(w4 * t0), (__bf16)(w4 * t1)});
+            if (!merged) {
+                if (f & 1) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s1 * pix_stride), v2bf{(__bf16)(w1 * t0), (__bf16)(w1 * t1)});
+                if (f & 2) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s2 * pix_stride), v2bf{(__bf16)(w2 * t0), (__bf16)(w2 * t1)});
+                if (f & 4) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s3 * pix_stride), v2bf{(__bf16)(w3 * t0), (__bf16)(w3 * t1)});
+                if (f & 8) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s4 * pix_stride), v2bf{(__bf16)(w4 * t0), (__bf16)(w4 * t1)});
+            }
             // clamped indices are always legal: all four were loaded, select by the validity bits
             const uint32_t q1 = (f & 1) ? rr[i][0] : 0u, q2 = (f & 2) ? rr[i][1] : 0u, q3 = (f & 4) ? rr[i][2] : 0u, q4 = (f & 8) ? rr[i][3] : 0u;
             const float a1x = __uint_as_float(q1 << 16), a1y = __uint_as_float(q1 & 0xffff0000u);
@@ -815,9 +857,10 @@ int grit_msda_bwd_bf16acc(const void* value, const int64_t* spatial_shapes, cons
     // image-interleaved workgroup order when the rows of an image fill whole workgroups (GRIT_MSDA_BWD_INTERLEAVE=0: off)
     static const bool interleave = !(getenv("GRIT_MSDA_BWD_INTERLEAVE") && atoi(getenv("GRIT_MSDA_BWD_INTERLEAVE")) == 0);
     const int images = (interleave && B > 1 && (Lq * M) % kRowsPerBlock == 0) ? B : 1;
+    static const bool no_merge = getenv("GRIT_MSDA_BWD_MERGE") && atoi(getenv("GRIT_MSDA_BWD_MERGE")) == 0;  // A/B knob
     hipLaunchKernelGGL(msda_bwd_d64_pk, dim3(nblk), dim3(kWave * kRowsPerBlock), 0, (hipStream_t)stream,
                        (const __hip_bfloat16*)value, spatial_shapes, level_start, loc, attn_w, (const __hip_bfloat16*)grad_out,
-                       S, M, L, Lq, P, (__hip_bfloat16*)grad_value, grad_loc, grad_attn_w, nrows, nblk, images);
+                       S, M, L, Lq, P, (__hip_bfloat16*)grad_value, grad_loc, grad_attn_w, nrows, nblk, images, no_merge ? 1 : 0);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 

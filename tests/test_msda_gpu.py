@@ -194,6 +194,36 @@ def test_bf16_value_maps_forward_backward(f32_accumulate):
     np.testing.assert_allclose(gl.cpu().numpy(), ogl, rtol=1e-3, atol=2e-3)
 
 
+def test_bf16_backward_merges_points_that_share_a_cell():
+    """Freshly initialised model: the P points of a level sit in one pixel cell (tiny offsets).  The bf16-accumulating
+    backward sums their bilinear weights and issues one update per corner; mixed here with levels whose points differ,
+    cells on the border (dead corners) and points outside the map.  Same tolerances as the spread case."""
+    value, shapes, lsi, loc, aw = _config2(B=2)
+    g = torch.Generator().manual_seed(9)
+    ref = torch.rand(2, 150, 1, 1, 1, 2, generator=g)
+    hw = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()[None, None, None, :, None, :]  # (W, H) per level
+    # cell-centred reference + offsets well inside the cell for levels 0, 2, 3; level 1 keeps spread points
+    centre = (torch.floor(ref * hw) + 1.0) / hw  # pixel coordinate k + 0.5: the middle of cell k
+    tight = centre + (torch.rand(2, 150, 8, 4, 4, 2, generator=g) - 0.5) * 0.6 / hw
+    loc = loc.clone()
+    for l in (0, 2, 3):
+        loc[:, :, :, l] = tight[:, :, :, l]
+    loc[0, :10] = -0.2            # entirely outside: no update at all
+    loc[1, :10, :, 3] = 0.999      # last cell of the coarsest level: right / bottom corners dead
+    v16 = value.bfloat16()
+    cot = torch.randn(2, 150, 512, generator=g).bfloat16()
+    out, gv, gl, ga = _run(v16.to(DEV), shapes.to(DEV), lsi.to(DEV), loc.to(DEV), aw.to(DEV), cot.to(DEV))
+    vr, cr = v16.float().numpy(), cot.float().numpy()
+    ogv, ogl, oga = omsda.msda_backward(vr, shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy(), cr)
+    got = gv.float().cpu().numpy()
+    rel = np.linalg.norm(got - ogv) / np.linalg.norm(ogv)
+    assert rel < 8e-3, rel
+    assert np.abs(got - ogv).max() < 3e-2 * np.abs(ogv).max()
+    assert (got[ogv == 0] == 0).all()
+    np.testing.assert_allclose(ga.cpu().numpy(), oga, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gl.cpu().numpy(), ogl, rtol=1e-3, atol=2e-3)
+
+
 @pytest.mark.parametrize("B", [1, 4, 32])
 def test_d64_backward_batches_and_level_layouts(B):
     """msda_bwd_d64 (geometry once per row + butterfly reductions) over several batch sizes and level layouts,

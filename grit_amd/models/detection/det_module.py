@@ -13,6 +13,7 @@ unchanged), and the cross-attention samples the value maps with the HIP MSDeform
 """
 import copy
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -23,6 +24,9 @@ from grit_amd.models.common.swin_model import DropPath
 from grit_amd.models.ops.modules import MSDeformAttn
 from grit_amd.ops.attention import attention as fused_attention
 from grit_amd.ops.layer_norm import linear_add_layer_norm
+from grit_amd.ops.linear import shared_input_linears
+
+_SHARED_VALUE_PROJ = os.environ.get('GRIT_SHARED_VALUE_PROJ', '1') != '0'  # A/B knob
 from grit_amd.utils.misc import inverse_sigmoid
 
 
@@ -96,7 +100,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         return mha.out_proj(out) if project else out
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, src_level_start_index,
-                src_valid_ratios, src_padding_mask=None):
+                src_valid_ratios, src_padding_mask=None, value=None):
         if reference_points.shape[-1] == 4:
             ratios = torch.cat([src_valid_ratios, src_valid_ratios], -1)
         else:
@@ -112,13 +116,13 @@ class DeformableTransformerDecoderLayer(nn.Module):
             tgt = tail(self.query_self_attention(tgt, query_pos, project=False), self.self_attn.out_proj, tgt, self.dropout2,
                        self.norm2)
             sampled = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
-                                      src_level_start_index, src_padding_mask, project=False)
+                                      src_level_start_index, src_padding_mask, project=False, value=value)
             tgt = tail(sampled, self.cross_attn.output_proj, tgt, self.dropout1, self.norm1)
             hidden = self.dropout3(self.activation(self.linear1(tgt)))
             return tail(hidden, self.linear2, tgt, self.dropout4, self.norm3)
         tgt = self.norm2(tgt + self.dropout2(self.query_self_attention(tgt, query_pos)))
         tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
-                               src_level_start_index, src_padding_mask)
+                               src_level_start_index, src_padding_mask, value=value)
         if self.drop_path is None:
             return self.forward_ffn(self.norm1(tgt + self.dropout1(tgt2)))
         tgt = tgt + self.drop_path(self.dropout1(tgt2))
@@ -233,8 +237,12 @@ class DetectionModule(nn.Module):
             od['src_padding_mask'] = None
         init_reference_out = od['reference_points']
         hs, refs = [od['tgt']], [init_reference_out]
+        values = None
+        if _SHARED_VALUE_PROJ and self.training and torch.is_grad_enabled() and od['src'].is_cuda and all(l.drop_path is None for l in self.decoder_layers):
+            # every layer's value_proj reads the same flat map: one node, so its gradient is accumulated by the GEMMs
+            values = shared_input_linears(od['src'], [l.cross_attn.value_proj for l in self.decoder_layers])
         for lid, layer in enumerate(self.decoder_layers):
-            od['tgt'] = layer(**od)
+            od['tgt'] = layer(**od) if values is None else layer(value=values[lid], **od)
             refine = self.bbox_embed[lid + 1] if self.bbox_embed is not None else None
             od['reference_points'] = self.bbox_refine(refine, od['tgt'], od['reference_points'])
             hs.append(od['tgt'])

@@ -54,14 +54,16 @@ class MSDeformAttn(nn.Module):
         constant_(self.output_proj.bias.data, 0.)
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
-                input_padding_mask=None, project=True):
+                input_padding_mask=None, project=True, value=None):
         """query (N, Lq, C); reference_points (N, Lq, L, 2|4) in [0,1]; input_flatten (N, sum H_l*W_l, C);
         input_spatial_shapes (L, 2) int64 (H, W); input_level_start_index (L,) int64; input_padding_mask (N, S) bool
-        -> (N, Lq, C)."""
+        -> (N, Lq, C).  `value`: this layer's value_proj(input_flatten) computed by the caller (the decoder projects the
+        map for all its layers in one node, grit_amd.ops.linear.shared_input_linears); the padding mask is still applied here."""
         N, Len_q, _ = query.shape
         _, Len_in, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
-        value = self.value_proj(input_flatten)
+        if value is None:
+            value = self.value_proj(input_flatten)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, M, self.d_model // M)

@@ -101,6 +101,58 @@ class _LinearFn(Function):
         return dx, dw, db
 
 
+class _SharedInputLinearsFn(Function):
+    """y_l = x W_l^T + b_l for n Linear layers that read the SAME input (the six value_proj of the deformable decoder all
+    read the flat feature map).  Left to autograd, dx is built as n GEMMs plus n - 1 full-size additions (5 x 3 x 278 MB of
+    traffic at batch 32); here the later GEMMs accumulate into the first one's output (addmm, beta = 1)."""
+
+    @staticmethod
+    def forward(ctx, x, n, *params):
+        weights, biases = params[:n], params[n:]
+        ctx.save_for_backward(x, *weights)
+        ctx.n = n
+        ctx.set_materialize_grads(False)  # an unused output arrives as None, not as a zero map to multiply
+        return tuple(F.linear(x, w, b) for w, b in zip(weights, biases))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dys):
+        x, weights = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        n = ctx.n
+        x2 = x.reshape(-1, x.shape[-1])
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        dx2, dws, dbs = None, [None] * n, [None] * n
+        for l in range(n):
+            if dys[l] is None:
+                continue
+            dy2 = dys[l].reshape(-1, dys[l].shape[-1])
+            dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+            if ctx.needs_input_grad[0]:
+                if dx2 is None:
+                    dx2 = torch.mm(dy2, weights[l])
+                else:
+                    dx2.addmm_(dy2, weights[l])
+            if ctx.needs_input_grad[2 + l]:
+                dws[l] = weight_grad(dy2, x2)
+            if ctx.needs_input_grad[2 + n + l]:
+                dbs[l] = column_sum(dy2, weights[l].dtype)
+        dx = None if dx2 is None else dx2.view(x.shape)
+        return (dx, None) + tuple(dws) + tuple(dbs)
+
+
+def shared_input_linears(x, linears):
+    """[lin(x) for lin in linears] with one fused input gradient; falls back to the modules themselves when the fused
+    node does not apply (CPU / oracle runs, no grad, mixed dtypes, missing bias)."""
+    fits = (backend.override() is None and x.is_cuda and torch.is_grad_enabled() and not torch.is_autocast_enabled()
+            and len(linears) > 1 and all(lin.bias is not None and lin.weight.dtype == x.dtype
+                                         and lin.weight.shape == linears[0].weight.shape for lin in linears)
+            and x.dtype in (torch.bfloat16, torch.float32) and linears[0].weight.shape[0] % 8 == 0
+            and x.numel() // x.shape[-1] >= MIN_ROWS)
+    if not fits:
+        return [lin(x) for lin in linears]
+    return list(_SharedInputLinearsFn.apply(x, len(linears), *[lin.weight for lin in linears], *[lin.bias for lin in linears]))
+
+
 def linear(x, weight, bias):
     fits = (backend.override() is None and x.is_cuda and torch.is_grad_enabled() and bias is not None
             and not torch.is_autocast_enabled()

@@ -291,3 +291,33 @@ def test_linear_add_layer_norm_dropout_mask_is_consistent(p):
     # a second call draws a different mask
     x2, _ = linear_add_layer_norm(inp, lin, sc, None, w, b, 1e-5, dropout_p=p, training=True)
     assert not torch.equal((x2.detach() - sc.detach()).abs() > 1e-6, keep)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_shared_input_linears_match_separate_linears(dtype):
+    """Six Linear layers on one input as one node (input gradient accumulated by the GEMMs) against the same six layers
+    applied separately through autograd; one output is left unused (its gradient is None in the node's backward)."""
+    from grit_amd.ops.linear import Linear, shared_input_linears
+    torch.manual_seed(0)
+    x = torch.randn(2, 4250, 256, device=DEV, dtype=dtype, requires_grad=True)
+    lins = [Linear(256, 256).to(DEV, dtype) for _ in range(6)]
+    cots = [torch.randn(2, 4250, 256, device=DEV, dtype=dtype) for _ in range(6)]
+    ys = shared_input_linears(x, lins)
+    loss = sum((y.float() * c.float()).sum() for i, (y, c) in enumerate(zip(ys, cots)) if i != 3)
+    loss.backward()
+    got = [x.grad.clone()] + [l.weight.grad.clone() if l.weight.grad is not None else None for l in lins] + \
+          [l.bias.grad.clone() if l.bias.grad is not None else None for l in lins]
+    x.grad = None
+    for l in lins:
+        l.weight.grad = l.bias.grad = None
+    ref_ys = [torch.nn.functional.linear(x, l.weight, l.bias) for l in lins]
+    for y, r in zip(ys, ref_ys):
+        assert torch.equal(y, r)
+    loss = sum((y.float() * c.float()).sum() for i, (y, c) in enumerate(zip(ref_ys, cots)) if i != 3)
+    loss.backward()
+    want = [x.grad] + [l.weight.grad for l in lins] + [l.bias.grad for l in lins]
+    assert got[1 + 3] is None and got[7 + 3] is None and want[1 + 3] is None
+    tol = dict(rtol=2e-2, atol=2e-1) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-3)
+    for g, w in zip(got, want):
+        if w is not None:
+            torch.testing.assert_close(g.float(), w.float(), **tol)

@@ -660,10 +660,32 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
             const float t0 = go0 * wt, t1 = go1 * wt;
             const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
             if (!merged) {
-                if (f & 1) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s1 * pix_stride), v2bf{(__bf16)(w1 * t0), (__bf16)(w1 * t1)});
-                if (f & 2) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s2 * pix_stride), v2bf{(__bf16)(w2 * t0), (__bf16)(w2 * t1)});
-                if (f & 4) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s3 * pix_stride), v2bf{(__bf16)(w3 * t0), (__bf16)(w3 * t1)});
-                if (f & 8) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s4 * pix_stride), v2bf{(__bf16)(w4 * t0), (__bf16)(w4 * t1)});
+                // the two points of this step (one per half-wave) in one cell: both halves would add to the same
+                // addresses in the same instruction -- every lane can form the sum itself (the halves hold the same
+                // channels), the lower half issues it
+                const bool pair = mergeable && 2 * i + 1 < LP &&
+                                  __builtin_amdgcn_readlane(e1, 2 * i) == __builtin_amdgcn_readlane(e1, 2 * i + 1) &&
+                                  __builtin_amdgcn_readlane(e2, 2 * i) == __builtin_amdgcn_readlane(e2, 2 * i + 1) &&
+                                  __builtin_amdgcn_readlane(e3, 2 * i) == __builtin_amdgcn_readlane(e3, 2 * i + 1) &&
+                                  __builtin_amdgcn_readlane(e4, 2 * i) == __builtin_amdgcn_readlane(e4, 2 * i + 1) &&
+                                  __builtin_amdgcn_readlane(flags, 2 * i) == __builtin_amdgcn_readlane(flags, 2 * i + 1);
+                float u1 = w1 * wt, u2 = w2 * wt, u3 = w3 * wt, u4 = w4 * wt;
+                bool issue = true;
+                if (pair) {
+                    // the other half's point: 2i + 1 for the lower half (the only one that issues)
+                    const float olh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.lh), 2 * i + 1));
+                    const float olw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.lw), 2 * i + 1));
+                    const float owt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pwt), 2 * i + 1));
+                    const float ohh = (1.f - olh) * owt, olhw = olh * owt;
+                    u1 += ohh * (1.f - olw); u2 += ohh * olw; u3 += olhw * (1.f - olw); u4 += olhw * olw;
+                    issue = !odd;
+                }
+                if (issue) {
+                    if (f & 1) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s1 * pix_stride), v2bf{(__bf16)(u1 * go0), (__bf16)(u1 * go1)});
+                    if (f & 2) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s2 * pix_stride), v2bf{(__bf16)(u2 * go0), (__bf16)(u2 * go1)});
+                    if (f & 4) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s3 * pix_stride), v2bf{(__bf16)(u3 * go0), (__bf16)(u3 * go1)});
+                    if (f & 8) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s4 * pix_stride), v2bf{(__bf16)(u4 * go0), (__bf16)(u4 * go1)});
+                }
             }
             // clamped indices are always legal: all four were loaded, select by the validity bits
             const uint32_t q1 = (f & 1) ? rr[i][0] : 0u, q2 = (f & 2) ? rr[i][1] : 0u, q3 = (f & 4) ? rr[i][2] : 0u, q4 = (f & 8) ? rr[i][3] : 0u;

@@ -52,8 +52,8 @@ def _baseline_metric():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)  # >= 20 warm-up + >= 50 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (metric is defined at 32)")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--caption-len", type=int, default=20)

@@ -53,6 +53,36 @@ def test_upscale_downscale_extremes_equal_oracle():
     np.testing.assert_array_equal(got_m.cpu().numpy(), want_m)
 
 
+@pytest.mark.parametrize("shape,target,ksize", [((60, 80), (48, 64), 7), ((100, 150), (60, 90), 9), ((100, 150), (40, 60), 11),
+                                                 ((90, 130), (30, 45), 13), ((64, 64), (3, 2), 0), ((3, 2), (64, 64), 5),
+                                                 ((2, 1), (1, 1), 0)])
+def test_each_tap_count_variant_equals_oracle(shape, target, ksize):
+    """One batch per horizontal-pass variant (<= 7, 9, 13 taps, generic) plus images narrower than a dword."""
+    from grit_amd.ops.image_batch import axis_taps
+    if ksize:
+        assert axis_taps(shape[1], target[1])[0] == ksize
+    rng = np.random.default_rng(sum(shape) + sum(target))
+    images = [rng.integers(0, 256, shape + (3,), dtype=np.uint8) for _ in range(3)]
+    want_t, want_m = oimg.image_batch(images, [target] * 3)
+    got_t, got_m = image_batch(images, [target] * 3, device='cuda')
+    np.testing.assert_array_equal(got_t.cpu().numpy(), want_t)
+    np.testing.assert_array_equal(got_m.cpu().numpy(), want_m)
+
+
+def test_pad_to_canvas():
+    rng = np.random.default_rng(31)
+    images = [rng.integers(0, 256, (50, 70, 3), dtype=np.uint8), rng.integers(0, 256, (80, 40, 3), dtype=np.uint8)]
+    sizes = [(40, 56), (64, 32)]
+    want_t, want_m = oimg.image_batch(images, sizes)
+    got_t, got_m = image_batch(images, sizes, device='cuda', pad_to=(96, 101))  # odd width: scalar-store path
+    assert got_t.shape == (2, 3, 96, 101) and got_m.shape == (2, 96, 101)
+    np.testing.assert_array_equal(got_t[:, :, :64, :56].cpu().numpy(), want_t)
+    np.testing.assert_array_equal(got_m[:, :64, :56].cpu().numpy(), want_m)
+    assert got_m[:, 64:].all() and got_m[:, :, 56:].all() and (got_t[:, :, 64:] == 0).all() and (got_t[:, :, :, 56:] == 0).all()
+    with pytest.raises(ValueError):
+        image_batch(images, sizes, device='cuda', pad_to=(32, 32))
+
+
 def test_full_size_properties_without_oracle():
     """BASELINE-size batch (32 x 640 x 640): resizing to the source size is the identity, so the output is exactly the
     ToTensor + Normalize table applied to the pixels; a constant image stays constant under any resize."""

@@ -292,7 +292,8 @@ template <int NIT>
 __global__ __launch_bounds__(kWave * kRowsPerBlock)
 void msda_fwd_bf16_d64(const __hip_bfloat16* __restrict__ value, const int64_t* __restrict__ shapes,
                        const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
-                       int S, int M, int L, int Lq, int P, __hip_bfloat16* __restrict__ out, int nrows, int nblk) {
+                       int S, int M, int L, int Lq, int P, __hip_bfloat16* __restrict__ out, int nrows, int nblk,
+                       int pix_el) {
     constexpr int D = 64, LPP = 8, G = 8;
     const int lane = threadIdx.x & (kWave - 1);
     const int row = xcd_logical_block(blockIdx.x, nblk) * kRowsPerBlock + (threadIdx.x >> 6);
@@ -303,8 +304,8 @@ void msda_fwd_bf16_d64(const __hip_bfloat16* __restrict__ value, const int64_t* 
     const float locv = lane < 2 * LP ? loc[(size_t)row * 2 * LP + lane] : 0.f;
     const float awv = lane < LP ? aw[(size_t)row * LP + lane] : 0.f;
     const int g = lane / LPP, c8 = lane % LPP;
-    const __hip_bfloat16* vrow = value + (size_t)b * S * M * D + (size_t)m * D + c8 * 8;
-    const size_t pix_stride = (size_t)M * D;
+    const size_t pix_stride = (size_t)pix_el;
+    const __hip_bfloat16* vrow = value + (size_t)b * S * pix_stride + (size_t)m * D + c8 * 8;
 
     uint4 v[NIT][4];
     float cw[NIT][4];
@@ -368,7 +369,8 @@ template <int BATCH>
 __global__ __launch_bounds__(256)
 void msda_fwd_bf16_rows4(const __hip_bfloat16* __restrict__ value, const int64_t* __restrict__ shapes,
                          const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
-                         int S, int M, int L, int Lq, int P, __hip_bfloat16* __restrict__ out, int nrows, int nblk) {
+                         int S, int M, int L, int Lq, int P, __hip_bfloat16* __restrict__ out, int nrows, int nblk,
+                         int pix_el) {
     constexpr int D = 64;
     __shared__ uint4 geo[4][64][2];
     const int lane = threadIdx.x & 63;
@@ -385,9 +387,10 @@ void msda_fwd_bf16_rows4(const __hip_bfloat16* __restrict__ value, const int64_t
         const int l = pc / P;
         const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
         const uint32_t m = rc % M, b = (rc / M) / Lq;
-        // byte offsets from `value` (M*D*2 bytes per pixel); the launcher checks that the whole map fits 32 bits
-        const uint32_t base = ((b * (uint32_t)S + (uint32_t)lsi[l]) * (uint32_t)M + m) * (D * 2);
-        const uint32_t pix = (uint32_t)M * (D * 2);
+        // byte offsets from `value` (pix_el elements per pixel, M*D when the map is dense); the launcher checks that
+        // the whole map fits 32 bits
+        const uint32_t pix = (uint32_t)pix_el * 2;
+        const uint32_t base = (b * (uint32_t)S + (uint32_t)lsi[l]) * pix + m * (D * 2);
         const Corners<float> c = make_corners<float>(xy.x, xy.y, H, W);
         geo[wave][lane][0] = make_uint4(base + c.o1 * pix, base + c.o2 * pix, base + c.o3 * pix, base + c.o4 * pix);
         geo[wave][lane][1] = make_uint4(__float_as_uint(c.k1 ? c.w1 * wt : 0.f), __float_as_uint(c.k2 ? c.w2 * wt : 0.f),
@@ -554,7 +557,7 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
                      const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
                      const __hip_bfloat16* __restrict__ grad_out, int S, int M, int L, int Lq, int P,
                      __hip_bfloat16* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_aw,
-                     int nrows, int nblk, int images_interleaved, int merge_disabled) {
+                     int nrows, int nblk, int images_interleaved, int merge_disabled, int pix_el) {
     constexpr int D = 64, kMaxLP = 16;
     typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
     typedef v2bf __attribute__((address_space(1))) * gv2bf_ptr;
@@ -572,7 +575,7 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
     const int LP = L * P;
     const int m = row % M;
     const int b = (row / M) / Lq;
-    const int pix_stride = M * D;
+    const int pix_stride = pix_el;  // elements per pixel: M * D for a dense map
     const bool odd = lane >= 32;            // this half's points: 2i + odd
     const int cp = lane & 31;               // channels 2cp, 2cp + 1
     const size_t head_off = (size_t)b * S * pix_stride + (size_t)m * D + 2 * cp;
@@ -825,18 +828,27 @@ int grit_msda_bwd_f64(const double* value, const int64_t* spatial_shapes, const 
 
 int grit_msda_fwd_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start, const float* loc,
                        const float* attn_w, int B, int S, int M, int D, int L, int Lq, int P, void* out, void* stream) {
+    return grit_msda_fwd_bf16_strided(value, (long)M * D, spatial_shapes, level_start, loc, attn_w, B, S, M, D, L, Lq, P, out,
+                                      stream);
+}
+
+int grit_msda_fwd_bf16_strided(const void* value, long pixel_stride, const int64_t* spatial_shapes,
+                               const int64_t* level_start, const float* loc, const float* attn_w, int B, int S, int M,
+                               int D, int L, int Lq, int P, void* out, void* stream) {
     if (!value || !spatial_shapes || !level_start || !loc || !attn_w || !out) return GRIT_ERR_BAD_ARG;
     if (!dims_ok(B, S, M, D, L, Lq, P)) return GRIT_ERR_BAD_ARG;
+    if (pixel_stride < (long)M * D || pixel_stride % 8 || pixel_stride > 0x3fffffffL) return GRIT_ERR_BAD_ARG;
+    const int pix_el = (int)pixel_stride;
     const int LP = L * P;
     if (D != 64 || LP > 32 || ((uintptr_t)value % 16) || ((uintptr_t)out % 16)) return GRIT_ERR_UNSUPPORTED;
     const int nrows = B * Lq * M;
-    if (LP <= 16 && (uint64_t)B * S * M * D * 2 < (1ull << 32)) {  // 4 rows per wave, 16 rows per workgroup
+    if (LP <= 16 && (uint64_t)B * S * (uint64_t)pixel_stride * 2 < (1ull << 32)) {  // 4 rows per wave, 16 rows per workgroup
         static const int batch = getenv("GRIT_MSDA_FWD_BATCH") ? atoi(getenv("GRIT_MSDA_FWD_BATCH")) : 2;
         const int nblk16 = (nrows + 15) / 16;
 #define GRIT_ROWS4(BATCH_)                                                                                           \
     hipLaunchKernelGGL((msda_fwd_bf16_rows4<BATCH_>), dim3(nblk16), dim3(256), 0, (hipStream_t)stream,               \
                        (const __hip_bfloat16*)value, spatial_shapes, level_start, loc, attn_w, S, M, L, Lq, P,       \
-                       (__hip_bfloat16*)out, nrows, nblk16)
+                       (__hip_bfloat16*)out, nrows, nblk16, pix_el)
         if (batch == 0) goto row_per_wave;
         if (batch == 1) GRIT_ROWS4(1); else if (batch == 4) GRIT_ROWS4(4); else if (batch == 8) GRIT_ROWS4(8); else GRIT_ROWS4(2);
 #undef GRIT_ROWS4
@@ -848,7 +860,7 @@ row_per_wave:
     const int nit = (LP + 7) / 8;
 #define GRIT_FWD16(NIT_)                                                                                          \
     hipLaunchKernelGGL((msda_fwd_bf16_d64<NIT_>), grid, block, 0, (hipStream_t)stream, (const __hip_bfloat16*)value, \
-                       spatial_shapes, level_start, loc, attn_w, S, M, L, Lq, P, (__hip_bfloat16*)out, nrows, nblk)
+                       spatial_shapes, level_start, loc, attn_w, S, M, L, Lq, P, (__hip_bfloat16*)out, nrows, nblk, pix_el)
     if (nit == 1) GRIT_FWD16(1); else if (nit == 2) GRIT_FWD16(2); else if (nit == 3) GRIT_FWD16(3); else GRIT_FWD16(4);
 #undef GRIT_FWD16
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
@@ -869,6 +881,15 @@ int grit_msda_bwd_bf16(const void* value, const int64_t* spatial_shapes, const i
 int grit_msda_bwd_bf16acc(const void* value, const int64_t* spatial_shapes, const int64_t* level_start, const float* loc,
                           const float* attn_w, const void* grad_out, int B, int S, int M, int D, int L, int Lq, int P,
                           void* grad_value, float* grad_loc, float* grad_attn_w, void* stream) {
+    return grit_msda_bwd_bf16acc_strided(value, (long)M * D, spatial_shapes, level_start, loc, attn_w, grad_out, B, S, M, D, L,
+                                         Lq, P, grad_value, grad_loc, grad_attn_w, stream);
+}
+
+int grit_msda_bwd_bf16acc_strided(const void* value, long pixel_stride, const int64_t* spatial_shapes,
+                                  const int64_t* level_start, const float* loc, const float* attn_w, const void* grad_out,
+                                  int B, int S, int M, int D, int L, int Lq, int P, void* grad_value, float* grad_loc,
+                                  float* grad_attn_w, void* stream) {
+    if (pixel_stride < (long)M * D || pixel_stride % 2 || pixel_stride > 0x3fffffffL) return GRIT_ERR_BAD_ARG;
     if (!value || !spatial_shapes || !level_start || !loc || !attn_w || !grad_out || !grad_value || !grad_loc || !grad_attn_w)
         return GRIT_ERR_BAD_ARG;
     if (!dims_ok(B, S, M, D, L, Lq, P)) return GRIT_ERR_BAD_ARG;
@@ -882,7 +903,7 @@ int grit_msda_bwd_bf16acc(const void* value, const int64_t* spatial_shapes, cons
     static const bool no_merge = getenv("GRIT_MSDA_BWD_MERGE") && atoi(getenv("GRIT_MSDA_BWD_MERGE")) == 0;  // A/B knob
     hipLaunchKernelGGL(msda_bwd_d64_pk, dim3(nblk), dim3(kWave * kRowsPerBlock), 0, (hipStream_t)stream,
                        (const __hip_bfloat16*)value, spatial_shapes, level_start, loc, attn_w, (const __hip_bfloat16*)grad_out,
-                       S, M, L, Lq, P, (__hip_bfloat16*)grad_value, grad_loc, grad_attn_w, nrows, nblk, images, no_merge ? 1 : 0);
+                       S, M, L, Lq, P, (__hip_bfloat16*)grad_value, grad_loc, grad_attn_w, nrows, nblk, images, no_merge ? 1 : 0, (int)pixel_stride);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 

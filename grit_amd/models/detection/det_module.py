@@ -24,9 +24,11 @@ from grit_amd.models.common.swin_model import DropPath
 from grit_amd.models.ops.modules import MSDeformAttn
 from grit_amd.ops.attention import attention as fused_attention
 from grit_amd.ops.layer_norm import linear_add_layer_norm
-from grit_amd.ops.linear import shared_input_linears
+from grit_amd.ops.linear import linear, shared_input_linears
+from grit_amd.ops.msda import StackedValueMaps
 
-_SHARED_VALUE_PROJ = os.environ.get('GRIT_SHARED_VALUE_PROJ', '1') != '0'  # A/B knob
+_SHARED_VALUE_PROJ = os.environ.get('GRIT_SHARED_VALUE_PROJ', '1') != '0'  # A/B knobs
+_STACKED_VALUE_MAPS = os.environ.get('GRIT_STACKED_VALUE_MAPS', '1') != '0'
 from grit_amd.utils.misc import inverse_sigmoid
 
 
@@ -228,6 +230,26 @@ class DetectionModule(nn.Module):
             'reference_points': reference_points,
         }
 
+    def project_values(self, src, padding_mask):
+        """value_proj of every decoder layer on the flat map.  bf16 training: ONE GEMM over the concatenated weights into a
+        [B, S, layers, M, D] tensor that the layers sample in place and whose gradient the layers' backward kernels fill
+        in place (grit_amd/ops/msda.py StackedValueMaps) -- the input gradient is then one GEMM as well.  Otherwise: the
+        layers' projections as one node with a GEMM-accumulated input gradient (shared_input_linears)."""
+        projs = [l.cross_attn.value_proj for l in self.decoder_layers]
+        heads, points = self.decoder_layers[0].cross_attn.n_heads, self.decoder_layers[0].cross_attn.n_points
+        levels, n = self.decoder_layers[0].cross_attn.n_levels, len(projs)
+        B, S, C = src.shape
+        if _STACKED_VALUE_MAPS and src.dtype == torch.bfloat16 and C // heads == 64 and levels * points <= 16 \
+                and B * S * n * C * 2 < (1 << 32) and all(p.weight.dtype == src.dtype and p.bias is not None for p in projs):
+            weight = torch.cat([p.weight for p in projs])  # [layers * C, C]: 3 MB, the split of its gradient is free
+            bias = torch.cat([p.bias for p in projs])
+            stacked = linear(src, weight, bias)  # [B, S, layers * C]
+            if padding_mask is not None:
+                stacked = stacked.masked_fill(padding_mask[..., None], float(0))
+            maps = StackedValueMaps(stacked.view(B, S, n, heads, C // heads), n)
+            return [(maps, l) for l in range(n)]
+        return shared_input_linears(src, projs)
+
     def forward(self, srcs, masks, no_padding=False, src_flatten=None, shapes=None):
         """no_padding=True (caller knows every mask is all-False) drops the padding mask handed to MSDeformAttn, whose
         masked_fill would be a full copy of each value map that changes nothing.  `src_flatten` / `shapes`: the levels
@@ -239,8 +261,7 @@ class DetectionModule(nn.Module):
         hs, refs = [od['tgt']], [init_reference_out]
         values = None
         if _SHARED_VALUE_PROJ and self.training and torch.is_grad_enabled() and od['src'].is_cuda and all(l.drop_path is None for l in self.decoder_layers):
-            # every layer's value_proj reads the same flat map: one node, so its gradient is accumulated by the GEMMs
-            values = shared_input_linears(od['src'], [l.cross_attn.value_proj for l in self.decoder_layers])
+            values = self.project_values(od['src'], od['src_padding_mask'])
         for lid, layer in enumerate(self.decoder_layers):
             od['tgt'] = layer(**od) if values is None else layer(value=values[lid], **od)
             refine = self.bbox_embed[lid + 1] if self.bbox_embed is not None else None

@@ -11,6 +11,8 @@ from torch.nn.init import constant_, xavier_uniform_
 
 from grit_amd.ops.linear import Linear
 
+from grit_amd.ops.msda import ms_deform_attn_stacked
+
 from ..functions.ms_deform_attn_func import deformable_sample
 
 
@@ -57,18 +59,21 @@ class MSDeformAttn(nn.Module):
                 input_padding_mask=None, project=True, value=None):
         """query (N, Lq, C); reference_points (N, Lq, L, 2|4) in [0,1]; input_flatten (N, sum H_l*W_l, C);
         input_spatial_shapes (L, 2) int64 (H, W); input_level_start_index (L,) int64; input_padding_mask (N, S) bool
-        -> (N, Lq, C).  `value`: this layer's value_proj(input_flatten) computed by the caller (the decoder projects the
-        map for all its layers in one node, grit_amd.ops.linear.shared_input_linears); the padding mask is still applied here."""
+        -> (N, Lq, C).  `value`: this layer's value_proj(input_flatten) computed by the caller -- either the tensor itself
+        (the padding mask is still applied here) or `(StackedValueMaps, layer)`: the decoder projected the map for all its
+        layers with one GEMM (mask already applied) and this layer samples its slice in place (grit_amd/ops/msda.py)."""
         N, Len_q, _ = query.shape
         _, Len_in, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
-        if value is None:
-            value = self.value_proj(input_flatten)
-        if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], float(0))
-        value = value.view(N, Len_in, M, self.d_model // M)
+        stacked = value if isinstance(value, tuple) else None
+        if stacked is None:
+            if value is None:
+                value = self.value_proj(input_flatten)
+            if input_padding_mask is not None:
+                value = value.masked_fill(input_padding_mask[..., None], float(0))
+            value = value.view(N, Len_in, M, self.d_model // M)
         # the (tiny) query-side arithmetic runs in fp32 whatever the projections' dtype: locations need sub-pixel precision
-        cdt = torch.float64 if value.dtype == torch.float64 else torch.float32
+        cdt = torch.float64 if (stacked is None and value.dtype == torch.float64) else torch.float32
         offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2).to(cdt)
         weights = F.softmax(self.attention_weights(query).view(N, Len_q, M, L * P).to(cdt), -1).view(N, Len_q, M, L, P)
         reference_points = reference_points.to(cdt)
@@ -81,7 +86,11 @@ class MSDeformAttn(nn.Module):
         else:
             raise ValueError('Last dim of reference_points must be 2 or 4, but get {} instead.'.format(
                 reference_points.shape[-1]))
-        sampled = deformable_sample(value, input_spatial_shapes, input_level_start_index, locations, weights,
-                                    self.im2col_step)
-        sampled = sampled.to(value.dtype)
+        if stacked is not None:
+            sampled = ms_deform_attn_stacked(stacked[0], stacked[1], input_spatial_shapes, input_level_start_index,
+                                             locations, weights)
+        else:
+            sampled = deformable_sample(value, input_spatial_shapes, input_level_start_index, locations, weights,
+                                        self.im2col_step)
+            sampled = sampled.to(value.dtype)
         return self.output_proj(sampled) if project else sampled

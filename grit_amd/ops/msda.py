@@ -151,6 +151,75 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return [gv.to(value.dtype), gl.to(sampling_loc.dtype), ga.to(attn_weight.dtype)]
 
 
+class StackedValueMaps(object):
+    """The value maps of all decoder layers in ONE tensor [B, S, layers, M, D] (bf16) -- the output of a single projection
+    GEMM -- plus the bookkeeping that lets the layers' backward kernels accumulate into ONE gradient buffer of the same
+    layout.  Autograd sees the stacked tensor as an input of every layer's sampling node; only the node that runs last in
+    the backward pass (the first layer's) hands the shared buffer back as the gradient, the others return None, so the
+    engine neither materialises per-layer gradients nor adds them up."""
+
+    def __init__(self, stacked, layers):
+        assert stacked.dim() == 5 and stacked.is_contiguous() and stacked.dtype == torch.bfloat16
+        self.stacked, self.layers = stacked, layers
+        self.pending, self.grad = 0, None
+
+    def layer_ptr(self, tensor, layer):
+        B, S, n, M, D = self.stacked.shape
+        return ctypes.c_void_p(tensor.data_ptr() + layer * M * D * tensor.element_size())
+
+
+class _StackedMSDAFn(Function):
+    """ms_deform_attn on slice `layer` of a StackedValueMaps (bf16, D = 64, L*P <= 16: the strided kernels)."""
+
+    @staticmethod
+    def forward(ctx, stacked, maps, layer, shapes, lsi, loc, aw):
+        B, S, n, M, D = stacked.shape
+        _, Lq, _, L, P, _ = loc.shape
+        loc, aw = loc.float().contiguous(), aw.float().contiguous()
+        out = torch.empty((B, Lq, M * D), dtype=torch.bfloat16, device=stacked.device)
+        with torch.cuda.device(stacked.device), _Timed("fwd_bf16", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, 2, 4)):
+            st = _lib.load().grit_msda_fwd_bf16_strided(maps.layer_ptr(stacked, layer), n * M * D, _ptr(shapes), _ptr(lsi),
+                                                        _ptr(loc), _ptr(aw), B, S, M, D, L, Lq, P, _ptr(out),
+                                                        _lib.current_stream_ptr())
+        _lib.check(st, "grit_msda_fwd_bf16_strided")
+        ctx.save_for_backward(stacked, shapes, lsi, loc, aw)
+        ctx.maps, ctx.layer = maps, layer
+        maps.pending += 1
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        stacked, shapes, lsi, loc, aw = ctx.saved_tensors
+        maps, layer = ctx.maps, ctx.layer
+        B, S, n, M, D = stacked.shape
+        _, Lq, _, L, P, _ = loc.shape
+        if maps.grad is None:
+            maps.grad = torch.zeros_like(stacked)  # one fill for all layers; the kernels add into their slices
+        go = grad_output.to(torch.bfloat16).contiguous()
+        gl, ga = torch.empty_like(loc), torch.empty_like(aw)
+        with torch.cuda.device(stacked.device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 2)):
+            st = _lib.load().grit_msda_bwd_bf16acc_strided(maps.layer_ptr(stacked, layer), n * M * D, _ptr(shapes), _ptr(lsi),
+                                                           _ptr(loc), _ptr(aw), _ptr(go), B, S, M, D, L, Lq, P,
+                                                           maps.layer_ptr(maps.grad, layer), _ptr(gl), _ptr(ga),
+                                                           _lib.current_stream_ptr())
+        _lib.check(st, "grit_msda_bwd_bf16acc_strided")
+        maps.pending -= 1
+        gstacked = None
+        if maps.pending == 0:  # every layer has added its part
+            gstacked, maps.grad = maps.grad, None
+        return gstacked, None, None, None, None, gl, ga
+
+
+def stacked_fast_path(stacked, L, P):
+    return (stacked.is_cuda and stacked.dtype == torch.bfloat16 and stacked.shape[-1] == 64 and L * P <= 16
+            and not F32_ACCUMULATE and stacked.numel() * 2 < (1 << 32))
+
+
+def ms_deform_attn_stacked(maps, layer, shapes, lsi, loc, aw):
+    return _StackedMSDAFn.apply(maps.stacked, maps, layer, shapes, lsi, loc, aw)
+
+
 class MSDeformAttnFunction(Function):
     """Same call signature and gradient tuple as the reference Function."""
 

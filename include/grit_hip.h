@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 16
+#define GRIT_ABI_VERSION 17
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -108,6 +108,18 @@ int grit_msda_bwd_bf16(const void* value, const int64_t* spatial_shapes, const i
 int grit_msda_bwd_bf16acc(const void* value, const int64_t* spatial_shapes, const int64_t* level_start, const float* loc,
                           const float* attn_w, const void* grad_out, int B, int S, int M, int D, int L, int Lq, int P,
                           void* grad_value, float* grad_loc, float* grad_attn_w, void* stream);
+/* The same two kernels on a value map whose pixels are `pixel_stride` elements apart (>= M*D, a multiple of 8; image b
+ * starts at b * S * pixel_stride): the deformable decoder projects the flat feature map for ALL its layers with one GEMM,
+ * value_proj of models/ops/modules/ms_deform_attn.py:93 x 6 layers of models/detection/det_module.py:274-349 -> one
+ * [B, S, layers, M, D] tensor, and each layer samples its slice in place.  grad_value has the same layout (one zero-filled
+ * buffer that all layers' backward kernels add into), so the projection's input gradient is ONE GEMM over K = layers*M*D. */
+int grit_msda_fwd_bf16_strided(const void* value, long pixel_stride, const int64_t* spatial_shapes,
+                               const int64_t* level_start, const float* loc, const float* attn_w, int B, int S, int M,
+                               int D, int L, int Lq, int P, void* out, void* stream);
+int grit_msda_bwd_bf16acc_strided(const void* value, long pixel_stride, const int64_t* spatial_shapes,
+                                  const int64_t* level_start, const float* loc, const float* attn_w, const void* grad_out,
+                                  int B, int S, int M, int D, int L, int Lq, int P, void* grad_value, float* grad_loc,
+                                  float* grad_attn_w, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Scaled-dot attention core, fp32 arithmetic, head_dim D = 64 (also the 150-query

@@ -274,3 +274,40 @@ def test_bf16_forward_kernels_layouts_and_dead_corners(shapes_l, M, Lq, P, B):
     assert out.dtype == torch.bfloat16 and torch.isfinite(out.float()).all()
     ref = omsda.msda_forward(torch.nan_to_num(value.float()).numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy())
     np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)
+
+
+def test_stacked_value_maps_equal_per_layer_maps():
+    """Strided kernels (grit_msda_*_strided): three layers' value maps interleaved in one [B, S, 3, M, D] tensor.  Forward
+    and the per-row gradients are those of the dense kernels bit for bit (same kernels, other pixel stride); the value
+    gradients of all layers land in one buffer that only the node running last hands to autograd."""
+    from grit_amd.ops.msda import MSDeformAttnFunction, StackedValueMaps, ms_deform_attn_stacked, stacked_fast_path
+    value, shapes, lsi, loc, aw = _config2(B=2)
+    g = torch.Generator().manual_seed(17)
+    n = 3
+    stacked = torch.randn(2, value.shape[1], n, 8, 64, generator=g).bfloat16().to(DEV).requires_grad_(True)
+    shapes, lsi = shapes.to(DEV), lsi.to(DEV)
+    locs = [(loc + 0.01 * l).clamp(-0.05, 1.05).to(DEV).requires_grad_(True) for l in range(n)]
+    aws = [torch.softmax(torch.randn(2, 150, 8, 16, generator=g), -1).view(2, 150, 8, 4, 4).to(DEV).requires_grad_(True) for _ in range(n)]
+    cots = [torch.randn(2, 150, 512, generator=g).bfloat16().to(DEV) for _ in range(n)]
+    assert stacked_fast_path(stacked, 4, 4)
+    maps = StackedValueMaps(stacked.detach().requires_grad_(True), n)
+    outs = [ms_deform_attn_stacked(maps, l, shapes, lsi, locs[l], aws[l]) for l in range(n)]
+    assert maps.pending == n
+    # layers run their backward in reverse order, as in the decoder
+    total = sum((o.float() * c.float()).sum() for o, c in zip(outs, cots))
+    total.backward()
+    assert maps.pending == 0 and maps.grad is None
+    got_gv = maps.stacked.grad
+    got = [(locs[l].grad.clone(), aws[l].grad.clone()) for l in range(n)]
+    for l in range(n):
+        locs[l].grad = aws[l].grad = None
+        v = stacked.detach()[:, :, l].contiguous().requires_grad_(True)
+        out = MSDeformAttnFunction.apply(v, shapes, lsi, locs[l], aws[l], 64)
+        assert torch.equal(out, outs[l])
+        (out.float() * cots[l].float()).sum().backward()
+        assert torch.equal(locs[l].grad, got[l][0]) and torch.equal(aws[l].grad, got[l][1])
+        want, have = v.grad.float(), got_gv[:, :, l].float()
+        assert torch.linalg.norm(have - want) / torch.linalg.norm(want) < 1e-2  # bf16 atomics: order-dependent rounding
+        assert (have - want).abs().max() < 3e-2 * want.abs().max()
+        touched = want.abs().sum(-1) > 0  # (image, pixel, head) rows some point reached
+        assert (have.abs().sum(-1)[~touched] == 0).all()

@@ -9,6 +9,7 @@ import torch.nn.functional as F
 from grit_amd.models.common.swin_model import swin_base_win7_384
 from grit_amd.models.detection.det_module import build_det_module_with_config
 from grit_amd.ops.group_norm import group_norm_levels
+from grit_amd.ops.linear import linear
 from grit_amd.utils.misc import NestedTensor, nested_tensor_from_tensor_list
 
 
@@ -37,7 +38,8 @@ class Detector(nn.Module):
         for (conv, _), feature in zip(self.input_proj, features):
             B, C, H, W = feature.shape
             t = feature.permute(0, 2, 3, 1).reshape(B, H * W, C)
-            tokens.append(F.linear(t, conv.weight.view(conv.out_channels, C), conv.bias))
+            # grit_amd.ops.linear: split-M weight gradient (M = 204 800 on the finest level) + streaming bias gradient
+            tokens.append(linear(t, conv.weight.view(conv.out_channels, C), conv.bias))
             shapes.append((H, W))
         norms = [gn for _, gn in self.input_proj]
         flat = group_norm_levels(tokens, [gn.weight for gn in norms], [gn.bias for gn in norms], norms[0].num_groups,

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from grit_amd.ops.layer_norm import LayerNorm, add_layer_norm, linear_add_layer_norm
-from grit_amd.ops.linear import Linear
+from grit_amd.ops.linear import Linear, linear
 from grit_amd.ops.rel_bias import relative_position_bias
 from grit_amd.ops.window_attention import window_attention
 
@@ -254,7 +254,7 @@ class PatchMerging(nn.Module):
         Hh, Wh = (H + 1) // 2, (W + 1) // 2
         # [B, Hh, 2(dy), Wh, 2(dx), C] -> channel blocks ordered (dy,dx) = (0,0),(1,0),(0,1),(1,1)
         x = x.view(B, Hh, 2, Wh, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, Hh * Wh, 4 * C)
-        return self.reduction(self.norm(x))
+        return linear(self.norm(x), self.reduction.weight, None)  # split-M weight gradient (grit_amd/ops/linear.py)
 
 
 class BasicLayer(nn.Module):

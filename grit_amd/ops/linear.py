@@ -156,7 +156,7 @@ def shared_input_linears(x, linears):
 
 
 def linear(x, weight, bias):
-    fits = (backend.override() is None and x.is_cuda and torch.is_grad_enabled() and bias is not None
+    fits = (backend.override() is None and x.is_cuda and torch.is_grad_enabled()
             and not torch.is_autocast_enabled()
             and (x.requires_grad or weight.requires_grad) and x.dtype == weight.dtype
             and x.dtype in (torch.bfloat16, torch.float32) and weight.shape[0] % 8 == 0

@@ -286,7 +286,7 @@ __device__ __forceinline__ v8bf join(v4s a, v4s b) {
     return __builtin_bit_cast(v8bf, r);
 }
 
-template <bool kExplicitMask, bool kDbgHotLoads = false>
+template <bool kExplicitMask>
 __global__ __launch_bounds__(kThreads)
 void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_bias, const __bf16* __restrict__ pad_qkv,
                  const float* __restrict__ mask, Geom g, const __bf16* __restrict__ out, const __bf16* __restrict__ dout,
@@ -330,8 +330,7 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     for (int win = grp; win < NW; win += ngrp) {
         const int b = win / (g.nWh * g.nWw), wrem = win - b * (g.nWh * g.nWw);
         const int wy = wrem / g.nWw, wx = wrem - wy * g.nWw;
-        size_t img = (size_t)b * g.T;
-        if (kDbgHotLoads) img = (size_t)((grp / (g.nWh * g.nWw)) % g.B) * g.T;  // timing experiment only: cache-hot operands
+        const size_t img = (size_t)b * g.T;
 
         // ---- global fetches: staging chunks + this wave's K / V fragments (B operands of phase 1)
         int reg;
@@ -612,12 +611,7 @@ int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pa
         hipLaunchKernelGGL(winattn_bwd<true>, dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdLds, (hipStream_t)stream,
                            (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
                            (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad);
-    else if (getenv("GRIT_WINATTN_DBG_HOT")) {  // diagnostic (wrong gradients): how much of the time is exposed load latency
-        hipFuncSetAttribute((const void*)winattn_bwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds);
-        hipLaunchKernelGGL((winattn_bwd<false, true>), dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdLds, (hipStream_t)stream,
-                               (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
-                               (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad);
-    } else
+    else
         hipLaunchKernelGGL(winattn_bwd<false>, dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdLds, (hipStream_t)stream,
                            (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
                            (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad);

@@ -126,3 +126,12 @@ def test_cosine_scheduler_closed_form():
     s2 = CosineLRScheduler(opt, 2, 10)
     s2.load_state_dict(s.state_dict())
     assert s2.global_steps == 20 and s2.init_lr == 5e-4
+
+
+def test_weight_gradient_slab_policy():
+    """split_k (grit_amd/ops/linear.py): slabs divide M, powers of two on the GRIT shapes, 4 slabs for Swin stage 3."""
+    from grit_amd.ops.linear import split_k
+    assert split_k(51200) == 16 and split_k(204800) == 64 and split_k(272000) == 64 and split_k(819200) == 64
+    assert split_k(12800) == 4 and split_k(6400) == 4 and split_k(4800) == 1 and split_k(25600) == 8
+    for M in (25600, 38400, 51200, 61440, 100000, 204800, 272000):
+        assert M % split_k(M) == 0 and 1 <= split_k(M) <= 64

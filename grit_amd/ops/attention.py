@@ -104,5 +104,5 @@ def attention(q, k, v, mask=None, scale=None, dropout_p=0.0, training=False):
     k, v = k.to(q.dtype), v.to(q.dtype)
     p = float(dropout_p) if training else 0.0
     # the dropout seed lives in device memory and is drawn by torch's device generator: no host sync
-    seed_dev = torch.empty(1, dtype=torch.int64, device=q.device).random_() if p > 0 else None
+    seed_dev = backend.dropout_seed(q.device) if p > 0 else None
     return _AttentionFn.apply(q, k, v, mask, float(scale), p, 0, seed_dev)

@@ -26,3 +26,29 @@ def use_reference_ops(impl):
 
 def override():
     return _override
+
+
+class _SeedPool(object):
+    """Dropout seeds in device memory, drawn from torch's device generator 256 at a time: a fused dropout node takes a
+    one-element view (its kernels read the seed through the pointer, forward and backward), so a training step launches
+    one tiny RNG kernel every few steps instead of one per node (54 per step)."""
+
+    def __init__(self, block=256):
+        self.block, self.buf, self.used = block, None, 0
+
+    def take(self, device):
+        import torch
+        if self.buf is None or self.used >= self.block or self.buf.device != device:
+            with torch.inference_mode(False):
+                self.buf = torch.empty(self.block, dtype=torch.int64, device=device).random_()
+            self.used = 0
+        seed = self.buf[self.used:self.used + 1]
+        self.used += 1
+        return seed
+
+
+_seeds = _SeedPool()
+
+
+def dropout_seed(device):
+    return _seeds.take(device)

@@ -211,7 +211,7 @@ def linear_add_layer_norm(inp, linear, shortcut, scale, weight, bias, eps=1e-5, 
         return add_layer_norm(shortcut, branch, scale, weight, bias, eps)
     if scale is not None:
         scale = scale.reshape(-1).float().contiguous()
-    seed_dev = torch.empty(1, dtype=torch.int64, device=inp.device).random_() if p > 0 else None
+    seed_dev = backend.dropout_seed(inp.device) if p > 0 else None
     return _LinearAddLayerNormFn.apply(inp, linear.weight, linear.bias, shortcut, scale, weight.contiguous(), bias.contiguous(),
                                        float(eps), p, seed_dev)
 

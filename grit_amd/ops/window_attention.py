@@ -85,8 +85,9 @@ class _WindowAttentionFn(Function):
         C = C3 // 3
         dout = dout.contiguous().to(torch.bfloat16)
         dqkv = torch.empty_like(qkv)
-        dbias = torch.zeros_like(rel_bias)  # accumulated across windows with float atomics
-        dpad = torch.zeros(C3, dtype=torch.float32, device=qkv.device)
+        # d(bias) and d(pad) are accumulated across workgroups with float atomics: one zero fill for both
+        acc = torch.zeros(rel_bias.numel() + C3, dtype=torch.float32, device=qkv.device)
+        dbias, dpad = acc[:rel_bias.numel()].view_as(rel_bias), acc[rel_bias.numel():]
         nWm = 0 if mask is None else mask.shape[0]
         flops = _core_flops(B, -(-H // window), -(-W // window), num_heads, window * window, 5)
         with torch.cuda.device(qkv.device), _Timed("bwd", flops):

@@ -36,6 +36,9 @@ def to_2tuple(x):
     return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
 
 
+_POOLED_DROP_PATH = os.environ.get('GRIT_POOLED_DROP_PATH', '1') != '0'  # A/B knob
+
+
 class DropPath(nn.Module):
     """Per-sample stochastic depth (timm.models.layers.DropPath semantics: keep w.p. 1-p, rescale by 1/(1-p))."""
 
@@ -206,6 +209,11 @@ class SwinTransformerBlock(nn.Module):
         """Per-sample stochastic-depth factors (0 or 1/keep) of this call, or None when drop-path is inactive."""
         dp = self.drop_path
         if isinstance(dp, DropPath) and dp.drop_prob > 0. and self.training:
+            ready = getattr(self, '_drop_path_ready', None)
+            if ready:  # drawn for the whole backbone in one go (SwinTransformer._draw_drop_path): no launch here
+                scale = ready.pop()
+                if scale.shape[0] == x.shape[0]:
+                    return scale if scale.dtype == dtype else scale.to(dtype)
             keep = 1.0 - dp.drop_prob
             return torch.empty(x.shape[0], dtype=dtype, device=x.device).bernoulli_(keep).div_(keep)
         return None
@@ -387,8 +395,26 @@ class SwinTransformer(nn.Module):
                 for p in stage.parameters():
                     p.requires_grad = False
 
+    def _draw_drop_path(self, B, device):
+        """Stochastic-depth factors of every trainable block for this forward pass -- two per block (attention branch, MLP
+        branch), each a per-sample 0 or 1/keep -- drawn with four launches for the whole backbone instead of two tiny
+        launches per branch (88 per step).  Same distribution as DropPath.forward; blocks pick theirs up in call order."""
+        blocks = [blk for stage in self.layers for blk in stage.blocks
+                  if blk.training and isinstance(blk.drop_path, DropPath) and blk.drop_path.drop_prob > 0.]
+        if not blocks:
+            return
+        keep = getattr(self, '_drop_path_keep', None)
+        if keep is None or keep.device != device or keep.shape[0] != 2 * len(blocks):
+            probs = [1.0 - blk.drop_path.drop_prob for blk in blocks for _ in range(2)]
+            keep = self._drop_path_keep = torch.tensor(probs, dtype=torch.float32).to(device)[:, None]  # once per device
+        scales = (torch.rand(keep.shape[0], B, device=device) < keep).to(torch.float32) / keep
+        for j, blk in enumerate(blocks):
+            blk._drop_path_ready = [scales[2 * j + 1], scales[2 * j]]  # popped from the end: attention first
+
     def forward(self, x):
         B = x.shape[0]
+        if _POOLED_DROP_PATH and self.training and x.is_cuda and torch.is_grad_enabled():
+            self._draw_drop_path(B, x.device)
         x, Wh, Ww = self.patch_embed.tokens(x.to(self.patch_embed.proj.weight.dtype))
         if self.ape:
             pos = F.interpolate(self.absolute_pos_embed, size=(Wh, Ww), mode='bicubic')

@@ -92,10 +92,12 @@ class DeformableTransformerDecoderLayer(nn.Module):
         E, h = mha.embed_dim, mha.num_heads
         B, Lq, _ = tgt.shape
         qk_in = self.with_pos_embed(tgt, query_pos)
-        qk = F.linear(qk_in, mha.in_proj_weight[:2 * E], mha.in_proj_bias[:2 * E])  # one GEMM for q and k
-        v = F.linear(tgt, mha.in_proj_weight[2 * E:], mha.in_proj_bias[2 * E:])
-        q = qk[..., :E].view(B, Lq, h, E // h)
-        k = qk[..., E:].view(B, Lq, h, E // h)
+        # split (not slices): the backward of a split is one concatenation, a slice's is a zero fill + copy + add each
+        w_qk, w_v = mha.in_proj_weight.split([2 * E, E])
+        b_qk, b_v = mha.in_proj_bias.split([2 * E, E])
+        qk = F.linear(qk_in, w_qk, b_qk)  # one GEMM for q and k
+        v = F.linear(tgt, w_v, b_v)
+        q, k = (t.view(B, Lq, h, E // h) for t in qk.split(E, -1))
         out = fused_attention(q, k, v.view(B, Lq, h, E // h), None, scale=1.0 / math.sqrt(E // h),
                               dropout_p=mha.dropout, training=self.training)
         out = out.reshape(B, Lq, E)

@@ -103,6 +103,7 @@ class _AddLayerNormFn(Function):
         _lib.check(st, "grit_add_layernorm_fwd")
         ctx.save_for_backward(x, weight, mean, rstd, scale)
         ctx.shape = shortcut.shape
+        ctx.set_materialize_grads(False)  # an unused output (the post-norm decoders drop x) arrives as None, not a zero map
         return x.view(shortcut.shape), y.view(shortcut.shape)
 
     @staticmethod
@@ -172,6 +173,7 @@ class _LinearAddLayerNormFn(Function):
         _lib.check(st, "grit_add_layernorm_fwd")
         ctx.save_for_backward(x, weight, mean, rstd, scale, inp, lin_w, seed_dev)
         ctx.shape, ctx.drop_p = shortcut.shape, drop_p
+        ctx.set_materialize_grads(False)  # see _AddLayerNormFn
         return x.view(shortcut.shape), y.view(shortcut.shape)
 
     @staticmethod

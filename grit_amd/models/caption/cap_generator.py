@@ -14,6 +14,7 @@ from torch.nn import functional as F
 from grit_amd.models.caption.containers import Module, ModuleList
 from grit_amd.models.common.attention import MultiHeadAttention
 from grit_amd.models.common.pos_embed import FeedForward, sinusoid_encoding_table
+from grit_amd.ops.linear import Linear
 
 
 class GeneratorLayer(Module):
@@ -30,7 +31,7 @@ class ParallelAttentionLayer(GeneratorLayer):
         super().__init__(d_model=d_model, n_heads=n_heads, d_ff=d_ff, dropout=dropout, n_memories=0)
         self.vis_att1 = MultiHeadAttention(d_model, n_heads, dropout, can_be_stateful=False, n_memories=n_memories)
         self.vis_att2 = MultiHeadAttention(d_model, n_heads, dropout, can_be_stateful=False, n_memories=n_memories)
-        self.fc_alpha1 = nn.Linear(d_model + d_model, d_model)
+        self.fc_alpha1 = Linear(d_model + d_model, d_model)
         self.fc_alpha2 = nn.Linear(d_model + d_model, d_model)  # never used in forward (reference quirk)
         self.activation = activation
         self.init_weights()

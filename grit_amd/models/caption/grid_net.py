@@ -14,6 +14,7 @@ from torch import nn
 
 from grit_amd.models.common.attention import MultiHeadAttention
 from grit_amd.models.common.pos_embed import FeedForward
+from grit_amd.ops.linear import Linear
 
 
 class TransformerLayer(nn.Module):
@@ -34,7 +35,7 @@ class GridFeatureNetwork(nn.Module):
     def __init__(self, n_layers, d_in=1024, d_model=512, n_heads=8, d_ff=2048, dropout=0.1, n_memories=0):
         super().__init__()
         self.d_model = d_model
-        self.fc = nn.Linear(d_in, d_model)
+        self.fc = Linear(d_in, d_model)
         self.dropout = nn.Dropout(p=dropout)
         self.layer_norm = nn.LayerNorm(d_model)
         stack = (TransformerLayer(d_model, n_heads, d_ff, dropout, n_memories=n_memories) for _ in range(n_layers))

@@ -13,6 +13,7 @@ from torch import nn
 from grit_amd.models.caption.containers import Module
 from grit_amd.ops.attention import attention as fused_attention
 from grit_amd.ops.layer_norm import linear_add_layer_norm
+from grit_amd.ops.linear import Linear
 
 
 def init_params(module):
@@ -32,10 +33,10 @@ class Attention(nn.Module):
         super().__init__()
         if n_memories > 0:
             raise NotImplementedError("memory slots are not used by GRIT (n_memories is always 0 on its path)")
-        self.fc_q = nn.Linear(d_model, d_model)
-        self.fc_k = nn.Linear(d_model, d_model)
-        self.fc_v = nn.Linear(d_model, d_model)
-        self.fc_o = nn.Linear(d_model, d_model)
+        self.fc_q = Linear(d_model, d_model)
+        self.fc_k = Linear(d_model, d_model)
+        self.fc_v = Linear(d_model, d_model)
+        self.fc_o = Linear(d_model, d_model)
         self.dropout = nn.Dropout(p=dropout)
         self.d_model, self.n_heads, self.n_memories = d_model, n_heads, n_memories
         self.d_k = d_model // n_heads

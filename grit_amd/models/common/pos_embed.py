@@ -3,6 +3,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 from grit_amd.ops.layer_norm import linear_add_layer_norm
+from grit_amd.ops.linear import Linear
 
 
 def position_embedding(input, d_model):
@@ -27,7 +28,7 @@ class FeedForward(nn.Module):
 
     def __init__(self, d_model=512, d_ff=2048, dropout=0.1):
         super().__init__()
-        self.fc1 = nn.Linear(d_model, d_ff)
+        self.fc1 = Linear(d_model, d_ff)
         self.fc2 = nn.Linear(d_ff, d_model)
         self.dropout = nn.Dropout(p=dropout)
         self.dropout_2 = nn.Dropout(p=dropout)

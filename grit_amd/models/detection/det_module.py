@@ -24,7 +24,7 @@ from grit_amd.models.common.swin_model import DropPath
 from grit_amd.models.ops.modules import MSDeformAttn
 from grit_amd.ops.attention import attention as fused_attention
 from grit_amd.ops.layer_norm import linear_add_layer_norm
-from grit_amd.ops.linear import linear, shared_input_linears
+from grit_amd.ops.linear import Linear, linear, shared_input_linears
 from grit_amd.ops.msda import StackedValueMaps
 
 _SHARED_VALUE_PROJ = os.environ.get('GRIT_SHARED_VALUE_PROJ', '1') != '0'  # A/B knobs
@@ -69,7 +69,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)  # parameter container
         self.dropout2 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
-        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear1 = Linear(d_model, d_ffn)
         self.activation = _get_activation_fn(activation)
         self.dropout3 = nn.Dropout(dropout)
         self.linear2 = nn.Linear(d_ffn, d_model)

@@ -32,8 +32,8 @@ class MSDeformAttn(nn.Module):
             warnings.warn("MSDeformAttn: head dims 64 and 32 take the wide-load kernel; other sizes use the generic one.")
         self.im2col_step = 64  # accepted for interface parity; the HIP op does not chunk the batch
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
-        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
-        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.sampling_offsets = Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = Linear(d_model, n_heads * n_levels * n_points)
         self.value_proj = Linear(d_model, d_model)  # M = B*S rows: split-K weight gradient
         self.output_proj = nn.Linear(d_model, d_model)
         self._reset_parameters()

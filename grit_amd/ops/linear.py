@@ -19,7 +19,7 @@ from torch.autograd.function import once_differentiable
 from grit_amd import lib as _lib
 from grit_amd.ops import backend
 
-MIN_ROWS = 4096  # below this the launch overhead dominates: leave it to torch
+MIN_ROWS = int(os.environ.get("GRIT_LINEAR_MIN_ROWS", "512"))  # below this the launch overhead dominates: leave it to torch
 
 
 def slab_sum(partial, out_dtype, slabs=None):
@@ -41,7 +41,10 @@ def slab_sum(partial, out_dtype, slabs=None):
 def column_sum(x2d, out_dtype=torch.float32):
     """[M, N] (bf16 / f32, contiguous, N % 8 == 0) -> [N] in out_dtype (f32 accumulation)."""
     M, N = x2d.shape
-    slabs = max(1, min(256, (M * N) // (1 << 18), 2048 // max(1, (N + 511) // 512)))
+    strips = max(1, (N + 511) // 512)
+    slabs = max(1, min(256, (M * N) // (1 << 18), 2048 // strips))
+    # small maps (the decoders' M = 640 .. 4 800 rows): enough slabs to put a workgroup on every CU, >= 16 rows each
+    slabs = max(slabs, min(-(-256 // strips), M // 16, 256))
     partial = torch.empty(slabs, N, dtype=torch.float32, device=x2d.device)
     with torch.cuda.device(x2d.device):
         st = _lib.load().grit_colsum(ctypes.c_void_p(x2d.data_ptr()), M, N, int(x2d.dtype == torch.bfloat16), slabs,

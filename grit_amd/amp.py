@@ -84,7 +84,7 @@ class FlatAdam(torch.optim.Optimizer):
         lib = _lib.load()
         for bucket, compute, master, mom, var, start, end in self._runs:
             n = end - start
-            with torch.cuda.device(master.device):
+            with _lib.device_guard(master.device):
                 st = lib.grit_adam_flat(
                     ctypes.c_void_p(master[start:].data_ptr()), ctypes.c_void_p(bucket.flat[start:].data_ptr()),
                     int(bucket.flat.dtype == torch.bfloat16), ctypes.c_void_p(mom[start:].data_ptr()),

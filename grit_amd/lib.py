@@ -86,9 +86,31 @@ def check(status, what):
         raise GritHipError("%s failed: %s" % (what, load().grit_status_string(status).decode()))
 
 
-def current_stream_ptr():
+class _NoGuard(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(device):
+    """`with device_guard(t.device):` = torch.cuda.device(t.device), but free when that device is already current (the
+    one-process-per-GPU case): a training step enters this ~1 000 times and the generic context manager costs ~5 us each."""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    index = device.index
+    if index is None or index == torch._C._cuda_getDevice():
+        return _NO_GUARD
+    return torch.cuda.device(device)
+
+
+def current_stream_ptr():
+    """hipStream_t of torch's current stream on the current device (raw handle, no Stream object)."""
+    import torch
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def require_device(*tensors):

@@ -60,7 +60,7 @@ class _AttentionFn(Function):
         lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
         L = _lib.load()
         fn = L.grit_attn_fwd_bf16 if q.dtype == torch.bfloat16 else L.grit_attn_fwd_f32
-        with torch.cuda.device(q.device):
+        with _lib.device_guard(q.device):
             st = fn(_ptr(q), ldq, bsq, _ptr(k), ldk, bsk, _ptr(v), ldv, bsv, _ptr(m), msb, msq, B, H, Tq, Nk, D,
                     scale, dropout_p, seed, _ptr(seed_dev), _ptr(out), _ptr(lse), _lib.current_stream_ptr())
         _lib.check(st, "grit_attn_fwd")
@@ -81,7 +81,7 @@ class _AttentionFn(Function):
         dv = torch.empty((B, Nk, H, D), dtype=q.dtype, device=q.device)
         L = _lib.load()
         fn = L.grit_attn_bwd_bf16 if q.dtype == torch.bfloat16 else L.grit_attn_bwd_f32
-        with torch.cuda.device(q.device):
+        with _lib.device_guard(q.device):
             st = fn(_ptr(q), q.stride(1), q.stride(0), _ptr(k), k.stride(1), k.stride(0), _ptr(v), v.stride(1),
                     v.stride(0), _ptr(m), msb, msq, _ptr(out), _ptr(dout), _ptr(lse), B, H, Tq, Nk, D, scale,
                     dropout_p, seed, _ptr(seed_dev), _ptr(dq), _ptr(dk), _ptr(dv), _lib.current_stream_ptr())

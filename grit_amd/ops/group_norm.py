@@ -36,7 +36,7 @@ class _GroupNormLevelsFn(Function):
         xb, wb = int(flat.dtype == torch.bfloat16), int(ws[0].dtype == torch.bfloat16)
         lib = _lib.load()
         start = 0
-        with torch.cuda.device(flat.device):
+        with _lib.device_guard(flat.device):
             stream = _lib.current_stream_ptr()
             for l in range(n_levels):
                 out = flat[:, start:start + Ts[l]]
@@ -62,7 +62,7 @@ class _GroupNormLevelsFn(Function):
         lib = _lib.load()
         dxs, dws, dbs = [], [], []
         start = 0
-        with torch.cuda.device(dflat.device):
+        with _lib.device_guard(dflat.device):
             stream = _lib.current_stream_ptr()
             for l in range(n_levels):
                 dy = dflat[:, start:start + Ts[l]]

@@ -143,7 +143,7 @@ def image_batch(images, sizes, mean=MEAN, std=STD, device=None, pad_to=None):
             raise ValueError("pad_to %s is smaller than the largest resized image (%d, %d)" % (tuple(pad_to), H, W))
         H, W = int(pad_to[0]), int(pad_to[1])
     B = len(imgs)
-    with torch.cuda.device(device):
+    with _lib.device_guard(device):
         if all(im.is_cuda for im in imgs):
             src = torch.cat([im.reshape(-1) for im in imgs] + [torch.zeros(SRC_PAD, dtype=torch.uint8, device=device)])
         elif all(im.is_cuda or im.is_pinned() for im in imgs):  # decoder wrote into pinned memory: no staging copy

@@ -36,7 +36,7 @@ class _LayerNormFn(Function):
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         xb, wb = int(x2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             st = _lib.load().grit_layernorm_fwd(_ptr(x2), _ptr(weight), _ptr(bias), rows, C, eps, xb, wb, _ptr(y), _ptr(mean),
                                                 _ptr(rstd), _lib.current_stream_ptr())
         _lib.check(st, "grit_layernorm_fwd")
@@ -59,7 +59,7 @@ class _LayerNormFn(Function):
         nblk = min(-(-rows // rows_per_block), LN_BWD_PARTIALS)
         base = torch.empty(2, LN_BWD_PARTIALS, C, dtype=torch.float32, device=x2.device)
         xb, wb = int(x2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
-        with torch.cuda.device(x2.device):
+        with _lib.device_guard(x2.device):
             st = _lib.load().grit_layernorm_bwd(_ptr(x2), _ptr(weight), _ptr(dy2), _ptr(mean), _ptr(rstd), rows, C, xb, wb,
                                                 _ptr(dx), _ptr(base[0]), _ptr(base[1]), _lib.current_stream_ptr())
         _lib.check(st, "grit_layernorm_bwd")
@@ -96,7 +96,7 @@ class _AddLayerNormFn(Function):
         rstd = torch.empty(rows, dtype=torch.float32, device=s2.device)
         xb, wb = int(s2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
         per_sample = rows // shortcut.shape[0]
-        with torch.cuda.device(s2.device):
+        with _lib.device_guard(s2.device):
             st = _lib.load().grit_add_layernorm_fwd(_ptr(s2), _ptr(b2), _ptr(scale) if scale is not None else None, per_sample,
                                                     0.0, None, _ptr(weight), _ptr(bias), rows, C, eps, xb, wb, _ptr(x), _ptr(y),
                                                     _ptr(mean), _ptr(rstd), _lib.current_stream_ptr())
@@ -136,7 +136,7 @@ def _add_layer_norm_backward(x2, weight, mean, rstd, scale, gx, gy, batch, branc
     n_sums = 3 if branch_colsum else 2
     base = torch.empty(n_sums, LN_BWD_PARTIALS, C, dtype=torch.float32, device=x2.device)
     xb, wb = int(x2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
-    with torch.cuda.device(x2.device):
+    with _lib.device_guard(x2.device):
         st = _lib.load().grit_add_layernorm_bwd(
             _ptr(x2), _ptr(weight), _ptr(gy2), _ptr(gx2) if gx2 is not None else None, _ptr(mean), _ptr(rstd),
             _ptr(scale) if scale is not None else None, rows // batch, float(drop_p),
@@ -164,7 +164,7 @@ class _LinearAddLayerNormFn(Function):
         mean = torch.empty(rows, dtype=torch.float32, device=s2.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=s2.device)
         xb, wb = int(s2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
-        with torch.cuda.device(s2.device):
+        with _lib.device_guard(s2.device):
             st = _lib.load().grit_add_layernorm_fwd(_ptr(s2), _ptr(b2), _ptr(scale) if scale is not None else None,
                                                     rows // shortcut.shape[0], float(drop_p),
                                                     _ptr(seed_dev) if drop_p > 0 else None, _ptr(weight), _ptr(bias), rows, C,

@@ -31,7 +31,7 @@ def slab_sum(partial, out_dtype, slabs=None):
     for d in tail:
         n *= d
     out = torch.empty((partial.shape[0],) + tuple(tail), dtype=out_dtype, device=partial.device)
-    with torch.cuda.device(partial.device):
+    with _lib.device_guard(partial.device):
         st = _lib.load().grit_slab_sum(ctypes.c_void_p(partial.data_ptr()), partial.shape[0], partial.stride(0), slabs, n,
                                        ctypes.c_void_p(out.data_ptr()), int(out_dtype == torch.bfloat16), _lib.current_stream_ptr())
     _lib.check(st, "grit_slab_sum")
@@ -46,7 +46,7 @@ def column_sum(x2d, out_dtype=torch.float32):
     # small maps (the decoders' M = 640 .. 4 800 rows): enough slabs to put a workgroup on every CU, >= 16 rows each
     slabs = max(slabs, min(-(-256 // strips), M // 16, 256))
     partial = torch.empty(slabs, N, dtype=torch.float32, device=x2d.device)
-    with torch.cuda.device(x2d.device):
+    with _lib.device_guard(x2d.device):
         st = _lib.load().grit_colsum(ctypes.c_void_p(x2d.data_ptr()), M, N, int(x2d.dtype == torch.bfloat16), slabs,
                                      ctypes.c_void_p(partial.data_ptr()), _lib.current_stream_ptr())
     _lib.check(st, "grit_colsum")

@@ -93,7 +93,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     if _bf16_fast_path(value, D, L, P):  # value map stays bf16: no fp32 staging copy
         loc, aw = sampling_loc.float(), attn_weight.float()
         out = torch.empty((B, Lq, M * D), dtype=torch.bfloat16, device=value.device)
-        with torch.cuda.device(value.device), _Timed("fwd_bf16", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, 2, 4)):
+        with _lib.device_guard(value.device), _Timed("fwd_bf16", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, 2, 4)):
             st = _lib.load().grit_msda_fwd_bf16(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc),
                                                 _ptr(aw), B, S, M, D, L, Lq, P, _ptr(out), _lib.current_stream_ptr())
         _lib.check(st, "grit_msda_fwd_bf16")
@@ -102,7 +102,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     v, loc, aw = value.to(cdt), sampling_loc.to(cdt), attn_weight.to(cdt)
     out = torch.empty((B, Lq, M * D), dtype=cdt, device=value.device)
     fn = _lib.load().grit_msda_fwd_f64 if cdt == torch.float64 else _lib.load().grit_msda_fwd_f32
-    with torch.cuda.device(value.device), _Timed("fwd", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, v.element_size())):
+    with _lib.device_guard(value.device), _Timed("fwd", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, v.element_size())):
         st = fn(_ptr(v), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(aw),
                 B, S, M, D, L, Lq, P, _ptr(out), _lib.current_stream_ptr())
     _lib.check(st, "grit_msda_fwd")
@@ -120,7 +120,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         go = grad_output.to(torch.bfloat16).contiguous()
         gv = torch.zeros(value.shape, dtype=torch.bfloat16, device=value.device)
         gl, ga = torch.empty_like(loc), torch.empty_like(aw)
-        with torch.cuda.device(value.device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 2)):
+        with _lib.device_guard(value.device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 2)):
             st = _lib.load().grit_msda_bwd_bf16acc(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc),
                                                    _ptr(aw), _ptr(go), B, S, M, D, L, Lq, P, _ptr(gv), _ptr(gl), _ptr(ga),
                                                    _lib.current_stream_ptr())
@@ -131,7 +131,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         go = grad_output.to(torch.bfloat16).contiguous()
         gv = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
         gl, ga = torch.empty_like(loc), torch.empty_like(aw)
-        with torch.cuda.device(value.device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 4)):
+        with _lib.device_guard(value.device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 4)):
             st = _lib.load().grit_msda_bwd_bf16(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc),
                                                 _ptr(aw), _ptr(go), B, S, M, D, L, Lq, P, _ptr(gv), _ptr(gl), _ptr(ga),
                                                 _lib.current_stream_ptr())
@@ -144,7 +144,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     gl = torch.empty_like(loc)
     ga = torch.empty_like(aw)
     fn = _lib.load().grit_msda_bwd_f64 if cdt == torch.float64 else _lib.load().grit_msda_bwd_f32
-    with torch.cuda.device(value.device), _Timed("bwd", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, v.element_size())):
+    with _lib.device_guard(value.device), _Timed("bwd", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, v.element_size())):
         st = fn(_ptr(v), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(aw), _ptr(go),
                 B, S, M, D, L, Lq, P, _ptr(gv), _ptr(gl), _ptr(ga), _lib.current_stream_ptr())
     _lib.check(st, "grit_msda_bwd")
@@ -177,7 +177,7 @@ class _StackedMSDAFn(Function):
         _, Lq, _, L, P, _ = loc.shape
         loc, aw = loc.float().contiguous(), aw.float().contiguous()
         out = torch.empty((B, Lq, M * D), dtype=torch.bfloat16, device=stacked.device)
-        with torch.cuda.device(stacked.device), _Timed("fwd_bf16", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, 2, 4)):
+        with _lib.device_guard(stacked.device), _Timed("fwd_bf16", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, 2, 4)):
             st = _lib.load().grit_msda_fwd_bf16_strided(maps.layer_ptr(stacked, layer), n * M * D, _ptr(shapes), _ptr(lsi),
                                                         _ptr(loc), _ptr(aw), B, S, M, D, L, Lq, P, _ptr(out),
                                                         _lib.current_stream_ptr())
@@ -198,7 +198,7 @@ class _StackedMSDAFn(Function):
             maps.grad = torch.zeros_like(stacked)  # one fill for all layers; the kernels add into their slices
         go = grad_output.to(torch.bfloat16).contiguous()
         gl, ga = torch.empty_like(loc), torch.empty_like(aw)
-        with torch.cuda.device(stacked.device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 2)):
+        with _lib.device_guard(stacked.device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 2)):
             st = _lib.load().grit_msda_bwd_bf16acc_strided(maps.layer_ptr(stacked, layer), n * M * D, _ptr(shapes), _ptr(lsi),
                                                            _ptr(loc), _ptr(aw), _ptr(go), B, S, M, D, L, Lq, P,
                                                            maps.layer_ptr(maps.grad, layer), _ptr(gl), _ptr(ga),

@@ -44,7 +44,7 @@ class _RelBiasFn(Function):
         n_rows, nH = table.shape
         n_pos = index.numel()
         out = torch.empty((nH,) + tuple(index.shape), dtype=torch.float32, device=table.device)
-        with torch.cuda.device(table.device):
+        with _lib.device_guard(table.device):
             st = _lib.load().grit_relbias_fwd(_ptr(table), _ptr(index), n_rows, nH, n_pos, int(table.dtype == torch.bfloat16),
                                               _ptr(out), _lib.current_stream_ptr())
         _lib.check(st, "grit_relbias_fwd")
@@ -58,7 +58,7 @@ class _RelBiasFn(Function):
         order, offsets = _sorted_positions(ctx.index, n_rows)
         dbias = dbias.float().contiguous()
         dtable = torch.empty(n_rows, nH, dtype=dtype, device=dbias.device)
-        with torch.cuda.device(dbias.device):
+        with _lib.device_guard(dbias.device):
             st = _lib.load().grit_relbias_bwd(_ptr(dbias), _ptr(order), _ptr(offsets), n_rows, nH, n_pos,
                                               int(dtype == torch.bfloat16), _ptr(dtable), _lib.current_stream_ptr())
         _lib.check(st, "grit_relbias_bwd")

@@ -67,7 +67,7 @@ class _WindowAttentionFn(Function):
         out = torch.empty((B, T, C), dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty((B * nWh * nWw, num_heads, N), dtype=torch.float32, device=qkv.device)
         nWm = 0 if mask is None else mask.shape[0]
-        with torch.cuda.device(qkv.device), _Timed("fwd", _core_flops(B, nWh, nWw, num_heads, N, 2)):
+        with _lib.device_guard(qkv.device), _Timed("fwd", _core_flops(B, nWh, nWw, num_heads, N, 2)):
             st = _lib.load().grit_winattn_fwd_bf16(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, B, H, W, C,
                                                    num_heads, window, shift, scale, _ptr(out), _ptr(lse),
                                                    _lib.current_stream_ptr())
@@ -90,7 +90,7 @@ class _WindowAttentionFn(Function):
         dbias, dpad = acc[:rel_bias.numel()].view_as(rel_bias), acc[rel_bias.numel():]
         nWm = 0 if mask is None else mask.shape[0]
         flops = _core_flops(B, -(-H // window), -(-W // window), num_heads, window * window, 5)
-        with torch.cuda.device(qkv.device), _Timed("bwd", flops):
+        with _lib.device_guard(qkv.device), _Timed("bwd", flops):
             st = _lib.load().grit_winattn_bwd_bf16(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, _ptr(out),
                                                    _ptr(dout), _ptr(lse), B, H, W, C, num_heads, window, shift, scale,
                                                    _ptr(dqkv), _ptr(dbias), _ptr(dpad), _lib.current_stream_ptr())

@@ -53,7 +53,12 @@ class Detector(nn.Module):
             images = nested_tensor_from_tensor_list(list(images))
         x, mask = images.tensors, images.mask
         features = self.backbone(x)
-        masks = [F.interpolate(mask[None].float(), size=f.shape[-2:]).to(torch.bool)[0] for f in features]
+        if getattr(images, 'any_padding', None) is False:
+            # the batch builder knows no pixel is padding: the down-sampled masks are all False, no need to convert and
+            # resample the full-resolution mask once per level
+            masks = [mask.new_zeros((mask.shape[0],) + tuple(f.shape[-2:])) for f in features]
+        else:
+            masks = [F.interpolate(mask[None].float(), size=f.shape[-2:]).to(torch.bool)[0] for f in features]
         out = {
             'gri_feat': features[-1].flatten(2).transpose(1, 2),
             'gri_mask': masks[-1].flatten(1)[:, None, None, :],

@@ -196,3 +196,17 @@ def test_caption_stream_pipelined_equals_sequential(g7_model):
     for (ts, ls), (tp, lp) in zip(seq, piped):
         assert torch.equal(ts, tp) and torch.equal(ls, lp)
     assert model.cached_features is False
+
+
+def test_no_padding_shortcuts_change_nothing(g7_model):
+    """NestedTensor(any_padding=False) lets the detector skip mask resampling, valid-ratio arithmetic and the padding mask;
+    the features must be those of the general path bit for bit."""
+    from grit_amd.utils.misc import NestedTensor
+    model, _ = g7_model
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(3)).to(DEV)
+    mask = torch.zeros(2, 224, 224, dtype=torch.bool, device=DEV)
+    with torch.no_grad():
+        general = model.detector(NestedTensor(x, mask))
+        fast = model.detector(NestedTensor(x, mask, any_padding=False))
+    for k in general:
+        assert torch.equal(general[k], fast[k]), k

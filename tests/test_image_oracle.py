@@ -113,3 +113,25 @@ def test_paired_collator_captions_follow_the_reference_padding():
     out = PairedCollator(Field(), device='cpu', max_len=4)(batch)
     assert out['captions'].tolist() == [[2, 5, 6, 7, 3, 1, 1], [2, 8, 3, 1, 1, 1, 1], [2, 9, 9, 9, 9, 3, 1]]
     assert out['samples']['gri_feat'].shape == (3, 4, 8) and out['image_id'] == [11, 12, 13]
+
+
+def test_image_collator_fails_loudly_without_a_device():
+    """No CPU fallback: the deferred resize can only be carried out by the HIP kernels."""
+    from grit_amd.datasets.caption.coco import DictionaryCollator
+    from grit_amd.datasets.caption.transforms import collate_images, get_transform
+    from grit_amd.lib import GritHipError
+
+    class Cfg(object):
+        size, resize_name, randaug = (48, 64), 'maxwh', False
+
+    policy = get_transform(Cfg())['valid']
+    item = policy(np.zeros((60, 80, 3), np.uint8))
+    with pytest.raises(GritHipError, match="Not implemented on the CPU"):
+        collate_images([item], device='cpu')
+    with pytest.raises(GritHipError, match="Not implemented on the CPU"):
+        DictionaryCollator(device='cpu')([(item, [4, 5], 7)])
+    with pytest.raises(TypeError):
+        collate_images([np.zeros((60, 80, 3), np.uint8)], device='cpu')  # not a Deferred record
+    Cfg.randaug = True
+    with pytest.raises(NotImplementedError):
+        get_transform(Cfg())

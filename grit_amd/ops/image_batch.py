@@ -85,7 +85,8 @@ def _as_u8(img):
     if isinstance(img, torch.Tensor):
         t = img
     else:
-        t = torch.from_numpy(np.ascontiguousarray(np.asarray(img)))  # numpy array or PIL image (decoded, RGB)
+        arr = np.ascontiguousarray(np.asarray(img))  # numpy array or PIL image (decoded, RGB)
+        t = torch.from_numpy(arr if arr.flags.writeable else arr.copy())  # PIL hands out read-only views
     if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
         raise ValueError("expected decoded RGB images as [h, w, 3] uint8, got %s %s" % (tuple(t.shape), t.dtype))
     return t.contiguous()

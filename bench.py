@@ -217,9 +217,10 @@ def main():
                     "traffic_frac": (traffic / avg_t / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                     "launches": len(fwd), "avg_launch_us": avg_t * 1e6, "algorithmic_bytes_per_launch": int(nbytes),
                     "empty_event_pair_us": empty_pair_us}
-        if bwd:  # informational: the backward is bound by the chip-wide float-atomic rate, not by HBM
+        if bwd:  # informational: the backward is bound by the chip-wide memory-side atomic rate, not by HBM
             avg_b = sum(t for t, _ in bwd) / len(bwd)
-            msda_bwd = {"kernel": "msda_bwd_d64", "launches": len(bwd), "avg_launch_us": avg_b * 1e6,
+            msda_bwd = {"kernel": "msda_bwd_d64 (f32 atomics)" if (args.fp32 or msda_op.F32_ACCUMULATE)
+                        else "msda_bwd_d64_pk (packed-bf16 atomics, same-cell merges)", "launches": len(bwd), "avg_launch_us": avg_b * 1e6,
                         "algorithmic_bytes_per_launch": int(bwd[0][1]), "achieved_GBps": bwd[0][1] / avg_b / 1e9}
         # informational: the other hand-written hot-path kernels, timed the same way (HIP events around each launch).
         # Window attention is VALU / issue bound (exp + softmax bookkeeping around 16x16x32 MFMAs on 32-wide heads), so

@@ -1,0 +1,458 @@
+// bf16 MFMA GEMM with fused epilogues for the long token maps of GRIT's Swin backbone (gfx950).
+//
+//   C[M, N] = epilogue( A[M, K] . B[N, K]^T )        A, B, C bf16 row-major (both operands K-contiguous), fp32 accumulation
+//
+// replaces "library GEMM + separate elementwise / reduction passes" around the Mlp of every Swin block
+// (davidnvq/grit models/common/swin_model.py:31-37 Mlp.forward, :289-298 block tail):
+//   GRIT_GEMM_BIAS        C = acc + bias                                   (any Linear)
+//   GRIT_GEMM_BIAS_GELU   aux = acc + bias ; C = gelu(aux)                 (fc1 + exact-erf GELU; aux = pre-activation kept for backward)
+//   GRIT_GEMM_DGELU       C = acc * gelu'(aux) ; colsum[slab, n] = sum_rows C   (fc2 input gradient x GELU' + fc1 bias gradient)
+// so the [M, 4C] hidden map is written once per pass instead of written, re-read and re-written by GELU / GeluBackward / column-sum kernels.
+//
+// Structure (MI355X_MICROARCH.md / cdna_hip_programming.md section 5):
+//   * workgroup = 4 waves (2 x 2) on a 256 x 128 tile, K step 32, three-stage LDS ring (72 KB) filled by global_load_lds_dwordx4
+//     with a counted vmcnt (one stage stays in flight across the barrier) -- two workgroups per CU, so one workgroup's
+//     prologue / epilogue (bias, GELU, LDS transpose, 128-byte row stores) runs under the other's MFMA loop;
+//   * LDS image is lane-linear per wave-instruction (the DMA's rule); bank conflicts of the ds_read_b128 fragment reads are
+//     removed by permuting the 16-byte chunks on the SOURCE address and on the read (tools/micro/lds_bank_sim.py);
+//   * operands are fed to v_mfma_f32_16x16x32_bf16 swapped (weight rows as the MFMA A operand, token rows as B), which puts a
+//     token on the lane and 4 consecutive output channels in the accumulator registers: the epilogue packs 8-byte pieces,
+//     transposes through the (now idle) stage ring and stores whole 128-byte row segments;
+//   * XCD-aware tile order: the 8 groups of blockIdx % 8 walk disjoint bands of row panels, so an A panel is fetched from HBM
+//     by one L2 only and re-used by the N / 128 column tiles that run next to each other.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "../../include/grit_hip.h"
+
+namespace {
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct GemmArgs {
+    const __bf16* A; long lda;
+    const __bf16* B; long ldb;
+    __bf16* C; long ldc;
+    const __bf16* bias;
+    __bf16* aux; long ldaux;
+    float* colsum;
+    int M, N, K, tiles_m, tiles_n;
+#ifdef GRIT_GEMM_STAMPS
+    unsigned long long* stamps;  // diagnostic build only (tools/micro/gemm_stamps.hip): [workgroup][wave][16] s_memtime values
+#endif
+};
+
+#ifdef GRIT_GEMM_STAMPS
+#define GRIT_STAMP(slot)                                                                                          \
+    if (g.stamps && (threadIdx.x & 63) == 0)                                                                      \
+        g.stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_amdgcn_s_memtime();
+#else
+#define GRIT_STAMP(slot)
+#endif
+
+// GELU on the epilogue's VALU budget.  The erf form costs ~18 vector instructions per element (two transcendental, a compare /
+// select pair, hazard nops): at 128 elements per lane that is as long as the whole MFMA main loop of the tile (measured with
+// tools/micro/gemm_stamps.hip).  Evaluated instead as
+//     gelu(x) = x * sigmoid(x * (c0 + c1 x^2 + c2 x^4)),   x^2 clamped at 50,
+// with (c0, c1, c2) fitted to the erf form over [-9, 9]: |gelu error| <= 2.6e-5, |derivative error| <= 1.1e-4 absolute
+// (tools/micro/fit_gelu.py) -- below the bf16 resolution of the stored activations except next to zero; the backward uses the
+// exact derivative of the same expression, so forward and backward stay consistent.  7 (forward) / 13 (backward) plain
+// instructions + exp2 + rcp per element.  The fp32 parity path of the model never comes here (torch's erf GELU runs there).
+constexpr float kGeluC0 = 1.5950157685537665f, kGeluC1 = 0.07401129205936302f, kGeluC2 = -0.0007030335796160927f;
+constexpr float kNegLog2e = -1.4426950408889634f;
+
+__device__ __forceinline__ float gelu_f(float x) {
+    const float xx = fminf(x * x, 50.0f);
+    float p = fmaf(kNegLog2e * kGeluC2, xx, kNegLog2e * kGeluC1);
+    p = fmaf(p, xx, kNegLog2e * kGeluC0);
+    const float e = __builtin_amdgcn_exp2f(x * p);           // exp(-u), u = x P(x^2); +inf for very negative x -> s = 0
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+__device__ __forceinline__ float dgelu_f(float x) {
+    const float xx = fminf(x * x, 50.0f);
+    float p = fmaf(kNegLog2e * kGeluC2, xx, kNegLog2e * kGeluC1);
+    p = fmaf(p, xx, kNegLog2e * kGeluC0);
+    const float e = __builtin_amdgcn_exp2f(x * p);
+    const float s = __builtin_amdgcn_rcpf(1.0f + e);        // sigmoid(u)
+    float q = fmaf(5.0f * kGeluC2, xx, 3.0f * kGeluC1);      // du/dx = c0 + 3 c1 x^2 + 5 c2 x^4
+    q = fmaf(q, xx, kGeluC0);
+    return s * fmaf(x * q, 1.0f - s, 1.0f);                  // s + x s (1 - s) u'
+}
+
+template <int BK> __device__ __forceinline__ int chunk_swizzle(int r16) {
+    // permutation of the 16-byte chunks of row r16 (row index within its 16-row block) that makes the ds_read_b128 fragment
+    // reads conflict-free (BK = 32: 64-byte rows, 4 chunks; BK = 64: 128-byte rows, 8 chunks)
+    return BK == 32 ? ((-(r16 >> 2)) & 3) : ((r16 >> 1) & 7);
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int EPI>
+__global__ __launch_bounds__(WM * WN * 64, 2)
+void gemm_nt_bf16(const GemmArgs g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
+    constexpr int MT = WTM / 16, NTL = WTN / 16, KS = BK / 32;
+    constexpr int ROWB = BK * 2, CPR = ROWB / 16;  // bytes / 16-byte chunks per staged row
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int LA = A_BYTES / (NT * 16), LB = B_BYTES / (NT * 16), LOADS = LA + LB;
+    static_assert(A_BYTES % (NT * 16) == 0 && B_BYTES % (NT * 16) == 0, "stage must be a whole number of DMA rounds");
+    static_assert(WTN == 64, "epilogue stores 128-byte row segments per wave");
+    constexpr int EPI_BYTES = WTM * WTN * 2;  // per wave
+    static_assert(WM * WN * EPI_BYTES <= NSTAGE * STAGE, "epilogue transpose must fit the stage ring");
+
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+    // XCD-aware tile id: blocks with equal blockIdx % 8 share an L2; give each such group a contiguous band of tiles (bijective)
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int qd = nwg >> 3, rm = nwg & 7;
+    const int tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    // ---- DMA source pointers (one per round) and LDS destinations -------------------------------------------------
+    const __bf16* asrc[LA];
+    const __bf16* bsrc[LB];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int c = i * NT + tid, row = c / CPR, pc = c % CPR;
+        const int lc = pc ^ chunk_swizzle<BK>(row & 15);
+        const int m = min(m0 + row, g.M - 1);
+        asrc[i] = g.A + (size_t)m * g.lda + lc * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int c = i * NT + tid, row = c / CPR, pc = c % CPR;
+        const int lc = pc ^ chunk_swizzle<BK>(row & 15);
+        bsrc[i] = g.B + (size_t)(n0 + row) * g.ldb + lc * 8;
+    }
+    const int wave_dst = wave * 1024;  // byte offset of this wave's 1 KiB piece inside a DMA round
+
+    auto stage = [&](int slot, int kt) {
+        char* base = lds + slot * STAGE;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < LA; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + k0), (lptr_t)(base + i * NT * 16 + wave_dst), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i] + k0), (lptr_t)(base + A_BYTES + i * NT * 16 + wave_dst), 16, 0, 0);
+    };
+
+    // ---- fragment read offsets --------------------------------------------------------------------------------
+    int foff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) foff[s] = l15 * ROWB + (((s * 4 + lq) ^ chunk_swizzle<BK>(l15)) * 16);
+    const int a_wave = wm * WTM * ROWB, b_wave = A_BYTES + wn * WTN * ROWB;
+
+    v4f acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    GRIT_STAMP(0)
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nk) stage(s, s);
+    GRIT_STAMP(1)
+
+    // One K step of the main loop.  Fragments of a 32-deep k-step: NTL weight-row blocks + MT token-row blocks (one
+    // ds_read_b128 each).  All reads of a k-step are issued before its first MFMA; the DMA pieces of the stage that is being
+    // prefetched and (BK = 64) the reads of the second k-step are spread between the MFMAs, so the wave's instruction stream
+    // stays MFMA-dense and the other wave of the SIMD fills what is left.
+    auto read_frags = [&](const char* sb, int ks, v8bf (&w)[NTL], v8bf (&x)[MT]) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) w[j] = *reinterpret_cast<const v8bf*>(sb + b_wave + j * 16 * ROWB + foff[ks]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) x[i] = *reinterpret_cast<const v8bf*>(sb + a_wave + i * 16 * ROWB + foff[ks]);
+    };
+    auto dma_piece = [&](int slot, int kt, int i) {
+        char* base = lds + slot * STAGE;
+        const int k0 = kt * BK;
+        if (i < LA)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i < LA ? i : 0] + k0), (lptr_t)(base + i * NT * 16 + wave_dst), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i >= LA ? i - LA : 0] + k0),
+                                             (lptr_t)(base + A_BYTES + (i - LA) * NT * 16 + wave_dst), 16, 0, 0);
+    };
+    auto k_tile = [&](int t, const bool kStage) {  // kStage is wave-uniform: scalar branches around the DMA pieces only
+        const char* sb = lds + (t % NSTAGE) * STAGE;
+        const int pslot = (t + NSTAGE - 1) % NSTAGE, pkt = t + NSTAGE - 1;
+        v8bf w0[NTL], x0[MT];
+        read_frags(sb, 0, w0, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KS == 1) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], x0[i], acc[i][j], 0, 0, 0);
+                if (i < LOADS && kStage) dma_piece(pslot, pkt, i);
+            }
+        } else {
+            v8bf w1[NTL], x1[MT];
+            // k-step 0 MFMAs, with the reads of k-step 1 and the first DMA pieces in between
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) w1[j] = *reinterpret_cast<const v8bf*>(sb + b_wave + j * 16 * ROWB + foff[KS - 1]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], x0[i], acc[i][j], 0, 0, 0);
+                x1[i] = *reinterpret_cast<const v8bf*>(sb + a_wave + i * 16 * ROWB + foff[KS - 1]);
+                if (i < LOADS / 2 && kStage) dma_piece(pslot, pkt, i);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j], x1[i], acc[i][j], 0, 0, 0);
+                if (i < LOADS - LOADS / 2 && kStage) dma_piece(pslot, pkt, LOADS / 2 + i);
+            }
+        }
+    };
+
+#ifdef GRIT_GEMM_STAMPS
+    unsigned long long ph_wait = 0, ph_barrier = 0, ph_compute = 0, ph_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    for (int t = 0; t < nk; ++t) {
+        // tile t has landed once at most the (NSTAGE - 2) younger tiles' DMAs are still counted
+        if (t + NSTAGE - 2 < nk) {
+            if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (LOADS * (NSTAGE - 2) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (LOADS * (NSTAGE - 2) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (LOADS * (NSTAGE - 2) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (LOADS * (NSTAGE - 2) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#ifdef GRIT_GEMM_STAMPS
+        const unsigned long long ph_t1 = __builtin_amdgcn_s_memtime();
+#endif
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#ifdef GRIT_GEMM_STAMPS
+        const unsigned long long ph_t2 = __builtin_amdgcn_s_memtime();
+#endif
+        if (t == 0) { GRIT_STAMP(2) }
+        if (t == 1) { GRIT_STAMP(3) }
+        if (t == 2) { GRIT_STAMP(4) }
+        k_tile(t, t + NSTAGE - 1 < nk);
+#ifdef GRIT_GEMM_STAMPS
+        {
+            const unsigned long long ph_t3 = __builtin_amdgcn_s_memtime();
+            if (t > 0) { ph_wait += ph_t1 - ph_t0; ph_barrier += ph_t2 - ph_t1; ph_compute += ph_t3 - ph_t2; }
+            ph_t0 = ph_t3;
+        }
+#endif
+    }
+    GRIT_STAMP(5)
+#ifdef GRIT_GEMM_STAMPS
+    if (g.stamps && (threadIdx.x & 63) == 0) {
+        unsigned long long* o = g.stamps + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
+        o[8] = ph_wait; o[9] = ph_barrier; o[10] = ph_compute;
+    }
+#endif
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    // acc[i][j][r] = C[m0 + wm*WTM + 16 i + l15][n0 + wn*WTN + 16 j + 4 lq + r]
+    __builtin_amdgcn_s_barrier();  // every wave is done with the last stage: the ring becomes the transpose buffer
+    asm volatile("" ::: "memory");
+    GRIT_STAMP(6)
+    char* eb = lds + wave * EPI_BYTES;
+    const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+
+    v4f bias4[NTL];
+    if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const v4bf b = *reinterpret_cast<const v4bf*>(g.bias + nw + 16 * j + 4 * lq);
+            bias4[j] = v4f{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+        }
+    }
+
+    // write one packed 8-byte piece per (i, j) into the wave's [WTM][64] bf16 image (16-byte chunks XOR-ed with row & 7)
+    auto put = [&](int i, int j, const v4f& v) {
+        v4bf p;
+        p[0] = (__bf16)v[0]; p[1] = (__bf16)v[1]; p[2] = (__bf16)v[2]; p[3] = (__bf16)v[3];
+        const int row = 16 * i + l15;
+        const int chunk = (2 * j + (lq >> 1)) ^ (row & 7);
+        *reinterpret_cast<v4bf*>(eb + row * 128 + chunk * 16 + (lq & 1) * 8) = p;
+    };
+    // stream the image out: 8 rows x 128 B per wave-instruction
+    const bool full_rows = mw + WTM <= g.M;  // wave-uniform: no per-store row test on interior tiles
+    auto flush = [&](__bf16* dst, long ld) {
+        __bf16* base = dst + (size_t)(mw + (lane >> 3)) * ld + nw + (lane & 7) * 8;
+        if (full_rows) {
+#pragma unroll
+            for (int it = 0; it < WTM / 8; ++it) {
+                const int row = it * 8 + (lane >> 3), chunk = lane & 7;
+                *reinterpret_cast<uint4*>(base + (size_t)it * 8 * ld) =
+                    *reinterpret_cast<const uint4*>(eb + row * 128 + ((chunk ^ (row & 7)) * 16));
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < WTM / 8; ++it) {
+                const int row = it * 8 + (lane >> 3), chunk = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(eb + row * 128 + ((chunk ^ (row & 7)) * 16));
+                if (mw + row < g.M) *reinterpret_cast<uint4*>(base + (size_t)it * 8 * ld) = v;
+            }
+        }
+    };
+
+    if constexpr (EPI == GRIT_GEMM_NONE || EPI == GRIT_GEMM_BIAS) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                v4f v = acc[i][j];
+                if constexpr (EPI == GRIT_GEMM_BIAS) v += bias4[j];
+                put(i, j, v);
+            }
+        flush(g.C, g.ldc);
+    } else if constexpr (EPI == GRIT_GEMM_BIAS_GELU) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) acc[i][j] += bias4[j];
+        if (g.aux) {  // the pre-activation, kept for the backward pass (not needed under no_grad / in frozen stages)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) put(i, j, acc[i][j]);
+            flush(g.aux, g.ldaux);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                v4f v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(acc[i][j][r]);
+                put(i, j, v);
+            }
+        flush(g.C, g.ldc);
+    } else {  // GRIT_GEMM_DGELU
+        // the pre-activation tile comes in the way the result goes out: whole 128-byte row segments (one DMA piece = 8 rows) into
+        // the wave's transpose image, from where every lane picks its 8-byte pieces -- accumulator-shaped global loads (16 rows x
+        // 32 bytes per instruction) cost 11k cycles per tile more (tools/micro/gemm_stamps.hip)
+        {
+            const int chunk = lane & 7;
+#pragma unroll
+            for (int it = 0; it < WTM / 8; ++it) {
+                const int row = it * 8 + (lane >> 3);
+                const int m = min(mw + row, g.M - 1);
+                // image chunk (lane & 7) of row holds logical chunk (lane & 7) ^ (row & 7): permute on the source address
+                const __bf16* src = g.aux + (size_t)m * g.ldaux + nw + ((chunk ^ (row & 7)) * 8);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(eb + it * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        v4f cs[NTL];
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) cs[j] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = 16 * i + l15;
+            const bool live = full_rows || mw + row < g.M;
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int chunk = (2 * j + (lq >> 1)) ^ (row & 7);
+                const v4bf x = *reinterpret_cast<const v4bf*>(eb + row * 128 + chunk * 16 + (lq & 1) * 8);
+                v4f v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[i][j][r] * dgelu_f((float)x[r]);
+                    cs[j][r] += live ? v[r] : 0.f;  // bias gradient from the unrounded products
+                }
+                put(i, j, v);  // in place: this lane's piece of the image
+            }
+        }
+        flush(g.C, g.ldc);
+        // column sums over this wave's WTM rows: fold the 16 token lanes of each quarter
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = cs[j][r];
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 8, 64);
+                cs[j][r] = v;
+            }
+        if (l15 == 0) {
+            float* dst = g.colsum + (size_t)(mw / WTM) * g.N + nw + 4 * lq;
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) *reinterpret_cast<v4f*>(dst + 16 * j) = cs[j];
+        }
+    }
+    GRIT_STAMP(7)
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
+int launch(const GemmArgs& a, int epilogue, hipStream_t st) {
+    constexpr int STAGE = (BM + BN) * BK * 2;
+    constexpr int LDS = NSTAGE * STAGE;
+    GemmArgs g = a;
+    g.tiles_m = (a.M + BM - 1) / BM;
+    g.tiles_n = a.N / BN;
+    const dim3 grid(g.tiles_m * g.tiles_n), block(WM * WN * 64);
+#define GRIT_GEMM_LAUNCH(E)                                                                                          \
+    {                                                                                                                \
+        auto kern = gemm_nt_bf16<BM, BN, BK, WM, WN, NSTAGE, E>;                                                     \
+        static bool attr_done = false; /* idempotent: racing threads set the same value */                           \
+        if (!attr_done) {                                                                                            \
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) \
+                return GRIT_ERR_LAUNCH;                                                                              \
+            attr_done = true;                                                                                        \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kern, grid, block, LDS, st, g);                                                           \
+    }
+    switch (epilogue) {
+        case GRIT_GEMM_NONE: GRIT_GEMM_LAUNCH(GRIT_GEMM_NONE) break;
+        case GRIT_GEMM_BIAS: GRIT_GEMM_LAUNCH(GRIT_GEMM_BIAS) break;
+        case GRIT_GEMM_BIAS_GELU: GRIT_GEMM_LAUNCH(GRIT_GEMM_BIAS_GELU) break;
+        case GRIT_GEMM_DGELU: GRIT_GEMM_LAUNCH(GRIT_GEMM_DGELU) break;
+        default: return GRIT_ERR_BAD_ARG;
+    }
+#undef GRIT_GEMM_LAUNCH
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                                 int epilogue, const void* bias, void* aux, long ldaux, float* colsum, int variant,
+                                 void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return GRIT_ERR_BAD_ARG;
+    if ((epilogue == GRIT_GEMM_BIAS || epilogue == GRIT_GEMM_BIAS_GELU) && !bias) return GRIT_ERR_BAD_ARG;
+    if (epilogue == GRIT_GEMM_DGELU && !aux) return GRIT_ERR_BAD_ARG;
+    if (epilogue == GRIT_GEMM_DGELU && !colsum) return GRIT_ERR_BAD_ARG;
+    // 16-byte DMA pieces and row stores: leading dimensions in multiples of 8 elements, 16-byte aligned bases
+    if ((lda | ldb | ldc | (aux ? ldaux : 0)) & 7) return GRIT_ERR_UNSUPPORTED;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)aux | (uintptr_t)bias) & 15) return GRIT_ERR_UNSUPPORTED;
+    if (N % 128 || K % 32) return GRIT_ERR_UNSUPPORTED;
+    GemmArgs a;
+    a.A = (const __bf16*)A; a.lda = lda; a.B = (const __bf16*)B; a.ldb = ldb; a.C = (__bf16*)C; a.ldc = ldc;
+    a.bias = (const __bf16*)bias; a.aux = (__bf16*)aux; a.ldaux = ldaux; a.colsum = colsum;
+    a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (variant == 0) variant = (N % 256 == 0 && K % 64 == 0) ? 4 : 1;  // measured: tools/bench_gemm.py
+    switch (variant) {
+        case 1: return launch<256, 128, 32, 2, 2, 3>(a, epilogue, st);
+        case 2: return (K % 64) ? GRIT_ERR_UNSUPPORTED : launch<256, 128, 64, 2, 2, 2>(a, epilogue, st);  // needs 96 KB: 1 WG / CU
+        case 3: return launch<256, 128, 32, 2, 2, 4>(a, epilogue, st);  // deeper ring, 96 KB
+        case 4: return (K % 64 || N % 256) ? GRIT_ERR_UNSUPPORTED : launch<256, 256, 64, 2, 4, 2>(a, epilogue, st);  // 8 waves, 128 KB
+        default: return GRIT_ERR_BAD_ARG;
+    }
+}

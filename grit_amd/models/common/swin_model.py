@@ -28,6 +28,7 @@ import torch.utils.checkpoint as checkpoint
 
 from grit_amd.ops.layer_norm import LayerNorm, add_layer_norm, linear_add_layer_norm
 from grit_amd.ops.linear import Linear, linear
+from grit_amd.ops.mlp import mlp as fused_mlp, mlp_add_layer_norm
 from grit_amd.ops.rel_bias import relative_position_bias
 from grit_amd.ops.window_attention import window_attention
 
@@ -37,6 +38,7 @@ def to_2tuple(x):
 
 
 _POOLED_DROP_PATH = os.environ.get('GRIT_POOLED_DROP_PATH', '1') != '0'  # A/B knob
+_FUSED_MLP = os.environ.get('GRIT_FUSED_MLP', '1') != '0'  # A/B knob: Mlp on the fused-epilogue GEMM (grit_amd/ops/mlp.py)
 
 
 class DropPath(nn.Module):
@@ -73,6 +75,10 @@ class Mlp(nn.Module):
 
     def forward(self, x):
         return self.drop(self.fc2(self.hidden(x)))
+
+    def run(self, x):
+        """forward(x) through the fused-epilogue GEMM node when it applies (grit_amd/ops/mlp.py)."""
+        return fused_mlp(x, self) if _FUSED_MLP else self(x)
 
 
 def masked_sin_pos_encoding(x, mask, num_pos_feats, temperature=10000, scale=2 * math.pi):
@@ -195,10 +201,14 @@ class SwinTransformerBlock(nn.Module):
             # output projection + residual + following LayerNorm as one node (the norm's backward kernel then also
             # yields the projection's bias gradient): attn.proj -> norm2, mlp.fc2 -> the next block's norm1
             x, n2 = self._residual_linear_norm(x, self.attn.attend_heads(n1, H, W, self.shift_size), self.attn.proj, self.norm2)
-            h = self.mlp.hidden(n2)
             if next_norm is None:
-                return self._residual(x, self.mlp.fc2(h))
-            return self._residual_linear_norm(x, h, self.mlp.fc2, next_norm)
+                return self._residual(x, self.mlp.run(n2))
+            # fc1 + GELU + fc2 + drop-path + residual + the next block's norm1 as one node (fused-epilogue GEMMs)
+            scale = self._drop_path_scale(x, torch.float32)
+            fused = mlp_add_layer_norm(n2, self.mlp, x, scale, next_norm) if _FUSED_MLP else None
+            if fused is not None:
+                return fused
+            return self._residual_linear_norm(x, self.mlp.hidden(n2), self.mlp.fc2, next_norm, scale=scale, drawn=True)
         x, n2 = self._residual_norm(x, self.attn.attend_map(n1, H, W, self.shift_size), self.norm2)
         h = self.mlp(n2)
         if next_norm is None:
@@ -225,12 +235,16 @@ class SwinTransformerBlock(nn.Module):
             return torch.addcmul(x, branch, scale.view(-1, 1, 1))
         return x + branch
 
-    def _residual_linear_norm(self, x, inp, linear, norm):
-        """(x + drop_path(linear(inp)), norm(x + drop_path(linear(inp))))."""
+    def _residual_linear_norm(self, x, inp, linear, norm, scale=None, drawn=False):
+        """(x + drop_path(linear(inp)), norm(x + drop_path(linear(inp)))); `scale` (with drawn=True) = this call's
+        stochastic-depth factors when the caller has already drawn them."""
+        if not drawn:
+            scale = self._drop_path_scale(x, torch.float32)
         if isinstance(norm, LayerNorm) and norm.elementwise_affine and len(norm.normalized_shape) == 1:
-            return linear_add_layer_norm(inp, linear, x, self._drop_path_scale(x, torch.float32), norm.weight, norm.bias,
-                                         norm.eps)
-        return self._residual_norm(x, linear(inp), norm)
+            return linear_add_layer_norm(inp, linear, x, scale, norm.weight, norm.bias, norm.eps)
+        branch = linear(inp)
+        x = x + branch if scale is None else torch.addcmul(x, branch, scale.to(x.dtype).view(-1, 1, 1))
+        return x, norm(x)
 
     def _residual_norm(self, x, branch, norm):
         """(x + drop_path(branch), norm(x + drop_path(branch)))."""

@@ -1,0 +1,151 @@
+"""The Mlp of a Swin block (fc1 -> exact GELU -> fc2, reference models/common/swin_model.py:31-37) and the block tail that
+follows it (drop-path, residual add, the next LayerNorm; :289-298) as ONE autograd node on the fused-epilogue GEMM.
+
+  forward   fc1 + bias + GELU            grit_gemm_bf16_nt / GRIT_GEMM_BIAS_GELU   (pre-activation and activation in one pass)
+            fc2 + bias                   library GEMM
+            residual + LayerNorm         grit_add_layernorm_fwd
+  backward  LayerNorm / residual         grit_add_layernorm_bwd   (also fc2's bias gradient)
+            fc2 input gradient x GELU'   grit_gemm_bf16_nt / GRIT_GEMM_DGELU       (also fc1's bias gradient, as slab sums)
+            weight gradients, fc1 input gradient: library GEMMs (split-M, grit_amd/ops/linear.py)
+
+Nothing else touches the [M, 4C] hidden map: no GELU, GeluBackward or column-sum kernel (4.8 + 2 ms of the 67 ms step)."""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from grit_amd import lib as _lib
+from grit_amd.ops import backend
+from grit_amd.ops import gemm as G
+from grit_amd.ops import layer_norm as LN
+from grit_amd.ops.linear import column_sum, slab_sum, weight_grad
+
+MIN_ROWS = 2048
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _rows(t):
+    t2 = t.reshape(-1, t.shape[-1])
+    return t2 if t2.is_contiguous() else t2.contiguous()
+
+
+def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs):
+    """Gradients of branch = fc2(gelu(fc1(n2))) w.r.t. (n2, w1, b1, w2) given d_branch [M, C]; b2's comes from the caller."""
+    need_x, need_w1, need_b1, need_w2 = needs
+    d_w2 = weight_grad(d_branch, act) if need_w2 else None
+    d_n2 = d_w1 = d_b1 = None
+    if need_x or need_w1 or need_b1:
+        d_pre, partial = G.input_grad_dgelu(d_branch, w2.t().contiguous(), pre)
+        if need_b1:
+            d_b1 = slab_sum(partial.unsqueeze(0), w1.dtype)[0]
+        if need_x:
+            d_n2 = torch.mm(d_pre, w1)
+        if need_w1:
+            d_w1 = weight_grad(d_pre, n2)
+    return d_n2, d_w1, d_b1, d_w2
+
+
+class _MlpFn(Function):
+    """branch = fc2(gelu(fc1(x)))."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x2 = _rows(x)
+        pre, act = G.linear_bias_gelu(x2, w1, b1)
+        out = F.linear(act, w2, b2)
+        ctx.save_for_backward(x2, w1, pre, act, w2)
+        ctx.shape = x.shape
+        return out.view(x.shape[:-1] + (w2.shape[0],))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, w1, pre, act, w2 = ctx.saved_tensors
+        d_branch = _rows(dy)
+        ni = ctx.needs_input_grad
+        d_x, d_w1, d_b1, d_w2 = _mlp_backward(d_branch, x2, w1, pre, act, w2, (ni[0], ni[1], ni[2], ni[3]))
+        d_b2 = column_sum(d_branch, w2.dtype) if ni[4] else None
+        return (None if d_x is None else d_x.view(ctx.shape)), d_w1, d_b1, d_w2, d_b2
+
+
+class _MlpAddLayerNormFn(Function):
+    """(x_in, shortcut, scale) -> (x, LayerNorm(x)) with x = shortcut + scale[b] * fc2(gelu(fc1(x_in)))."""
+
+    @staticmethod
+    def forward(ctx, x_in, w1, b1, w2, b2, shortcut, scale, weight, bias, eps):
+        x2 = _rows(x_in)
+        pre, act = G.linear_bias_gelu(x2, w1, b1)
+        branch = F.linear(act, w2, b2)
+        C = shortcut.shape[-1]
+        s2 = _rows(shortcut)
+        rows = s2.shape[0]
+        x = torch.empty_like(s2)
+        y = torch.empty_like(s2)
+        mean = torch.empty(rows, dtype=torch.float32, device=s2.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=s2.device)
+        xb, wb = int(s2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
+        with _lib.device_guard(s2.device):
+            st = _lib.load().grit_add_layernorm_fwd(_ptr(s2), _ptr(branch), _ptr(scale), rows // shortcut.shape[0], 0.0, None,
+                                                    _ptr(weight), _ptr(bias), rows, C, eps, xb, wb, _ptr(x), _ptr(y),
+                                                    _ptr(mean), _ptr(rstd), _lib.current_stream_ptr())
+        _lib.check(st, "grit_add_layernorm_fwd")
+        ctx.save_for_backward(x, weight, mean, rstd, scale, x2, w1, pre, act, w2)
+        ctx.shape, ctx.in_shape = shortcut.shape, x_in.shape
+        ctx.set_materialize_grads(False)
+        return x.view(shortcut.shape), y.view(shortcut.shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gx, gy):
+        x, weight, mean, rstd, scale, x2, w1, pre, act, w2 = ctx.saved_tensors
+        dx, d_branch, sums = LN._add_layer_norm_backward(x, weight, mean, rstd, scale, gx, gy, ctx.shape[0], True, 0.0, None)
+        ni = ctx.needs_input_grad
+        d_x, d_w1, d_b1, d_w2 = _mlp_backward(d_branch, x2, w1, pre, act, w2, (ni[0], ni[1], ni[2], ni[3]))
+        return ((None if d_x is None else d_x.view(ctx.in_shape)), d_w1, d_b1, d_w2, sums[2].to(w2.dtype), dx.view(ctx.shape),
+                None, sums[0], sums[1], None)
+
+
+def _fits(x, mlp):
+    fc1, fc2 = mlp.fc1, mlp.fc2
+    return (backend.override() is None and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_autocast_enabled()
+            and isinstance(mlp.act, torch.nn.GELU) and getattr(mlp.act, "approximate", "none") == "none"
+            and (mlp.drop.p == 0. or not mlp.training)
+            and fc1.bias is not None and fc2.bias is not None and fc1.weight.dtype == torch.bfloat16
+            and fc2.weight.dtype == torch.bfloat16 and fc1.bias.dtype == torch.bfloat16
+            and x.numel() // x.shape[-1] >= MIN_ROWS
+            and fc1.weight.is_contiguous() and fc2.weight.is_contiguous()
+            and G.supported(x.reshape(-1, x.shape[-1]), fc1.weight) and fc2.weight.shape[0] % 128 == 0
+            and fc1.bias.data_ptr() % 16 == 0)
+
+
+def mlp(x, module):
+    """module(x) for a Swin Mlp; the fused node when it applies, the module itself otherwise."""
+    if not _fits(x, module):
+        return module(x)
+    fc1, fc2 = module.fc1, module.fc2
+    if not (torch.is_grad_enabled() and (x.requires_grad or fc1.weight.requires_grad or fc2.weight.requires_grad)):
+        act = G.gemm_nt(_rows(x), fc1.weight, G.BIAS_GELU, bias=fc1.bias)  # frozen stage / inference: no pre-activation kept
+        return F.linear(act, fc2.weight, fc2.bias).view(x.shape[:-1] + (fc2.weight.shape[0],))
+    return _MlpFn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+
+
+def mlp_add_layer_norm(x_in, module, shortcut, scale, norm):
+    """(x, norm(x)) with x = shortcut + scale[b] * module(x_in), or None when the fused node does not apply."""
+    C = shortcut.shape[-1]
+    ok = (_fits(x_in, module) and torch.is_grad_enabled()
+          and (x_in.requires_grad or module.fc1.weight.requires_grad or module.fc2.weight.requires_grad)
+          and isinstance(norm, LN.LayerNorm) and norm.elementwise_affine and len(norm.normalized_shape) == 1
+          and C in LN.SUPPORTED_C and C <= 1024 and module.fc2.weight.shape[0] == C and shortcut.dtype == torch.bfloat16
+          and norm.weight.dtype == norm.bias.dtype == torch.bfloat16 and x_in.shape[:-1] == shortcut.shape[:-1])
+    if not ok:
+        return None
+    if scale is not None:
+        scale = scale.reshape(-1).float().contiguous()
+    fc1, fc2 = module.fc1, module.fc2
+    return _MlpAddLayerNormFn.apply(x_in, fc1.weight, fc1.bias, fc2.weight, fc2.bias, shortcut, scale, norm.weight.contiguous(),
+                                    norm.bias.contiguous(), float(norm.eps))

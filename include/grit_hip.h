@@ -32,7 +32,9 @@
  *                           (datasets/caption/transforms/utils.py:4-45), ToTensor + Normalize
  *                           (datasets/caption/transforms/__init__.py:6-32), zero padding + mask of
  *                           nested_tensor_from_tensor_list (engine/utils.py:278-295)
- * (none of the last six groups has a native ancestor in the reference: they replace chains of torch / PIL ops)
+ *   grit_gemm_bf16_nt    <- nn.Linear + nn.GELU of Mlp (models/common/swin_model.py:31-37) and their autograd backward:
+ *                           fc1 + bias + exact GELU in one pass; fc2's input gradient x GELU' + fc1's bias gradient in one pass
+ * (none of the last seven groups has a native ancestor in the reference: they replace chains of torch / PIL ops)
  */
 #ifndef GRIT_HIP_H
 #define GRIT_HIP_H
@@ -43,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 17
+#define GRIT_ABI_VERSION 18
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -309,6 +311,30 @@ int grit_resample_taps_bicubic(int in_size, int out_size, int32_t* bounds, int32
 int grit_image_batch_fwd(const uint8_t* src, const int64_t* desc, const int32_t* tables, uint8_t* tmp, const float* lut,
                          int batch, int max_src_h, int max_dst_w, int max_kx, int out_h, int out_w, float* out,
                          uint8_t* mask, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM with fused epilogues (Swin Mlp, models/common/swin_model.py:31-37, on the [B*H*W, C] token maps).
+ *
+ *   C[M, N] = epilogue(A[M, K] . B[N, K]^T)    A, B, C, aux, bias bf16; fp32 accumulation; row-major with leading
+ *                                              dimensions lda / ldb / ldc / ldaux in elements (multiples of 8)
+ *   GRIT_GEMM_NONE       C = acc
+ *   GRIT_GEMM_BIAS       C = acc + bias[n]
+ *   GRIT_GEMM_BIAS_GELU  aux = acc + bias[n] (written when aux != NULL: the pre-activation the backward needs);
+ *                        C = gelu(acc + bias[n]) in fp32 on the unrounded sum, GELU as x * sigmoid(x * P(x^2)) fitted to the
+ *                        erf form (|error| <= 2.6e-5 absolute, below bf16 resolution; tools/micro/fit_gelu.py)
+ *   GRIT_GEMM_DGELU      C = acc * gelu'(aux[m, n]) (aux read; the exact derivative of the same expression); colsum[s, n] = sum over rows [128 s, 128 s + 128) of C
+ *                        (fp32, before the bf16 rounding of C), s < ceil(M / GRIT_GEMM_COLSUM_ROWS): fully overwritten, to be summed over s
+ *                        with grit_slab_sum (the bias gradient of the Linear that produced aux)
+ * Needs N % 128 == 0, K % 32 == 0, 16-byte aligned bases; M is free.  variant 0 = tile configuration chosen from the
+ * shape (1..4 = explicit configurations for A/B runs; results are identical).
+ * ------------------------------------------------------------------------------------------------------ */
+#define GRIT_GEMM_NONE 0
+#define GRIT_GEMM_BIAS 1
+#define GRIT_GEMM_BIAS_GELU 2
+#define GRIT_GEMM_DGELU 3
+#define GRIT_GEMM_COLSUM_ROWS 128
+int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                      int epilogue, const void* bias, void* aux, long ldaux, float* colsum, int variant, void* stream);
 
 #ifdef __cplusplus
 }

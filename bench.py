@@ -12,10 +12,21 @@ forward + backward + gradient all-reduce (RCCL, bucketed, overlapped with backwa
 the order of reference engine/caption_engine.py:312-350.  Weak scaling: the per-GPU batch is fixed.
 
 One JSON line on rank 0.  Besides the contract keys:
-  roofline      MSDeformAttn forward kernel (HBM-bound gather): algorithmic bytes per launch / average launch
-                time measured with HIP events on the launch stream inside the timed region, against 8 TB/s.
+  roofline      MSDeformAttn forward kernel (HBM-bound gather) as it runs INSIDE the step: algorithmic bytes per launch /
+                average launch time measured with HIP events on the launch stream inside the timed region, against 8 TB/s.
+                Algorithmic bytes = the distinct 128-byte lines of the value map that the launch's sampling points touch (counted
+                from the recorded sampling locations after the timed region) + locations + weights + output, each once -- so the
+                fraction cannot exceed 1 by construction (charging the whole map, as round 1 did, gave 1.29).
+  roofline_msda_spread   the same kernel(s) stand-alone on SURVEY 8d config 2's point distribution (learned-offset-like spread
+                points), value maps rotated through > 512 MB so the 256 MB Infinity Cache cannot serve them: bf16 B = 32 and the
+                fp32 kernel at B = 8 (config 2 itself).
+  roofline_winattn_bwd / _fwd   window attention against its compulsory HBM bytes (7 resp. 4 bf16 [144, 32] slices per window-head).
+  gemm          aggregate rate of the GEMMs of the long token maps (library and own), timed per launch in extra steps after the
+                timed region (an event pair per GEMM inside it would cost ~2 ms per step).
   cpu_baseline  (N = 1 only) the same training step on the host CPU: this repo's modules with the oracle ops
                 (oracle/torch_ref.py) injected -- a port, not the reference -- on a bounded sample (batch 1, few steps).
+Diagnostic flags (recorded in config, never the default): --points spread (decoder sampling locations replaced by config 2's
+distribution), --ragged (images of different sizes: the general padding-mask path), --fp32, GRIT_MSDA_BWD_F32ACC=1.
 """
 import argparse
 import json
@@ -61,7 +72,81 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--fp32", action="store_true", help="diagnostic: no autocast (not the metric's dtype)")
+    ap.add_argument("--points", choices=("model", "spread"), default="model",
+                    help="spread: MSDeformAttn sampling locations replaced by SURVEY 8d config 2's distribution (diagnostic)")
+    ap.add_argument("--ragged", action="store_true", help="diagnostic: images of different sizes (general padding-mask path)")
+    ap.add_argument("--no-analysis", action="store_true", help="skip the post-run analysis steps / micro-benchmarks")
     return ap.parse_args()
+
+
+def spread_locations(B, Lq, M, L, P, device, seed=0):
+    """ref ~ U(0,1) per (b, q); loc = clamp(ref + 0.05 N(0,1), -0.05, 1.05) per sampling point."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    ref = torch.rand(B, Lq, 1, 1, 1, 2, device=device, generator=g)
+    return (ref + 0.05 * torch.randn(B, Lq, M, L, P, 2, device=device, generator=g)).clamp_(-0.05, 1.05)
+
+
+class _SpreadOverride(object):
+    """loc -> config-2 locations of the same shape (one fixed draw per shape)."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def __call__(self, loc):
+        key = (tuple(loc.shape), loc.device)
+        if key not in self.cache:
+            B, Lq, M, L, P, _ = loc.shape
+            self.cache[key] = spread_locations(B, Lq, M, L, P, loc.device)
+        return self.cache[key]
+
+
+def _event_us(pairs):
+    return [a.elapsed_time(b) * 1e3 for a, b in pairs]
+
+
+def msda_forward_bytes(cells, cell_bytes, B, Lq, M, D, L, P, out_esize):
+    """Algorithmic bytes of one forward launch: distinct value cells touched + sampling locations (2 f32) + weights (1 f32)
+    per point + the output rows."""
+    return cells * cell_bytes + 3 * 4 * B * Lq * M * L * P + out_esize * B * Lq * M * D
+
+
+def msda_spread_microbench(device, iters=30):
+    """MSDeformAttn forward stand-alone on config 2's distribution with the value maps rotated so that consecutive launches
+    cannot find their map in the Infinity Cache (total > 512 MB)."""
+    from grit_amd.ops import msda as msda_op
+    shapes = torch.tensor([[80, 80], [40, 40], [20, 20], [10, 10]], device=device)
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S, M, D, Lq, L, P = 8500, 8, 64, 150, 4, 4
+    out = {}
+    for name, B, dtype in (("bf16_B32", 32, torch.bfloat16), ("fp32_B8_config2", 8, torch.float32)):
+        esize = 2 if dtype == torch.bfloat16 else 4
+        nmaps = max(3, -(-(600 << 20) // (B * S * M * D * esize)))
+        maps = [torch.randn(B, S, M, D, device=device, dtype=dtype) for _ in range(nmaps)]
+        loc = spread_locations(B, Lq, M, L, P, device)
+        aw = torch.softmax(torch.randn(B, Lq, M, L * P, device=device), -1).view(B, Lq, M, L, P)
+        for i in range(3):
+            msda_op.ms_deform_attn_forward(maps[i % nmaps], shapes, lsi, loc, aw)
+        pairs = []
+        for i in range(iters):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            msda_op.ms_deform_attn_forward(maps[i % nmaps], shapes, lsi, loc, aw)
+            b.record()
+            pairs.append((a, b))
+        torch.cuda.synchronize()
+        us = sorted(_event_us(pairs))
+        avg_us = sum(us) / len(us)
+        cells = msda_op.unique_lines_touched(loc, shapes.cpu(), lsi.cpu(), S, M)
+        nbytes = msda_forward_bytes(cells, 64 * esize, B, Lq, M, D, L, P, esize)
+        whole_map = esize * B * S * M * D
+        out[name] = {"kernel": "msda_fwd_bf16_rows4<2>" if esize == 2 else "msda_fwd_vec4<16,4>", "bound": "hbm",
+                     "avg_launch_us": avg_us, "median_launch_us": us[len(us) // 2], "launches": iters,
+                     "rotating_value_maps": nmaps, "rotated_bytes": nmaps * whole_map,
+                     "algorithmic_bytes_per_launch": int(nbytes), "value_cells_touched_frac": cells * 64 * esize / whole_map,
+                     "achieved": nbytes / avg_us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": nbytes / avg_us / 1e3 / HBM_PEAK_GBPS}
+        del maps
+    return out
 
 
 def build(device, config):
@@ -144,6 +229,7 @@ def main():
     from grit_amd.ddp import BucketedDataParallel
     from grit_amd.engine.caption_engine import build_optimizers, train_xe_step
     from grit_amd.ops import msda as msda_op
+    from grit_amd.ops import profiling
     from grit_amd.ops import window_attention as wa_op
 
     config = default_config()
@@ -155,8 +241,11 @@ def main():
     optimizers = build_optimizers(wrapped, config, mode="xe")
     loss_fn = torch.nn.NLLLoss(ignore_index=1)
     # inputs resident in HBM before the timed region; 4 distinct batches per rank, cycled
-    batches = [synthetic_batch(args.batch, args.size, args.size, args.caption_len, device=device, seed=1000 * rank + i)
-               for i in range(4)]
+    batches = [synthetic_batch(args.batch, args.size, args.size, args.caption_len, device=device, seed=1000 * rank + i,
+                               ragged=args.ragged) for i in range(4)]
+    if args.points == "spread":
+        msda_op.LOC_OVERRIDE = _SpreadOverride()
+
     def step(i):
         return train_xe_step(wrapped, batches[i % len(batches)], optimizers, loss_fn)
 
@@ -184,6 +273,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
 
+    # ---- after the timed region: analysis steps (every rank takes them: the gradient all-reduce is collective) -----------
+    geom_events, gemm_events = [], []
+    if not args.no_analysis:
+        msda_op.PROFILE_EVENTS, msda_op.PROFILE_RECORD_GEOMETRY, profiling.EVENTS = geom_events, True, gemm_events
+        for i in range(2):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        msda_op.PROFILE_EVENTS, msda_op.PROFILE_RECORD_GEOMETRY, profiling.EVENTS = None, False, None
+
     # what an event pair reads with NOTHING between its two markers: the part of every per-launch figure below that is
     # marker / dispatch latency, not kernel time (reported, not subtracted: the roofline figures stay conservative)
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
@@ -198,41 +296,74 @@ def main():
         value = images / elapsed
         roof, msda_bwd = None, None
         fwd_kind = "fwd" if args.fp32 else "fwd_bf16"
-        fwd = [(a.elapsed_time(b) * 1e-3, n) for kind, a, b, n in events if kind == fwd_kind]
-        bwd = [(a.elapsed_time(b) * 1e-3, n) for kind, a, b, n in events if kind == fwd_kind.replace("fwd", "bwd")]
+        fwd = [(a.elapsed_time(b) * 1e-3, n) for kind, a, b, n, _ in events if kind == fwd_kind]
+        bwd = [(a.elapsed_time(b) * 1e-3, n) for kind, a, b, n, _ in events if kind == fwd_kind.replace("fwd", "bwd")]
+        # distinct value-map cells the in-step launches touch, from the sampling locations recorded in the analysis steps
+        cells, whole_map = [], None
+        for kind, a, b, n, geo in geom_events:
+            if kind == fwd_kind and geo is not None:
+                loc, shapes, lsi, B, S, M, esize = geo
+                cells.append(msda_op.unique_lines_touched(loc, shapes.cpu(), lsi.cpu(), S, M))
+                _, Lq, _, L, P, _ = loc.shape
+                whole_map = (B, S, M, 64, L, Lq, P, esize)
         if fwd:
             avg_t = sum(t for t, _ in fwd) / len(fwd)
-            nbytes = sum(n for _, n in fwd) / len(fwd)
-            achieved = nbytes / avg_t / 1e9
+            whole_bytes = sum(n for _, n in fwd) / len(fwd)  # every tensor once, whole value map (round-1 convention)
+            if cells:
+                B, S, M, D, L, Lq, P, esize = whole_map
+                nbytes = msda_forward_bytes(sum(cells) / len(cells), D * esize, B, Lq, M, D, L, P, esize)
+                basis = ("distinct value-map cells touched by the recorded sampling locations (mean over %d launches: %.1f %% of the "
+                         "map) + locations + weights + output" % (len(cells), 100.0 * sum(cells) / len(cells) * D * esize
+                                                                  / (esize * B * S * M * D)))
+            else:  # --no-analysis: no recorded geometry; fall back to PMC traffic so the fraction stays <= 1
+                nbytes, basis = None, "not counted (--no-analysis)"
             # HBM-side bytes per launch of this kernel at this shape from the committed PMC profile (separate
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 note); PMC collection
             # cannot run inside the timed benchmark, so the figure is quoted only for the shape it was measured on
-            traffic = MSDA_FWD_TRAFFIC_B32[fwd_kind] if (args.batch == 32 and args.size == 640) else None
-            roof = {"bound": "hbm", "kernel": MSDA_FWD_KERNEL[fwd_kind], "achieved": achieved,
+            traffic = MSDA_FWD_TRAFFIC_B32[fwd_kind] if (args.batch == 32 and args.size == 640 and args.points == "model"
+                                                         and not args.ragged) else None
+            achieved = (nbytes if nbytes is not None else (traffic or 0)) / avg_t / 1e9
+            roof = {"bound": "hbm", "kernel": MSDA_FWD_KERNEL[fwd_kind] + ", in the training step", "achieved": achieved,
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                     "traffic_source": MSDA_FWD_TRAFFIC_SOURCE[fwd_kind] if traffic else None,
-                    # the algorithmic convention charges the whole value map; the gather touches a fraction of it (45 % with
-                    # spread points, less in this randomly initialised model), so frac can exceed 1 -- traffic_frac prices the
-                    # measured HBM-side bytes instead
                     "traffic_frac": (traffic / avg_t / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                    "launches": len(fwd), "avg_launch_us": avg_t * 1e6, "algorithmic_bytes_per_launch": int(nbytes),
-                    "empty_event_pair_us": empty_pair_us}
+                    "launches": len(fwd), "avg_launch_us": avg_t * 1e6,
+                    "algorithmic_bytes_per_launch": int(nbytes) if nbytes is not None else None,
+                    "algorithmic_bytes_basis": basis, "whole_map_bytes_per_launch": int(whole_bytes),
+                    "points": args.points, "empty_event_pair_us": empty_pair_us}
         if bwd:  # informational: the backward is bound by the chip-wide memory-side atomic rate, not by HBM
             avg_b = sum(t for t, _ in bwd) / len(bwd)
             msda_bwd = {"kernel": "msda_bwd_d64 (f32 atomics)" if (args.fp32 or msda_op.F32_ACCUMULATE)
                         else "msda_bwd_d64_pk (packed-bf16 atomics, same-cell merges)", "launches": len(bwd), "avg_launch_us": avg_b * 1e6,
-                        "algorithmic_bytes_per_launch": int(bwd[0][1]), "achieved_GBps": bwd[0][1] / avg_b / 1e9}
-        # informational: the other hand-written hot-path kernels, timed the same way (HIP events around each launch).
-        # Window attention is VALU / issue bound (exp + softmax bookkeeping around 16x16x32 MFMAs on 32-wide heads), so
-        # its MFMA fraction is structurally low; the backward is 5 products + the recomputed softmax.
+                        "whole_map_bytes_per_launch": int(bwd[0][1])}
+        # window attention against its compulsory HBM bytes (memory-bound at 72 flop/B; the MFMA fraction is informational)
         window_attention = {}
-        for kind, name in (("fwd", "winattn_fwd"), ("bwd", "winattn_bwd")):
+        for kind, name, products, tensors in (("fwd", "winattn_fwd", 2, 4), ("bwd", "winattn_bwd", 5, 7)):
             ev = [(a.elapsed_time(b) * 1e-3, f) for k, a, b, f in wa_events if k == kind]
             if ev:
                 tt, ff = sum(t for t, _ in ev), sum(f for _, f in ev)
-                window_attention[name] = {"launches_per_step": len(ev) / args.steps, "ms_per_step": tt / args.steps * 1e3,
-                                          "avg_launch_us": tt / len(ev) * 1e6, "achieved_TFLOPs": ff / tt / 1e12,
-                                          "mfma_frac_bf16": ff / tt / MFMA_PEAK_BF16}
+                units = ff / (products * 2 * 144 * 144 * 32)             # (window, head) pairs over all launches
+                nbytes = units * tensors * 144 * 32 * 2
+                window_attention[name] = {"bound": "hbm", "kernel": name, "launches_per_step": len(ev) / args.steps,
+                                          "ms_per_step": tt / args.steps * 1e3, "avg_launch_us": tt / len(ev) * 1e6,
+                                          "algorithmic_bytes_per_step": int(nbytes / args.steps),
+                                          "algorithmic_bytes_basis": "%d bf16 [144, 32] slices per (window, head)" % tensors,
+                                          "achieved": nbytes / tt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                          "frac": nbytes / tt / 1e9 / HBM_PEAK_GBPS,
+                                          "achieved_TFLOPs": ff / tt / 1e12, "mfma_frac_bf16": ff / tt / MFMA_PEAK_BF16}
+        gemm = None
+        if gemm_events:
+            gemm = {"note": "GEMMs of the long token maps (Swin blocks, value / input projections), per-launch HIP events in "
+                            "2 extra steps after the timed region"}
+            for kind in ("gemm_lib", "gemm_own"):
+                ev = [(a.elapsed_time(b) * 1e-3, pl["flops"]) for k, a, b, pl in gemm_events if k == kind]
+                if ev:
+                    tt, ff = sum(t for t, _ in ev), sum(f for _, f in ev)
+                    gemm[kind] = {"launches_per_step": len(ev) / 2, "ms_per_step": tt / 2 * 1e3, "PFLOPs": ff / tt / 1e15,
+                                  "mfma_frac_bf16": ff / tt / MFMA_PEAK_BF16}
+            ev = [(a.elapsed_time(b) * 1e-3, pl["flops"]) for k, a, b, pl in gemm_events]
+            tt, ff = sum(t for t, _ in ev), sum(f for _, f in ev)
+            gemm["all"] = {"ms_per_step": tt / 2 * 1e3, "PFLOPs": ff / tt / 1e15, "mfma_frac_bf16": ff / tt / MFMA_PEAK_BF16}
         out = {
             "metric": _baseline_metric(),
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -243,15 +374,22 @@ def main():
                                    f"caption length {args.caption_len}, Adam x2, dropout on",
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                        "parallelism": f"dp{world}", "grad_allreduce": "RCCL bucketed (64 MiB flat bf16 buckets), overlapped with backward"
-                       if world > 1 else "none (1 GPU)"},
+                       if world > 1 else "none (1 GPU)",
+                       "points": args.points, "ragged": bool(args.ragged),
+                       "msda_backward_accumulation": "f32" if (args.fp32 or msda_op.F32_ACCUMULATE) else "bf16 (packed atomics)"},
             "mfma_roofline_frac_bf16": value / world * FLOP_PER_IMAGE_FWD_BWD / MFMA_PEAK_BF16,
             "final_loss": final_loss,
             "roofline": roof,
             "msda_backward": msda_bwd,
-            "window_attention": window_attention,
+            "roofline_winattn_bwd": window_attention.get("winattn_bwd"),
+            "roofline_winattn_fwd": window_attention.get("winattn_fwd"),
+            "gemm": gemm,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_analysis:
             del wrapped, optimizers, model
+            torch.cuda.empty_cache()
+            out["roofline_msda_spread"] = msda_spread_microbench(device)
+        if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(config, args.size, args.caption_len, args.cpu_steps)
         print(json.dumps(out), flush=True)

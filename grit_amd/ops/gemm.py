@@ -10,6 +10,7 @@ import os
 import torch
 
 from grit_amd import lib as _lib
+from grit_amd.ops.profiling import timed
 
 NONE, BIAS, BIAS_GELU, DGELU = 0, 1, 2, 3
 COLSUM_ROWS = 128
@@ -35,7 +36,7 @@ def gemm_nt(a, b, epilogue=NONE, bias=None, aux=None, colsum=None, out=None, var
     N = b.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
-    with _lib.device_guard(a.device):
+    with _lib.device_guard(a.device), timed("gemm_own", flops=2.0 * M * N * K, epilogue=epilogue):
         st = _lib.load().grit_gemm_bf16_nt(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0), M, N, K,
                                            epilogue, _ptr(bias), _ptr(aux), aux.stride(0) if aux is not None else 0,
                                            _ptr(colsum), VARIANT if variant is None else variant, _lib.current_stream_ptr())

@@ -14,6 +14,7 @@ from torch.autograd.function import once_differentiable
 from grit_amd import lib as _lib
 from grit_amd.ops import backend
 from grit_amd.ops.linear import slab_sum
+from grit_amd.ops.profiling import timed
 
 SUPPORTED_C = (128, 256, 512, 1024, 2048, 4096)
 LN_BWD_PARTIALS = 1024  # GRIT_LN_BWD_PARTIALS in include/grit_hip.h
@@ -153,7 +154,8 @@ class _LinearAddLayerNormFn(Function):
 
     @staticmethod
     def forward(ctx, inp, lin_w, lin_b, shortcut, scale, weight, bias, eps, drop_p, seed_dev):
-        branch = F.linear(inp, lin_w, lin_b)
+        with timed("gemm_lib", flops=2.0 * inp.numel() * lin_w.shape[0]):
+            branch = F.linear(inp, lin_w, lin_b)
         C = shortcut.shape[-1]
         s2 = shortcut.reshape(-1, C)
         s2 = s2 if s2.is_contiguous() else s2.contiguous()
@@ -186,7 +188,10 @@ class _LinearAddLayerNormFn(Function):
         inp2 = inp.reshape(-1, inp.shape[-1])
         if not inp2.is_contiguous():
             inp2 = inp2.contiguous()
-        d_inp = torch.mm(d_branch, lin_w).view(inp.shape) if ctx.needs_input_grad[0] else None
+        d_inp = None
+        if ctx.needs_input_grad[0]:
+            with timed("gemm_lib", flops=2.0 * d_branch.numel() * lin_w.shape[1]):
+                d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
         d_lin_w = weight_grad(d_branch, inp2) if ctx.needs_input_grad[1] else None
         return d_inp, d_lin_w, sums[2].to(lin_w.dtype), dx.view(ctx.shape), None, sums[0], sums[1], None, None, None
 

@@ -18,6 +18,7 @@ from torch.autograd.function import once_differentiable
 
 from grit_amd import lib as _lib
 from grit_amd.ops import backend
+from grit_amd.ops.profiling import timed
 
 MIN_ROWS = int(os.environ.get("GRIT_LINEAR_MIN_ROWS", "512"))  # below this the launch overhead dominates: leave it to torch
 
@@ -72,9 +73,10 @@ def weight_grad(dy2, x2):
     """dW [N, K] = dy2^T [N, M] @ x2 [M, K], split over M into one batched GEMM with fp32 partial sums."""
     M, N = dy2.shape
     S = split_k(M) if (dy2.is_cuda and dy2.dtype == torch.bfloat16) else 1
-    if S == 1:
-        return torch.mm(dy2.t(), x2)
-    part = torch.bmm(dy2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, x2.shape[1]), out_dtype=torch.float32)
+    with timed("gemm_lib", flops=2.0 * M * N * x2.shape[1]):
+        if S == 1:
+            return torch.mm(dy2.t(), x2)
+        part = torch.bmm(dy2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, x2.shape[1]), out_dtype=torch.float32)
     return slab_sum(part.unsqueeze(0), dy2.dtype)[0]
 
 
@@ -84,7 +86,8 @@ class _LinearFn(Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        with timed("gemm_lib", flops=2.0 * x.numel() * weight.shape[0]):
+            return F.linear(x, weight, bias)
 
     @staticmethod
     @once_differentiable
@@ -98,7 +101,8 @@ class _LinearFn(Function):
             x2 = x2.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(dy2, weight).view(x.shape)
+            with timed("gemm_lib", flops=2.0 * dy2.numel() * weight.shape[1]):
+                dx = torch.mm(dy2, weight).view(x.shape)
         if ctx.needs_input_grad[1]:
             dw = weight_grad(dy2, x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -117,7 +121,8 @@ class _SharedInputLinearsFn(Function):
         ctx.save_for_backward(x, *weights)
         ctx.n = n
         ctx.set_materialize_grads(False)  # an unused output arrives as None, not as a zero map to multiply
-        return tuple(F.linear(x, w, b) for w, b in zip(weights, biases))
+        with timed("gemm_lib", flops=2.0 * x.numel() * weights[0].shape[0] * n):
+            return tuple(F.linear(x, w, b) for w, b in zip(weights, biases))
 
     @staticmethod
     @once_differentiable
@@ -133,10 +138,11 @@ class _SharedInputLinearsFn(Function):
             dy2 = dys[l].reshape(-1, dys[l].shape[-1])
             dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
             if ctx.needs_input_grad[0]:
-                if dx2 is None:
-                    dx2 = torch.mm(dy2, weights[l])
-                else:
-                    dx2.addmm_(dy2, weights[l])
+                with timed("gemm_lib", flops=2.0 * dy2.numel() * weights[l].shape[1]):
+                    if dx2 is None:
+                        dx2 = torch.mm(dy2, weights[l])
+                    else:
+                        dx2.addmm_(dy2, weights[l])
             if ctx.needs_input_grad[2 + l]:
                 dws[l] = weight_grad(dy2, x2)
             if ctx.needs_input_grad[2 + n + l]:

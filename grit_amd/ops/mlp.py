@@ -21,6 +21,7 @@ from grit_amd.ops import backend
 from grit_amd.ops import gemm as G
 from grit_amd.ops import layer_norm as LN
 from grit_amd.ops.linear import column_sum, slab_sum, weight_grad
+from grit_amd.ops.profiling import timed
 
 MIN_ROWS = 2048
 
@@ -44,7 +45,8 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs):
         if need_b1:
             d_b1 = slab_sum(partial.unsqueeze(0), w1.dtype)[0]
         if need_x:
-            d_n2 = torch.mm(d_pre, w1)
+            with timed("gemm_lib", flops=2.0 * d_pre.numel() * w1.shape[1]):
+                d_n2 = torch.mm(d_pre, w1)
         if need_w1:
             d_w1 = weight_grad(d_pre, n2)
     return d_n2, d_w1, d_b1, d_w2
@@ -57,7 +59,8 @@ class _MlpFn(Function):
     def forward(ctx, x, w1, b1, w2, b2):
         x2 = _rows(x)
         pre, act = G.linear_bias_gelu(x2, w1, b1)
-        out = F.linear(act, w2, b2)
+        with timed("gemm_lib", flops=2.0 * act.numel() * w2.shape[0]):
+            out = F.linear(act, w2, b2)
         ctx.save_for_backward(x2, w1, pre, act, w2)
         ctx.shape = x.shape
         return out.view(x.shape[:-1] + (w2.shape[0],))
@@ -80,7 +83,8 @@ class _MlpAddLayerNormFn(Function):
     def forward(ctx, x_in, w1, b1, w2, b2, shortcut, scale, weight, bias, eps):
         x2 = _rows(x_in)
         pre, act = G.linear_bias_gelu(x2, w1, b1)
-        branch = F.linear(act, w2, b2)
+        with timed("gemm_lib", flops=2.0 * act.numel() * w2.shape[0]):
+            branch = F.linear(act, w2, b2)
         C = shortcut.shape[-1]
         s2 = _rows(shortcut)
         rows = s2.shape[0]

@@ -22,6 +22,13 @@ from grit_amd import lib as _lib
 # recorded on the launch stream right around the kernel, so the roofline figure is measured inside the real step
 PROFILE_EVENTS = None
 
+# bench.py --points spread: a callable loc -> loc that replaces the sampling locations right before the launch (diagnostic:
+# a randomly initialised decoder keeps every point near the image centre; a trained one spreads them -- SURVEY 8d config 2)
+LOC_OVERRIDE = None
+# bench.py sets this to have forward launches also record (loc, spatial_shapes, level_start_index, B, S, M, value element size),
+# from which the cache lines the gather touches are counted afterwards (unique_lines_touched)
+PROFILE_RECORD_GEOMETRY = False
+
 # GRIT_MSDA_BWD_F32ACC=1: bf16 maps keep an f32 staging map for grad_value (f32 atomics + one final rounding) instead of
 # accumulating in bf16 with packed atomics
 F32_ACCUMULATE = os.environ.get("GRIT_MSDA_BWD_F32ACC", "0") == "1"
@@ -44,10 +51,35 @@ def _algorithmic_bytes(kind, B, S, M, D, L, Lq, P, esize, geom_esize=None, grad_
     return esize * (B * S * M * D + B * Lq * M * D) + grad_esize * 2 * B * S * M * D + geom_esize * 2 * 3 * pts
 
 
+def unique_lines_touched(loc, shapes, lsi, S, M, line_pixels=1):
+    """Number of distinct (image, pixel, head) cells the bilinear gather of one forward launch reads: for D = 64 a cell is one
+    128-byte line of a bf16 map (two lines of an fp32 map).  Same in-range rule as the kernel
+    (ms_deform_im2col_cuda.cuh:288, 56-78): a point counts if -1 < h < H and -1 < w < W, a corner if it lies inside the map."""
+    B, Lq, _, L, P, _ = loc.shape
+    loc = loc.float()
+    keys = []
+    for l in range(L):
+        H, W = int(shapes[l, 0]), int(shapes[l, 1])
+        x = loc[:, :, :, l, :, 0] * W - 0.5
+        y = loc[:, :, :, l, :, 1] * H - 0.5
+        ok = (y > -1) & (x > -1) & (y < H) & (x < W)
+        x0, y0 = torch.floor(x).long(), torch.floor(y).long()
+        b = torch.arange(B, device=loc.device).view(B, 1, 1, 1)
+        m = torch.arange(M, device=loc.device).view(1, 1, M, 1)
+        for dy in (0, 1):
+            for dx in (0, 1):
+                xx, yy = x0 + dx, y0 + dy
+                inside = ok & (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+                cell = ((b * S + int(lsi[l]) + yy * W + xx) * M + m)
+                keys.append(cell[inside])
+    keys = torch.cat(keys)
+    return int(torch.unique(keys).numel()) if keys.numel() else 0
+
+
 class _Timed(object):
 
-    def __init__(self, kind, nbytes):
-        self.kind, self.nbytes = kind, nbytes
+    def __init__(self, kind, nbytes, geometry=None):
+        self.kind, self.nbytes, self.geometry = kind, nbytes, geometry
 
     def __enter__(self):
         self.on = PROFILE_EVENTS is not None and not torch.cuda.is_current_stream_capturing()
@@ -59,7 +91,7 @@ class _Timed(object):
     def __exit__(self, *exc):
         if self.on and PROFILE_EVENTS is not None:
             self.b.record()
-            PROFILE_EVENTS.append((self.kind, self.a, self.b, self.nbytes))
+            PROFILE_EVENTS.append((self.kind, self.a, self.b, self.nbytes, self.geometry if PROFILE_RECORD_GEOMETRY else None))
         return False
 
 
@@ -90,10 +122,13 @@ def _bf16_fast_path(value, D, L, P):
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
     B, S, M, D, L, Lq, P = _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    if LOC_OVERRIDE is not None:
+        sampling_loc = LOC_OVERRIDE(sampling_loc).to(sampling_loc.dtype).contiguous()
     if _bf16_fast_path(value, D, L, P):  # value map stays bf16: no fp32 staging copy
         loc, aw = sampling_loc.float(), attn_weight.float()
         out = torch.empty((B, Lq, M * D), dtype=torch.bfloat16, device=value.device)
-        with _lib.device_guard(value.device), _Timed("fwd_bf16", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, 2, 4)):
+        geometry = (loc, spatial_shapes, level_start_index, B, S, M, 2) if PROFILE_RECORD_GEOMETRY else None
+        with _lib.device_guard(value.device), _Timed("fwd_bf16", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, 2, 4), geometry):
             st = _lib.load().grit_msda_fwd_bf16(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc),
                                                 _ptr(aw), B, S, M, D, L, Lq, P, _ptr(out), _lib.current_stream_ptr())
         _lib.check(st, "grit_msda_fwd_bf16")
@@ -102,7 +137,8 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     v, loc, aw = value.to(cdt), sampling_loc.to(cdt), attn_weight.to(cdt)
     out = torch.empty((B, Lq, M * D), dtype=cdt, device=value.device)
     fn = _lib.load().grit_msda_fwd_f64 if cdt == torch.float64 else _lib.load().grit_msda_fwd_f32
-    with _lib.device_guard(value.device), _Timed("fwd", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, v.element_size())):
+    geometry = (loc, spatial_shapes, level_start_index, B, S, M, v.element_size()) if PROFILE_RECORD_GEOMETRY else None
+    with _lib.device_guard(value.device), _Timed("fwd", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, v.element_size()), geometry):
         st = fn(_ptr(v), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(aw),
                 B, S, M, D, L, Lq, P, _ptr(out), _lib.current_stream_ptr())
     _lib.check(st, "grit_msda_fwd")
@@ -176,8 +212,11 @@ class _StackedMSDAFn(Function):
         B, S, n, M, D = stacked.shape
         _, Lq, _, L, P, _ = loc.shape
         loc, aw = loc.float().contiguous(), aw.float().contiguous()
+        if LOC_OVERRIDE is not None:
+            loc = LOC_OVERRIDE(loc).float().contiguous()
         out = torch.empty((B, Lq, M * D), dtype=torch.bfloat16, device=stacked.device)
-        with _lib.device_guard(stacked.device), _Timed("fwd_bf16", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, 2, 4)):
+        geometry = (loc, shapes, lsi, B, S, M, 2) if PROFILE_RECORD_GEOMETRY else None
+        with _lib.device_guard(stacked.device), _Timed("fwd_bf16", _algorithmic_bytes("fwd", B, S, M, D, L, Lq, P, 2, 4), geometry):
             st = _lib.load().grit_msda_fwd_bf16_strided(maps.layer_ptr(stacked, layer), n * M * D, _ptr(shapes), _ptr(lsi),
                                                         _ptr(loc), _ptr(aw), B, S, M, D, L, Lq, P, _ptr(out),
                                                         _lib.current_stream_ptr())

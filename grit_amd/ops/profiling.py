@@ -1,0 +1,27 @@
+"""Per-launch HIP-event timing hook for bench.py's analysis steps (never active in the product path: EVENTS is None).
+
+`with timed("gemm_lib", flops=...)` records an event pair on the current stream around the enclosed launches and appends
+(kind, start, end, payload) to EVENTS.  An event pair costs ~5 us of marker latency, so the GEMM hooks (hundreds per step) are
+only switched on for a few extra steps AFTER the timed region."""
+import torch
+
+EVENTS = None
+
+
+class timed(object):
+
+    def __init__(self, kind, **payload):
+        self.kind, self.payload = kind, payload
+
+    def __enter__(self):
+        self.on = EVENTS is not None and not torch.cuda.is_current_stream_capturing()
+        if self.on:
+            self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on and EVENTS is not None:
+            self.b.record()
+            EVENTS.append((self.kind, self.a, self.b, self.payload))
+        return False

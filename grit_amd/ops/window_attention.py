@@ -47,6 +47,12 @@ class _Timed(object):
         return False
 
 
+def hbm_bytes(B, nWh, nWw, num_heads, N, tensors):
+    """Compulsory HBM bytes of a launch: `tensors` bf16 [N, head_dim] slices per (window, head) -- forward q, k, v, out (4);
+    backward q, k, v, dout, dq, dk, dv (7)."""
+    return tensors * N * HEAD_DIM * 2 * B * nWh * nWw * num_heads
+
+
 def _core_flops(B, nWh, nWw, num_heads, N, products):
     """2*N*N*head_dim flops per product per (window, head): forward QK^T + PV (2), backward S, dP, dV, dK, dQ (5)."""
     return products * 2 * N * N * HEAD_DIM * B * nWh * nWw * num_heads

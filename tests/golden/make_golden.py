@@ -495,5 +495,87 @@ def make_g11():
 MAKERS.update({'g10': make_g10, 'g11': make_g11})
 MAKERS.update({'keys': make_keys, 'g3': make_g3, 'g4': make_g4, 'g6': make_g6, 'g7': make_g7, 'g8': make_g8, 'g9': make_g9})
 
+
+def make_g12():
+    """DetectionModule (models/detection/det_module.py:135-213) row level: 6 deformable decoder layers with box refinement
+    (reference points are 4-d from the first layer on), ragged padding masks (valid ratios != 1, masked_fill of the value maps),
+    from STORED level maps -> hs (all 7) and the reference boxes.  Dropout 0, eval mode; sampling offsets are filled ~ N(0,1) so
+    the points leave the maps as well."""
+    import_reference()
+    from models.detection.det_module import build_det_module_with_config
+    cfg = _cfg(**{'model.detector.dropout': 0.0})
+    mod = build_det_module_with_config(cfg.model.detector)
+    _fill()(mod, 'g12.')
+    mod.eval()
+    g = torch.Generator().manual_seed(12)
+    B = 2
+    shapes = [(12, 10), (6, 5), (3, 3), (2, 2)]
+    valid = [[(12, 10), (6, 5), (3, 3), (2, 2)], [(9, 7), (5, 4), (3, 2), (2, 1)]]  # image 1 is smaller: padding on the right / bottom
+    srcs, masks = [], []
+    for l, (h, w) in enumerate(shapes):
+        src = torch.randn(B, 512, h, w, generator=g)
+        mask = torch.zeros(B, h, w, dtype=torch.bool)
+        for b in range(B):
+            vh, vw = valid[b][l]
+            mask[b, vh:, :] = True
+            mask[b, :, vw:] = True
+        srcs.append(src)
+        masks.append(mask)
+    with torch.no_grad():
+        hs, init_ref, inter_refs = mod(srcs, masks)
+    out = {'hs_first': hs[1].numpy(), 'hs_last': hs[-1].numpy(), 'init_ref': init_ref.numpy(), 'inter_refs': inter_refs.numpy()}
+    for l in range(4):
+        out['src%d' % l] = srcs[l].numpy()
+        out['mask%d' % l] = masks[l].numpy()
+    np.savez_compressed(os.path.join(HERE, 'det_g12.npz'), **out)
+    print('g12 hs', tuple(hs.shape), float(hs[-1].abs().mean()), 'refs', tuple(inter_refs.shape))
+
+
+MAKERS.update({'g12': make_g12})
+
+
+def make_g13():
+    """One self-critical step from CACHED features (reference train_sc with model.cached_features = True,
+    engine/caption_engine.py:421-443 + models/caption/transformer.py:138-142): the reference detector's outputs for the G9
+    images are stored, the decoder (grid net + caption generator) runs the beam search with gradient on them.  On any device
+    with fp32 decoder arithmetic the beams are the same, so loss and gradients can be asserted unconditionally."""
+    import json
+    import_reference()
+    from engine.utils import NestedTensor
+    model, cfg = _ref_model(3, **{'model.dropout': 0.0, 'model.detector.dropout': 0.0})
+    model.train()
+    g9 = np.load(os.path.join(HERE, 'sc_g9.npz'))
+    images = torch.from_numpy(g9['images'])
+    reward = torch.from_numpy(g9['reward'])
+    B, beam, T = images.shape[0], reward.shape[1], 6
+    with torch.no_grad():
+        vis = model.detector(NestedTensor(images, torch.zeros(B, 224, 224, dtype=torch.bool)))
+    feats = {k: v.clone() for k, v in vis.items()}
+    model.cached_features = True
+    outs, log_probs = model({k: v.clone() for k, v in feats.items()}, seq=None, use_beam_search=True, max_len=T, eos_idx=3,
+                            beam_size=beam, out_size=beam, return_probs=False)
+    baseline = torch.mean(reward, -1, keepdim=True)
+    loss = (-torch.mean(log_probs, -1) * (reward - baseline)).mean()
+    loss.backward()
+    norms = {}
+    for n, p in model.named_parameters():
+        if p.requires_grad and p.grad is not None:
+            top = n.split('.')[0]
+            norms[top] = norms.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+    norms = {k: v**0.5 for k, v in norms.items()}
+    sel = {}
+    for n in ('cap_generator.fc.weight', 'grid_net.fc.weight', 'cap_generator.layers.0.vis_att1.attention.fc_k.weight',
+              'cap_generator.layers.2.fc_alpha1.weight', 'grid_net.layers.2.pwff.fc2.bias'):
+        sel[n] = dict(model.named_parameters())[n].grad.flatten()[:64].numpy()
+    np.savez_compressed(os.path.join(HERE, 'sc_g13.npz'), reward=reward.numpy(), tokens=outs.numpy(),
+                        log_probs=log_probs.detach().numpy(), loss=np.array(loss.item()),
+                        **{'feat:' + k: v.numpy() for k, v in feats.items()}, **{'grad:' + k: v for k, v in sel.items()})
+    with open(os.path.join(HERE, 'sc_g13.json'), 'w') as f:
+        json.dump({'loss': loss.item(), 'grad_norms': norms}, f, indent=1)
+    print('g13 loss', loss.item(), 'tokens', outs.tolist(), norms)
+
+
+MAKERS.update({'g13': make_g13})
+
 if __name__ == "__main__":
     main()

@@ -164,16 +164,8 @@ def test_self_critical_step_on_hip_path_matches_reference():
     agree = (seen['tokens'].numpy() == g["tokens"]).mean()
     assert seen['tokens'].shape == (B, beam, T) and agree > 0.8, agree
     assert torch.isfinite(loss) and abs(reward.item() - g["reward"].mean()) < 1e-6
-    if agree == 1.0:  # same beams -> same objective: loss and gradient norms must match the reference
-        assert abs(loss.item() - ref["loss"]) < 5e-2 * abs(ref["loss"]) + 1e-5
-        params = dict(model.named_parameters())
-        norms = {}
-        for n, p in params.items():
-            if p.requires_grad and p.grad is not None:
-                top = '.'.join(n.split('.')[:2]) if n.startswith('detector') else n.split('.')[0]
-                norms[top] = norms.get(top, 0.0) + float(p.grad.double().pow(2).sum())
-        for k, v in ref["grad_norms"].items():
-            assert abs(norms[k]**0.5 - v) < 8e-2 * v, (k, norms[k]**0.5, v)
+    # loss and gradients of the self-critical objective are asserted UNCONDITIONALLY on the reference's cached features in
+    # tests/test_det_rows.py::test_self_critical_step_from_cached_features_on_hip_g13 (same beams by construction there)
 
 
 def test_caption_stream_pipelined_equals_sequential(g7_model):

@@ -32,6 +32,17 @@ def canvas_size(transform_cfg):
     raise ValueError(transform_cfg.resize_name)
 
 
+def grid_tokens(H, W):
+    """Tokens of the coarsest Swin map (gri_feat) for an H x W canvas: PatchEmbed pads to a multiple of 4, each of the four
+    PatchMerging steps pads odd sizes (ceil), models/common/swin_model.py:324-349, 482-499 -- 1333 -> 21, not 1333 // 64 = 20."""
+    def down(n):
+        n = -(-n // 4)
+        for _ in range(4):
+            n = (n + 1) // 2
+        return n
+    return down(H) * down(W)
+
+
 class ImageFolder(object):
     """Every image file under `root`, id = the number after the last underscore of the file name (COCO naming)."""
 
@@ -54,7 +65,7 @@ def extract_vis_features(detector, images, image_ids, config, out_path, device='
     detector = detector.eval()
     policy = get_transform(config.dataset.transform_cfg)['valid']
     H, W = canvas_size(config.dataset.transform_cfg)
-    tokens = (H // 64) * (W // 64)  # coarsest Swin map (stage -1)
+    tokens = grid_tokens(H, W)
     synced = dist.is_available() and dist.is_initialized() and world_size > 1
     det = config.model.detector
     queries, d_model = (det.num_queries, det.d_model) if config.model.use_reg_feat else (None, None)

@@ -39,7 +39,9 @@ class FlatAdam(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._owner = owner
         mine = {p for g in self.param_groups for p in g['params']}
+        self._mine = mine
         self._runs = owner._runs(mine)
+        self._layout_version = owner.ddp.layout_version
         self._t = 0
         self._step_tensor = torch.tensor(0.0)
         self._link_state()
@@ -78,9 +80,13 @@ class FlatAdam(torch.optim.Optimizer):
         lr, (b1, b2), eps, wd, amsgrad, maximize = next(iter(hyper))
         if wd != 0 or amsgrad or maximize:
             raise NotImplementedError("FlatAdam implements Adam with weight_decay = 0, amsgrad = False, maximize = False")
+        if self._layout_version != self._owner.ddp.layout_version:  # the live parameter set changed: parameters without a
+            self._runs = self._owner._runs(self._mine)                # gradient are not stepped (torch.optim.Adam skips them)
+            self._layout_version = self._owner.ddp.layout_version
         self._t += 1
         self._step_tensor.fill_(float(self._t))
         bc1, bc2s = 1.0 - b1 ** self._t, math.sqrt(1.0 - b2 ** self._t)
+        grad_scale = 1.0 / self._owner.ddp.world  # the buckets hold the SUM over ranks: the average is folded in here
         lib = _lib.load()
         for bucket, compute, master, mom, var, start, end in self._runs:
             n = end - start
@@ -89,7 +95,7 @@ class FlatAdam(torch.optim.Optimizer):
                     ctypes.c_void_p(master[start:].data_ptr()), ctypes.c_void_p(bucket.flat[start:].data_ptr()),
                     int(bucket.flat.dtype == torch.bfloat16), ctypes.c_void_p(mom[start:].data_ptr()),
                     ctypes.c_void_p(var[start:].data_ptr()), ctypes.c_void_p(compute[start:].data_ptr()), n, float(lr),
-                    float(b1), float(b2), float(eps), bc1, bc2s, 1.0, _lib.current_stream_ptr())
+                    float(b1), float(b2), float(eps), bc1, bc2s, grad_scale, _lib.current_stream_ptr())
             _lib.check(st, "grit_adam_flat")
         return None
 
@@ -104,13 +110,18 @@ class Bf16Compute(nn.Module):
             for p in module.parameters():  # rank 0's fp32 initialisation is THE model: masters must start from it
                 dist.broadcast(p.data, src=0, group=process_group)
         fp32 = {p: p.detach().clone().float() for p in module.parameters() if p.requires_grad}
+        # floating tensors that are not trained (frozen stages, buffers) keep an fp32 original for checkpoints: exporting the
+        # bf16 compute copy would round a frozen pretrained detector in every save
+        self._frozen_fp32 = {k: v.detach().clone() for k, v in module.state_dict().items()
+                             if v.is_floating_point() and v.dtype != torch.bfloat16
+                             and not (k in dict(module.named_parameters()) and dict(module.named_parameters())[k].requires_grad)}
         module.to(torch.bfloat16)  # parameters and floating buffers; integer buffers untouched
-        self.ddp = BucketedDataParallel(module, bucket_mb=bucket_mb, process_group=process_group, repack_unused=False,
-                                        broadcast_parameters=False, slot_align=SLOT_ALIGN)
-        self.module = module
         # flat Adam (grit_adam_flat) when the state lives on a GPU; on the CPU (gloo tests) torch's Adam steps the masters
         # from fp32 copies of the gradients and the compute weights are refreshed by a copy
         self.flat_optimizer = all(p.is_cuda for p in fp32) if flat_optimizer is None else flat_optimizer
+        self.ddp = BucketedDataParallel(module, bucket_mb=bucket_mb, process_group=process_group, repack_unused=False,
+                                        broadcast_parameters=False, slot_align=SLOT_ALIGN, average=not self.flat_optimizer)
+        self.module = module
         self._masters, self._pairs, self._moment_views, self._slots = [], [], {}, []
         for b in self.ddp.buckets:
             n = b.flat.numel()
@@ -134,8 +145,13 @@ class Bf16Compute(nn.Module):
                 compute_flat[off:off + k].view_as(p).copy_(m.data)
                 p.data = compute_flat[off:off + k].view_as(p)  # the module now computes on the flat bf16 copy
                 self._masters.append((names[p], m))
-                self._slots.append((m, len(self._pairs), off, off + -(-k // SLOT_ALIGN) * SLOT_ALIGN))
+                self._slots.append((m, len(self._pairs), off, off + -(-k // SLOT_ALIGN) * SLOT_ALIGN, p))
             self._pairs.append((b, compute_flat, master_flat, master_grad, mom, var))
+        self._master_of = {name: m for name, m in self._masters}
+        self._compute_of = {name: p for p, name in names.items()}
+        # `wrapped.module.load_state_dict(ckpt['state_dict'])` (reference train_caption.py:131-132, before every self-critical
+        # epoch) must reach the fp32 masters, not only the bf16 compute views the module's parameters are
+        module._register_load_state_dict_pre_hook(self._on_module_load)
 
     # ------------------------------------------------------------------ what the engine calls
     def forward(self, *args, **kwargs):
@@ -151,8 +167,9 @@ class Bf16Compute(nn.Module):
     def _runs(self, masters):
         """Maximal contiguous slot ranges of each bucket whose parameters all belong to `masters`."""
         runs, cur = [], None
-        for m, bi, start, end in self._slots:
-            if m in masters:
+        dead = self.ddp._dead
+        for m, bi, start, end, p in self._slots:
+            if m in masters and p not in dead:
                 if cur is not None and cur[0] == bi and cur[2] == start:
                     cur[2] = end
                 else:
@@ -175,6 +192,13 @@ class Bf16Compute(nn.Module):
         if not self.flat_optimizer:
             for b, _, _, master_grad, _, _ in self._pairs:
                 master_grad.copy_(b.flat)  # bf16 -> fp32, one kernel per bucket
+            # torch.optim.Adam skips parameters whose .grad is None: parameters outside the live set must not be stepped
+            dead = self.ddp._dead
+            for m, bi, start, end, p in self._slots:
+                if p in dead:
+                    m.grad = None
+                elif m.grad is None:
+                    m.grad = self._pairs[bi][3][start:start + m.numel()].view_as(m)
 
     def after_optimizer_step(self):
         if not self.flat_optimizer:
@@ -182,11 +206,35 @@ class Bf16Compute(nn.Module):
                 compute_flat.copy_(master_flat)  # fp32 -> bf16
 
     def master_state_dict(self):
-        """fp32 state dict under the reference's key names (masters for trainable tensors, upcast copies otherwise)."""
+        """fp32 state dict under the reference's key names: masters for trainable tensors, the kept fp32 originals for frozen
+        ones, upcast copies for floating buffers that only exist in bf16 (beam caches)."""
         sd = {k: (v.float() if v.is_floating_point() else v).clone() for k, v in self.module.state_dict().items()}
+        for name, v in self._frozen_fp32.items():
+            if name in sd and sd[name].shape == v.shape:
+                sd[name] = v.detach().clone()
         for name, m in self._masters:
             sd[name] = m.detach().clone()
         return sd
+
+    def _on_module_load(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Pre-hook of module.load_state_dict (root call only): incoming values go to the fp32 masters / frozen originals in
+        full precision; the regular load then writes the same values, rounded, into the bf16 compute views."""
+        if prefix != '':
+            return
+        with torch.no_grad():
+            for name, m in self._masters:
+                v = state_dict.get(name)
+                if v is not None and v.shape == m.shape:
+                    m.data.copy_(v)
+            for name in list(self._frozen_fp32):
+                v = state_dict.get(name)
+                if v is not None and v.shape == self._frozen_fp32[name].shape:
+                    self._frozen_fp32[name] = v.detach().to(self._frozen_fp32[name].device, torch.float32).clone()
+
+    def load_master_state_dict(self, state_dict, strict=True):
+        """Load a checkpoint made by master_state_dict() / the reference (key 'state_dict'): masters in fp32, compute copies
+        refreshed from them.  Optimizer moments are not touched (load the optimizers' own state dicts for a resume)."""
+        return self.module.load_state_dict(state_dict, strict=strict)
 
     @property
     def unused_parameters(self):

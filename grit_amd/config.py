@@ -36,7 +36,7 @@ _DEFAULTS = {
     'exp': dict(seed=42, name='eval', rank=0, ngpus_per_node=8, world_size=8, checkpoint='', eval=False, resume=False),
     'dataset': dict(overfit=False, ann_root='', img_root='', hdf5_path='', vocab_path='',
                     use_gri_feat=True, use_reg_feat=True,
-                    transform_cfg=dict(size=[384, 640], resize_name='maxwh', randaug=True)),
+                    transform_cfg=dict(size=[384, 640], resize_name='maxwh', randaug=False)),  # reference yaml: randaug true (host-side PIL, not provided)
     'model': dict(
         use_gri_feat=True, use_reg_feat=True, grid_feat_dim=1024, frozen_stages=2, beam_size=5, beam_len=20,
         dropout=0.2, attn_dropout=0.2, vocab_size=10201, max_len=54, pad_idx=1, bos_idx=2, eos_idx=3, d_model=512,

@@ -8,12 +8,17 @@ from grit_amd.utils.misc import NestedTensor
 
 from .utils import Deferred, FixedResize, MaxWHResize, MinMaxResize
 
-RESIZE = {'normal': FixedResize, 'minmax': MinMaxResize, 'maxwh': MaxWHResize}
+RESIZE = {'minmax': MinMaxResize, 'maxwh': MaxWHResize}
 
 
 def get_transform(cfg):
     if getattr(cfg, 'randaug', False):
-        raise NotImplementedError("RandAugment is host-side PIL augmentation; not provided by the device pipeline")
+        raise NotImplementedError("RandAugment is host-side PIL augmentation; not provided by the device pipeline "
+                                  "(grit_amd.config.default_config sets transform_cfg.randaug = False for that reason)")
+    if cfg.resize_name == 'normal':
+        # the reference's 'normal' policy is torchvision Resize = PIL BILINEAR; the device resampler implements Pillow's
+        # BICUBIC taps only, and silently resampling with another filter would change the input pixels
+        raise NotImplementedError("resize_name='normal' (bilinear torchvision Resize) is not provided; use 'maxwh' or 'minmax'")
     resize = RESIZE[cfg.resize_name](cfg.size)
     return {'train': resize, 'valid': resize}
 

@@ -12,16 +12,27 @@ broadcast_buffers=False) and lets NCCL's ring all-reduce 25 MB buckets.  This is
   * buckets are filled in reverse registration order (~ reverse of forward = the order backward produces
     gradients); a post-accumulate-grad hook counts arrivals and, when a bucket is complete, launches
     `all_reduce(flat, async_op=True)` -- on the `nccl` (= RCCL) backend that runs on the process group's
-    own HIP stream, ordered after the producing kernels by an event, i.e. it overlaps the rest of backward;
-  * the set of parameters that never receive a gradient is static in GRIT (fc_alpha2, dead
-    Swin norms, class/bbox heads behind .detach(), ...).  It is discovered in the first iteration and
-    then excluded, instead of torch DDP's per-iteration graph walk for find_unused_parameters=True;
+    own HIP stream, ordered after the producing kernels by an event, i.e. it overlaps the rest of backward.
+    The LAST bucket (the parameters whose gradients arrive last: nothing is left to overlap it with) is kept
+    small (`tail_mb`, default 8 MiB), so the exposed part of the reduction is a small collective;
+  * the set of parameters that receive no gradient is static in GRIT most of the time (fc_alpha2, dead
+    Swin norms, class/bbox heads behind .detach(), ...) but it does change between phases of the reference's recipe
+    (cached-feature epochs with the detector unused, then `model.module.cached_features = False`,
+    train_caption.py:105-107).  The ranks agree on which parameters received a gradient anywhere (one tiny
+    all-reduce of a flag vector: when the live set is first decided and whenever a rank sees a change; every step
+    with agree_every_step=True); a bucket waits only for the parameters of the current *live* set, a gradient that
+    arrives for a parameter outside it (or after its bucket was sent) is reduced separately in that one step, and
+    the live set -- bucket completion counts, or the bucket layout itself -- is rebuilt whenever the agreed set
+    changes.  This replaces torch DDP's per-iteration graph walk for find_unused_parameters=True and cannot
+    silently drop or corrupt a gradient;
+  * slots of live parameters that got no gradient in a step are zeroed, so an optimizer that steps whole flat
+    runs never sees the previous step's values;
   * optional bf16 transport halves the bytes on the wire (sum in bf16 over <= 8 ranks, master grads fp32);
   * buffers are never broadcast (the beam-search caches are registered buffers; reference passes
     broadcast_buffers=False for the same reason).  Parameters are broadcast from rank 0 once.
 
 `finish_gradient_sync()` must be called after loss.backward() and before optimizer.step(); the engine's
-train_xe_step does it.  Works on any backend (tests run it on gloo, world_size 2, CPU).
+train_xe_step does it.  Works on any backend (tests run it on gloo, world_size 2 and 4, CPU).
 """
 import torch
 import torch.distributed as dist
@@ -43,29 +54,42 @@ class _Bucket(object):
 class BucketedDataParallel(nn.Module):
 
     def __init__(self, module, bucket_mb=64, process_group=None, wire_dtype=None, broadcast_parameters=True,
-                 repack_unused=True, slot_align=1):
+                 repack_unused=True, slot_align=1, tail_mb=8, average=True, agree_every_step=False):
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.bucket_bytes = int(bucket_mb * 2**20)
+        self.tail_bytes = int(min(tail_mb, bucket_mb) * 2**20)
         self.wire_dtype = wire_dtype
         self.repack_unused = repack_unused  # False: keep the bucket layout (others hold views into it)
         self.slot_align = slot_align  # every parameter's slot in a flat buffer starts at a multiple of this many elements
-        self._seen = set()
-        self._static_unused = None  # decided after the first iteration
+        # average=False: the 1/world factor is left to the optimizer (FlatAdam folds it into its gradient scale)
+        self.average = average
+        # The used-parameter flags are all-reduced when the live set is first decided and whenever THIS rank sees a change
+        # (a late gradient, a different used set).  That assumes what GRIT guarantees -- the graph does not depend on the
+        # data, so every rank sees the change in the same step.  agree_every_step=True reduces the flags in every step
+        # (safe for data-dependent graphs; costs a host read of the flags per step).
+        self.agree_every_step = agree_every_step
+        self._dead = set()        # agreed: parameters outside the live set (no gradient anywhere in the last step)
+        self._used_now = set()    # parameters whose hook fired in the current backward pass
+        self._late = set()        # ... and whose gradient is not part of a bucket reduction of this step
+        self._decided = False     # the live set has been agreed at least once
+        self.layout_version = 0   # bumped whenever the live set changes (FlatAdam re-derives its runs)
         self._iteration = 0
         if self.world > 1 and broadcast_parameters:
             for p in module.parameters():
                 dist.broadcast(p.data, src=0, group=process_group)
-        trainable = [p for p in module.parameters() if p.requires_grad]
-        self._build_buckets(trainable)
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in trainable]
+        self._params = [p for p in module.parameters() if p.requires_grad]
+        self._index = {p: i for i, p in enumerate(self._params)}
+        self._build_buckets(self._params)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self._params]
 
     # ------------------------------------------------------------------ bucket layout
     def _build_buckets(self, params):
-        """Reverse registration order; params are grouped by (device, dtype) and packed up to bucket_bytes."""
-        self.buckets, self._where = [], {}
+        """Reverse registration order; params are grouped by (device, dtype) and packed up to bucket_bytes; the last
+        group (gradients that arrive last) is cut down to tail_bytes."""
+        self.buckets, self._where, self._view_of = [], {}, {}
         cur, cur_bytes, key = [], 0, None
         groups = []
         for p in reversed(params):
@@ -79,6 +103,16 @@ class BucketedDataParallel(nn.Module):
             cur_bytes += nbytes
         if cur:
             groups.append(cur)
+        if groups and len(groups[-1]) > 1:
+            last, tail, tail_bytes = groups[-1], [], 0
+            while len(last) > 1 and tail_bytes + last[-1].numel() * last[-1].element_size() <= self.tail_bytes:
+                p = last.pop()
+                tail.insert(0, p)
+                tail_bytes += p.numel() * p.element_size()
+            if tail and last:
+                groups.append(tail)
+            elif tail:
+                groups[-1] = tail
         al = self.slot_align
         for plist in groups:
             total = sum(-(-p.numel() // al) * al for p in plist)
@@ -92,33 +126,46 @@ class BucketedDataParallel(nn.Module):
                 views.append(view)
                 off += -(-p.numel() // al) * al  # padding stays zero: it is reduced and optimised as zeros
             b = _Bucket(plist, views, flat)
-            for p in plist:
+            for p, view in zip(plist, views):
                 self._where[p] = b
+                self._view_of[p] = view
             self.buckets.append(b)
+        self._refresh_expected()
+
+    def _refresh_expected(self):
+        for b in self.buckets:
+            b.expected = b.pending = sum(1 for p in b.params if p not in self._dead)
 
     # ------------------------------------------------------------------ backward-time hooks
     def _on_grad(self, param):
+        self._used_now.add(param)
         b = self._where.get(param)
-        if b is None:
+        if b is None or param in self._dead or b.packed:
+            # outside the live set, or its bucket has already been sent: reduced on its own in finish_gradient_sync
+            self._late.add(param)
             return
-        if self._static_unused is None:
-            self._seen.add(param)
         b.pending -= 1
         if b.pending == 0:
             self._pack(b)
             self._launch(b)
 
     def _pack(self, b):
-        """Gradients of the bucket -> flat buffer with one multi-tensor copy; .grad becomes the view."""
+        """Gradients of the bucket -> flat buffer with one multi-tensor copy; .grad becomes the view.  Slots of live
+        parameters without a gradient are zeroed (the flat buffer still holds the previous step's values there)."""
         if b.packed:
             return
-        src, dst = [], []
+        src, dst, stale = [], [], []
         for p, view in zip(b.params, b.views):
-            if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+            if p.grad is None:
+                if p not in self._dead:
+                    stale.append(view)
+            elif p.grad.data_ptr() != view.data_ptr():
                 src.append(p.grad)
                 dst.append(view)
         if src:
             torch._foreach_copy_(dst, src)
+        if stale:
+            torch._foreach_zero_(stale)
         for p, view in zip(b.params, b.views):
             if p.grad is not None:
                 p.grad = view
@@ -134,38 +181,81 @@ class BucketedDataParallel(nn.Module):
             b.work = dist.all_reduce(b.flat, group=self.group, async_op=True)
 
     def finish_gradient_sync(self):
-        """Launch what is still pending (first iteration / unused params), wait, average."""
+        """Launch what is still pending, agree on the used / late parameters, wait, reduce late gradients, average,
+        and re-derive the live set if it changed."""
         for b in self.buckets:
-            if b.work is None:
+            if b.expected == 0 and self._decided:
+                continue  # every parameter of the bucket is outside the live set (agreed by all ranks): nothing to send
+            if not b.packed:
                 self._pack(b)
+            if b.work is None:
                 self._launch(b)
+        # one flag per trainable parameter: bit 0 = received a gradient on this rank, bit 1 = not covered by a bucket
+        flags = [0] * len(self._params)
+        for p in self._used_now:
+            flags[self._index[p]] = 1
+        for p in self._late:
+            flags[self._index[p]] = 3
+        local_dead = {p for i, p in enumerate(self._params) if not flags[i] & 1}
+        flag_work = flag_t = None
+        if self.world > 1 and (self.agree_every_step or not self._decided or self._late or local_dead != self._dead):
+            flag_t = torch.tensor(flags, dtype=torch.int32, device=self._params[0].device)
+            flag_work = dist.all_reduce(flag_t, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
                 if b.wire is not None:
                     b.flat.copy_(b.wire)
                     b.wire = None
-                b.flat.mul_(1.0 / self.world)
                 b.work = None
-            b.pending = b.expected
-        if self._static_unused is None:
-            # freeze the unused set and re-pack the buckets without those parameters
-            used = [p for p in self.module.parameters() if p.requires_grad and p in self._seen]
-            unused = [p for p in self.module.parameters() if p.requires_grad and p not in self._seen]
-            self._static_unused = unused
-            if unused and self.repack_unused:
-                for p in unused:
-                    p.grad = None
-                self._build_buckets(used)
-            elif unused:  # keep the layout, but a bucket is complete once its *used* parameters have arrived
-                dead = set(unused)
-                for b in self.buckets:
-                    b.expected = b.pending = sum(1 for p in b.params if p not in dead)
+        if flag_work is not None:
+            flag_work.wait()
+            flags = flag_t.cpu().tolist()
+        # gradients outside the bucket reductions of this step (a phase change of the model, first-step surprises): the
+        # agreed list in index order, so every rank issues the same collectives.  What a slot already holds after the bucket
+        # reduction (the contributions of the ranks that had the gradient in the bucket; zeros from the others: stale and
+        # dead slots are kept zero) + the sum of the late local gradients = the full sum.
+        scale = 1.0 / self.world
+        for i, f in enumerate(flags):
+            if not f & 2:
+                continue
+            p = self._params[i]
+            view = self._view_of.get(p)
+            in_bucket = view is not None and p.grad is not None and p.grad.data_ptr() == view.data_ptr()
+            g = torch.zeros_like(p) if (p.grad is None or in_bucket) else p.grad
+            if self.world > 1:
+                dist.all_reduce(g, group=self.group)
+            if view is not None:
+                view.add_(g)
+                p.grad = view
+            else:
+                p.grad = g.mul_(scale) if (self.average and self.world > 1) else g
+        if self.average and self.world > 1:
+            for b in self.buckets:
+                b.flat.mul_(scale)
+        # live set = parameters that received a gradient on some rank in this step
+        dead = {p for i, p in enumerate(self._params) if not flags[i] & 1}
+        if dead != self._dead or not self._decided:
+            changed = dead != self._dead
+            self._dead = dead
+            self._decided = True
+            if changed:
+                if self.repack_unused:
+                    for p in dead:
+                        p.grad = None
+                    self._build_buckets([p for p in self._params if p not in dead])
+                else:
+                    for b in self.buckets:
+                        stale = [v for p, v in zip(b.params, b.views) if p in dead and p.grad is None]
+                        if stale:
+                            torch._foreach_zero_(stale)
+                self.layout_version += 1
+        self._refresh_expected()
         self._iteration += 1
 
     @property
     def unused_parameters(self):
-        return list(self._static_unused or [])
+        return [p for p in self._params if p in self._dead]
 
     def forward(self, *args, **kwargs):
         self.release_gradients()
@@ -174,10 +264,13 @@ class BucketedDataParallel(nn.Module):
     def release_gradients(self):
         """Start of a step: .grad = None everywhere, so backward assigns instead of accumulating (no add kernels).
         (Gradient accumulation over several backward passes is therefore not supported by this wrapper.)"""
+        self._used_now.clear()
+        self._late.clear()
+        for p in self._params:
+            p.grad = None
         for b in self.buckets:
             b.packed = False
-            for p in b.params:
-                p.grad = None
+            b.pending = b.expected
 
     def gradient_bytes(self):
         return sum(b.flat.numel() * b.flat.element_size() for b in self.buckets)

@@ -77,6 +77,15 @@ def caption_stream(model, batches, config, beam_size=None):
 
     pending = None
     for samples in batches:
+        # `batches` may produce its items lazily on the caller's stream (device collator kernels, pinned-memory uploads):
+        # order the detector after whatever has been enqueued there so far, and keep the batch's memory from being reused by
+        # the caller-side allocator while the detector stream still reads it
+        fetched = torch.cuda.Event()
+        fetched.record(caller)
+        det_stream.wait_event(fetched)
+        for tns in (getattr(samples, 'tensors', None), getattr(samples, 'mask', None)):
+            if isinstance(tns, torch.Tensor) and tns.is_cuda:
+                tns.record_stream(det_stream)
         with torch.cuda.stream(det_stream):
             vis = dict(model.detector(samples))
             ready = torch.cuda.Event()

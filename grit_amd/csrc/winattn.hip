@@ -535,6 +535,177 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fp32 arithmetic (the parity path: fp32 weights -> the reference's fp32 WindowAttention within 1e-4, swin_model.py:155-186)
+// ---------------------------------------------------------------------------------------------------
+// Plain fmaf chains, no matrix cores: one workgroup per (window, head), thread = query row (forward, dQ) or key row
+// (dK, dV, d(bias)); K / V / Q / dO rows in LDS and read as broadcasts.  Not a throughput path: it runs when the model is
+// evaluated or trained in fp32 (tests, config 1 on the device, the --fp32 diagnostic of bench.py).
+constexpr int kFP = 33;          // fp32 row pitch (floats): odd -> the per-thread row reads of the backward are conflict-free
+constexpr int kF32Threads = 192;
+
+__device__ __forceinline__ float logit_f32(const float* __restrict__ qrow, const float* __restrict__ krow, float scale,
+                                           float bias, float maskv) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < kHd; ++d) s = fmaf(qrow[d] * scale, krow[d], s);  // (q * scale) @ k^T, as the reference orders it
+    return s + bias + maskv;
+}
+
+__global__ __launch_bounds__(kF32Threads)
+void winattn_fwd_f32(const float* __restrict__ qkv, const float* __restrict__ rel_bias, const float* __restrict__ pad_qkv,
+                     const float* __restrict__ mask, Geom g, float* __restrict__ out, float* __restrict__ lse) {
+    __shared__ float Ks[kN * kFP], Vs[kN * kFP];
+    __shared__ uint8_t rid[kN];
+    const int unit = blockIdx.x, win = unit / g.nH, h = unit - win * g.nH;
+    const int b = win / (g.nWh * g.nWw), wrem = win - b * (g.nWh * g.nWw);
+    const int wy = wrem / g.nWw, wx = wrem - wy * g.nWw;
+    const size_t img = (size_t)b * g.T;
+    const int C3 = 3 * g.C, hoff = h * kHd, t = threadIdx.x;
+    int reg = 0, tq = -1;
+    float q[kHd];
+    if (t < kN) {
+        tq = token_of(t, wy, wx, g, reg);
+        const float* src = tq >= 0 ? qkv + (img + tq) * C3 + hoff : pad_qkv + hoff;
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) {
+            q[d] = src[d];
+            Ks[t * kFP + d] = src[g.C + d];
+            Vs[t * kFP + d] = src[2 * g.C + d];
+        }
+        rid[t] = (uint8_t)reg;
+    }
+    __syncthreads();
+    if (t >= kN) return;
+    const bool analytic = (mask == nullptr) && g.shift > 0;
+    const float* brow = rel_bias + ((size_t)h * kN + t) * kN;
+    const float* mrow = mask ? mask + ((size_t)(win % g.nWm) * kN + t) * kN : nullptr;
+    // two passes over the keys: row maximum first, then exp / sum / PV (the logits are recomputed: 144 x 32 fmaf)
+    float m = -INFINITY;
+    for (int k = 0; k < kN; ++k) {
+        const float mv = mrow ? mrow[k] : (analytic && rid[k] != reg ? -100.0f : 0.0f);
+        m = fmaxf(m, logit_f32(q, &Ks[k * kFP], g.scale, brow[k], mv));
+    }
+    float o[kHd], sum = 0.f;
+#pragma unroll
+    for (int d = 0; d < kHd; ++d) o[d] = 0.f;
+    for (int k = 0; k < kN; ++k) {
+        const float mv = mrow ? mrow[k] : (analytic && rid[k] != reg ? -100.0f : 0.0f);
+        const float p = expf(logit_f32(q, &Ks[k * kFP], g.scale, brow[k], mv) - m);
+        sum += p;
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) o[d] = fmaf(p, Vs[k * kFP + d], o[d]);
+    }
+    const float inv = 1.0f / sum;
+    if (tq >= 0) {
+        float* orow = out + (img + tq) * g.C + hoff;
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) orow[d] = o[d] * inv;
+    }
+    lse[((size_t)win * g.nH + h) * kN + t] = m + logf(sum);  // natural log
+}
+
+__global__ __launch_bounds__(kF32Threads)
+void winattn_bwd_f32(const float* __restrict__ qkv, const float* __restrict__ rel_bias, const float* __restrict__ pad_qkv,
+                     const float* __restrict__ mask, Geom g, const float* __restrict__ out, const float* __restrict__ dout,
+                     const float* __restrict__ lse, float* __restrict__ dqkv, float* __restrict__ dbias,
+                     float* __restrict__ dpad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // 77.5 KB: above the static limit
+    float* Qs = reinterpret_cast<float*>(smem_raw);
+    float* Ks = Qs + kN * kFP;
+    float* Vs = Ks + kN * kFP;
+    float* dOs = Vs + kN * kFP;
+    float* lse_s = dOs + kN * kFP;
+    float* delta_s = lse_s + kN;
+    uint8_t* rid = reinterpret_cast<uint8_t*>(delta_s + kN);
+    const int unit = blockIdx.x, win = unit / g.nH, h = unit - win * g.nH;
+    const int b = win / (g.nWh * g.nWw), wrem = win - b * (g.nWh * g.nWw);
+    const int wy = wrem / g.nWw, wx = wrem - wy * g.nWw;
+    const size_t img = (size_t)b * g.T;
+    const int C3 = 3 * g.C, hoff = h * kHd, t = threadIdx.x;
+    int reg = 0, tk = -1;
+    if (t < kN) {
+        tk = token_of(t, wy, wx, g, reg);
+        const float* src = tk >= 0 ? qkv + (img + tk) * C3 + hoff : pad_qkv + hoff;
+        float delta = 0.f;
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) {
+            Qs[t * kFP + d] = src[d];
+            Ks[t * kFP + d] = src[g.C + d];
+            Vs[t * kFP + d] = src[2 * g.C + d];
+            const float go = tk >= 0 ? dout[(img + tk) * g.C + hoff + d] : 0.f;  // cropped rows get no gradient
+            const float oo = tk >= 0 ? out[(img + tk) * g.C + hoff + d] : 0.f;
+            dOs[t * kFP + d] = go;
+            delta = fmaf(go, oo, delta);
+        }
+        rid[t] = (uint8_t)reg;
+        lse_s[t] = lse[((size_t)win * g.nH + h) * kN + t];
+        delta_s[t] = delta;
+    }
+    __syncthreads();
+    if (t >= kN) return;
+    const bool analytic = (mask == nullptr) && g.shift > 0;
+    const float* mbase = mask ? mask + (size_t)(win % g.nWm) * kN * kN : nullptr;
+    // ---- thread = query t: dQ
+    {
+        float dq[kHd];
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) dq[d] = 0.f;
+        const float* brow = rel_bias + ((size_t)h * kN + t) * kN;
+        for (int k = 0; k < kN; ++k) {
+            const float mv = mbase ? mbase[t * kN + k] : (analytic && rid[k] != reg ? -100.0f : 0.0f);
+            const float p = expf(logit_f32(&Qs[t * kFP], &Ks[k * kFP], g.scale, brow[k], mv) - lse_s[t]);
+            float dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) dp = fmaf(dOs[t * kFP + d], Vs[k * kFP + d], dp);
+            const float ds = p * (dp - delta_s[t]);
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) dq[d] = fmaf(ds, Ks[k * kFP + d], dq[d]);
+        }
+        if (tk >= 0) {
+            float* base = dqkv + (img + tk) * C3 + hoff;
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) base[d] = dq[d] * g.scale;
+        } else {
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) atomicAdd(&dpad[hoff + d], dq[d] * g.scale);
+        }
+    }
+    // ---- thread = key t: dK, dV, d(bias)[:, t]
+    {
+        float dk[kHd], dv[kHd];
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) dk[d] = dv[d] = 0.f;
+        for (int qi = 0; qi < kN; ++qi) {
+            const float mv = mbase ? mbase[qi * kN + t] : (analytic && (int)rid[qi] != reg ? -100.0f : 0.0f);
+            const float bias = rel_bias[((size_t)h * kN + qi) * kN + t];
+            const float p = expf(logit_f32(&Qs[qi * kFP], &Ks[t * kFP], g.scale, bias, mv) - lse_s[qi]);
+            float dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) dp = fmaf(dOs[qi * kFP + d], Vs[t * kFP + d], dp);
+            const float ds = p * (dp - delta_s[qi]);
+            if (ds != 0.f) atomicAdd(&dbias[((size_t)h * kN + qi) * kN + t], ds);
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) {
+                dk[d] = fmaf(ds, Qs[qi * kFP + d], dk[d]);
+                dv[d] = fmaf(p, dOs[qi * kFP + d], dv[d]);
+            }
+        }
+        if (tk >= 0) {
+            float* base = dqkv + (img + tk) * C3 + hoff;
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) { base[g.C + d] = dk[d] * g.scale; base[2 * g.C + d] = dv[d]; }
+        } else {
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) {
+                atomicAdd(&dpad[g.C + hoff + d], dk[d] * g.scale);
+                atomicAdd(&dpad[2 * g.C + hoff + d], dv[d]);
+            }
+        }
+    }
+}
+
+constexpr size_t kBwdF32Lds = (size_t)4 * kN * kFP * 4 + 2 * kN * 4 + kN;
 constexpr size_t kBwdLds = (size_t)kN * kBP * 4 + 3 * (size_t)kN * kTP * 2 + (size_t)kN * kSP * 2 + 2 * kN * 4 + 3 * kHd * 4 + kN;
 
 int check_geom(int B, int H, int W, int C, int nH, int window, int shift) {
@@ -615,6 +786,42 @@ int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pa
         hipLaunchKernelGGL(winattn_bwd<false>, dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdLds, (hipStream_t)stream,
                            (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
                            (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+int grit_winattn_fwd_f32(const float* qkv, const float* rel_bias, const float* pad_qkv, const float* mask, int n_mask_windows,
+                         int B, int H, int W, int C, int num_heads, int window, int shift, float scale,
+                         float* out, float* lse, void* stream) {
+    if (!qkv || !rel_bias || !pad_qkv || !out || !lse) return GRIT_ERR_BAD_ARG;
+    const int st = check_geom(B, H, W, C, num_heads, window, shift);
+    if (st != GRIT_OK) return st;
+    if (mask && n_mask_windows <= 0) return GRIT_ERR_BAD_ARG;
+    const Geom g = make_geom(B, H, W, C, num_heads, shift, scale, n_mask_windows);
+    const long long units = (long long)B * g.nWh * g.nWw * num_heads;
+    if (units > 0x7fffffffLL) return GRIT_ERR_BAD_ARG;
+    hipLaunchKernelGGL(winattn_fwd_f32, dim3((unsigned)units), dim3(kF32Threads), 0, (hipStream_t)stream, qkv, rel_bias, pad_qkv,
+                       mask, g, out, lse);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+int grit_winattn_bwd_f32(const float* qkv, const float* rel_bias, const float* pad_qkv, const float* mask, int n_mask_windows,
+                         const float* out, const float* dout, const float* lse, int B, int H, int W, int C, int num_heads,
+                         int window, int shift, float scale, float* dqkv, float* drel_bias, float* dpad, void* stream) {
+    if (!qkv || !rel_bias || !pad_qkv || !out || !dout || !lse || !dqkv || !drel_bias || !dpad) return GRIT_ERR_BAD_ARG;
+    const int st = check_geom(B, H, W, C, num_heads, window, shift);
+    if (st != GRIT_OK) return st;
+    if (mask && n_mask_windows <= 0) return GRIT_ERR_BAD_ARG;
+    const Geom g = make_geom(B, H, W, C, num_heads, shift, scale, n_mask_windows);
+    const long long units = (long long)B * g.nWh * g.nWw * num_heads;
+    if (units > 0x7fffffffLL) return GRIT_ERR_BAD_ARG;
+    static bool f32_attr_set = false;  // idempotent attribute, racing first calls set the same value
+    if (!f32_attr_set) {
+        if (hipFuncSetAttribute((const void*)winattn_bwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdF32Lds) != hipSuccess)
+            return GRIT_ERR_LAUNCH;
+        f32_attr_set = true;
+    }
+    hipLaunchKernelGGL(winattn_bwd_f32, dim3((unsigned)units), dim3(kF32Threads), kBwdF32Lds, (hipStream_t)stream, qkv, rel_bias,
+                       pad_qkv, mask, g, out, dout, lse, dqkv, drel_bias, dpad);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 

@@ -70,14 +70,16 @@ class _WindowAttentionFn(Function):
         C = C3 // 3
         nWh, nWw = -(-H // window), -(-W // window)
         N = window * window
-        out = torch.empty((B, T, C), dtype=torch.bfloat16, device=qkv.device)
+        out = torch.empty((B, T, C), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((B * nWh * nWw, num_heads, N), dtype=torch.float32, device=qkv.device)
         nWm = 0 if mask is None else mask.shape[0]
-        with _lib.device_guard(qkv.device), _Timed("fwd", _core_flops(B, nWh, nWw, num_heads, N, 2)):
-            st = _lib.load().grit_winattn_fwd_bf16(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, B, H, W, C,
+        fwd = _lib.load().grit_winattn_fwd_f32 if qkv.dtype == torch.float32 else _lib.load().grit_winattn_fwd_bf16
+        with _lib.device_guard(qkv.device), _Timed("fwd" if qkv.dtype == torch.bfloat16 else "fwd_f32",
+                                                   _core_flops(B, nWh, nWw, num_heads, N, 2)):
+            st = fwd(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, B, H, W, C,
                                                    num_heads, window, shift, scale, _ptr(out), _ptr(lse),
                                                    _lib.current_stream_ptr())
-        _lib.check(st, "grit_winattn_fwd_bf16")
+        _lib.check(st, "grit_winattn_fwd")
         ctx.save_for_backward(qkv, rel_bias, pad_qkv, mask, out, lse)
         ctx.geom = (H, W, num_heads, window, shift, scale)
         return out
@@ -89,18 +91,19 @@ class _WindowAttentionFn(Function):
         H, W, num_heads, window, shift, scale = ctx.geom
         B, T, C3 = qkv.shape
         C = C3 // 3
-        dout = dout.contiguous().to(torch.bfloat16)
+        dout = dout.contiguous().to(qkv.dtype)
         dqkv = torch.empty_like(qkv)
         # d(bias) and d(pad) are accumulated across workgroups with float atomics: one zero fill for both
         acc = torch.zeros(rel_bias.numel() + C3, dtype=torch.float32, device=qkv.device)
         dbias, dpad = acc[:rel_bias.numel()].view_as(rel_bias), acc[rel_bias.numel():]
         nWm = 0 if mask is None else mask.shape[0]
         flops = _core_flops(B, -(-H // window), -(-W // window), num_heads, window * window, 5)
-        with _lib.device_guard(qkv.device), _Timed("bwd", flops):
-            st = _lib.load().grit_winattn_bwd_bf16(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, _ptr(out),
+        bwd = _lib.load().grit_winattn_bwd_f32 if qkv.dtype == torch.float32 else _lib.load().grit_winattn_bwd_bf16
+        with _lib.device_guard(qkv.device), _Timed("bwd" if qkv.dtype == torch.bfloat16 else "bwd_f32", flops):
+            st = bwd(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, _ptr(out),
                                                    _ptr(dout), _ptr(lse), B, H, W, C, num_heads, window, shift, scale,
                                                    _ptr(dqkv), _ptr(dbias), _ptr(dpad), _lib.current_stream_ptr())
-        _lib.check(st, "grit_winattn_bwd_bf16")
+        _lib.check(st, "grit_winattn_bwd")
         return dqkv, dbias, dpad.to(pad_qkv.dtype), None, None, None, None, None, None, None
 
 
@@ -116,8 +119,10 @@ def window_attention(qkv, rel_bias, pad_qkv, H, W, num_heads, window, shift, sca
         raise _lib.GritHipError("fused window attention is built for window 12 / head_dim 32 (GRIT's Swin-B); got "
                                 "window %d head_dim %d" % (window, C // num_heads))
     in_dtype = qkv.dtype
-    out = _WindowAttentionFn.apply(qkv.to(torch.bfloat16).contiguous(), rel_bias.float().contiguous(),
-                                   pad_qkv.to(torch.bfloat16).contiguous(),
+    # fp32 tensors keep fp32 storage and arithmetic (the reference's precision: parity path); everything else runs the bf16
+    # MFMA kernels
+    cdt = torch.float32 if in_dtype in (torch.float32, torch.float64) else torch.bfloat16
+    out = _WindowAttentionFn.apply(qkv.to(cdt).contiguous(), rel_bias.float().contiguous(), pad_qkv.to(cdt).contiguous(),
                                    None if mask is None else mask.float().contiguous(), H, W, num_heads, window, shift,
                                    float(scale))
     return out.to(in_dtype)

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 18
+#define GRIT_ABI_VERSION 19
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -183,6 +183,16 @@ int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pa
                           const void* out, const void* dout, const float* lse,
                           int B, int H, int W, int C, int num_heads, int window, int shift, float scale,
                           void* dqkv, float* drel_bias, float* dpad, void* stream);
+
+/* The same two entry points in fp32 storage and plain fp32 arithmetic (fmaf chains, no matrix cores; lse in natural-log
+ * units): the parity path for fp32 weights -- the reference's WindowAttention is fp32 (swin_model.py:155-186).  Not tuned for
+ * throughput; a forward of one precision pairs only with the backward of the same precision. */
+int grit_winattn_fwd_f32(const float* qkv, const float* rel_bias, const float* pad_qkv, const float* mask, int n_mask_windows,
+                         int B, int H, int W, int C, int num_heads, int window, int shift, float scale,
+                         float* out, float* lse, void* stream);
+int grit_winattn_bwd_f32(const float* qkv, const float* rel_bias, const float* pad_qkv, const float* mask, int n_mask_windows,
+                         const float* out, const float* dout, const float* lse, int B, int H, int W, int C, int num_heads,
+                         int window, int shift, float scale, float* dqkv, float* drel_bias, float* dpad, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension for the Swin token maps (nn.LayerNorm at swin_model.py:229,233,315,495).

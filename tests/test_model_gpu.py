@@ -1,6 +1,7 @@
-"""Whole model on the HIP path: fp32 weights against the reference fixture G7 (bf16 window attention sets the
-tolerance of the visual features; the decoder is fp32 and must reproduce the beam tokens from the reference's own
-features bit for bit), and the bf16-compute training step (grit_amd.amp) against G8 + a short descent check."""
+"""Whole model on the HIP path: fp32 weights run fp32 kernels end to end (window attention, MSDA, decoder attention,
+LayerNorm / GroupNorm) and must reproduce the reference fixture G7 -- detector features within 1e-3, beam-search tokens bit
+for bit from the image (BASELINE config 1 on the device) -- and the bf16-compute training step (grit_amd.amp) against G8
++ a short descent check."""
 import json
 import os
 
@@ -29,9 +30,9 @@ def test_detector_features_close_to_reference(g7_model):
     for key in ("gri_feat", "reg_feat"):
         got, ref = vis[key].float().cpu().numpy(), g[key]
         scale = np.abs(ref).max()
-        # 24 Swin blocks of bf16 window attention in front of these features
-        assert np.abs(got - ref).max() < 6e-2 * scale, (key, np.abs(got - ref).max(), scale)
-        assert np.abs(got - ref).mean() < 6e-3 * scale, key
+        # fp32 kernels all the way (24 Swin blocks, 6 deformable decoder layers): 1e-3 of the data scale
+        assert np.abs(got - ref).max() < 1e-3 * scale, (key, np.abs(got - ref).max(), scale)
+        assert np.abs(got - ref).mean() < 1e-4 * scale, key
 
 
 @pytest.mark.parametrize("beam", [1, 5])
@@ -54,15 +55,17 @@ def test_decoder_beam_tokens_bit_exact_from_reference_features(g7_model, beam):
     np.testing.assert_array_equal(top.indices[..., 0].cpu().numpy(), g["tf_top_idx"][..., 0])
 
 
-def test_end_to_end_greedy_tokens_mostly_agree(g7_model):
-    """Full pipeline (bf16 window attention inside): token agreement is not guaranteed bit-exact, but the
-    first tokens -- decided with margins far above the feature error -- must match the reference's."""
+@pytest.mark.parametrize("beam", [1, 5])
+def test_end_to_end_tokens_bit_exact_from_the_image(g7_model, beam):
+    """BASELINE config 1 on the device: image -> fp32 detector -> fp32 decoder -> beam search; greedy (beam 1) and beam-5
+    token ids equal the reference's bit for bit (its recorded candidate margins are >= 9e-4, the features agree to 1e-3 of
+    their scale and the decoder's log-probs to 1e-4)."""
     from inference_caption import caption_tokens
     model, cfg = g7_model
     g = load("model_g7.npz")
-    tokens, _ = caption_tokens(model, t(g["image"], device=DEV)[0], cfg, beam_size=1)
-    assert tokens.shape == (1, 20)
-    assert (tokens.cpu().numpy()[0, :3] == g["beam1_tokens"][0, :3]).all()
+    tokens, lps = caption_tokens(model, t(g["image"], device=DEV)[0], cfg, beam_size=beam)
+    np.testing.assert_array_equal(tokens.cpu().numpy(), g[f"beam{beam}_tokens"])
+    np.testing.assert_allclose(lps.cpu().numpy(), g[f"beam{beam}_logprobs"], rtol=2e-3, atol=2e-3)
 
 
 def test_bf16_training_step_matches_reference_loss_and_descends():
@@ -91,7 +94,7 @@ def test_bf16_training_step_matches_reference_loss_and_descends():
 
 
 def test_fp32_training_step_gradients_close_to_reference():
-    """fp32 weights, HIP kernels (window attention still bf16): per-module gradient norms within a few percent."""
+    """fp32 weights, fp32 HIP kernels end to end: loss within 1e-4, per-module gradient norms within 1e-3 of the reference."""
     from grit_amd.utils.misc import NestedTensor
     g = load("step_g8.npz")
     ref = json.load(open(os.path.join(GOLDEN, "step_g8.json")))
@@ -102,14 +105,18 @@ def test_fp32_training_step_gradients_close_to_reference():
     out = model(NestedTensor(t(g["images"], device=DEV), t(g["mask"], device=DEV)), caps)
     loss = torch.nn.NLLLoss(ignore_index=1)(out[:, :-1].reshape(-1, out.shape[-1]), caps[:, 1:].reshape(-1))
     loss.backward()
-    assert abs(loss.item() - ref["loss"]) < 5e-3 * ref["loss"]
+    assert abs(loss.item() - ref["loss"]) < 1e-4 * ref["loss"]
     norms = {}
     for n, p in model.named_parameters():
         if p.requires_grad and p.grad is not None:
             top = '.'.join(n.split('.')[:2]) if n.startswith('detector') else n.split('.')[0]
             norms[top] = norms.get(top, 0.0) + float(p.grad.double().pow(2).sum())
     for k, v in ref["grad_norms"].items():
-        assert abs(norms[k]**0.5 - v) < 5e-2 * v, (k, norms[k]**0.5, v)
+        assert abs(norms[k]**0.5 - v) < 1e-3 * v, (k, norms[k]**0.5, v)
+    for k in g.files:
+        if k.startswith("grad:"):
+            got = dict(model.named_parameters())[k[5:]].grad.flatten()[:64].cpu().numpy()
+            assert np.abs(got - g[k]).max() < 2e-3 * np.abs(g[k]).max() + 1e-7, k
 
 
 def test_beam_search_batched_equals_per_image(g7_model):
@@ -138,10 +145,9 @@ def test_beam_search_batched_equals_per_image(g7_model):
 
 
 def test_self_critical_step_on_hip_path_matches_reference():
-    """train_sc_step (next-row N2) on the GPU in fp32: beam search with gradient through the HIP kernels (window
-    attention in bf16 storage, MSDA / decoder attention fp32) vs fixture G9 of the reference model.  The backbone's bf16
-    window attention perturbs the features (rel. 1e-2), so beams are compared where the reference's own candidate
-    margins allow and the loss / gradients within that budget."""
+    """train_sc_step (next-row N2) on the GPU in fp32 from the IMAGES: beam search with gradient through the fp32 HIP kernels
+    vs fixture G9 of the reference model -- same beams, loss and per-module gradient norms (detector included),
+    unconditionally."""
     from grit_amd.engine.caption_engine import build_optimizers, train_sc_step
     from grit_amd.utils.misc import NestedTensor
     g = load("sc_g9.npz")
@@ -161,11 +167,16 @@ def test_self_critical_step_on_hip_path_matches_reference():
     images = t(g["images"], device=DEV)
     batch = {'samples': NestedTensor(images, torch.zeros(images.shape[0], *images.shape[-2:], dtype=torch.bool, device=DEV))}
     loss, reward, baseline = train_sc_step(model, batch, opts, reward_fn, cfg)
-    agree = (seen['tokens'].numpy() == g["tokens"]).mean()
-    assert seen['tokens'].shape == (B, beam, T) and agree > 0.8, agree
-    assert torch.isfinite(loss) and abs(reward.item() - g["reward"].mean()) < 1e-6
-    # loss and gradients of the self-critical objective are asserted UNCONDITIONALLY on the reference's cached features in
-    # tests/test_det_rows.py::test_self_critical_step_from_cached_features_on_hip_g13 (same beams by construction there)
+    np.testing.assert_array_equal(seen['tokens'].numpy(), g["tokens"])
+    assert abs(reward.item() - g["reward"].mean()) < 1e-6
+    assert abs(loss.item() - ref["loss"]) < 2e-3 * abs(ref["loss"]) + 1e-7, (loss.item(), ref["loss"])
+    norms = {}
+    for n, p in model.named_parameters():
+        if p.requires_grad and p.grad is not None:
+            top = '.'.join(n.split('.')[:2]) if n.startswith('detector') else n.split('.')[0]
+            norms[top] = norms.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+    for k, v in ref["grad_norms"].items():
+        assert abs(norms[k]**0.5 - v) < 1e-2 * v, (k, norms[k]**0.5, v)
 
 
 def test_caption_stream_pipelined_equals_sequential(g7_model):

@@ -1,5 +1,6 @@
-"""HIP window attention (bf16 MFMA) against the PyTorch oracle evaluated on the same bf16-rounded inputs, and against
-the reference fixture G4 (WindowAttention call form + a whole BasicLayer with shift / pad / crop / merge)."""
+"""HIP window attention against the PyTorch oracle and the reference fixture G4 (WindowAttention call form + a whole
+BasicLayer with shift / pad / crop / merge): the bf16 MFMA kernels on the same bf16-rounded inputs at bf16 tolerances, the
+fp32 kernels (fp32 tensors: the reference's precision) at 1e-4."""
 import numpy as np
 import pytest
 import torch
@@ -59,22 +60,49 @@ def test_backward_vs_oracle(B, H, W, nH, shift):
         assert (got - ref).abs().mean().item() < 6e-3 * scale, name
 
 
-def test_explicit_mask_call_form_and_fixture(golden_dir):
-    """WindowAttention.forward(x_windows, mask) (swin_model.py:155-186) on the HIP path vs the reference output."""
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_explicit_mask_call_form_and_fixture(golden_dir, dtype):
+    """WindowAttention.forward(x_windows, mask) (swin_model.py:155-186) on the HIP path vs the reference output: bf16 weights
+    -> MFMA kernels (bf16 tolerances), fp32 weights -> fp32 kernels (1e-4, north_star's fp32 bar)."""
     from grit_amd.models.common.swin_model import BasicLayer, PatchMerging
     g = load("win_g4.npz")
     layer = BasicLayer(dim=128, depth=2, num_heads=4, window_size=12, drop_path=[0.0, 0.1], downsample=PatchMerging)
-    layer = deterministic_fill_(layer, "g4.").eval().to(DEV)
+    layer = deterministic_fill_(layer, "g4.").eval().to(DEV, dtype)
     attn = layer.blocks[1].attn
     with torch.no_grad():
-        o0 = attn(t(g["xw"], device=DEV), None)
-        o1 = attn(t(g["xw"], device=DEV), t(g["attn_mask"], device=DEV))
-        x_out, H, W, x_down, Wh, Ww = layer(t(g["x"], device=DEV), 20, 20)
-    np.testing.assert_allclose(o0.cpu().numpy(), g["o_nomask"], rtol=RTOL, atol=ATOL)
-    np.testing.assert_allclose(o1.cpu().numpy(), g["o_mask"], rtol=RTOL, atol=ATOL)
-    # two blocks + merge accumulate bf16 rounding on O(1) activations
-    np.testing.assert_allclose(x_out.cpu().numpy(), g["x_out"], rtol=5e-2, atol=5e-2)
-    np.testing.assert_allclose(x_down.cpu().numpy(), g["x_down"], rtol=5e-2, atol=5e-2)
+        o0 = attn(t(g["xw"], device=DEV).to(dtype), None)
+        o1 = attn(t(g["xw"], device=DEV).to(dtype), t(g["attn_mask"], device=DEV))
+        x_out, H, W, x_down, Wh, Ww = layer(t(g["x"], device=DEV).to(dtype), 20, 20)
+    rtol, atol, rl, al = (RTOL, ATOL, 5e-2, 5e-2) if dtype == torch.bfloat16 else (1e-4, 1e-4, 1e-4, 1e-4)
+    np.testing.assert_allclose(o0.float().cpu().numpy(), g["o_nomask"], rtol=rtol, atol=atol)
+    np.testing.assert_allclose(o1.float().cpu().numpy(), g["o_mask"], rtol=rtol, atol=atol)
+    # two blocks + merge (bf16: accumulated rounding on O(1) activations)
+    np.testing.assert_allclose(x_out.float().cpu().numpy(), g["x_out"], rtol=rl, atol=al)
+    np.testing.assert_allclose(x_down.float().cpu().numpy(), g["x_down"], rtol=rl, atol=al)
+
+
+@pytest.mark.parametrize("B,H,W,nH,shift", [(2, 20, 20, 4, 0), (2, 20, 20, 4, 6), (1, 24, 36, 8, 6), (3, 13, 30, 2, 6),
+                                            (1, 12, 12, 1, 0), (1, 7, 5, 4, 6)])
+def test_fp32_kernels_vs_oracle(B, H, W, nH, shift):
+    """fp32 storage + fp32 arithmetic: forward and all three gradients within 1e-4 of the oracle (fp32 on the CPU)."""
+    from grit_amd.ops.window_attention import window_attention
+    qkv, bias, pad = _inputs(B, H, W, nH, seed=H * W + shift)
+    qkv, pad = qkv.float(), pad.float()
+    cot = torch.randn(B, H * W, 32 * nH, generator=torch.Generator().manual_seed(1))
+    a, b_, c = qkv.clone().requires_grad_(True), bias.clone().requires_grad_(True), pad.clone().requires_grad_(True)
+    ref = _oracle(a, b_, c, H, W, nH, shift)
+    ref.backward(cot)
+    x, y, z = qkv.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True), pad.to(DEV).requires_grad_(True)
+    out = window_attention(x, y, z, H, W, nH, 12, shift, 32**-0.5)
+    assert out.dtype == torch.float32
+    out.backward(cot.to(DEV))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    for name, got, want in (("dqkv", x.grad, a.grad), ("dbias", y.grad, b_.grad), ("dpad", z.grad, c.grad)):
+        if want is None:
+            assert not got.any()
+            continue
+        scale = want.abs().max().item() + 1e-6
+        assert (got.cpu() - want).abs().max().item() < 1e-4 * scale, (name, (got.cpu() - want).abs().max().item(), scale)
 
 
 def test_properties_at_benchmark_size():

@@ -44,6 +44,10 @@ class FlatAdam(torch.optim.Optimizer):
         self._layout_version = owner.ddp.layout_version
         self._t = 0
         self._step_tensor = torch.tensor(0.0)
+        for p in mine:  # a NEW optimizer starts from zero moments (build_optimizers is called again when the phase changes)
+            m, v = owner._moment_views[p]
+            m.zero_()
+            v.zero_()
         self._link_state()
 
     def _link_state(self):

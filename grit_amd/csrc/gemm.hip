@@ -399,6 +399,307 @@ void gemm_nt_bf16(const GemmArgs g) {
     GRIT_STAMP(7)
 }
 
+// =====================================================================================================================
+// Persistent "ping-pong" kernel (variant 5): 256 x 256 tiles, K step 32, four-slot LDS ring (128 KB) + a 32 KB epilogue
+// image, one 8-wave workgroup per CU that walks its share of the tiles.
+//
+// What the per-tile kernel above leaves on the table (tools/micro/gemm_stamps.hip, M = 51200, N = 2048, K = 512): of the 33k
+// cycles a 256 x 256 tile takes, 16.4k are MFMA; ~3k are the prologue (first DMAs of every tile), ~4k DMA waits + barrier
+// skew inside the loop (a two-slot ring gives a DMA one K step to land), ~4k fragment-read latency that both waves of a SIMD
+// pay at the same moment, ~6k the epilogue.  Here
+//   * the K steps of consecutive tiles form ONE stream: the DMAs of the next tile's first steps are issued during the last
+//     steps of the current one, three steps ahead (a DMA has ~3k cycles to land, counted vmcnt, never drained in the loop);
+//   * the two waves of every SIMD run half a step apart (waves 4-7 pass one extra barrier up front): while one wave reads its
+//     fragments from LDS the other issues its 32 MFMAs, so the matrix pipe does not idle during LDS latency and barrier skew
+//     (MI355X_MICROARCH.md "Two waves per SIMD", cdna_hip_programming.md 8-phase template);
+//   * the epilogue goes through a private 4 KB LDS image per wave, so the ring keeps filling meanwhile.
+//
+// Barrier phases (b = barrier index; L(q) = fragment reads of step q, M(q) = its MFMAs + the DMAs of step q + 3):
+//   waves 0-3:  L(q) in [2q, 2q+1)    M(q) in [2q+1, 2q+2)        waves 4-7:  L(q) in [2q+1, 2q+2)   M(q) in [2q+2, 2q+3)
+//   WAR: the DMAs of step q+3 overwrite slot (q-1) % 4, last read in L(q-1) -- finished (lgkmcnt(0)) before barrier 2q;
+//   RAW: step s is first read at barrier 2s; its DMAs were issued in M(s-3); waves 0-3 wait vmcnt(8) at the end of M(s-1)
+//        (the DMAs of steps s+1, s+2 may stay in flight), waves 4-7 vmcnt(4) at the end of L(s-1) (step s+1 may), both before
+//        barrier 2s.
+template <int EPI>
+__global__ __launch_bounds__(512, 2)
+void gemm_pp_bf16(const GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 32, NSLOT = 4;
+    constexpr int ROWB = BK * 2;                       // 64-byte rows, 4 chunks of 16 B
+    constexpr int A_BYTES = BM * ROWB, SLOT = (BM + BN) * ROWB;
+    constexpr int MT = 8, NTL = 4;                     // wave tile 128 x 64
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    char* epi = lds + NSLOT * SLOT;                    // 8 x 4 KB
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, wu = wave & 3;          // group = row half, wu = 64-column strip
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    // tiles of this workgroup: the 8 XCD groups (blockIdx % 8) own contiguous bands of the row-major tile list; inside a band
+    // the workgroups take tiles round-robin, so the CUs of an XCD work on neighbouring tiles (shared A panels, B in L2)
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_xcd = (gridDim.x + 7 - xcd) >> 3;
+    const int band_lo = (int)((long long)ntiles * xcd / 8), band_hi = (int)((long long)ntiles * (xcd + 1) / 8);
+    const int my_tiles = band_lo + idx < band_hi ? (band_hi - band_lo - idx + per_xcd - 1) / per_xcd : 0;
+    if (my_tiles == 0) return;
+    const int KT = g.K / BK;
+    const int total = my_tiles * KT;
+    auto tile_of = [&](int i) { return band_lo + idx + i * per_xcd; };
+
+    // ---- DMA side: this wave moves pieces {wave, wave + 8} of A and of B (16 rows x 64 B each) per step
+    const int prow = lane >> 2;
+    const int pchunk = (lane & 3) ^ chunk_swizzle<BK>(prow);
+    const __bf16* asrc[2];
+    const __bf16* bsrc[2];
+    int lti = 0, lks = 0, lslot = 0;  // DMA side of the stream: tile, k step and ring slot of the next step to be fetched
+    auto set_load_tile = [&](int i) {
+        const int t = tile_of(i), tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = 16 * (wave + 8 * j) + prow;
+            asrc[j] = g.A + (size_t)min(tm * BM + r, g.M - 1) * g.lda + pchunk * 8;
+            bsrc[j] = g.B + (size_t)(tn * BN + r) * g.ldb + pchunk * 8;
+        }
+    };
+    set_load_tile(0);
+    auto dma = [&](int piece) {  // piece 0,1: A; 2,3: B -- of the step (lti, lks), into slot lslot
+        char* slot = lds + lslot * SLOT;
+        const int j = piece & 1;
+        if (piece < 2)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[j] + lks * BK), (lptr_t)(slot + (wave + 8 * j) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[j] + lks * BK), (lptr_t)(slot + A_BYTES + (wave + 8 * j) * 1024), 16, 0, 0);
+    };
+    auto advance_load = [&]() {
+        lslot = (lslot + 1) & (NSLOT - 1);
+        if (++lks == KT) {
+            lks = 0;
+            if (++lti < my_tiles) set_load_tile(lti);
+        }
+    };
+
+    // ---- fragment reads
+    const int foff = l15 * ROWB + ((lq ^ chunk_swizzle<BK>(l15)) * 16);
+    const int a_wave = grp * 128 * ROWB, b_wave = A_BYTES + wu * 64 * ROWB;
+
+    v4f acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    // ---- epilogue of one finished tile (no barrier inside: it only lengthens this wave's phase)
+    char* eb = epi + wave * 4096;
+    auto epilogue = [&](int ti) {
+        const int t = tile_of(ti), tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+        const int mw = tm * BM + grp * 128, nw = tn * BN + wu * 64;
+        v4f bias4[NTL];
+        if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const v4bf b = *reinterpret_cast<const v4bf*>(g.bias + nw + 16 * j + 4 * lq);
+                bias4[j] = v4f{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+            }
+        }
+        const bool full_rows = mw + 128 <= g.M;
+        auto put = [&](int il, int j, const v4f& v) {  // il = m-tile within the 32-row chunk
+            v4bf p;
+            p[0] = (__bf16)v[0]; p[1] = (__bf16)v[1]; p[2] = (__bf16)v[2]; p[3] = (__bf16)v[3];
+            const int row = 16 * il + l15;
+            const int chunk = (2 * j + (lq >> 1)) ^ (row & 7);
+            *reinterpret_cast<v4bf*>(eb + row * 128 + chunk * 16 + (lq & 1) * 8) = p;
+        };
+        auto flush = [&](__bf16* dst, long ld, int c) {  // rows 32 c .. 32 c + 31 of the wave tile
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (lane >> 3), chunk = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(eb + row * 128 + ((chunk ^ (row & 7)) * 16));
+                const int m = mw + 32 * c + row;
+                if (full_rows || m < g.M) *reinterpret_cast<uint4*>(dst + (size_t)m * ld + nw + chunk * 8) = v;
+            }
+            asm volatile("" ::: "memory");
+        };
+        v4f cs[NTL];
+        if constexpr (EPI == GRIT_GEMM_DGELU) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) cs[j] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if constexpr (EPI == GRIT_GEMM_NONE || EPI == GRIT_GEMM_BIAS) {
+#pragma unroll
+                for (int il = 0; il < 2; ++il)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) {
+                        v4f v = acc[2 * c + il][j];
+                        if constexpr (EPI == GRIT_GEMM_BIAS) v += bias4[j];
+                        put(il, j, v);
+                    }
+                flush(g.C, g.ldc, c);
+            } else if constexpr (EPI == GRIT_GEMM_BIAS_GELU) {
+#pragma unroll
+                for (int il = 0; il < 2; ++il)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) acc[2 * c + il][j] += bias4[j];
+                if (g.aux) {
+#pragma unroll
+                    for (int il = 0; il < 2; ++il)
+#pragma unroll
+                        for (int j = 0; j < NTL; ++j) put(il, j, acc[2 * c + il][j]);
+                    flush(g.aux, g.ldaux, c);
+                }
+#pragma unroll
+                for (int il = 0; il < 2; ++il)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) {
+                        v4f v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_f(acc[2 * c + il][j][r]);
+                        put(il, j, v);
+                    }
+                flush(g.C, g.ldc, c);
+            } else {  // GRIT_GEMM_DGELU: pre-activation pieces straight from memory in accumulator shape
+#pragma unroll
+                for (int il = 0; il < 2; ++il) {
+                    const int m = mw + 32 * c + 16 * il + l15;
+                    const bool live = full_rows || m < g.M;
+                    const __bf16* xr = g.aux + (size_t)min(m, g.M - 1) * g.ldaux + nw + 4 * lq;
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) {
+                        const v4bf x = *reinterpret_cast<const v4bf*>(xr + 16 * j);
+                        v4f v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] = acc[2 * c + il][j][r] * dgelu_f((float)x[r]);
+                            cs[j][r] += live ? v[r] : 0.f;
+                        }
+                        put(il, j, v);
+                    }
+                }
+                flush(g.C, g.ldc, c);
+            }
+        }
+        if constexpr (EPI == GRIT_GEMM_DGELU) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = cs[j][r];
+                    v += __shfl_xor(v, 1, 64);
+                    v += __shfl_xor(v, 2, 64);
+                    v += __shfl_xor(v, 4, 64);
+                    v += __shfl_xor(v, 8, 64);
+                    cs[j][r] = v;
+                }
+            if (l15 == 0) {
+                float* dst = g.colsum + (size_t)(mw / 128) * g.N + nw + 4 * lq;
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) *reinterpret_cast<v4f*>(dst + 16 * j) = cs[j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- prologue: steps 0, 1, 2 in flight, step 0 landed for everybody
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (q < total) {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) dma(pc);
+            advance_load();
+        }
+    if (total > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger: waves 4-7 run one phase behind
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+
+    int ks = 0, ti = 0, cslot = 0;  // compute side of the stream
+    for (int q = 0; q < total; ++q) {
+        // ---- L(q): the 12 fragments of this step
+        const char* sb = lds + cslot * SLOT;
+        v8bf wf[NTL], xf[MT];
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) wf[j] = *reinterpret_cast<const v8bf*>(sb + b_wave + j * 16 * ROWB + foff);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const v8bf*>(sb + a_wave + i * 16 * ROWB + foff);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grp == 1) {  // step q + 1 (read by waves 0-3 right after the coming barrier) must have landed
+            if (q + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- M(q): 32 MFMAs, the four DMA pieces of step q + 3 in between
+        const bool more = q + 3 < total;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            if ((i & 1) && more) dma(i >> 1);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (more) advance_load();
+        if (grp == 0) {  // step q + 1 is read by this group right after the coming barrier
+            if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        cslot = (cslot + 1) & (NSLOT - 1);
+        if (++ks == KT) {
+            epilogue(ti);
+            ks = 0;
+            ++ti;
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+}
+
+int launch_pp(const GemmArgs& a, int epilogue, hipStream_t st) {
+    constexpr int LDS = 4 * (256 + 256) * 64 + 8 * 4096;  // 160 KB: the whole CU
+    GemmArgs g = a;
+    g.tiles_m = (a.M + 255) / 256;
+    g.tiles_n = a.N / 256;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GRIT_ERR_LAUNCH;
+        cus = prop.multiProcessorCount;
+    }
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const dim3 grid(ntiles < cus ? ntiles : cus), block(512);
+#define GRIT_GEMM_LAUNCH_PP(E)                                                                                       \
+    {                                                                                                                \
+        auto kern = gemm_pp_bf16<E>;                                                                                 \
+        static bool attr_done = false;                                                                               \
+        if (!attr_done) {                                                                                            \
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) \
+                return GRIT_ERR_LAUNCH;                                                                              \
+            attr_done = true;                                                                                        \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kern, grid, block, LDS, st, g);                                                           \
+    }
+    switch (epilogue) {
+        case GRIT_GEMM_NONE: GRIT_GEMM_LAUNCH_PP(GRIT_GEMM_NONE) break;
+        case GRIT_GEMM_BIAS: GRIT_GEMM_LAUNCH_PP(GRIT_GEMM_BIAS) break;
+        case GRIT_GEMM_BIAS_GELU: GRIT_GEMM_LAUNCH_PP(GRIT_GEMM_BIAS_GELU) break;
+        case GRIT_GEMM_DGELU: GRIT_GEMM_LAUNCH_PP(GRIT_GEMM_DGELU) break;
+        default: return GRIT_ERR_BAD_ARG;
+    }
+#undef GRIT_GEMM_LAUNCH_PP
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
 template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
 int launch(const GemmArgs& a, int epilogue, hipStream_t st) {
     constexpr int STAGE = (BM + BN) * BK * 2;
@@ -453,6 +754,7 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
         case 2: return (K % 64) ? GRIT_ERR_UNSUPPORTED : launch<256, 128, 64, 2, 2, 2>(a, epilogue, st);  // needs 96 KB: 1 WG / CU
         case 3: return launch<256, 128, 32, 2, 2, 4>(a, epilogue, st);  // deeper ring, 96 KB
         case 4: return (K % 64 || N % 256) ? GRIT_ERR_UNSUPPORTED : launch<256, 256, 64, 2, 4, 2>(a, epilogue, st);  // 8 waves, 128 KB
+        case 5: return (N % 256) ? GRIT_ERR_UNSUPPORTED : launch_pp(a, epilogue, st);  // persistent ping-pong, 160 KB
         default: return GRIT_ERR_BAD_ARG;
     }
 }

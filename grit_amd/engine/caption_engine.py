@@ -239,19 +239,24 @@ def train_sc_step(model, batch, optimizers, reward_fn, config):
 
 
 def cider_reward_fn(cider, text_field, tokenizer_pool=None, tokenize=None):
-    """The reference's reward (:433-438) from its host objects: text_field.decode -> PTB tokenisation of generated and
-    ground-truth captions (tokenizer_pool.map(tokenize, ...), or tokenize directly) -> cider.compute_score(...)[1]."""
+    """The reference's reward (:433-438): text_field.decode -> PTB tokenisation of generated and ground-truth captions ->
+    cider.compute_score(...)[1].  `tokenize` defaults to the native PTB-style tokenizer
+    (grit_amd.datasets.caption.metrics.PTBTokenizer.tokenize; the reference's is a Java program); with a `tokenizer_pool` the
+    two corpora are tokenised through pool.map as the reference does."""
     import itertools
 
     import numpy as np
+
+    if tokenize is None:
+        from grit_amd.datasets.caption.metrics import PTBTokenizer
+        tokenize = PTBTokenizer.tokenize
 
     def reward_fn(tokens, batch):
         B, beam, T = tokens.shape
         caps_gen = text_field.decode(tokens.view(-1, T))
         caps_gt = list(itertools.chain(*([c] * beam for c in batch['captions'])))
-        if tokenize is not None:
-            caps_gen, caps_gt = (tokenizer_pool.map(tokenize, [caps_gen, caps_gt]) if tokenizer_pool is not None
-                                 else (tokenize(caps_gen), tokenize(caps_gt)))
+        caps_gen, caps_gt = (tokenizer_pool.map(tokenize, [caps_gen, caps_gt]) if tokenizer_pool is not None
+                             else (tokenize(caps_gen), tokenize(caps_gt)))
         reward = cider.compute_score(caps_gt, caps_gen)[1].astype(np.float32)
         return torch.from_numpy(reward).view(B, beam)
 

@@ -577,5 +577,78 @@ def make_g13():
 
 MAKERS.update({'g13': make_g13})
 
+
+def make_g14():
+    """CIDEr-D reward (reference datasets/caption/metrics/cider/*.py, pure Python: loaded from its files) on seeded synthetic
+    captions: corpus statistics from a "training set" of 40 images x 5 references, then (a) the self-critical call form --
+    5 beams per image against the image's references repeated per beam -- and (b) a call without corpus statistics."""
+    import importlib
+    import json
+    pkg = types.ModuleType('refcider')
+    pkg.__path__ = [os.path.join(REF, 'datasets', 'caption', 'metrics', 'cider')]
+    sys.modules['refcider'] = pkg
+    cider_mod = importlib.import_module('refcider.cider')
+    rng = np.random.default_rng(14)
+    vocab = ['a', 'the', 'man', 'woman', 'dog', 'cat', 'sitting', 'standing', 'on', 'in', 'of', 'with', 'red', 'blue', 'bench',
+             'street', 'table', 'plate', 'food', 'two', 'and', 'next', 'to', 'holding', 'umbrella', 'riding', 'bike', 'field']
+
+    def sentence():
+        return ' '.join(rng.choice(vocab, size=int(rng.integers(4, 13))))
+
+    train = {i: [sentence() for _ in range(5)] for i in range(40)}
+    cider = cider_mod.Cider(train)
+    B, beam = 6, 5
+    refs = [[sentence() for _ in range(5)] for _ in range(B)]
+    gts, res = {}, {}
+    for b in range(B):
+        for j in range(beam):
+            hyp = refs[b][j % 5].split()
+            if j:  # perturb: drop / repeat / swap words so that clipping and the length penalty matter
+                hyp = hyp[: max(2, len(hyp) - j)] + list(rng.choice(vocab, size=j - 1))
+            gts[b * beam + j] = refs[b]
+            res[b * beam + j] = [' '.join(hyp)]
+    mean, scores = cider.compute_score(gts, res)
+    mean2, scores2 = cider_mod.Cider().compute_score(gts, res)
+    out = {'train': {str(k): v for k, v in train.items()}, 'gts': {str(k): v for k, v in gts.items()},
+           'res': {str(k): v for k, v in res.items()}, 'mean': float(mean), 'scores': [float(x) for x in scores],
+           'mean_nocorpus': float(mean2), 'scores_nocorpus': [float(x) for x in scores2]}
+    with open(os.path.join(HERE, 'cider_g14.json'), 'w') as f:
+        json.dump(out, f)
+    print('g14 mean', mean, 'first scores', scores[:4], 'no corpus', mean2)
+
+
+MAKERS.update({'g14': make_g14})
+
+
+def make_h5():
+    """tests/golden/features_ref.h5: a miniature of the reference's feature cache (tools/extract_features.py:66-155) written by
+    the HDF5 C library itself -- the same calls h5py's create_dataset issues (contiguous layout, int64 / float32 / the int8 enum
+    {FALSE, TRUE} numpy bool maps to) -- through the generator tests/golden/make_features_ref_h5.c.  h5py is not installed here
+    but an HDF5 1.10 library happens to sit under /opt/conda in the build image; the same library then reads a file written by
+    grit_amd.datasets.caption.hdf5_min (h5diff: 0 differences)."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from grit_amd.datasets.caption import hdf5_min
+    conda = '/opt/conda'
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, 'gen')
+        subprocess.check_call(['gcc', os.path.join(HERE, 'make_features_ref_h5.c'), '-I' + conda + '/include', '-L' + conda + '/lib',
+                               '-lhdf5', '-Wl,-rpath,' + conda + '/lib', '-o', exe])
+        out = os.path.join(HERE, 'features_ref.h5')
+        subprocess.check_call([exe, out])
+        ref = hdf5_min.H5File(out)
+        mine = os.path.join(tmp, 'mine.h5')
+        w = hdf5_min.create(mine, {k: (v['shape'], np.bool_ if v['bool'] else v['dtype']) for k, v in ref.datasets.items()})
+        for k in ref.keys():
+            w[k][...] = ref[k]
+        w.close()
+        r = subprocess.run([conda + '/bin/h5diff', '-v', out, mine], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        print('h5: library file read back;', r.stdout.count('0 differences found'), 'objects identical under h5diff')
+
+
+MAKERS.update({'h5': make_h5})
+
 if __name__ == "__main__":
     main()

@@ -1,6 +1,7 @@
 """Cached-feature path (SURVEY next-row N3): the feature store with the reference's dataset names / shapes / dtypes
 (tools/extract_features.py:76-86), ImageField.preprocess in cached mode (datasets/caption/field.py:47-63), the collator's
 cached branch (datasets/caption/coco.py:39-47) -- CPU -- and the extraction itself on the HIP path (GPU)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -75,3 +76,72 @@ def test_extraction_writes_what_the_detector_computes(tmp_path):
     model.train()
     loss = train_xe_step(model, batch, build_optimizers(model, cfg, mode='xe'), torch.nn.NLLLoss(ignore_index=1))
     assert torch.isfinite(loss)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HDF5 container (the reference's format, tools/extract_features.py:66-155) without h5py
+def _expected_ref():
+    import numpy as np
+    i = np.arange(30)
+    return {"image_ids": np.array([139, 285, 632, 724, 776], np.int64),
+            "gri_feat": ((np.arange(5 * 6 * 16) % 97) * 0.25 - 3.0).astype(np.float32).reshape(5, 6, 16),
+            "gri_mask": ((i % 7 == 3) | (i % 5 == 0)).reshape(5, 1, 1, 6),
+            "reg_feat": ((np.arange(160) ** 2 % 31) - 15.5).astype(np.float32).reshape(5, 4, 8),
+            "reg_mask": np.zeros((5, 1, 1, 4), bool)}
+
+
+def test_hdf5_reader_on_a_file_written_by_the_hdf5_library():
+    """tests/golden/features_ref.h5 was written by libhdf5 with the calls h5py's create_dataset makes (make_golden.py h5)."""
+    import numpy as np
+    from grit_amd.datasets.caption.feature_store import FeatureStore
+    from grit_amd.datasets.caption.hdf5_min import H5File
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "features_ref.h5")
+    exp = _expected_ref()
+    h5 = H5File(path)
+    assert sorted(h5.keys()) == sorted(exp)
+    for k, v in exp.items():
+        got = h5[k]
+        assert got.dtype == v.dtype and got.shape == v.shape, k
+        np.testing.assert_array_equal(np.asarray(got), v)
+    store = FeatureStore.open(path)  # the interface ImageField uses
+    np.testing.assert_array_equal(store["image_ids"], exp["image_ids"])
+    np.testing.assert_array_equal(np.asarray(store["gri_feat"][3]), exp["gri_feat"][3])
+    assert store["gri_mask"][2].dtype == np.bool_
+
+
+def test_hdf5_writer_round_trip_and_layout(tmp_path):
+    """A store created as .h5: rows written through the memory maps come back through a fresh reader; the file starts with the
+    same superblock / group structure bytes as the library's (signature, version 0, 8-byte offsets, K values)."""
+    import numpy as np
+    from grit_amd.datasets.caption.feature_store import FeatureStore
+    from grit_amd.datasets.caption.field import ImageField
+    path = str(tmp_path / "feats.h5")
+    exp = _expected_ref()
+    store = FeatureStore.create(path, exp["image_ids"], 6, 16, queries=4, d_model=8)
+    for k in ("gri_feat", "gri_mask", "reg_feat", "reg_mask"):
+        for row in range(5):  # row-wise writes, as extract_features does per rank
+            store[k][row] = exp[k][row]
+    store.flush()
+    again = FeatureStore.open(path)
+    for k, v in exp.items():
+        np.testing.assert_array_equal(np.asarray(again[k]), v)
+    ref = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "features_ref.h5"), "rb").read(24)
+    assert open(path, "rb").read(24) == ref
+    field = ImageField(hdf5_path=path, use_gri_feat=True, use_reg_feat=True, use_hdf5_feat=True)
+    out = field.preprocess("COCO_val2014_000000000632.jpg")
+    np.testing.assert_array_equal(out["gri_feat"].numpy(), exp["gri_feat"][2])
+    assert out["gri_mask"].dtype == torch.bool and out["reg_feat"].shape == (4, 8)
+
+
+def test_hdf5_rejects_what_it_does_not_implement(tmp_path):
+    from grit_amd.datasets.caption.hdf5_min import H5File, H5FormatError, create
+    import numpy as np
+    import pytest
+    bad = tmp_path / "x.h5"
+    bad.write_bytes(b"not an hdf5 file at all" * 8)
+    with pytest.raises(H5FormatError):
+        H5File(str(bad))
+    with pytest.raises(H5FormatError):
+        create(str(tmp_path / "y.h5"), {"n%d" % i: ((2,), np.float32) for i in range(9)})  # more than one symbol-table node
+    with pytest.raises(H5FormatError):
+        create(str(tmp_path / "z.h5"), {"c": ((2,), np.complex64)})

@@ -31,6 +31,7 @@ int main(int argc, char** argv) {
         switch (variant) {
             case 1: return launch<256, 128, 32, 2, 2, 3>(a, epi, 0);
             case 4: return launch<256, 256, 64, 2, 4, 2>(a, epi, 0);
+            case 5: return launch_pp(a, epi, 0);
             default: return 1;
         }
     };
@@ -39,6 +40,7 @@ int main(int argc, char** argv) {
     hipEventRecord(e0); for (int i = 0; i < 10; ++i) run(nullptr); hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("variant %d epilogue %d: %.1f us per launch (no stamps)\n", variant, epi, ms * 100);
+    if (variant == 5) return 0;  // the persistent kernel carries no stamps
     hipMemset(stamps, 0, (size_t)waves_total * 16 * 8);
     run(stamps); hipDeviceSynchronize();
     std::vector<unsigned long long> h((size_t)waves_total * 16);

@@ -7,6 +7,12 @@ GPU, torch.distributed 'nccl' (= RCCL on ROCm) over xGMI.
 hydra is not installed in this image; configuration is grit_amd.config (same keys as configs/caption/coco_config.yaml,
 dotted key=value overrides).  The COCO reader is out of scope of this build: batches come from
 grit_amd.data.SyntheticLoader unless the caller passes its own `dataloaders` dict to main().
+
+Phases follow the reference's epoch schedule (train_caption.py:92-147): fr_xe -> fr_sc -> ft_xe -> ft_sc, `cached_features`
+while the loader serves cached detector outputs, optimizers rebuilt when the mode flips between 'xe' and 'sc', and the best
+validation checkpoint loaded into the (wrapped) model before every self-critical epoch.  The self-critical phases need
+`dataloaders['train_dict']`, a `text_field` (decode) and the training captions for the CIDEr statistics; without them they are
+skipped (synthetic runs).
 """
 import argparse
 import os
@@ -22,13 +28,32 @@ from grit_amd.data import SyntheticLoader
 from grit_amd.amp import Bf16Compute
 from grit_amd.ddp import BucketedDataParallel
 from engine.caption_engine import *  # noqa: F401,F403  (reference does the same star import)
-from engine.caption_engine import build_optimizers, save_checkpoint, train_xe
+from engine.caption_engine import build_optimizers, save_checkpoint, train_sc, train_xe
 from models.caption import Transformer
 from models.caption.detector import build_detector
 from utils.cap_scheduler import CosineLRScheduler
 
 
-def main(gpu, config, dataloaders=None):
+def phase_of(epoch, opt):
+    """reference train_caption.py:92-107."""
+    fr_xe = opt.freezing_xe_epochs
+    fr_sc = fr_xe + opt.freezing_sc_epochs
+    ft_xe = fr_sc + opt.finetune_xe_epochs
+    ft_sc = ft_xe + opt.finetune_sc_epochs
+    if epoch < fr_xe:
+        return 'fr_xe'
+    if epoch < fr_sc:
+        return 'fr_sc'
+    if epoch < ft_xe:
+        return 'ft_xe'
+    return 'ft_sc' if epoch < ft_sc else None
+
+
+def main(gpu, config, dataloaders=None, text_field=None, cider=None, tokenizer_pool=None, finetune_dataloaders=None):
+    """dataloaders: {'train': ...} (+ 'train_dict' for the self-critical phases, 'valid' for the validation loss); when the
+    first phases run on cached detector features pass those loaders here and the image loaders as `finetune_dataloaders`
+    (the reference rebuilds them at the switch, train_caption.py:105-107).  cider: a Cider built from the tokenised training
+    captions (grit_amd.datasets.caption.metrics)."""
     rank = int(os.environ.get('RANK', config.exp.rank * config.exp.ngpus_per_node + gpu))
     world = int(os.environ.get('WORLD_SIZE', config.exp.world_size))
     use_cuda = torch.cuda.is_available()
@@ -43,15 +68,19 @@ def main(gpu, config, dataloaders=None):
 
     detector = build_detector(config).to(device)
     model = Transformer(detector=detector, config=config).to(device)
-    if getattr(config.optimizer, 'freeze_backbone', False):
-        for n, p in model.named_parameters():
-            if 'backbone' in n:
-                p.requires_grad = False
-    if getattr(config.optimizer, 'freeze_detector', False):
-        for n, p in model.named_parameters():
-            if 'detector' in n:
-                p.requires_grad = False
-    model.cached_features = False
+    opt = config.optimizer
+    start_epoch = int(getattr(config.exp, 'start_epoch', 0))
+    if start_epoch < opt.freezing_xe_epochs:
+        if getattr(opt, 'freeze_backbone', False):
+            for n, p in model.named_parameters():
+                if 'backbone' in n:
+                    p.requires_grad = False
+        if getattr(opt, 'freeze_detector', False):
+            for n, p in model.named_parameters():
+                if 'detector' in n:
+                    p.requires_grad = False
+    raw = model
+    raw.cached_features = bool(getattr(config.exp, 'cached_features', False))
     # precision: bf16 compute copies + fp32 master weights on the GPU (grit_amd/amp.py; gradients are produced and
     # all-reduced in flat bf16 buckets), plain fp32 with exp.bf16=False or on CPU
     if getattr(config.exp, 'bf16', use_cuda):
@@ -59,24 +88,57 @@ def main(gpu, config, dataloaders=None):
     else:
         model = BucketedDataParallel(model)
     optimizers = build_optimizers(model, config, mode='xe')
+    resume = getattr(config.exp, 'resume_from', '')
+    if resume:  # reference-format checkpoint (engine/caption_engine.py save_checkpoint): weights (+ optimizer state when present)
+        ckpt = torch.load(resume, map_location='cpu')
+        raw.load_state_dict(ckpt['state_dict'], strict=False)  # reaches the fp32 masters through the wrapper's hook
+        for k in ('model', 'backbone'):
+            if ckpt.get('optim_' + k) and getattr(config.exp, 'resume_optimizers', True):
+                try:
+                    optimizers[k].load_state_dict(ckpt['optim_' + k])
+                except (ValueError, KeyError) as e:  # a checkpoint of another phase / parameter grouping
+                    print(f"optimizer state of '{k}' not restored: {e}")
+        start_epoch = max(start_epoch, int(ckpt.get('epoch', -1)) + 1)
 
     if dataloaders is None:
         steps = getattr(config.exp, 'synthetic_steps', 20)
         h, w = getattr(config.exp, 'synthetic_size', [640, 640])
-        dataloaders = {'train': SyntheticLoader(steps, config.optimizer.batch_size, h, w, device=device, rank=rank)}
-    epochs = config.optimizer.freezing_xe_epochs + config.optimizer.finetune_xe_epochs
-    scheduler = CosineLRScheduler(optimizers['model'], num_epochs=epochs, num_its_per_epoch=len(dataloaders['train']),
-                                  init_lr=config.optimizer.xe_lr, min_lr=config.optimizer.min_lr,
-                                  warmup_init_lr=config.optimizer.warmup_init_lr)
+        dataloaders = {'train': SyntheticLoader(steps, opt.batch_size, h, w, device=device, rank=rank)}
+    xe_epochs = opt.freezing_xe_epochs + opt.finetune_xe_epochs
+    scheduler = CosineLRScheduler(optimizers['model'], num_epochs=xe_epochs, num_its_per_epoch=len(dataloaders['train']),
+                                  init_lr=opt.xe_lr, min_lr=opt.min_lr, warmup_init_lr=opt.warmup_init_lr)
+    total = xe_epochs + opt.freezing_sc_epochs + opt.finetune_sc_epochs
+    can_sc = 'train_dict' in dataloaders and text_field is not None and cider is not None
+    save = getattr(config.exp, 'save', False)
     results = []
-    for epoch in range(getattr(config.exp, 'max_epochs', epochs)):
-        print(f"Train: rank={rank}, epoch={epoch}, phase=ft_xe")
-        res = train_xe(model, dataloaders, optimizers=optimizers, text_field=None, epoch=epoch, rank=rank, config=config,
-                       scheduler=scheduler, writer=None, checkpoint=getattr(config.exp, 'save', False))
+    for epoch in range(start_epoch, min(total, getattr(config.exp, 'max_epochs', total))):
+        phase = phase_of(epoch, opt)
+        if phase in ('fr_sc', 'ft_sc') and not can_sc:
+            continue  # synthetic run: no captions to score
+        if phase in ('ft_xe', 'ft_sc') and raw.cached_features:
+            raw.cached_features = False  # from here on the detector is part of the graph (the wrapper re-derives its live set)
+            if finetune_dataloaders is not None:
+                dataloaders = finetune_dataloaders
+        if phase in ('fr_sc', 'ft_sc') and optimizers['mode'] == 'xe':
+            optimizers = build_optimizers(model, config, mode='sc')
+        if phase in ('fr_xe', 'ft_xe') and optimizers['mode'] == 'sc':
+            optimizers = build_optimizers(model, config, mode='xe')
+        print(f"Train: rank={rank}, epoch={epoch}, phase={phase}")
+        if phase in ('fr_xe', 'ft_xe'):
+            res = train_xe(model, dataloaders, optimizers=optimizers, text_field=text_field, epoch=epoch, rank=rank,
+                           config=config, scheduler=scheduler, writer=None, checkpoint=save)
+        else:
+            best = getattr(config.exp, 'best_checkpoint', 'checkpoint_best_valid.pth')
+            if os.path.exists(best):  # reference :131-132
+                missing, unexpected = raw.load_state_dict(torch.load(best, map_location='cpu')['state_dict'], strict=False)
+                print(f"Start self-critical optimization: missing={len(missing)}, unexpected={len(unexpected)}")
+            res = train_sc(model, dataloaders, optimizers=optimizers, cider=cider, text_field=text_field,
+                           tokenizer_pool=tokenizer_pool, device=device, epoch=epoch, config=config, rank=rank, writer=None,
+                           evaluate='valid' in dataloaders, checkpoint=save)
         results.append(res)
-        if rank == 0 and getattr(config.exp, 'save', False):
+        if rank == 0 and save:
             save_checkpoint(model, optimizers, epoch=epoch, scores=[], best_ciders=[0, 0], config=config,
-                            filename='checkpoint_ft_xe.pth', scheduler=scheduler)
+                            filename=f'checkpoint_{phase}.pth', scheduler=scheduler)
         dist.barrier()
     if dist.is_initialized() and getattr(config.exp, 'destroy_group', True):
         dist.destroy_process_group()

@@ -416,10 +416,10 @@ void gemm_nt_bf16(const GemmArgs g) {
 //
 // Barrier phases (b = barrier index; L(q) = fragment reads of step q, M(q) = its MFMAs + the DMAs of step q + 3):
 //   waves 0-3:  L(q) in [2q, 2q+1)    M(q) in [2q+1, 2q+2)        waves 4-7:  L(q) in [2q+1, 2q+2)   M(q) in [2q+2, 2q+3)
-//   WAR: the DMAs of step q+3 overwrite slot (q-1) % 4, last read in L(q-1) -- finished (lgkmcnt(0)) before barrier 2q;
-//   RAW: step s is first read at barrier 2s; its DMAs were issued in M(s-3); waves 0-3 wait vmcnt(8) at the end of M(s-1)
-//        (the DMAs of steps s+1, s+2 may stay in flight), waves 4-7 vmcnt(4) at the end of L(s-1) (step s+1 may), both before
-//        barrier 2s.
+//   WAR: the DMAs of step q+3 (issued in L(q), i.e. after barrier 2q) overwrite slot (q-1) % 4, last read in L(q-1) -- finished
+//        (lgkmcnt(0)) before barrier 2q by both groups;
+//   RAW: step s is first read at barrier 2s; its DMAs were issued in L(s-3); both groups wait vmcnt(8) (the DMAs of steps
+//        s+1, s+2 may stay in flight) before barrier 2s: waves 0-3 at the end of M(s-1), waves 4-7 at the end of L(s-1).
 template <int EPI>
 __global__ __launch_bounds__(512, 2)
 void gemm_pp_bf16(const GemmArgs g) {
@@ -437,8 +437,9 @@ void gemm_pp_bf16(const GemmArgs g) {
     // tiles of this workgroup: the 8 XCD groups (blockIdx % 8) own contiguous bands of the row-major tile list; inside a band
     // the workgroups take tiles round-robin, so the CUs of an XCD work on neighbouring tiles (shared A panels, B in L2)
     const int ntiles = g.tiles_m * g.tiles_n;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_xcd = (gridDim.x + 7 - xcd) >> 3;
-    const int band_lo = (int)((long long)ntiles * xcd / 8), band_hi = (int)((long long)ntiles * (xcd + 1) / 8);
+    const int ngroups = gridDim.x < 8 ? (int)gridDim.x : 8;
+    const int xcd = blockIdx.x % ngroups, idx = blockIdx.x / ngroups, per_xcd = ((int)gridDim.x - xcd + ngroups - 1) / ngroups;
+    const int band_lo = (int)((long long)ntiles * xcd / ngroups), band_hi = (int)((long long)ntiles * (xcd + 1) / ngroups);
     const int my_tiles = band_lo + idx < band_hi ? (band_hi - band_lo - idx + per_xcd - 1) / per_xcd : 0;
     if (my_tiles == 0) return;
     const int KT = g.K / BK;
@@ -515,7 +516,11 @@ void gemm_pp_bf16(const GemmArgs g) {
                 const int row = it * 8 + (lane >> 3), chunk = lane & 7;
                 const uint4 v = *reinterpret_cast<const uint4*>(eb + row * 128 + ((chunk ^ (row & 7)) * 16));
                 const int m = mw + 32 * c + row;
+#ifdef GRIT_GEMM_NOSTORE  // diagnostic build: everything but the global stores (only rows that cannot exist are "stored")
+                if (m < 0) *reinterpret_cast<uint4*>(dst + (size_t)m * ld + nw + chunk * 8) = v;
+#else
                 if (full_rows || m < g.M) *reinterpret_cast<uint4*>(dst + (size_t)m * ld + nw + chunk * 8) = v;
+#endif
             }
             asm volatile("" ::: "memory");
         };
@@ -619,8 +624,22 @@ void gemm_pp_bf16(const GemmArgs g) {
     asm volatile("" ::: "memory");
 
     int ks = 0, ti = 0, cslot = 0;  // compute side of the stream
+#ifdef GRIT_GEMM_STAMPS
+    unsigned long long ph_l = 0, ph_b1 = 0, ph_m = 0, ph_b2 = 0, ph_epi = 0, ph_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long ph_start = ph_t;
+#define GRIT_PH(acc_var) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_var += now_ - ph_t; ph_t = now_; }
+#else
+#define GRIT_PH(acc_var)
+#endif
     for (int q = 0; q < total; ++q) {
-        // ---- L(q): the 12 fragments of this step
+        // ---- L(q): the DMA pieces of step q + 3 (their issue is slow -- ~100 cycles each -- and must not sit between this
+        // wave's MFMAs: the partner wave owns the matrix pipe during this phase), then the 12 fragments of this step
+        const bool more = q + 3 < total;
+        if (more) {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) dma(pc);
+            advance_load();
+        }
         const char* sb = lds + cslot * SLOT;
         v8bf wf[NTL], xf[MT];
 #pragma unroll
@@ -629,39 +648,48 @@ void gemm_pp_bf16(const GemmArgs g) {
         for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const v8bf*>(sb + a_wave + i * 16 * ROWB + foff);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (grp == 1) {  // step q + 1 (read by waves 0-3 right after the coming barrier) must have landed
-            if (q + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        GRIT_PH(ph_l)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // ---- M(q): 32 MFMAs, the four DMA pieces of step q + 3 in between
-        const bool more = q + 3 < total;
+        GRIT_PH(ph_b1)
+        // ---- M(q): 32 MFMAs
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-            if ((i & 1) && more) dma(i >> 1);
-        }
         __builtin_amdgcn_s_setprio(0);
-        if (more) advance_load();
         if (grp == 0) {  // step q + 1 is read by this group right after the coming barrier
             if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         cslot = (cslot + 1) & (NSLOT - 1);
+        GRIT_PH(ph_m)
         if (++ks == KT) {
             epilogue(ti);
             ks = 0;
             ++ti;
+            GRIT_PH(ph_epi)
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        GRIT_PH(ph_b2)
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
+#ifdef GRIT_GEMM_STAMPS
+    if (g.stamps && (threadIdx.x & 63) == 0) {
+        unsigned long long* o = g.stamps + ((size_t)blockIdx.x * 8 + wave) * 16;
+        o[0] = ph_start; o[7] = __builtin_amdgcn_s_memtime();
+        o[8] = ph_l; o[9] = ph_b1; o[10] = ph_m; o[11] = ph_b2; o[12] = ph_epi; o[13] = (unsigned long long)total;
+    }
+#endif
+#undef GRIT_PH
 }
 
 int launch_pp(const GemmArgs& a, int epilogue, hipStream_t st) {

@@ -185,10 +185,6 @@ void winattn_fwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
         __syncthreads();
         if (win + ngrp < NW) nxt = fetch(win + ngrp);  // in flight during this window's compute
 
-        // A query tile made of window-padding tokens only (the last window row of a 40 -> 48 padded map: 6 of 9 tiles) has no
-        // output -- the reference crops it away, swin_model.py:289-293 -- and the backward skips the same tiles, so neither
-        // its rows of `out` nor its log-sum-exp are ever read: the wave only takes part in the staging.
-        if (__all(tq < 0)) continue;
         // ---- S^T = K Q^T : acc[kt][r] = <q(16w + l15), k(16kt + 4lg + r)>
         v4f acc[kTiles];
 #pragma unroll
@@ -306,7 +302,6 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     float* delta_s = lse_s + kN;                                            // [144]
     float* pad_s = delta_s + kN;                                            // [96]
     uint8_t* rid = reinterpret_cast<uint8_t*>(pad_s + 3 * kHd);             // [144]
-    uint8_t* tile_pad = rid + kN;                                           // [16]: tile t holds window padding only
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -369,16 +364,7 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
         *reinterpret_cast<uint4*>(&dOs[sn * kTP + sc * 8]) = do_c;
         if (sc == 0) { rid[sn] = (uint8_t)reg; delta_s[sn] = dpart; }
         if (tid < kN) lse_s[tid] = lse_v;
-        const bool all_pad = __all(tkk < 0);  // wave-uniform: all 16 tokens of tile w are window padding
-        if (lane == 0) tile_pad[w] = (uint8_t)all_pad;
         __syncthreads();
-        // Query tiles of padding tokens only: their dO is zero (the forward output is cropped there, swin_model.py:289-293), so
-        // P^T dO, dS and dQ vanish -- phase 1 skips them as query tiles, phase 2 skips the wave (6 of 9 tiles in the last
-        // window row of a 40 -> 48 padded map).  Padding KEYS stay: they carry the qkv bias and take part in every softmax.
-        unsigned skip = 0;
-#pragma unroll
-        for (int i = 0; i < kTiles; ++i) skip |= (unsigned)tile_pad[i] << i;
-        skip = __builtin_amdgcn_readfirstlane(skip);
 
         // Per-lane LDS offsets, made opaque once per window: without this hipcc hoists ~90 loop-invariant LDS
         // addresses out of the window loop, runs out of registers and reloads them from scratch before every read.
@@ -404,18 +390,15 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
             s_out = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             dp_out = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         };
-        v4f s_cur = {0.f, 0.f, 0.f, 0.f}, dp_cur = s_cur;
-        if (!(skip & 1u)) score_tiles(0, s_cur, dp_cur);
+        v4f s_cur, dp_cur;
+        score_tiles(0, s_cur, dp_cur);
 #pragma unroll
         for (int qt = 0; qt < kTiles; ++qt) {
             const v4f s = s_cur, dp = dp_cur;
-            const bool live = !((skip >> qt) & 1u);
-            if (qt + 1 < kTiles && !((skip >> (qt + 1)) & 1u)) {  // next tile's MFMAs and LDS reads fly under this tile's element-wise work
+            if (qt + 1 < kTiles) {  // next tile's MFMAs and LDS reads fly under this tile's element-wise work
                 score_tiles(qt + 1, s_cur, dp_cur);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            v4bf pp = {0, 0, 0, 0}, sp = {0, 0, 0, 0};
-            if (live) {
             // element-wise part, two score elements per instruction: the loop is instruction-issue bound and hipcc does not
             // form packed-fp32 operations from this code by itself, so the fma / sub / mul / add pairs are spelled out
             // (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 on 64-bit register pairs, which the halves of an MFMA result are)
@@ -452,13 +435,10 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
                 const v2f a = pk_add_asm(v2f{dB[qt][0], dB[qt][1]}, ds_lo), b = pk_add_asm(v2f{dB[qt][2], dB[qt][3]}, ds_hi);
                 dB[qt] = v4f{a[0], a[1], b[0], b[1]};
             }
-            pp = v4bf{(__bf16)p_lo[0], (__bf16)p_lo[1], (__bf16)p_hi[0], (__bf16)p_hi[1]};
-            sp = v4bf{(__bf16)ds_lo[0], (__bf16)ds_lo[1], (__bf16)ds_hi[0], (__bf16)ds_hi[1]};
+            const v4bf pp = {(__bf16)p_lo[0], (__bf16)p_lo[1], (__bf16)p_hi[0], (__bf16)p_hi[1]};
+            const v4bf sp = {(__bf16)ds_lo[0], (__bf16)ds_lo[1], (__bf16)ds_hi[0], (__bf16)ds_hi[1]};
             *reinterpret_cast<v4bf*>(&dSt[oW + 16 * qt]) = sp;
-            }  // live
-            // the pair's products are skipped when both of its query tiles are (an unpaired last tile: when it is)
-            const bool pair_live = (qt & 1) ? (live || !((skip >> (qt - 1)) & 1u)) : live;
-            if (((qt & 1) || qt == kTiles - 1) && pair_live) {
+            if ((qt & 1) || qt == kTiles - 1) {
                 const bool single = !(qt & 1);  // last, unpaired tile: upper 16 k-slots are zero
                 const v8bf pf = single ? v8bf{pp[0], pp[1], pp[2], pp[3], 0, 0, 0, 0}
                                        : v8bf{pprev[0], pprev[1], pprev[2], pprev[3], pp[0], pp[1], pp[2], pp[3]};
@@ -508,7 +488,6 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
 
         // ================= phase 2: wave w = query tile w : dQ^T[d][q] = scale * sum_k K^T[d][k] dS^T[k][q]
         // k-slot (lg, j) = key 32s + 8lg + j; the last step covers keys 128..143 only (lanes lg >= 2 contribute zeros)
-        if ((skip >> w) & 1u) continue;  // this wave's queries are padding: dQ = 0, nothing to store or to add to d(pad)
         v4f dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
         int oS2 = (8 * lg + trq) * kSP + 16 * w + 4 * trp, oK2 = (8 * lg + trq) * kTP + 4 * trp;
         int oS2d = trq * kSP + 16 * w + 4 * trp - 128 * kSP, oK2d = trq * kTP + 4 * trp - 128 * kTP;  // dead lanes, s5 = 4
@@ -727,7 +706,7 @@ void winattn_bwd_f32(const float* __restrict__ qkv, const float* __restrict__ re
 }
 
 constexpr size_t kBwdF32Lds = (size_t)4 * kN * kFP * 4 + 2 * kN * 4 + kN;
-constexpr size_t kBwdLds = (size_t)kN * kBP * 4 + 3 * (size_t)kN * kTP * 2 + (size_t)kN * kSP * 2 + 2 * kN * 4 + 3 * kHd * 4 + kN + 16;
+constexpr size_t kBwdLds = (size_t)kN * kBP * 4 + 3 * (size_t)kN * kTP * 2 + (size_t)kN * kSP * 2 + 2 * kN * 4 + 3 * kHd * 4 + kN;
 
 int check_geom(int B, int H, int W, int C, int nH, int window, int shift) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || nH <= 0) return GRIT_ERR_BAD_ARG;

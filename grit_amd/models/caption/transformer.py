@@ -7,6 +7,8 @@ a finished beam keeps its score only at vocabulary index 0 (-999 elsewhere), sel
 the flattened [beam*V] candidates, beam = index // V, every registered state is re-gathered per step, final beams
 re-sorted by score.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -16,10 +18,15 @@ from grit_amd.models.caption.grid_net import GridFeatureNetwork
 from grit_amd.utils.misc import NestedTensor
 
 
+# GRIT_GRAPH_DECODE=0: never replay beam search from a captured HIP graph (A/B knob, tools/bench_decode.py)
+_GRAPH_DECODE = os.environ.get('GRIT_GRAPH_DECODE', '1') != '0'
+
+
 class Transformer(BaseCaptioner):
 
     def __init__(self, detector, config=None):
         super().__init__()
+        self._decode_graphs = {}
         m = config.model
         # d_model 512 / 8 heads / d_ff 2048 are the constructor defaults on purpose: the reference never forwards
         # config.model.n_heads, grid_net.n_memories or cap_generator.decoder_name
@@ -62,6 +69,57 @@ class Transformer(BaseCaptioner):
 
     # ------------------------------------------------------------------ beam search
     def beam_search(self, images, max_len, eos_idx, beam_size, out_size, return_probs, **kwargs):
+        """Inference on a HIP device (no autograd, eval mode): the decode loop -- grid net + `max_len` decoder steps + beam
+        bookkeeping, ~5 000 small kernels whose launches bound the loop at ~2.7 ms of host time per step -- is captured ONCE per
+        (batch, beam, length, feature shapes) into a HIP graph and replayed from then on (next-row N1: the device-side beam
+        loop).  Same kernels, same order, same data: tokens and log-probs are those of the eager loop bit for bit.  Training
+        (self-critical: beam search with gradient), CPU runs and return_probs keep the eager loop."""
+        if self._graph_eligible(images, return_probs, kwargs):
+            vis = images if self.cached_features else self.detector(images)
+            return self._beam_search_graphed(dict(vis), max_len, eos_idx, beam_size, out_size)
+        return self._beam_search_eager(images, max_len, eos_idx, beam_size, out_size, return_probs, **kwargs)
+
+    def _graph_eligible(self, images, return_probs, kwargs):
+        if not _GRAPH_DECODE or return_probs or kwargs or self.training or torch.is_grad_enabled():
+            return False
+        _, device = self.get_bs_device(images)
+        return device.type == 'cuda' and not torch.cuda.is_current_stream_capturing()
+
+    def _decode_from_features(self, vis, max_len, eos_idx, beam_size, out_size):
+        was = self.cached_features
+        self.cached_features = True
+        try:
+            return self._beam_search_eager(vis, max_len, eos_idx, beam_size, out_size, False)
+        finally:
+            self.cached_features = was
+
+    def _beam_search_graphed(self, vis, max_len, eos_idx, beam_size, out_size):
+        names = sorted(k for k, v in vis.items() if isinstance(v, torch.Tensor))
+        key = (max_len, eos_idx, beam_size, out_size, torch.is_inference_mode_enabled(), vis[names[0]].device.index) + \
+            tuple((k, tuple(vis[k].shape), vis[k].dtype) for k in names)
+        entry = self._decode_graphs.get(key)
+        if entry is None:
+            if len(self._decode_graphs) >= 8:  # a few live shapes at most (each graph keeps its activations)
+                self._decode_graphs.clear()
+            static_in = {k: vis[k].clone() for k in names}
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):  # warm-up on a side stream: library workspaces, lazily built caches
+                self._decode_from_features(dict(static_in), max_len, eos_idx, beam_size, out_size)
+            cur.wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self._decode_from_features(dict(static_in), max_len, eos_idx, beam_size, out_size)
+            entry = self._decode_graphs[key] = (graph, static_in, static_out)
+        graph, static_in, static_out = entry
+        for k in names:
+            if vis[k].data_ptr() != static_in[k].data_ptr():
+                static_in[k].copy_(vis[k])
+        graph.replay()
+        return tuple(o.clone() for o in static_out)
+
+    def _beam_search_eager(self, images, max_len, eos_idx, beam_size, out_size, return_probs, **kwargs):
         batch_size, device = self.get_bs_device(images)
         self.seq_mask = torch.ones((batch_size, beam_size, 1), device=device)      # 1 while the beam is alive
         self.seq_logprob = torch.zeros((batch_size, 1, 1), device=device)          # running score per beam
@@ -176,14 +234,20 @@ class Transformer(BaseCaptioner):
         beam_col = selected_beam.unsqueeze(-1)
         self.seq_logprob = selected_logprob.unsqueeze(-1)
         self.seq_mask = torch.gather(self.seq_mask, 1, beam_col)
-        outputs = [torch.gather(o, 1, beam_col) for o in outputs]
+        # the history of every surviving beam moves with it: ONE gather of the concatenated columns instead of one per past
+        # step (the lists hold a single [B, beam, t] tensor from step 1 on)
+        if outputs:
+            hist = outputs[0] if len(outputs) == 1 else torch.cat(outputs, -1)
+            outputs = [torch.gather(hist, 1, beam_col.expand(batch_size, beam_size, hist.shape[-1]))]
         outputs.append(selected_words.unsqueeze(-1))
         if return_probs:
             lp = word_logprob.expand((batch_size, beam_size, -1)) if timestep == 0 else word_logprob
             self.all_log_probs.append(lp.unsqueeze(2))
         picked = torch.gather(word_logprob, 1, beam_col.expand(batch_size, beam_size, V))
         picked = torch.gather(picked, 2, selected_words.unsqueeze(-1))
-        self.log_probs = [torch.gather(o, 1, beam_col) for o in self.log_probs]
+        if self.log_probs:
+            hist = self.log_probs[0] if len(self.log_probs) == 1 else torch.cat(self.log_probs, -1)
+            self.log_probs = [torch.gather(hist, 1, beam_col.expand(batch_size, beam_size, hist.shape[-1]))]
         self.log_probs.append(picked)
         self.selected_words = selected_words.view(-1, 1)
         return samples, outputs

@@ -40,7 +40,28 @@ int main(int argc, char** argv) {
     hipEventRecord(e0); for (int i = 0; i < 10; ++i) run(nullptr); hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("variant %d epilogue %d: %.1f us per launch (no stamps)\n", variant, epi, ms * 100);
-    if (variant == 5) return 0;  // the persistent kernel carries no stamps
+    if (variant == 5) {  // persistent kernel: per-wave sums over its whole stream of K steps
+        hipMemset(stamps, 0, (size_t)waves_total * 16 * 8);
+        run(stamps); hipDeviceSynchronize();
+        std::vector<unsigned long long> h((size_t)waves_total * 16);
+        hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        const char* pn[] = {"L phase (DMA issue + fragment reads)", "barrier after L", "M phase (32 MFMAs + vmcnt)", "barrier after M", "epilogues"};
+        for (int grp = 0; grp < 2; ++grp) {
+            printf("  waves %d-%d, cycles per K step (32 deep); epilogue: per tile\n", 4 * grp, 4 * grp + 3);
+            for (int s = 0; s < 5; ++s) {
+                std::vector<double> d;
+                for (int wg = 0; wg < 256; ++wg)
+                    for (int w = 4 * grp; w < 4 * grp + 4; ++w) {
+                        const unsigned long long* o = &h[((size_t)wg * 8 + w) * 16];
+                        if (o[13]) d.push_back((double)o[8 + s] / (s == 4 ? (double)o[13] / (K / 32) : (double)o[13]));
+                    }
+                if (d.empty()) continue;
+                std::sort(d.begin(), d.end());
+                printf("    %-40s median %7.0f  p10 %7.0f  p90 %7.0f\n", pn[s], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
+            }
+        }
+        return 0;
+    }
     hipMemset(stamps, 0, (size_t)waves_total * 16 * 8);
     run(stamps); hipDeviceSynchronize();
     std::vector<unsigned long long> h((size_t)waves_total * 16);

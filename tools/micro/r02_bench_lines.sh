@@ -1,19 +1,18 @@
 # The bench lines profiles/r02 records next to the headline (run on the GPU box from the repo root).
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
 cd $R
-python -m pytest tests/test_winattn_gpu.py -q -x 2>&1 | tail -2
-python bench.py > $O/bench_default.json 2> $O/bench_default.err
-GRIT_MSDA_BWD_F32ACC=1 python bench.py --no-cpu-baseline --steps 30 --warmup 10 > $O/bench_msda_f32acc.json 2>/dev/null
-python bench.py --no-cpu-baseline --steps 30 --warmup 10 --points spread > $O/bench_points_spread.json 2>/dev/null
-python bench.py --no-cpu-baseline --steps 30 --warmup 10 --ragged > $O/bench_ragged.json 2>/dev/null
-python bench.py --no-cpu-baseline --steps 6 --warmup 3 --fp32 > $O/bench_fp32.json 2>/dev/null
+timeout 240 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+GRIT_MSDA_BWD_F32ACC=1 timeout 240 python bench.py --no-cpu-baseline --steps 30 --warmup 10 > $O/bench_msda_f32acc.json 2>/dev/null
+timeout 240 python bench.py --no-cpu-baseline --steps 30 --warmup 10 --points spread > $O/bench_points_spread.json 2>/dev/null
+timeout 240 python bench.py --no-cpu-baseline --steps 30 --warmup 10 --ragged > $O/bench_ragged.json 2>/dev/null
+timeout 240 python bench.py --no-cpu-baseline --steps 6 --warmup 3 --fp32 > $O/bench_fp32.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/default_stats -- python3 $R/bench.py --no-cpu-baseline --no-analysis > $O/bench_default_under_rocprof.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/default_stats -- python3 $R/bench.py --no-cpu-baseline --no-analysis > $O/bench_default_under_rocprof.json 2>/dev/null
 cp /tmp/default_stats/*/*_kernel_stats.csv $O/bench_default_command_kernel_stats.csv
-rocprofv3 --kernel-trace --output-format csv -d /tmp/steady -- python3 $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-analysis > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/steady -- python3 $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-analysis > /dev/null 2>&1
 python3 $R/tools/steady_profile.py /tmp/steady > $O/bench_bs32_steady_state.txt 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --no-analysis --steps 4 --warmup 3 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 $R/bench.py --no-cpu-baseline --no-analysis --steps 4 --warmup 3 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --no-analysis --steps 4 --warmup 3 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 $R/bench.py --no-cpu-baseline --no-analysis --steps 4 --warmup 3 > /dev/null 2>&1
 python3 - <<'PY' > $O/pmc_in_step.txt
 import csv, glob, collections
 print("HBM-side traffic of the hand-written kernels INSIDE the benchmark step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,")

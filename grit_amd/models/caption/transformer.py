@@ -7,12 +7,15 @@ a finished beam keeps its score only at vocabulary index 0 (-999 elsewhere), sel
 the flattened [beam*V] candidates, beam = index // V, every registered state is re-gathered per step, final beams
 re-sorted by score.
 """
+import ctypes
 import os
 
 import torch
 from torch import nn
 
+from grit_amd import lib as _lib
 from grit_amd.models.caption.base import BaseCaptioner
+from grit_amd.ops import backend
 from grit_amd.models.caption.cap_generator import CaptionGenerator
 from grit_amd.models.caption.grid_net import GridFeatureNetwork
 from grit_amd.utils.misc import NestedTensor
@@ -186,9 +189,22 @@ class Transformer(BaseCaptioner):
 
     def select(self, t, candidate_logprob, beam_size, **kwargs):
         """[B, Beam, V] -> the `beam_size` best of the flattened candidates, best first.  The reference takes the head of
-        a full descending torch.sort over beam*V = 51 005 scores per image per step (transformer.py:184-188); top-k
-        returns the same values in the same order (the order among exactly tied scores is unspecified in both)."""
+        a full descending torch.sort over beam*V = 51 005 scores per image per step (transformer.py:184-188); the selection
+        kernel (grit_topk_rows_f32: one workgroup per image, the row read once) returns the same values in the same order --
+        the order among exactly tied scores is unspecified in the reference and is by ascending index here."""
         flat = candidate_logprob.reshape(candidate_logprob.shape[0], -1)
+        if flat.is_cuda and flat.dtype == torch.float32 and beam_size <= 8 and not flat.requires_grad \
+                and backend.override() is None:
+            flat = flat if flat.stride(1) == 1 else flat.contiguous()
+            idx = torch.empty((flat.shape[0], beam_size), dtype=torch.int64, device=flat.device)
+            logprob = torch.empty((flat.shape[0], beam_size), dtype=torch.float32, device=flat.device)
+            with _lib.device_guard(flat.device):
+                st = _lib.load().grit_topk_rows_f32(ctypes.c_void_p(flat.data_ptr()), flat.stride(0), flat.shape[0],
+                                                    flat.shape[1], beam_size, ctypes.c_void_p(idx.data_ptr()),
+                                                    ctypes.c_void_p(logprob.data_ptr()), _lib.current_stream_ptr())
+            _lib.check(st, "grit_topk_rows_f32")
+            return idx, logprob
+        # with gradient (self-critical training), on the CPU (oracle runs) and for wide beams: the library selection
         logprob, idx = torch.topk(flat, beam_size, dim=-1, largest=True, sorted=True)
         return idx, logprob
 

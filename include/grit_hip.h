@@ -34,7 +34,8 @@
  *                           nested_tensor_from_tensor_list (engine/utils.py:278-295)
  *   grit_gemm_bf16_nt    <- nn.Linear + nn.GELU of Mlp (models/common/swin_model.py:31-37) and their autograd backward:
  *                           fc1 + bias + exact GELU in one pass; fc2's input gradient x GELU' + fc1's bias gradient in one pass
- * (none of the last seven groups has a native ancestor in the reference: they replace chains of torch / PIL ops)
+ *   grit_topk_rows_f32   <- Transformer.select (models/caption/transformer.py:184-188): sort of beam x vocabulary candidates
+ * (none of the last eight groups has a native ancestor in the reference: they replace chains of torch / PIL ops)
  */
 #ifndef GRIT_HIP_H
 #define GRIT_HIP_H
@@ -45,7 +46,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 19
+#define GRIT_ABI_VERSION 20
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -345,6 +346,14 @@ int grit_image_batch_fwd(const uint8_t* src, const int64_t* desc, const int32_t*
 #define GRIT_GEMM_COLSUM_ROWS 128
 int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                       int epilogue, const void* bias, void* aux, long ldaux, float* colsum, int variant, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Beam-search candidate selection (reference models/caption/transformer.py:184-188: descending sort of the flattened
+ * [beam * vocabulary] candidates, first `beam` kept).  x [rows, n] float32 with row stride ld (elements); the k <= 8 best of
+ * every row, best first: idx_out [rows, k] int64 (position in the row), val_out [rows, k].  Equal values: lower index first;
+ * NaN ranks above every number (torch's order).  Safe to capture in a HIP graph (no workspace, no host state).
+ * ------------------------------------------------------------------------------------------------------ */
+int grit_topk_rows_f32(const float* x, long ld, int rows, int n, int k, int64_t* idx_out, float* val_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -373,7 +373,9 @@ def main():
                                    f"3-layer caption decoder, 161M params, random init), {args.size}x{args.size} images, "
                                    f"caption length {args.caption_len}, Adam x2, dropout on",
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch,
-                       "parallelism": f"dp{world}", "grad_allreduce": "RCCL bucketed (64 MiB flat bf16 buckets), overlapped with backward"
+                       "parallelism": f"dp{world}",
+                       "grad_allreduce": (("RCCL" if backend == "nccl" else backend + " (plumbing run, not the contract backend)")
+                                          + " bucketed (64 MiB flat bf16 buckets, 8 MiB tail), overlapped with backward")
                        if world > 1 else "none (1 GPU)",
                        "points": args.points, "ragged": bool(args.ragged),
                        "msda_backward_accumulation": "f32" if (args.fp32 or msda_op.F32_ACCUMULATE) else "bf16 (packed atomics)"},

@@ -30,7 +30,7 @@ def build_hip(force=False, verbose=False):
     srcs = hip_sources()
     deps = srcs + [os.path.join(ROOT, "include", "grit_hip.h")] + \
         [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    if not force and _newer(LIB, deps):
+    if not force and _newer(LIB, deps) and os.path.lexists(os.path.join(CSRC, "libamdhip64.so.7")):
         return LIB
     # one object per source in parallel, then link
     objs, procs = [], []
@@ -48,11 +48,34 @@ def build_hip(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (s, out.decode()))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    # One HIP runtime per process, by construction: PyTorch-ROCm ships its own libamdhip64 (torch/lib, SONAME libamdhip64.so.7)
+    # and two runtimes in one process do not share streams.  The library looks for its runtime next to itself first ($ORIGIN),
+    # where `libamdhip64.so.7` is a link to torch's copy: whichever of torch / this library is loaded first, the loader ends up
+    # with the same file (it de-duplicates by inode), so there is no import-order rule any more.
+    _link_torch_hip_runtime()
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,$ORIGIN", "-Wl,--disable-new-dtags", "-o", LIB] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout.decode())
     return LIB
+
+
+def _link_torch_hip_runtime():
+    """csrc/libamdhip64.so.7 -> <torch>/lib/libamdhip64.so (when PyTorch-ROCm is installed; otherwise the system runtime is
+    found through hipcc's default run path)."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        torch_lib = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
+    except Exception:
+        torch_lib = None
+    link = os.path.join(CSRC, "libamdhip64.so.7")
+    if torch_lib and os.path.exists(torch_lib):
+        if os.path.islink(link) or os.path.exists(link):
+            if os.path.realpath(link) == os.path.realpath(torch_lib):
+                return
+            os.remove(link)
+        os.symlink(torch_lib, link)
 
 
 def build_oracle(force=False):

@@ -70,9 +70,8 @@ def load():
         raise GritHipError(
             "libgrit_hip.so not found at %s -- run `python -m grit_amd.build` (there is no CPU or "
             "PyTorch fallback for the GRIT kernels)" % LIB_PATH)
-    # torch first: it brings its own HIP runtime (torch/lib/libamdhip64.so); loading this library before torch would pull
-    # /opt/rocm's copy into the process and the two runtimes do not share streams (kernel launches then fail)
-    import torch  # noqa: F401
+    # The library resolves its HIP runtime to torch's copy by construction (grit_amd/build.py links libamdhip64.so.7 next to it
+    # and sets the run path to $ORIGIN), so the import order of torch and this library does not matter.
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -46,3 +46,22 @@ def test_cpu_tensors_are_rejected_like_the_reference():
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         ms_deform_attn_forward(torch.zeros(1, 4, 1, 4), shapes, lsi, torch.zeros(1, 1, 1, 1, 1, 2),
                                torch.zeros(1, 1, 1, 1, 1))
+
+
+def test_one_hip_runtime_whatever_is_loaded_first():
+    """libgrit_hip.so loaded BEFORE torch must end up on torch's HIP runtime (two runtimes in one process do not share streams):
+    the library finds `libamdhip64.so.7` next to itself, a link to torch's copy made by the build."""
+    import subprocess
+    import sys
+    from grit_amd import lib
+    code = (
+        "import ctypes\n"
+        "l = ctypes.CDLL(%r)\n"
+        "assert l.grit_abi_version() == %d\n"
+        "import torch, os\n"
+        "maps = open('/proc/self/maps').read()\n"
+        "libs = sorted({x.split()[-1] for x in maps.split('\\n') if 'libamdhip64' in x})\n"
+        "print(len(libs), os.path.realpath(libs[0]).startswith(os.path.dirname(torch.__file__)))\n" % (lib.LIB_PATH, lib.ABI_VERSION))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["1", "True"], out.stdout

@@ -43,10 +43,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_BF16 = 2.5e15
-# HBM-side bytes per launch at B = 32 (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes), per kernel, from profiles/r01/
+# HBM-side bytes per launch at B = 32 (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes), per kernel, from profiles/r01/ (fp32) and profiles/r02/ (bf16)
 # (bf16: measured on this benchmark's own launches -- value maps in the stacked layout, randomly initialised model)
-MSDA_FWD_TRAFFIC_B32 = {"fwd": int((2 * 130045.19 + 9600.0) * 1024), "fwd_bf16": int((2 * 31888.6 + 4800.0) * 1024)}
-MSDA_FWD_TRAFFIC_SOURCE = {"fwd": "profiles/r01/msda_pmc_b32.txt", "fwd_bf16": "profiles/r01/msda_pmc_in_step.txt"}
+MSDA_FWD_TRAFFIC_B32 = {"fwd": int((2 * 130045.19 + 9600.0) * 1024), "fwd_bf16": int((2 * 31856.0 + 4800.0) * 1024)}
+MSDA_FWD_TRAFFIC_SOURCE = {"fwd": "profiles/r01/msda_pmc_b32.txt", "fwd_bf16": "profiles/r02/pmc_in_step.txt"}
 MSDA_FWD_KERNEL = {"fwd": "msda_fwd_vec4<16,4> (MSDeformAttn forward, fp32 value map)",
                    "fwd_bf16": "msda_fwd_bf16_rows4<2> (MSDeformAttn forward, bf16 value map, fp32 sampling geometry)"}
 FLOP_PER_IMAGE_FWD_BWD = 955.8e9  # measured on the reference with torch.utils.flop_counter (640^2, T = 20)

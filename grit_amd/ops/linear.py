@@ -22,6 +22,55 @@ from grit_amd.ops.profiling import timed
 
 MIN_ROWS = int(os.environ.get("GRIT_LINEAR_MIN_ROWS", "512"))  # below this the launch overhead dominates: leave it to torch
 
+# The weight / bias gradients are not on the critical path of backward (nothing downstream of the node reads them), the input
+# gradient is.  With GRIT_WGRAD_STREAM=1 they are enqueued on a second HIP stream and the input-gradient GEMM on the current
+# one, so that the two GEMMs could fill each other's partial last wave of tiles and the small slab-sum / column-sum launches
+# run beside a GEMM instead of between two.  MEASURED SLOWER (64.4 -> 69.3 ms/step, profiles/r02/negative_results.txt): two
+# 128-KB-LDS GEMMs sharing the chip evict each other's L2 working set; the knob stays for A/B runs, default off.
+WGRAD_STREAM = os.environ.get("GRIT_WGRAD_STREAM", "0") == "1"
+_side_streams = {}
+
+
+def fork(*inputs):
+    """Side stream ordered after everything enqueued so far on the current stream (None when the knob is off / on CPU).
+    `inputs` are the tensors the side work reads: their memory is not handed out again before that work has run."""
+    if not (WGRAD_STREAM and inputs and inputs[0].is_cuda):
+        return None
+    dev = inputs[0].device
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    for t in inputs:
+        t.record_stream(side)
+    return side
+
+
+def join(side, *outputs):
+    """The current stream waits for the side work; `outputs` (allocated on the side stream) are consumed on the current one."""
+    if side is None:
+        return
+    main = torch.cuda.current_stream(side.device)
+    main.wait_stream(side)
+    for t in outputs:
+        if t is not None:
+            t.record_stream(main)
+
+
+class on_stream:
+    """`with on_stream(side):` -- torch.cuda.stream(side), or nothing when side is None."""
+
+    def __init__(self, side):
+        self.ctx = torch.cuda.stream(side) if side is not None else None
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
 
 def slab_sum(partial, out_dtype, slabs=None):
     """f32 partial sums [groups, slabs_allocated, n...] (contiguous) -> [groups, n...] in out_dtype: the sum over the first
@@ -100,13 +149,17 @@ class _LinearFn(Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         dx = dw = db = None
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        side = fork(dy2, x2) if (ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or need_b)) else None
+        with on_stream(side):
+            if ctx.needs_input_grad[1]:
+                dw = weight_grad(dy2, x2)
+            if need_b:
+                db = column_sum(dy2, weight.dtype)
         if ctx.needs_input_grad[0]:
             with timed("gemm_lib", flops=2.0 * dy2.numel() * weight.shape[1]):
                 dx = torch.mm(dy2, weight).view(x.shape)
-        if ctx.needs_input_grad[1]:
-            dw = weight_grad(dy2, x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = column_sum(dy2, weight.dtype)
+        join(side, dw, db)
         return dx, dw, db
 
 

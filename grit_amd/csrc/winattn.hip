@@ -327,29 +327,40 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
 
     const v4s z4s = {0, 0, 0, 0};
     const int sn = tid >> 2, sc = tid & 3;
-    for (int win = grp; win < NW; win += ngrp) {
+    // Global fetches of a window: the staging chunks (token sn, 16-byte chunk sc of Q / K / dO / O), this lane's K / V
+    // fragments (B operands of phase 1) and log-sum-exp.  They are issued one window AHEAD, after phase 1 of the previous
+    // window (where the register peak is), so that phase 2 and the gradient stores cover part of their latency.
+    struct Fetch { uint4 q_c, k_c, do_c, o_c, kf, vf; float lse_v; int reg, tkk, kreg, wy, wx; size_t img; };
+    auto fetch = [&](int win) {
+        Fetch f;
         const int b = win / (g.nWh * g.nWw), wrem = win - b * (g.nWh * g.nWw);
-        const int wy = wrem / g.nWw, wx = wrem - wy * g.nWw;
-        const size_t img = (size_t)b * g.T;
-
-        // ---- global fetches: staging chunks + this wave's K / V fragments (B operands of phase 1)
-        int reg;
-        const int tk = token_of(sn, wy, wx, g, reg);
-        const __bf16* src = tk >= 0 ? qkv + (img + tk) * C3 + hoff + sc * 8 : pad_qkv + hoff + sc * 8;
-        const uint4 q_c = load16(src);
-        const uint4 k_c = load16(src + g.C);
-        uint4 do_c = make_uint4(0, 0, 0, 0), o_c = make_uint4(0, 0, 0, 0);
+        f.wy = wrem / g.nWw; f.wx = wrem - f.wy * g.nWw;
+        f.img = (size_t)b * g.T;
+        const int tk = token_of(sn, f.wy, f.wx, g, f.reg);
+        const __bf16* src = tk >= 0 ? qkv + (f.img + tk) * C3 + hoff + sc * 8 : pad_qkv + hoff + sc * 8;
+        f.q_c = load16(src);
+        f.k_c = load16(src + g.C);
+        f.do_c = make_uint4(0, 0, 0, 0); f.o_c = make_uint4(0, 0, 0, 0);
         if (tk >= 0) {
-            do_c = load16(dout + (img + tk) * g.C + hoff + sc * 8);
-            o_c = load16(out + (img + tk) * g.C + hoff + sc * 8);
+            f.do_c = load16(dout + (f.img + tk) * g.C + hoff + sc * 8);
+            f.o_c = load16(out + (f.img + tk) * g.C + hoff + sc * 8);
         }
-        int kreg;
-        const int tkk = token_of(16 * w + l15, wy, wx, g, kreg);  // this lane's key in phase 1 / query in phase 2
-        const __bf16* ksrc = tkk >= 0 ? qkv + (img + tkk) * C3 + hoff + lg * 8 : pad_qkv + hoff + lg * 8;
-        const v8bf kf = as_v8bf(load16(ksrc + g.C));
-        const v8bf vf = as_v8bf(load16(ksrc + 2 * g.C));
-        float lse_v = 0.f;
-        if (tid < kN) lse_v = lse2[((size_t)win * g.nH + h) * kN + tid];
+        f.tkk = token_of(16 * w + l15, f.wy, f.wx, g, f.kreg);  // this lane's key in phase 1 / query in phase 2
+        const __bf16* ksrc = f.tkk >= 0 ? qkv + (f.img + f.tkk) * C3 + hoff + lg * 8 : pad_qkv + hoff + lg * 8;
+        f.kf = load16(ksrc + g.C);
+        f.vf = load16(ksrc + 2 * g.C);
+        f.lse_v = 0.f;
+        if (tid < kN) f.lse_v = lse2[((size_t)win * g.nH + h) * kN + tid];
+        return f;
+    };
+    Fetch nxt;
+    if (grp < NW) nxt = fetch(grp);
+    for (int win = grp; win < NW; win += ngrp) {
+        const int wy = nxt.wy, wx = nxt.wx, reg = nxt.reg, tkk = nxt.tkk, kreg = nxt.kreg;
+        const size_t img = nxt.img;
+        const uint4 q_c = nxt.q_c, k_c = nxt.k_c, do_c = nxt.do_c, o_c = nxt.o_c;
+        const v8bf kf = as_v8bf(nxt.kf), vf = as_v8bf(nxt.vf);
+        const float lse_v = nxt.lse_v;
         float dpart = 0.f;  // delta = rowsum(dO * O): 8 channels per thread, 4 threads per token
         {
             const v8bf a = as_v8bf(do_c), c = as_v8bf(o_c);
@@ -485,6 +496,7 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
             }
         }
         __syncthreads();  // dSt complete
+        if (win + ngrp < NW) nxt = fetch(win + ngrp);  // in flight during phase 2 and the stores
 
         // ================= phase 2: wave w = query tile w : dQ^T[d][q] = scale * sum_k K^T[d][k] dS^T[k][q]
         // k-slot (lg, j) = key 32s + 8lg + j; the last step covers keys 128..143 only (lanes lg >= 2 contribute zeros)

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -51,6 +51,9 @@ SIGNATURES = {
     "grit_attn_bwd_f32": _ATTN_IN + [_ptr] * 3 + [_int] * 5 + [_f32, _f32, _u64] + [_ptr] * 5,
     "grit_attn_bwd_bf16": _ATTN_IN + [_ptr] * 3 + [_int] * 5 + [_f32, _f32, _u64] + [_ptr] * 5,
     "grit_topk_rows_f32": [_ptr, _c.c_long, _int, _int, _int, _ptr, _ptr, _ptr],
+    "grit_beam_step_workspace": [_int, _int, _int],
+    "grit_beam_step_f32": [_ptr, _c.c_long, _ptr, _ptr, _ptr, _int, _int, _int, _int, _int, _int, _ptr, _c.c_long,
+                           _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "grit_gemm_bf16_nt": [_ptr, _c.c_long] * 3 + [_int] * 4 + [_ptr, _ptr, _c.c_long, _ptr, _int, _ptr],
 }
 
@@ -76,7 +79,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = _c.c_char_p if name == "grit_status_string" else _int
+        fn.restype = {"grit_status_string": _c.c_char_p, "grit_beam_step_workspace": _c.c_long}.get(name, _int)
     if lib.grit_abi_version() != ABI_VERSION:
         raise GritHipError("libgrit_hip.so ABI %d != binding ABI %d: rebuild" %
                            (lib.grit_abi_version(), ABI_VERSION))

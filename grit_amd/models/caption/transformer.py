@@ -16,6 +16,7 @@ from torch import nn
 from grit_amd import lib as _lib
 from grit_amd.models.caption.base import BaseCaptioner
 from grit_amd.ops import backend
+from grit_amd.ops import beam as beam_ops
 from grit_amd.models.caption.cap_generator import CaptionGenerator
 from grit_amd.models.caption.grid_net import GridFeatureNetwork
 from grit_amd.utils.misc import NestedTensor
@@ -23,6 +24,8 @@ from grit_amd.utils.misc import NestedTensor
 
 # GRIT_GRAPH_DECODE=0: never replay beam search from a captured HIP graph (A/B knob, tools/bench_decode.py)
 _GRAPH_DECODE = os.environ.get('GRIT_GRAPH_DECODE', '1') != '0'
+# GRIT_FUSED_BEAM_STEP=0: the candidate / selection / gather arithmetic of a beam step as separate torch ops + grit_topk_rows_f32
+_FUSED_BEAM_STEP = os.environ.get('GRIT_FUSED_BEAM_STEP', '1') != '0'
 
 
 class Transformer(BaseCaptioner):
@@ -224,32 +227,40 @@ class Transformer(BaseCaptioner):
         word_logprob = self.step(timestep, self.selected_words, samples, None, mode='feedback', **kwargs)
         word_logprob = word_logprob.view(batch_size, cur_beam, -1)
         V = word_logprob.shape[-1]
-        candidates = self.seq_logprob + word_logprob
-        if timestep > 0:
-            alive = (self.selected_words.view(batch_size, cur_beam) != eos_idx).float().unsqueeze(-1)
-            self.seq_mask = self.seq_mask * alive
-            word_logprob = word_logprob * self.seq_mask
-            frozen = self.seq_logprob.expand_as(candidates).contiguous()
-            frozen[:, :, 1:] = -999  # a finished beam survives only through vocabulary index 0
-            candidates = self.seq_mask * candidates + frozen * (1 - self.seq_mask)
+        fused = _FUSED_BEAM_STEP and not return_probs and not kwargs and beam_ops.supported(word_logprob, cur_beam, beam_size)
+        if fused:
+            # masking, candidate scores, selection and the score / mask / log-prob gathers in two launches (ops/beam.py)
+            selected_beam, selected_words, seq_logprob, seq_mask, picked = beam_ops.beam_step(
+                word_logprob, self.seq_logprob, self.seq_mask if timestep > 0 else None,
+                self.selected_words if timestep > 0 else None, eos_idx, beam_size)
+        else:
+            candidates = self.seq_logprob + word_logprob
+            if timestep > 0:
+                alive = (self.selected_words.view(batch_size, cur_beam) != eos_idx).float().unsqueeze(-1)
+                self.seq_mask = self.seq_mask * alive
+                word_logprob = word_logprob * self.seq_mask
+                frozen = self.seq_logprob.expand_as(candidates).contiguous()
+                frozen[:, :, 1:] = -999  # a finished beam survives only through vocabulary index 0
+                candidates = self.seq_mask * candidates + frozen * (1 - self.seq_mask)
 
-        selected_idx, selected_logprob = self.select(timestep, candidates, beam_size, **kwargs)
-        selected_beam = torch.div(selected_idx, V, rounding_mode='floor')
-        selected_words = selected_idx - selected_beam * V
+            selected_idx, selected_logprob = self.select(timestep, candidates, beam_size, **kwargs)
+            selected_beam = torch.div(selected_idx, V, rounding_mode='floor')
+            selected_words = selected_idx - selected_beam * V
 
         expand = self._expand_state(selected_beam, cur_beam, batch_size, beam_size)
-        if timestep > 0:
-            # all beams of an image carry the SAME visual memory: re-gathering it by the surviving beam index
-            # (reference :229) moves nothing.  Leaving those four states untouched also keeps their identity, which is
-            # what the hoisted K/V projections are keyed on.
-            visual = {id(getattr(self, n, None)) for n in ('gri_feat', 'gri_mask', 'reg_feat', 'reg_mask')} - {id(None)}
-            self.apply_to_states(lambda tensor: tensor if id(tensor) in visual else expand(tensor))
-        else:
-            self.apply_to_states(expand)
+        # All beams of an image carry the SAME visual memory: re-gathering it by the surviving beam index (reference :229)
+        # moves nothing, and replicating it per beam at step 0 only multiplies what every cross-attention reads.  The four
+        # visual states stay [B, ...]; Attention.forward groups the beams of an image onto its one copy.  Leaving them
+        # untouched also keeps their identity, which is what the hoisted K/V projections are keyed on.
+        visual = {id(getattr(self, n, None)) for n in ('gri_feat', 'gri_mask', 'reg_feat', 'reg_mask')} - {id(None)}
+        self.apply_to_states(lambda tensor: tensor if id(tensor) in visual else expand(tensor))
 
         beam_col = selected_beam.unsqueeze(-1)
-        self.seq_logprob = selected_logprob.unsqueeze(-1)
-        self.seq_mask = torch.gather(self.seq_mask, 1, beam_col)
+        if fused:
+            self.seq_logprob, self.seq_mask = seq_logprob, seq_mask
+        else:
+            self.seq_logprob = selected_logprob.unsqueeze(-1)
+            self.seq_mask = torch.gather(self.seq_mask, 1, beam_col)
         # the history of every surviving beam moves with it: ONE gather of the concatenated columns instead of one per past
         # step (the lists hold a single [B, beam, t] tensor from step 1 on)
         if outputs:
@@ -259,8 +270,9 @@ class Transformer(BaseCaptioner):
         if return_probs:
             lp = word_logprob.expand((batch_size, beam_size, -1)) if timestep == 0 else word_logprob
             self.all_log_probs.append(lp.unsqueeze(2))
-        picked = torch.gather(word_logprob, 1, beam_col.expand(batch_size, beam_size, V))
-        picked = torch.gather(picked, 2, selected_words.unsqueeze(-1))
+        if not fused:
+            picked = torch.gather(word_logprob, 1, beam_col.expand(batch_size, beam_size, V))
+            picked = torch.gather(picked, 2, selected_words.unsqueeze(-1))
         if self.log_probs:
             hist = self.log_probs[0] if len(self.log_probs) == 1 else torch.cat(self.log_probs, -1)
             self.log_probs = [torch.gather(hist, 1, beam_col.expand(batch_size, beam_size, hist.shape[-1]))]

@@ -51,18 +51,27 @@ class Attention(nn.Module):
         """q (b, nq, d_model), k/v (b, nk, d_model); attention_mask broadcastable to (b, h, nq, nk), True = masked.
         project=False returns the concatenated heads before fc_o (the caller fuses fc_o with what follows)."""
         b, nq, nk, h = q.shape[0], q.shape[1], k.shape[1], self.n_heads
+        bk = k.shape[0]
         qh = self.fc_q(q).view(b, nq, h, self.d_k)
+        if bk != b:
+            # beam search: the `g` beams of an image attend to ONE copy of its visual memory (Transformer.iter does not
+            # replicate it per beam) -- g queries per image instead of g images with one query each; K / V are read once
+            if b % bk or (attention_mask is not None and (attention_mask.shape[0] not in (1, bk) or attention_mask.shape[2] != 1)):
+                raise RuntimeError("queries [%d, %d] do not group onto keys [%d, %d]" % (b, nq, bk, nk))
+            qh = qh.view(bk, (b // bk) * nq, h, self.d_k)
         if self.hoist_kv and not self.training and k is v:
             # inference tensors carry no version counter; beam search never writes the visual memory in place
             tag = (k.data_ptr(), tuple(k.shape), 0 if k.is_inference() else k._version)
             if self._kv is None or self._kv[0] != tag:
-                self._kv = (tag, self.fc_k(k).view(b, nk, h, self.d_k), self.fc_v(v).view(b, nk, h, self.d_k))
+                self._kv = (tag, self.fc_k(k).view(bk, nk, h, self.d_k), self.fc_v(v).view(bk, nk, h, self.d_k))
             kh, vh = self._kv[1], self._kv[2]
         else:
-            kh = self.fc_k(k).view(b, nk, h, self.d_k)
-            vh = self.fc_v(v).view(b, nk, h, self.d_k)
+            kh = self.fc_k(k).view(bk, nk, h, self.d_k)
+            vh = self.fc_v(v).view(bk, nk, h, self.d_k)
         out = fused_attention(qh, kh, vh, attention_mask, scale=1.0 / np.sqrt(self.d_k), dropout_p=self.dropout.p,
                               training=self.training)
+        if bk != b:
+            out = out.view(b, nq, h * self.d_k)
         return self.fc_o(out) if project else out
 
 

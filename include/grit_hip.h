@@ -35,7 +35,9 @@
  *   grit_gemm_bf16_nt    <- nn.Linear + nn.GELU of Mlp (models/common/swin_model.py:31-37) and their autograd backward:
  *                           fc1 + bias + exact GELU in one pass; fc2's input gradient x GELU' + fc1's bias gradient in one pass
  *   grit_topk_rows_f32   <- Transformer.select (models/caption/transformer.py:184-188): sort of beam x vocabulary candidates
- * (none of the last eight groups has a native ancestor in the reference: they replace chains of torch / PIL ops)
+ *   grit_beam_step_f32   <- the body of Transformer.iter after the word log-probabilities (models/caption/transformer.py:208-240):
+ *                           finished-beam masking, candidate scores, selection, beam / word split, score / mask / log-prob gathers
+ * (none of the last nine groups has a native ancestor in the reference: they replace chains of torch / PIL ops)
  */
 #ifndef GRIT_HIP_H
 #define GRIT_HIP_H
@@ -46,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 20
+#define GRIT_ABI_VERSION 21
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -354,6 +356,25 @@ int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C,
  * NaN ranks above every number (torch's order).  Safe to capture in a HIP graph (no workspace, no host state).
  * ------------------------------------------------------------------------------------------------------ */
 int grit_topk_rows_f32(const float* x, long ld, int rows, int n, int k, int64_t* idx_out, float* val_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * One beam-search step after the decoder (reference models/caption/transformer.py:208-240, `iter`), for B images with
+ * cur_beam live beams each and a vocabulary of V words.  logp [B * cur_beam, V] float32 word log-probabilities (row stride ld),
+ * seq_logprob [B * cur_beam] running scores, seq_mask [B * cur_beam] 1 while a beam is alive, prev_words [B * cur_beam] int64
+ * the words chosen at the previous step (both ignored when first_step != 0: every beam alive).
+ *     alive      = seq_mask * (prev_words != eos)
+ *     candidate  = alive ? seq_logprob + logp : (word == 0 ? seq_logprob : -999)
+ *     the k <= 8 best candidates of each image over (beam, word), best first; equal scores by ascending beam * V + word
+ * Outputs, all [B, k]: sel_beam / sel_word int64, new_seq_logprob (the candidate score), new_seq_mask (alive of the source beam),
+ * picked_logprob = logp[sel_beam][sel_word] * alive.  Bit-identical to the reference's composed arithmetic.
+ * workspace: grit_beam_step_workspace(B, cur_beam, k) bytes of device memory, no initialisation needed.  Limits: cur_beam * k <= 64
+ * (16 at first_step), B <= 65535.  Two launches; safe to capture in a HIP graph.
+ * ------------------------------------------------------------------------------------------------------ */
+long grit_beam_step_workspace(int B, int cur_beam, int k);
+int grit_beam_step_f32(const float* logp, long ld, const float* seq_logprob, const float* seq_mask, const int64_t* prev_words,
+                       int eos, int first_step, int B, int cur_beam, int V, int k, void* workspace, long workspace_bytes,
+                       int64_t* sel_beam, int64_t* sel_word, float* new_seq_logprob, float* new_seq_mask, float* picked_logprob,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--bf16", action="store_true", help="bf16 weights (fp32 logits); default fp32 weights")
+    ap.add_argument("--decode-only", type=int, default=0, help="run the detector once, then N decodes only (for rocprofv3)")
     ap.add_argument("--inference-mode", action="store_true", help="torch.inference_mode instead of torch.no_grad")
     a = ap.parse_args()
     from grit_amd.config import default_config
@@ -40,6 +41,15 @@ def main():
         return out, time.perf_counter() - t0
 
     mode = torch.inference_mode if a.inference_mode else torch.no_grad
+    if a.decode_only:
+        with mode():
+            vis = model.detector(batch['samples'])
+            model.cached_features = True
+            for it in range(a.decode_only + 2):
+                (tokens, _), t_dec = sync_time(lambda: model(vis, seq=None, use_beam_search=True, max_len=20, eos_idx=3,
+                                                              beam_size=5, out_size=1))
+                print(json.dumps({"decode_20_steps_ms": t_dec * 1e3}))
+        return
     with mode():
         for it in range(a.iters + 1):
             vis, t_det = sync_time(lambda: model.detector(batch['samples']))

@@ -1,0 +1,135 @@
+// Element-wise fusion of the caption decoder's gated cross-attention merge at inference (davidnvq/grit
+// models/caption/cap_generator.py:44-56, ParallelAttentionLayer.forward):
+//
+//     enc1 = vis_att1(...) * mask_pad;  enc2 = vis_att2(...) * mask_pad
+//     gate1 = sigmoid(fc_alpha1(cat[self_att, enc1]));  gate2 = sigmoid(fc_alpha1(cat[self_att, enc2]))
+//     fused = (enc1 * gate1 + enc2 * gate2) / sqrt(2);   ff_in = fused * mask_pad
+//
+// Fourteen launches per layer in the composed form (two masks, two cats, two GEMMs, two sigmoids, two products, sum, scale,
+// mask); here gate_pack writes both GEMM inputs stacked ([2R, 2d]: ONE GEMM with fc_alpha1), gate_fuse does the rest.  Every
+// intermediate is rounded to the tensor dtype where the composed form rounds it (one torch kernel = one rounding) and products
+// and sums are kept un-contracted: in bf16 the result is the composed form's bit for bit (tests/test_gate_gpu.py), in fp32 to the
+// last place of exp / divide; the scale is the multiplication by 1.0f / float(sqrt(2)) torch performs for a division by a
+// Python scalar.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/grit_hip.h"
+
+namespace {
+
+template <typename T> struct Vec;
+template <> struct Vec<float> { static constexpr int n = 4; };
+template <> struct Vec<__bf16> { static constexpr int n = 8; };
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<__bf16>(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f<__bf16>(float v) { return (__bf16)v; }  // round to nearest even
+
+// The rounding a separate torch kernel would apply to its output.  For bf16 it is spelled on the bit pattern (round to nearest
+// even): a float -> __bf16 -> float cast pair is NOT a rounding under clang's default -fbfloat16-excess-precision=fast, which
+// keeps the float (measured: 21 % of the outputs off by up to a few bf16 ulps where the two products cancel).
+template <typename T> __device__ __forceinline__ float rnd(float v);
+template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
+template <> __device__ __forceinline__ float rnd<__bf16>(float v) {
+    uint32_t u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return v;  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xffff0000u);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void gate_pack(const T* __restrict__ self_att, const T* __restrict__ enc1, const T* __restrict__ enc2,
+               const T* __restrict__ mask_pad, int R, int d, T* __restrict__ X) {
+    constexpr int n = Vec<T>::n;
+    const int per_row = d / n;
+    const long total = (long)R * per_row;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / per_row), c = (int)(i - (long)r * per_row) * n;
+        const float m = to_f<T>(mask_pad[r]);
+        T s[n], a[n], b[n];
+        *reinterpret_cast<uint4*>(s) = *reinterpret_cast<const uint4*>(self_att + (size_t)r * d + c);
+        *reinterpret_cast<uint4*>(a) = *reinterpret_cast<const uint4*>(enc1 + (size_t)r * d + c);
+        *reinterpret_cast<uint4*>(b) = *reinterpret_cast<const uint4*>(enc2 + (size_t)r * d + c);
+#pragma unroll
+        for (int e = 0; e < n; ++e) {
+            a[e] = from_f<T>(rnd<T>(__fmul_rn(to_f<T>(a[e]), m)));
+            b[e] = from_f<T>(rnd<T>(__fmul_rn(to_f<T>(b[e]), m)));
+        }
+        T* x1 = X + (size_t)r * 2 * d;
+        T* x2 = X + ((size_t)R + r) * 2 * d;
+        *reinterpret_cast<uint4*>(x1 + c) = *reinterpret_cast<uint4*>(s);
+        *reinterpret_cast<uint4*>(x1 + d + c) = *reinterpret_cast<uint4*>(a);
+        *reinterpret_cast<uint4*>(x2 + c) = *reinterpret_cast<uint4*>(s);
+        *reinterpret_cast<uint4*>(x2 + d + c) = *reinterpret_cast<uint4*>(b);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void gate_fuse(const T* __restrict__ enc1, const T* __restrict__ enc2, const T* __restrict__ G, const T* __restrict__ mask_pad,
+               int R, int d, float inv_scale, T* __restrict__ out) {
+#pragma clang fp contract(off)  // fp32: a product and the following sum are two torch kernels, never one fma
+    constexpr int n = Vec<T>::n;
+    const int per_row = d / n;
+    const long total = (long)R * per_row;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / per_row), c = (int)(i - (long)r * per_row) * n;
+        const float m = to_f<T>(mask_pad[r]);
+        T a[n], b[n], g1[n], g2[n], o[n];
+        *reinterpret_cast<uint4*>(a) = *reinterpret_cast<const uint4*>(enc1 + (size_t)r * d + c);
+        *reinterpret_cast<uint4*>(b) = *reinterpret_cast<const uint4*>(enc2 + (size_t)r * d + c);
+        *reinterpret_cast<uint4*>(g1) = *reinterpret_cast<const uint4*>(G + (size_t)r * d + c);
+        *reinterpret_cast<uint4*>(g2) = *reinterpret_cast<const uint4*>(G + ((size_t)R + r) * d + c);
+#pragma unroll
+        for (int e = 0; e < n; ++e) {
+            const float e1 = rnd<T>(__fmul_rn(to_f<T>(a[e]), m)), e2 = rnd<T>(__fmul_rn(to_f<T>(b[e]), m));
+            const float s1 = rnd<T>(1.0f / (1.0f + expf(-to_f<T>(g1[e])))), s2 = rnd<T>(1.0f / (1.0f + expf(-to_f<T>(g2[e]))));
+            const float p1 = rnd<T>(__fmul_rn(e1, s1)), p2 = rnd<T>(__fmul_rn(e2, s2));
+            const float sum = rnd<T>(__fadd_rn(p1, p2));
+            const float scaled = rnd<T>(__fmul_rn(sum, inv_scale));
+            o[e] = from_f<T>(rnd<T>(__fmul_rn(scaled, m)));
+        }
+        *reinterpret_cast<uint4*>(out + (size_t)r * d + c) = *reinterpret_cast<uint4*>(o);
+    }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int grit_gate_pack(const void* self_att, const void* enc1, const void* enc2, const void* mask_pad, int rows, int d,
+                              int is_bf16, void* X, void* stream) {
+    if (!self_att || !enc1 || !enc2 || !mask_pad || !X || rows <= 0 || d <= 0) return GRIT_ERR_BAD_ARG;
+    if (d % 8 || !aligned16(self_att) || !aligned16(enc1) || !aligned16(enc2) || !aligned16(X)) return GRIT_ERR_UNSUPPORTED;
+    const long total = (long)rows * (d / (is_bf16 ? 8 : 4));
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (is_bf16)
+        hipLaunchKernelGGL(gate_pack<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const __bf16*)self_att, (const __bf16*)enc1, (const __bf16*)enc2,
+                           (const __bf16*)mask_pad, rows, d, (__bf16*)X);
+    else
+        hipLaunchKernelGGL(gate_pack<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)self_att,
+                           (const float*)enc1, (const float*)enc2, (const float*)mask_pad, rows, d, (float*)X);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+extern "C" int grit_gate_fuse(const void* enc1, const void* enc2, const void* gates, const void* mask_pad, int rows, int d,
+                              float divisor, int is_bf16, void* out, void* stream) {
+    if (!enc1 || !enc2 || !gates || !mask_pad || !out || rows <= 0 || d <= 0 || !(divisor != 0.f)) return GRIT_ERR_BAD_ARG;
+    if (d % 8 || !aligned16(enc1) || !aligned16(enc2) || !aligned16(gates) || !aligned16(out)) return GRIT_ERR_UNSUPPORTED;
+    const float inv = 1.0f / divisor;
+    const long total = (long)rows * (d / (is_bf16 ? 8 : 4));
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (is_bf16)
+        hipLaunchKernelGGL(gate_fuse<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const __bf16*)enc1, (const __bf16*)enc2, (const __bf16*)gates,
+                           (const __bf16*)mask_pad, rows, d, inv, (__bf16*)out);
+    else
+        hipLaunchKernelGGL(gate_fuse<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)enc1,
+                           (const float*)enc2, (const float*)gates, (const float*)mask_pad, rows, d, inv, (float*)out);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}

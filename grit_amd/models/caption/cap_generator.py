@@ -14,6 +14,8 @@ from torch.nn import functional as F
 from grit_amd.models.caption.containers import Module, ModuleList
 from grit_amd.models.common.attention import MultiHeadAttention
 from grit_amd.models.common.pos_embed import FeedForward, sinusoid_encoding_table
+from grit_amd.ops import backend
+from grit_amd.ops import gate as gate_ops
 from grit_amd.ops.linear import Linear
 
 
@@ -43,6 +45,11 @@ class ParallelAttentionLayer(GeneratorLayer):
 
     def forward(self, x, y1, y2, mask_pad, mask_x, mask_y1, mask_y2):
         self_att = self.self_att(x, x, x, mask_x) * mask_pad
+        if gate_ops.supported(self_att, self_att, self_att, mask_pad, self.fc_alpha1):
+            # inference on the device: the gate arithmetic below as pack -> ONE fc_alpha1 GEMM -> fuse (grit_amd/ops/gate.py)
+            enc1 = self.vis_att1(self_att, y1, y1, mask_y1)
+            enc2 = self.vis_att2(self_att, y2, y2, mask_y2)
+            return self.pwff(gate_ops.gated_merge(self_att, enc1, enc2, mask_pad, self.fc_alpha1)) * mask_pad
         enc1 = self.vis_att1(self_att, y1, y1, mask_y1) * mask_pad  # grid branch
         enc2 = self.vis_att2(self_att, y2, y2, mask_y2) * mask_pad  # region branch
         gate1 = torch.sigmoid(self.fc_alpha1(torch.cat([self_att, enc1], -1)))
@@ -96,5 +103,12 @@ class CaptionGenerator(Module):
             x = layer(x, y1, y2, mask_pad, mask_x, m1, m2)
         # vocabulary projection + log-softmax stay in float32: beam-search token identity depends on them
         with torch.autocast(x.device.type, enabled=False):
-            logits = F.linear(x.float(), self.fc.weight.float())
+            w = self.fc.weight
+            if x.is_cuda and x.dtype == w.dtype == torch.bfloat16 and not torch.is_grad_enabled() and backend.override() is None:
+                # products of two bf16 values are exact in float32, so the bf16 GEMM with float32 accumulation and float32
+                # output IS the float32 projection of the same operands (summation order aside) -- without up-casting the
+                # [V, 512] weight on every step and at the bf16 matrix-core rate
+                logits = torch.mm(x.reshape(-1, x.shape[-1]), w.t(), out_dtype=torch.float32).view(*x.shape[:-1], w.shape[0])
+            else:
+                logits = F.linear(x.float(), w.float())
             return F.log_softmax(logits, dim=-1)

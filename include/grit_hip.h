@@ -37,7 +37,10 @@
  *   grit_topk_rows_f32   <- Transformer.select (models/caption/transformer.py:184-188): sort of beam x vocabulary candidates
  *   grit_beam_step_f32   <- the body of Transformer.iter after the word log-probabilities (models/caption/transformer.py:208-240):
  *                           finished-beam masking, candidate scores, selection, beam / word split, score / mask / log-prob gathers
- * (none of the last nine groups has a native ancestor in the reference: they replace chains of torch / PIL ops)
+ *   grit_gate_pack, grit_gate_fuse
+ *                        <- the sigmoid-gated merge of the two cross-attentions at inference, ParallelAttentionLayer.forward
+ *                           (models/caption/cap_generator.py:44-56): masks, concatenations, sigmoids, products, sum, scale
+ * (none of the last ten groups has a native ancestor in the reference: they replace chains of torch / PIL ops)
  */
 #ifndef GRIT_HIP_H
 #define GRIT_HIP_H
@@ -48,7 +51,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 21
+#define GRIT_ABI_VERSION 22
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -375,6 +378,20 @@ int grit_beam_step_f32(const float* logp, long ld, const float* seq_logprob, con
                        int eos, int first_step, int B, int cur_beam, int V, int k, void* workspace, long workspace_bytes,
                        int64_t* sel_beam, int64_t* sel_word, float* new_seq_logprob, float* new_seq_mask, float* picked_logprob,
                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Gated merge of the grid / region cross-attentions of a caption decoder layer, inference only (reference
+ * models/caption/cap_generator.py:44-56).  All tensors [rows, d] row-major of one dtype (is_bf16: bfloat16, else float32),
+ * d % 8 == 0, 16-byte aligned; mask_pad [rows] of the same dtype (1 = real token, 0 = padding).
+ *   grit_gate_pack: X [2 * rows, 2 * d] with X[r] = (self_att[r], enc1[r] * mask_pad[r]), X[rows + r] = (self_att[r], enc2[r] * mask_pad[r])
+ *                   -- the two inputs of fc_alpha1, stacked so that ONE GEMM produces both gate pre-activations.
+ *   grit_gate_fuse: gates [2 * rows, d] = fc_alpha1(X);  out[r] = ((enc1*m * sigmoid(gates[r]) + enc2*m * sigmoid(gates[rows + r]))
+ *                   * (1 / divisor)) * m, every step rounded to the tensor dtype as the composed torch form rounds it.
+ * ------------------------------------------------------------------------------------------------------ */
+int grit_gate_pack(const void* self_att, const void* enc1, const void* enc2, const void* mask_pad, int rows, int d, int is_bf16,
+                   void* X, void* stream);
+int grit_gate_fuse(const void* enc1, const void* enc2, const void* gates, const void* mask_pad, int rows, int d, float divisor,
+                   int is_bf16, void* out, void* stream);
 
 #ifdef __cplusplus
 }

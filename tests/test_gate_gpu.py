@@ -1,0 +1,55 @@
+"""grit_gate_pack / grit_gate_fuse (grit_amd/ops/gate.py) against the composed arithmetic of the reference's
+ParallelAttentionLayer.forward (models/caption/cap_generator.py:44-56): bit-exact in bf16 (every intermediate rounded where the
+composed form rounds it), to the last place or two in fp32."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _composed(self_att, enc1, enc2, mask_pad, fc):
+    enc1 = enc1 * mask_pad
+    enc2 = enc2 * mask_pad
+    gate1 = torch.sigmoid(fc(torch.cat([self_att, enc1], -1)))
+    gate2 = torch.sigmoid(fc(torch.cat([self_att, enc2], -1)))
+    fused = (enc1 * gate1 + enc2 * gate2) / np.sqrt(2)
+    return fused * mask_pad
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,T", [(320, 1), (64, 1), (7, 20), (1, 1)])
+def test_gated_merge_is_the_composed_form(dtype, rows, T):
+    from grit_amd.ops import gate
+    torch.manual_seed(rows + T)
+    d = 512
+    fc = torch.nn.Linear(2 * d, d).cuda().to(dtype)
+    self_att = torch.randn(rows, T, d, device='cuda').to(dtype)
+    enc1 = (torch.randn(rows, T, d, device='cuda') * 2).to(dtype)
+    enc2 = (torch.randn(rows, T, d, device='cuda') * 2).to(dtype)
+    mask_pad = (torch.rand(rows, T, 1, device='cuda') > 0.2).to(dtype)
+    it = torch.int16 if dtype == torch.bfloat16 else torch.int32
+    with torch.no_grad():
+        assert gate.supported(self_att, enc1, enc2, mask_pad, fc)
+        e1, e2 = enc1 * mask_pad, enc2 * mask_pad
+        # pack == the two concatenations, stacked
+        X = gate.pack(self_att, enc1, enc2, mask_pad)
+        want_X = torch.cat([torch.cat([self_att, e1], -1), torch.cat([self_att, e2], -1)], 0).view(2 * rows * T, 2 * d)
+        assert torch.equal(X.view(it), want_X.view(it))
+        # fuse == the composed element-wise chain on the SAME gate pre-activations, bit for bit (signed zeros included)
+        G = fc(X)
+        got = gate.fuse(enc1, enc2, G, mask_pad)
+        Gv = G.view(2, rows, T, d)
+        want = ((e1 * torch.sigmoid(Gv[0]) + e2 * torch.sigmoid(Gv[1])) / np.sqrt(2)) * mask_pad
+        if dtype == torch.bfloat16:
+            assert torch.equal(got.view(it), want.view(it))
+        else:  # fp32: the device exp / divide of this library and of torch's kernels may differ in the last place
+            assert torch.allclose(got, want, rtol=2e-6, atol=1e-6)
+        # end to end against the reference's form (two GEMMs of R rows instead of one of 2R: the library may choose another
+        # kernel / reduction order, which moves a gate pre-activation by an ulp and, where the two products cancel, more)
+        full = gate.gated_merge(self_att, enc1, enc2, mask_pad, fc)
+        ref = _composed(self_att, enc1, enc2, mask_pad, fc)
+        tol = 6e-2 if dtype == torch.bfloat16 else 1e-5
+        assert (full.float() - ref.float()).abs().max().item() <= tol
+    with torch.enable_grad():
+        assert not gate.supported(self_att, enc1, enc2, mask_pad, fc)  # training keeps the differentiable composed form

@@ -12,7 +12,7 @@ from torch import nn
 
 from grit_amd.models.caption.containers import Module
 from grit_amd.ops.attention import attention as fused_attention
-from grit_amd.ops.layer_norm import linear_add_layer_norm
+from grit_amd.ops.layer_norm import add_layer_norm, linear_add_layer_norm
 from grit_amd.ops.linear import Linear
 
 
@@ -107,4 +107,5 @@ class MultiHeadAttention(Module):
             return linear_add_layer_norm(heads, self.attention.fc_o, queries, None, ln.weight, ln.bias, ln.eps,
                                          self.dropout.p, True)[1]
         out = self.dropout(self.attention(queries, keys, values, attention_mask))
-        return self.layer_norm(queries + out)
+        ln = self.layer_norm
+        return add_layer_norm(queries, out, None, ln.weight, ln.bias, ln.eps)[1]  # residual + LayerNorm in one launch on the device

@@ -2,7 +2,7 @@
 import torch
 from torch import nn
 from torch.nn import functional as F
-from grit_amd.ops.layer_norm import linear_add_layer_norm
+from grit_amd.ops.layer_norm import add_layer_norm, linear_add_layer_norm
 from grit_amd.ops.linear import Linear
 
 
@@ -39,4 +39,5 @@ class FeedForward(nn.Module):
         if self.training and torch.is_grad_enabled() and input.is_cuda:
             ln = self.layer_norm  # fc2 + dropout + residual + LayerNorm as one autograd node
             return linear_add_layer_norm(hidden, self.fc2, input, None, ln.weight, ln.bias, ln.eps, self.dropout.p, True)[1]
-        return self.layer_norm(input + self.dropout(self.fc2(hidden)))
+        ln = self.layer_norm
+        return add_layer_norm(input, self.dropout(self.fc2(hidden)), None, ln.weight, ln.bias, ln.eps)[1]

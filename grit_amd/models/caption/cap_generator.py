@@ -36,6 +36,7 @@ class ParallelAttentionLayer(GeneratorLayer):
         self.fc_alpha1 = Linear(d_model + d_model, d_model)
         self.fc_alpha2 = nn.Linear(d_model + d_model, d_model)  # never used in forward (reference quirk)
         self.activation = activation
+        self._q12 = None
         self.init_weights()
 
     def init_weights(self):
@@ -43,12 +44,22 @@ class ParallelAttentionLayer(GeneratorLayer):
             nn.init.xavier_uniform_(fc.weight)
             nn.init.constant_(fc.bias, 0)
 
+    def _cross_query_weights(self):
+        a, b = self.vis_att1.attention.fc_q, self.vis_att2.attention.fc_q
+        tag = tuple((p.data_ptr(), 0 if p.is_inference() else p._version, p.dtype) for p in (a.weight, a.bias, b.weight, b.bias))
+        if self._q12 is None or self._q12[0] != tag:
+            with torch.no_grad():
+                self._q12 = (tag, torch.cat([a.weight, b.weight], 0), torch.cat([a.bias, b.bias], 0))
+        return self._q12[1], self._q12[2]
+
     def forward(self, x, y1, y2, mask_pad, mask_x, mask_y1, mask_y2):
         self_att = self.self_att(x, x, x, mask_x) * mask_pad
         if gate_ops.supported(self_att, self_att, self_att, mask_pad, self.fc_alpha1):
             # inference on the device: the gate arithmetic below as pack -> ONE fc_alpha1 GEMM -> fuse (grit_amd/ops/gate.py)
-            enc1 = self.vis_att1(self_att, y1, y1, mask_y1)
-            enc2 = self.vis_att2(self_att, y2, y2, mask_y2)
+            d = self_att.shape[-1]
+            q12 = F.linear(self_att, *self._cross_query_weights())  # fc_q of both cross-attentions: one GEMM
+            enc1 = self.vis_att1(self_att, y1, y1, mask_y1, q_proj=q12[..., :d])
+            enc2 = self.vis_att2(self_att, y2, y2, mask_y2, q_proj=q12[..., d:])
             return self.pwff(gate_ops.gated_merge(self_att, enc1, enc2, mask_pad, self.fc_alpha1)) * mask_pad
         enc1 = self.vis_att1(self_att, y1, y1, mask_y1) * mask_pad  # grid branch
         enc2 = self.vis_att2(self_att, y2, y2, mask_y2) * mask_pad  # region branch

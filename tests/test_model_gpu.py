@@ -213,3 +213,39 @@ def test_no_padding_shortcuts_change_nothing(g7_model):
         fast = model.detector(NestedTensor(x, mask, any_padding=False))
     for k in general:
         assert torch.equal(general[k], fast[k]), k
+
+
+def test_device_decode_shortcuts_reproduce_the_reference_order_loop(g7_model, monkeypatch):
+    """The inference-only restructurings of the decode loop -- fused beam step (two launches), projected key/value cache with
+    one q/k/v GEMM, the gated merge as pack / GEMM / fuse, one copy of the visual memory per image -- against the loop that
+    composes the reference's operations one by one (every knob off, eager, no graph): same tokens, log-probs within fp32
+    round-off.  fp32 weights, three perturbed images, beam 5."""
+    import grit_amd.models.caption.transformer as T
+    import grit_amd.models.common.attention as A
+    from grit_amd.ops import gate as gate_ops
+    model, _ = g7_model
+    g = load("model_g7.npz")
+    gen = torch.Generator().manual_seed(5)
+    batch = {"gri_feat": torch.cat([t(g["gri_feat"], device=DEV) + 0.2 * i * torch.randn(1, 16, 1024, generator=gen).to(DEV)
+                                    for i in range(3)], 0),
+             "reg_feat": torch.cat([t(g["reg_feat"], device=DEV) + 0.2 * i * torch.randn(1, 150, 512, generator=gen).to(DEV)
+                                    for i in range(3)], 0),
+             "gri_mask": t(g["gri_mask"], device=DEV).expand(3, -1, -1, -1).contiguous(),
+             "reg_mask": t(g["reg_mask"], device=DEV).expand(3, -1, -1, -1).contiguous()}
+
+    def decode():
+        model.cached_features = True
+        try:
+            with torch.no_grad():
+                return model(batch, seq=None, use_beam_search=True, max_len=20, eos_idx=3, beam_size=5, out_size=1)
+        finally:
+            model.cached_features = False
+
+    fast_tokens, fast_lp = decode()
+    monkeypatch.setattr(T, "_GRAPH_DECODE", False)
+    monkeypatch.setattr(T, "_FUSED_BEAM_STEP", False)
+    monkeypatch.setattr(A, "_KV_CACHE", False)
+    monkeypatch.setattr(gate_ops, "supported", lambda *a, **k: False)
+    slow_tokens, slow_lp = decode()
+    assert torch.equal(fast_tokens, slow_tokens)
+    assert torch.allclose(fast_lp, slow_lp, rtol=1e-4, atol=1e-4)

@@ -51,9 +51,9 @@ __device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned lo
     return u >= p ? inv_keep : 0.0f;
 }
 
-// stage rows [0, n) of a [n, 64] bf16 matrix (row stride ld) into an LDS tile of pitch kP, zero rows [n, 160)
-__device__ __forceinline__ void stage_tile(__bf16* tile, const __bf16* src, long ld, int n) {
-    for (int i = threadIdx.x; i < kRows * 8; i += blockDim.x) {
+// stage rows [0, n) of a [n, 64] bf16 matrix (row stride ld) into an LDS tile of pitch kP, zero rows [n, rows)
+__device__ __forceinline__ void stage_tile(__bf16* tile, const __bf16* src, long ld, int n, int rows = kRows) {
+    for (int i = threadIdx.x; i < rows * 8; i += blockDim.x) {
         const int row = i >> 3, c = i & 7;
         uint4 val = make_uint4(0, 0, 0, 0);
         if (row < n) val = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c * 8);
@@ -74,13 +74,16 @@ void attn_mfma_fwd(const __bf16* __restrict__ q, long ldq, long bsq, const __bf1
     const int trq = l15 >> 2, trp = l15 & 3;
     const int nkt = (Nk + 15) >> 4;
 
-    stage_tile(Ks, k + (size_t)b * bsk + (size_t)h * kD, ldk, Nk);
-    stage_tile(Vs, v + (size_t)b * bsv + (size_t)h * kD, ldv, Nk);
+    // only the rows the products below touch: key tiles of 16 for S, k-steps of 32 keys for P V
+    const int staged = min(kRows, (Nk + 31) & ~31);
+    stage_tile(Ks, k + (size_t)b * bsk + (size_t)h * kD, ldk, Nk, staged);
+    stage_tile(Vs, v + (size_t)b * bsv + (size_t)h * kD, ldv, Nk, staged);
     const int row = 16 * w + l15;           // this lane's query
     const int rowc = min(row, Tq - 1);
     const __bf16* qrow = q + (size_t)b * bsq + (size_t)rowc * ldq + (size_t)h * kD + lg * 8;
     const v8bf qf0 = ld8(qrow), qf1 = ld8(qrow + 32);
     __syncthreads();
+    if (16 * w >= Tq) return;  // a wave launched only to help staging (few queries, step-wise decoding): no barrier follows
 
     const float c2 = scale * kLog2e;
     const uint8_t* mrow = mask ? mask + (size_t)b * msb + (size_t)rowc * msq : nullptr;
@@ -310,7 +313,9 @@ int grit_attn_mfma_fwd(const void* q, long ldq, long bsq, const void* k, long ld
                        float drop_p, unsigned long long seed, const unsigned long long* seed_dev, void* out, float* lse,
                        hipStream_t st) {
     if (!fits(q, ldq, bsq, k, ldk, bsk, v, ldv, bsv, Tq, Nk, D) || (uintptr_t)out % 16) return GRIT_ERR_UNSUPPORTED;
-    const int waves = (Tq + 15) / 16;
+    // at least 4 waves: with one or two query tiles (beam search: 1-8 queries per image) the K / V staging, not the math, is
+    // the critical path, and a single wave would issue its 2 x 20 row loads one after the other
+    const int waves = max(4, (Tq + 15) / 16);
     hipLaunchKernelGGL(attn_mfma_fwd, dim3(B * H), dim3(64 * waves), 0, st, (const __bf16*)q, ldq, bsq, (const __bf16*)k,
                        ldk, bsk, (const __bf16*)v, ldv, bsv, mask, msb, msq, H, Tq, Nk, scale, drop_p, seed, seed_dev, (__bf16*)out, lse);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;

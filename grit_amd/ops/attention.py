@@ -40,7 +40,8 @@ def _mask_args(mask, B, Tq, Nk):
     m = mask
     if m.dim() != 4 or m.shape[1] != 1 or m.shape[3] != Nk or m.shape[0] not in (1, B) or m.shape[2] not in (1, Tq):
         raise RuntimeError("attention mask must be [B|1, 1, Tq|1, Nk], got %s" % (tuple(m.shape),))
-    m = m.to(torch.uint8).contiguous()
+    # a bool tensor is one byte per element holding 0 / 1: reinterpreted in place (no conversion launch per attention call)
+    m = m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8).contiguous()
     sb = 0 if m.shape[0] == 1 else m.shape[2] * Nk
     sq = 0 if m.shape[2] == 1 else Nk
     return m, sb, sq

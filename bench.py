@@ -184,26 +184,10 @@ def cpu_baseline(config, size, caption_len, steps):
 
 
 def _enable_tuned_gemms():
-    """hipBLASLt / rocBLAS solution choices for this model's GEMM shapes, tuned once on an MI355X with PyTorch
-    TunableOp and shipped as data (grit_amd/tunableop_gfx950.csv).  Reading is validator-checked by torch (PyTorch /
-    ROCm / hipBLASLt versions, gfx arch): on any mismatch the file is ignored and the library defaults run.
-    No tuning happens inside the benchmark."""
-    path = os.path.join(ROOT, "grit_amd", "tunableop_gfx950.csv")
-    if os.environ.get("GRIT_TUNED_GEMMS", "1") != "1" or not os.path.exists(path):
-        return False
-    try:
-        import torch.cuda.tunable as tunable
-        tunable.enable(True)
-        tunable.tuning_enable(False)
-        if hasattr(tunable, "record_untuned_enable"):
-            tunable.record_untuned_enable(False)
-        if hasattr(tunable, "write_file_on_exit"):
-            tunable.write_file_on_exit(False)
-        tunable.set_filename(os.path.join("/tmp", f"grit_tunableop_scratch_{os.getpid()}.csv"))
-        return bool(tunable.read_file(path))
-    except Exception as e:  # never let a tuning-file problem break the measurement
-        print(f"[bench] tuned GEMM table not loaded: {e}", file=sys.stderr)
-        return False
+    """hipBLASLt / rocBLAS solution choices for this model's GEMM shapes, tuned once on an MI355X and shipped as data: the same
+    call every entry point of the package makes (grit_amd/tuning.py).  No tuning happens inside the benchmark."""
+    from grit_amd.tuning import load_tuned_gemms
+    return load_tuned_gemms()
 
 
 def main():

@@ -12,12 +12,15 @@ import os
 import torch
 
 from grit_amd.config import default_config
+from grit_amd.tuning import load_tuned_gemms
 from models.caption import Transformer
 from models.caption.detector import build_detector
 from engine.utils import nested_tensor_from_tensor_list
 
 
 def build_model(config, device, checkpoint=''):
+    if torch.device(device).type == 'cuda':
+        load_tuned_gemms()  # library GEMM solutions tuned for this model's shapes (grit_amd/tuning.py)
     detector = build_detector(config).to(device)
     model = Transformer(detector=detector, config=config).to(device)
     if checkpoint and os.path.exists(checkpoint):
@@ -51,6 +54,19 @@ def caption_stream(model, batches, config, beam_size=None):
             yield model(samples, seq=None, use_beam_search=True, max_len=config.model.beam_len, eos_idx=config.model.eos_idx,
                         beam_size=beam, out_size=1, return_probs=False)
         return
+    # The tuned GEMM table (grit_amd/tuning.py) is switched off while two streams issue library GEMMs side by side: with it, the
+    # detector stream stalls for tens of ms every few batches next to the replayed decode graph (63-91 ms per batch instead of 51,
+    # tools/micro/dbg_pipelined.py); the sequential path keeps it (detector 46.6 -> 40.5 ms).
+    import torch.cuda.tunable as tunable
+    tuned = tunable.is_enabled()
+    tunable.enable(False)
+    try:
+        yield from _caption_stream_device(model, batches, config, beam, device)
+    finally:
+        tunable.enable(tuned)
+
+
+def _caption_stream_device(model, batches, config, beam, device):
     det_stream, dec_stream = torch.cuda.Stream(device), torch.cuda.Stream(device)
     caller = torch.cuda.current_stream(device)
     det_stream.wait_stream(caller)

@@ -27,6 +27,8 @@ def main():
     from grit_amd.models.caption import Transformer
     from grit_amd.models.caption.detector import build_detector
     cfg = default_config()
+    from grit_amd.tuning import load_tuned_gemms
+    load_tuned_gemms()
     torch.manual_seed(0)
     model = Transformer(build_detector(cfg), cfg).cuda().eval()
     if a.bf16:
@@ -71,7 +73,14 @@ def main():
         outs = list(caption_stream(model, [batch['samples']] * n, cfg, 5))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    assert all(torch.equal(o[0], tokens) for o in outs)
+    # same kernels on the same data as a sequential run WITHOUT the tuned GEMM table (caption_stream switches it off, see there)
+    import torch.cuda.tunable as tunable
+    was = tunable.is_enabled()
+    tunable.enable(False)
+    with torch.no_grad():
+        ref_tokens = model(batch['samples'], seq=None, use_beam_search=True, max_len=20, eos_idx=3, beam_size=5, out_size=1)[0]
+    tunable.enable(was)
+    assert all(torch.equal(o[0], ref_tokens) for o in outs)
     print(json.dumps({"batch": a.batch, "dtype": "bf16" if a.bf16 else "fp32", "pipelined_batches": n,
                       "ms_per_batch": dt / n * 1e3, "captions_per_sec": a.batch * n / dt}))
 

@@ -2,6 +2,7 @@
 
     python tools/tune_gemms.py            # records untuned shapes to gpurun_out/tunableop_untuned.csv
     python tools/tune_gemms.py --tune     # tunes them (PyTorch TunableOp) and writes the merged table to gpurun_out/
+    python tools/tune_gemms.py --inference [--tune]      # same for captioning at batch 64 (detector forward + beam search)
 
 The merged table is copied over grit_amd/tunableop_gfx950.csv by hand after review; bench.py only ever reads it."""
 import argparse
@@ -18,6 +19,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tune", action="store_true")
     ap.add_argument("--max-ms", type=int, default=40)
+    ap.add_argument("--inference", action="store_true", help="the shapes of captioning at batch 64 (detector forward + eager beam "
+                    "search, bf16 weights) instead of the training step")
     args = ap.parse_args()
     import torch.cuda.tunable as tunable
     out_dir = os.path.join(ROOT, "gpurun_out")
@@ -33,6 +36,24 @@ def main():
     if not args.tune:
         os.environ["PYTORCH_TUNABLEOP_UNTUNED_FILENAME"] = os.path.join(out_dir, "tunableop_untuned.csv")
         tunable.record_untuned_enable(True)
+    if args.inference:
+        os.environ["GRIT_GRAPH_DECODE"] = "0"  # tuning launches candidates: not inside a graph capture
+        from grit_amd.config import default_config
+        from grit_amd.data import synthetic_batch
+        from grit_amd.models.caption import Transformer
+        from grit_amd.models.caption.detector import build_detector
+        cfg = default_config()
+        torch.manual_seed(0)
+        model = Transformer(build_detector(cfg), cfg).cuda().eval().to(torch.bfloat16)
+        batch = synthetic_batch(64, 640, 640, device="cuda", seed=1)
+        with torch.no_grad():
+            for _ in range(2):
+                model(batch['samples'], seq=None, use_beam_search=True, max_len=20, eos_idx=3, beam_size=5, out_size=1)
+        torch.cuda.synchronize()
+        if args.tune and hasattr(tunable, "write_file"):
+            tunable.write_file()
+        print("results:", len(tunable.get_results()))
+        return
     import bench
     from grit_amd.amp import Bf16Compute
     from grit_amd.config import default_config

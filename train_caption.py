@@ -27,6 +27,7 @@ from grit_amd.config import default_config, load_yaml
 from grit_amd.data import SyntheticLoader
 from grit_amd.amp import Bf16Compute
 from grit_amd.ddp import BucketedDataParallel
+from grit_amd.tuning import load_tuned_gemms
 from engine.caption_engine import *  # noqa: F401,F403  (reference does the same star import)
 from engine.caption_engine import build_optimizers, save_checkpoint, train_sc, train_xe
 from models.caption import Transformer
@@ -65,6 +66,7 @@ def main(gpu, config, dataloaders=None, text_field=None, cider=None, tokenizer_p
     device = torch.device(f"cuda:{gpu}" if use_cuda else "cpu")
     if use_cuda:
         torch.cuda.set_device(gpu)
+        load_tuned_gemms()  # library GEMM solutions tuned for this model's shapes (grit_amd/tuning.py)
 
     detector = build_detector(config).to(device)
     model = Transformer(detector=detector, config=config).to(device)

@@ -28,7 +28,7 @@ import torch.utils.checkpoint as checkpoint
 
 from grit_amd.ops.layer_norm import LayerNorm, add_layer_norm, linear_add_layer_norm
 from grit_amd.ops.linear import Linear, linear
-from grit_amd.ops.mlp import mlp as fused_mlp, mlp_add_layer_norm
+from grit_amd.ops.mlp import hidden as fused_hidden, mlp as fused_mlp, mlp_add_layer_norm
 from grit_amd.ops.rel_bias import relative_position_bias
 from grit_amd.ops.window_attention import window_attention
 
@@ -208,7 +208,8 @@ class SwinTransformerBlock(nn.Module):
             fused = mlp_add_layer_norm(n2, self.mlp, x, scale, next_norm) if _FUSED_MLP else None
             if fused is not None:
                 return fused
-            return self._residual_linear_norm(x, self.mlp.hidden(n2), self.mlp.fc2, next_norm, scale=scale, drawn=True)
+            hidden = fused_hidden(n2, self.mlp) if _FUSED_MLP else self.mlp.hidden(n2)
+            return self._residual_linear_norm(x, hidden, self.mlp.fc2, next_norm, scale=scale, drawn=True)
         x, n2 = self._residual_norm(x, self.attn.attend_map(n1, H, W, self.shift_size), self.norm2)
         h = self.mlp(n2)
         if next_norm is None:

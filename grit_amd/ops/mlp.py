@@ -148,6 +148,15 @@ def mlp(x, module):
     return _MlpFn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
 
 
+def hidden(x, module):
+    """module.hidden(x) = drop(gelu(fc1(x))); without autograd (inference, frozen stages) fc1 + bias + GELU is one launch."""
+    fc1 = module.fc1
+    if not _fits(x, module) or (torch.is_grad_enabled() and (x.requires_grad or fc1.weight.requires_grad)):
+        return module.hidden(x)
+    act = G.gemm_nt(_rows(x), fc1.weight, G.BIAS_GELU, bias=fc1.bias)
+    return act.view(x.shape[:-1] + (fc1.weight.shape[0],))
+
+
 def mlp_add_layer_norm(x_in, module, shortcut, scale, norm):
     """(x, norm(x)) with x = shortcut + scale[b] * module(x_in), or None when the fused node does not apply."""
     C = shortcut.shape[-1]

@@ -55,6 +55,11 @@ __device__ __forceinline__ v2f pk_sub_asm(v2f a, v2f b) {  // a - b: negate both
 }
 typedef __attribute__((address_space(3))) v4s lds_v4s;
 
+#ifdef GRIT_NT_WINATTN
+#define GRIT_ST4(ptr, val) __builtin_nontemporal_store((val), reinterpret_cast<v4bf*>(ptr))
+#else
+#define GRIT_ST4(ptr, val) (*reinterpret_cast<v4bf*>(ptr) = (val))
+#endif
 constexpr int kWs = 12, kN = 144, kHd = 32, kTiles = 9, kThreads = 576;
 constexpr int kKP = 40;      // pitch (bf16 elements) of row-read tiles: 80 B, spreads ds_read_b128 over banks
 constexpr int kVP = 32;      // pitch of tiles read through ds_read_b64_tr_b16 (64 B rows)
@@ -255,8 +260,8 @@ void winattn_fwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
             v4bf a, c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { a[r] = (__bf16)(o0[r] * inv); c[r] = (__bf16)(o1[r] * inv); }
-            *reinterpret_cast<v4bf*>(orow) = a;
-            *reinterpret_cast<v4bf*>(orow + 16) = c;
+            GRIT_ST4(orow, a);
+            GRIT_ST4(orow + 16, c);
         }
         if (lg == 0) lse2[((size_t)win * g.nH + h) * kN + 16 * w + l15] = m + __builtin_amdgcn_logf(sum);
     }
@@ -476,10 +481,10 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
                 a[r] = (__bf16)(dk0[r] * g.scale); c[r] = (__bf16)(dk1[r] * g.scale);
                 e[r] = (__bf16)dv0[r]; f[r] = (__bf16)dv1[r];
             }
-            *reinterpret_cast<v4bf*>(base + g.C) = a;
-            *reinterpret_cast<v4bf*>(base + g.C + 16) = c;
-            *reinterpret_cast<v4bf*>(base + 2 * g.C) = e;
-            *reinterpret_cast<v4bf*>(base + 2 * g.C + 16) = f;
+            GRIT_ST4(base + g.C, a);
+            GRIT_ST4(base + g.C + 16, c);
+            GRIT_ST4(base + 2 * g.C, e);
+            GRIT_ST4(base + 2 * g.C + 16, f);
         }
         if (__any(tkk < 0)) {  // gradient of window-padding tokens flows to pad_qkv: reduce over the tile first
             const float keep = tkk < 0 ? 1.f : 0.f;
@@ -519,8 +524,8 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
             v4bf a, c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { a[r] = (__bf16)(dq0[r] * g.scale); c[r] = (__bf16)(dq1[r] * g.scale); }
-            *reinterpret_cast<v4bf*>(base) = a;
-            *reinterpret_cast<v4bf*>(base + 16) = c;
+            GRIT_ST4(base, a);
+            GRIT_ST4(base + 16, c);
         }
         if (__any(tkk < 0)) {
             const float keep = tkk < 0 ? 1.f : 0.f;

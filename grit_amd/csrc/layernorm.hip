@@ -23,9 +23,16 @@ template <> struct Vec8<float> {
         const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     }
-    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8], bool nt = false) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        if (nt) {
+            __builtin_nontemporal_store(a, reinterpret_cast<v4f*>(p));
+            __builtin_nontemporal_store(b, reinterpret_cast<v4f*>(p + 4));
+        } else {
+            *reinterpret_cast<v4f*>(p) = a;
+            *reinterpret_cast<v4f*>(p + 4) = b;
+        }
     }
 };
 template <> struct Vec8<__hip_bfloat16> {
@@ -38,18 +45,18 @@ template <> struct Vec8<__hip_bfloat16> {
             v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
         }
     }
-    static __device__ __forceinline__ void store(__hip_bfloat16* p, const float (&v)[8]) {
+    static __device__ __forceinline__ void store(__hip_bfloat16* p, const float (&v)[8], bool nt = false) {
         typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
         v8bf o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
-        // streamed past L2: the maps are 50-400 MB, written once and read by a later kernel from HBM anyway, and keeping them out
-        // of the cache leaves the neighbouring GEMMs' operand panels resident (63.5 -> 62.9 ms per training step, A/B on one box)
-#ifdef GRIT_LN_PLAIN_STORES
-        *reinterpret_cast<v8bf*>(p) = o;
-#else
-        __builtin_nontemporal_store(o, reinterpret_cast<v8bf*>(p));
-#endif
+        // nt (wave-uniform, chosen per launch): maps of tens to hundreds of MB are written once and read by a later kernel from
+        // HBM anyway; streamed past L2 they leave the neighbouring GEMMs' operand panels resident (63.5 -> 62.9 ms per training
+        // step, A/B on one box).  Small maps (decoders, beam search) stay cached for their consumer.
+        if (nt)
+            __builtin_nontemporal_store(o, reinterpret_cast<v8bf*>(p));
+        else
+            *reinterpret_cast<v8bf*>(p) = o;
     }
 };
 
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(256)
 void ln_fwd(const T* __restrict__ x, const WT* __restrict__ w, const WT* __restrict__ b, int rows, float eps,
             T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
             const T* __restrict__ branch, const float* __restrict__ row_scale, int rows_per_sample, T* __restrict__ sum_out,
-            float drop_p, const unsigned long long* __restrict__ seed_dev) {
+            float drop_p, const unsigned long long* __restrict__ seed_dev, bool nt) {
     constexpr int C = LPR * 8 * CH, R = 64 / LPR;
     const unsigned long long seed = (branch && drop_p > 0.f) ? *seed_dev : 0ull;
     const float inv_keep = 1.0f / (1.0f - drop_p);
@@ -104,7 +111,7 @@ void ln_fwd(const T* __restrict__ x, const WT* __restrict__ w, const WT* __restr
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[c][i] = round_to<T>(__fadd_rn(v[c][i], __fmul_rn(br[i], sc)));
-            if (row < rows) Vec8<T>::store(sum_out + (size_t)row * C + (c * LPR + sub) * 8, v[c]);
+            if (row < rows) Vec8<T>::store(sum_out + (size_t)row * C + (c * LPR + sub) * 8, v[c], nt);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) s += v[c][i];
@@ -124,7 +131,7 @@ void ln_fwd(const T* __restrict__ x, const WT* __restrict__ w, const WT* __restr
             Vec8<WT>::load(b + (c * LPR + sub) * 8, bv);
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = fmaf((v[c][i] - mu) * rs, wv[i], bv[i]);
-            Vec8<T>::store(y + (size_t)row * C + (c * LPR + sub) * 8, o);
+            Vec8<T>::store(y + (size_t)row * C + (c * LPR + sub) * 8, o, nt);
         }
         if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
     }
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(256)
 void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restrict__ dy, const float* __restrict__ mean,
             const float* __restrict__ rstd, int rows, T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
             const T* __restrict__ dres, const float* __restrict__ row_scale, int rows_per_sample, T* __restrict__ dbranch,
-            float* __restrict__ dsum, float drop_p, const unsigned long long* __restrict__ seed_dev) {
+            float* __restrict__ dsum, float drop_p, const unsigned long long* __restrict__ seed_dev, bool nt) {
     constexpr int C = LPR * 8 * CH, R = 64 / LPR;
     const unsigned long long seed = (dbranch && drop_p > 0.f) ? *seed_dev : 0ull;
     const float inv_keep = 1.0f / (1.0f - drop_p);
@@ -193,7 +200,7 @@ void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restri
                     aw[c][i] = fmaf(g[c][i], xh[c][i], aw[c][i]);
                     ab[c][i] += g[c][i];
                 }
-                Vec8<T>::store(dx + (size_t)row * C + (c * LPR + sub) * 8, o);
+                Vec8<T>::store(dx + (size_t)row * C + (c * LPR + sub) * 8, o, nt);
                 if (dbranch) {  // gradient of the branch: the rounded dx times the sample's drop-path factor and/or the
                                 // element's dropout keep factor
                     const float sc = row_scale ? row_scale[row / rows_per_sample] : 1.0f;
@@ -203,7 +210,7 @@ void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restri
                         o[i] = round_to<T>(o[i]) * sc;
                         if (drop_p > 0.f) o[i] *= keep_scale(seed, e0 + i, drop_p, inv_keep);
                     }
-                    Vec8<T>::store(dbranch + (size_t)row * C + (c * LPR + sub) * 8, o);
+                    Vec8<T>::store(dbranch + (size_t)row * C + (c * LPR + sub) * 8, o, nt);
                 }
                 if constexpr (kBranchSum) {
                     if (dsum) {  // what the consumer of the branch gradient reads: the stored (rounded) values
@@ -261,14 +268,15 @@ int launch(bool fwd, const void* x, const void* w, const void* b_or_dy, const fl
     {                                                                                                                  \
         constexpr int R = 64 / LPR_;                                                                                   \
         const int blocks = (rows + 4 * R - 1) / (4 * R);                                                               \
+        const bool nt = (size_t)rows * C * sizeof(T) >= ((size_t)16 << 20);                                            \
         if (fwd)                                                                                                       \
             hipLaunchKernelGGL((ln_fwd<T, WT, LPR_, CH_>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const WT*)w,  \
                                (const WT*)b_or_dy, rows, eps, (T*)out, o1, o2, (const T*)fu.branch, fu.row_scale,        \
-                               fu.rows_per_sample, (T*)fu.sum_out, fu.drop_p, fu.seed_dev);                           \
+                               fu.rows_per_sample, (T*)fu.sum_out, fu.drop_p, fu.seed_dev, nt);                       \
         else                                                                                                           \
             hipLaunchKernelGGL((ln_bwd<T, WT, LPR_, CH_>), dim3(blocks < kBwdBlocks ? blocks : kBwdBlocks), dim3(256), 0, st, \
                                (const T*)x, (const WT*)w, (const T*)b_or_dy, mean_in, rstd_in, rows, (T*)out, o1, o2,  \
-                               (const T*)fu.dres, fu.row_scale, fu.rows_per_sample, (T*)fu.dbranch, fu.dsum, fu.drop_p, fu.seed_dev); \
+                               (const T*)fu.dres, fu.row_scale, fu.rows_per_sample, (T*)fu.dbranch, fu.dsum, fu.drop_p, fu.seed_dev, nt); \
         return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;                                            \
     }
     switch (C) {

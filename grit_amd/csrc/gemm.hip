@@ -42,7 +42,8 @@ struct GemmArgs {
     __bf16* C; long ldc;
     const __bf16* bias;
     __bf16* aux; long ldaux;
-    int nt_aux;  // non-temporal stores for 1: the saved pre-activation, 2: C of BIAS_GELU, 4: C of DGELU (GRIT_GEMM_NT_AUX, default 7:
+    int nt_aux;  // non-temporal 1: store of the saved pre-activation, 2: C of BIAS_GELU, 4: C of DGELU, 8: load of the pre-activation
+                 // in DGELU (GRIT_GEMM_NT_AUX, default 15:
                  // whole-tile outputs streamed past L2 leave the operand panels resident -- 63.4 -> 62.0 ms per training step)
     float* colsum;
     int M, N, K, tiles_m, tiles_n;
@@ -364,7 +365,10 @@ void gemm_nt_bf16(const GemmArgs g) {
                 const int m = min(mw + row, g.M - 1);
                 // image chunk (lane & 7) of row holds logical chunk (lane & 7) ^ (row & 7): permute on the source address
                 const __bf16* src = g.aux + (size_t)m * g.ldaux + nw + ((chunk ^ (row & 7)) * 8);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(eb + it * 1024), 16, 0, 0);
+                if (g.nt_aux & 8)  // read once: do not let the 210 MB of pre-activations displace the operand panels in L2
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(eb + it * 1024), 16, 0, 2);
+                else
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(eb + it * 1024), 16, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -785,7 +789,7 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
     GemmArgs a;
     a.A = (const __bf16*)A; a.lda = lda; a.B = (const __bf16*)B; a.ldb = ldb; a.C = (__bf16*)C; a.ldc = ldc;
     a.bias = (const __bf16*)bias; a.aux = (__bf16*)aux; a.ldaux = ldaux; a.colsum = colsum;
-    static const int nt_aux = [] { const char* e = getenv("GRIT_GEMM_NT_AUX"); return e ? atoi(e) : 7; }();
+    static const int nt_aux = [] { const char* e = getenv("GRIT_GEMM_NT_AUX"); return e ? atoi(e) : 15; }();
     a.nt_aux = nt_aux;
     a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
     hipStream_t st = (hipStream_t)stream;

@@ -37,8 +37,14 @@ template <> struct Vec8<float> {
 };
 template <> struct Vec8<__hip_bfloat16> {
     static __device__ __forceinline__ void load(const __hip_bfloat16* p, float (&v)[8]) {
+#ifdef GRIT_LN_NT_LOADS
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        const uint32_t w[4] = {u[0], u[1], u[2], u[3]};
+#else
         const uint4 u = *reinterpret_cast<const uint4*>(p);
         const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v[2 * i] = __uint_as_float(w[i] << 16);

@@ -90,6 +90,34 @@ __device__ __forceinline__ float dgelu_f(float x) {
     return s * fmaf(x * q, 1.0f - s, 1.0f);                  // s + x s (1 - s) u'
 }
 
+// Two elements per instruction for the polynomial parts (v_pk_mul_f32 / v_pk_fma_f32 on register pairs, which the halves of an
+// accumulator quad are): the epilogues run with no MFMA in flight, where the packed forms simply halve the issue slots.  Same
+// operations in the same order as gelu_f / dgelu_f: identical results.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f gelu2(v2f x) {
+    v2f xx = x * x;
+    xx = v2f{fminf(xx[0], 50.0f), fminf(xx[1], 50.0f)};
+    v2f p = __builtin_elementwise_fma(v2f{kNegLog2e * kGeluC2, kNegLog2e * kGeluC2}, xx, v2f{kNegLog2e * kGeluC1, kNegLog2e * kGeluC1});
+    p = __builtin_elementwise_fma(p, xx, v2f{kNegLog2e * kGeluC0, kNegLog2e * kGeluC0});
+    const v2f t = x * p;
+    const v2f d = v2f{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + v2f{1.0f, 1.0f};
+    return x * v2f{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+
+__device__ __forceinline__ v2f dgelu2(v2f x) {
+    v2f xx = x * x;
+    xx = v2f{fminf(xx[0], 50.0f), fminf(xx[1], 50.0f)};
+    v2f p = __builtin_elementwise_fma(v2f{kNegLog2e * kGeluC2, kNegLog2e * kGeluC2}, xx, v2f{kNegLog2e * kGeluC1, kNegLog2e * kGeluC1});
+    p = __builtin_elementwise_fma(p, xx, v2f{kNegLog2e * kGeluC0, kNegLog2e * kGeluC0});
+    const v2f t = x * p;
+    const v2f d = v2f{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + v2f{1.0f, 1.0f};
+    const v2f s = v2f{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    v2f q = __builtin_elementwise_fma(v2f{5.0f * kGeluC2, 5.0f * kGeluC2}, xx, v2f{3.0f * kGeluC1, 3.0f * kGeluC1});
+    q = __builtin_elementwise_fma(q, xx, v2f{kGeluC0, kGeluC0});
+    return s * __builtin_elementwise_fma(x * q, v2f{1.0f, 1.0f} - s, v2f{1.0f, 1.0f});
+}
+
 template <int BK> __device__ __forceinline__ int chunk_swizzle(int r16) {
     // permutation of the 16-byte chunks of row r16 (row index within its 16-row block) that makes the ds_read_b128 fragment
     // reads conflict-free (BK = 32: 64-byte rows, 4 chunks; BK = 64: 128-byte rows, 8 chunks)
@@ -347,10 +375,8 @@ void gemm_nt_bf16(const GemmArgs g) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NTL; ++j) {
-                v4f v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(acc[i][j][r]);
-                put(i, j, v);
+                const v2f lo = gelu2(v2f{acc[i][j][0], acc[i][j][1]}), hi = gelu2(v2f{acc[i][j][2], acc[i][j][3]});
+                put(i, j, v4f{lo[0], lo[1], hi[0], hi[1]});
             }
         flush(g.C, g.ldc, (g.nt_aux & 2) != 0);
     } else {  // GRIT_GEMM_DGELU
@@ -383,12 +409,10 @@ void gemm_nt_bf16(const GemmArgs g) {
             for (int j = 0; j < NTL; ++j) {
                 const int chunk = (2 * j + (lq >> 1)) ^ (row & 7);
                 const v4bf x = *reinterpret_cast<const v4bf*>(eb + row * 128 + chunk * 16 + (lq & 1) * 8);
-                v4f v;
+                const v2f dlo = dgelu2(v2f{(float)x[0], (float)x[1]}), dhi = dgelu2(v2f{(float)x[2], (float)x[3]});
+                const v4f v = {acc[i][j][0] * dlo[0], acc[i][j][1] * dlo[1], acc[i][j][2] * dhi[0], acc[i][j][3] * dhi[1]};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[i][j][r] * dgelu_f((float)x[r]);
-                    cs[j][r] += live ? v[r] : 0.f;  // bias gradient from the unrounded products
-                }
+                for (int r = 0; r < 4; ++r) cs[j][r] += live ? v[r] : 0.f;  // bias gradient from the unrounded products
                 put(i, j, v);  // in place: this lane's piece of the image
             }
         }

@@ -19,6 +19,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tune", action="store_true")
     ap.add_argument("--max-ms", type=int, default=40)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--fresh", action="store_true", help="ignore the shipped table: tune every shape from scratch")
     ap.add_argument("--inference", action="store_true", help="the shapes of captioning at batch 64 (detector forward + eager beam "
                     "search, bf16 weights) instead of the training step")
     args = ap.parse_args()
@@ -28,11 +30,12 @@ def main():
     tunable.enable(True)
     tunable.tuning_enable(bool(args.tune))
     tunable.set_max_tuning_duration(args.max_ms)
-    tunable.set_max_tuning_iterations(20)
+    tunable.set_max_tuning_iterations(args.iters)
     tunable.set_filename(os.path.join(out_dir, "tunableop_merged.csv"))
     if hasattr(tunable, "write_file_on_exit"):
         tunable.write_file_on_exit(bool(args.tune))
-    tunable.read_file(os.path.join(ROOT, "grit_amd", "tunableop_gfx950.csv"))
+    if not args.fresh:
+        tunable.read_file(os.path.join(ROOT, "grit_amd", "tunableop_gfx950.csv"))
     if not args.tune:
         os.environ["PYTORCH_TUNABLEOP_UNTUNED_FILENAME"] = os.path.join(out_dir, "tunableop_untuned.csv")
         tunable.record_untuned_enable(True)

@@ -382,8 +382,15 @@ void msda_fwd_bf16_rows4(const __hip_bfloat16* __restrict__ value, const int64_t
         const int row = r0 + (lane >> 4), p = lane & 15;
         const bool valid = row < nrows && p < LP;
         const int rc = min(row, nrows - 1), pc = min(p, LP - 1);
+#ifdef GRIT_MSDA_NT
+        typedef float v2f_t __attribute__((ext_vector_type(2)));
+        const v2f_t xyv = __builtin_nontemporal_load(reinterpret_cast<const v2f_t*>(loc + ((size_t)rc * LP + pc) * 2));
+        const float2 xy = make_float2(xyv[0], xyv[1]);
+        const float wt = valid ? __builtin_nontemporal_load(aw + (size_t)rc * LP + pc) : 0.f;
+#else
         const float2 xy = *reinterpret_cast<const float2*>(loc + ((size_t)rc * LP + pc) * 2);
         const float wt = valid ? aw[(size_t)rc * LP + pc] : 0.f;
+#endif
         const int l = pc / P;
         const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
         const uint32_t m = rc % M, b = (rc / M) / Lq;
@@ -446,7 +453,11 @@ void msda_fwd_bf16_rows4(const __hip_bfloat16* __restrict__ value, const int64_t
         v8bf o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (__bf16)r[e];
+#ifdef GRIT_MSDA_NT
+        __builtin_nontemporal_store(o, reinterpret_cast<v8bf*>(out + (size_t)row * D + c8 * 8));
+#else
         *reinterpret_cast<v8bf*>(out + (size_t)row * D + c8 * 8) = o;
+#endif
     }
 }
 

@@ -99,6 +99,33 @@ void gate_fuse(const T* __restrict__ enc1, const T* __restrict__ enc2, const T* 
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Key / value cache of step-wise decoding under beam search: the surviving beams take over the history of their source beam and
+// the new token's projected key / value is appended -- the re-gather of `running_keys` / `running_values` by the selected beam
+// (transformer.py:229 through containers.py apply_to_states) and the two torch.cat of attention.py:166-181, four launches per
+// layer and step, as one copy kernel.  out[(b, j)][0 .. t) = old[(b, src[b][j])][0 .. t),  out[(b, j)][t] = new[(b, j)].
+__global__ __launch_bounds__(256)
+void kv_append(const uint4* __restrict__ old_k, const uint4* __restrict__ old_v, const int64_t* __restrict__ src, int cur, int beam,
+               int t_old, int row16, const uint4* __restrict__ new_k, const uint4* __restrict__ new_v, long new_stride16,
+               long rows, uint4* __restrict__ out_k, uint4* __restrict__ out_v) {
+    const long per_row = (long)(t_old + 1) * row16;
+    const long total = rows * per_row;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < 2 * total; i += (long)gridDim.x * blockDim.x) {
+        const bool is_v = i >= total;
+        const long e = is_v ? i - total : i;
+        const long r = e / per_row, within = e - r * per_row;
+        const int t = (int)(within / row16), c = (int)(within - (long)t * row16);
+        uint4 val;
+        if (t < t_old) {
+            const long b = r / beam;
+            const long from = src ? b * cur + src[r] : r;
+            val = (is_v ? old_v : old_k)[(from * t_old + t) * row16 + c];
+        } else {
+            val = (is_v ? new_v : new_k)[r * new_stride16 + c];
+        }
+        (is_v ? out_v : out_k)[e] = val;
+    }
+}
+
 }  // namespace
 
 extern "C" int grit_gate_pack(const void* self_att, const void* enc1, const void* enc2, const void* mask_pad, int rows, int d,
@@ -131,5 +158,24 @@ extern "C" int grit_gate_fuse(const void* enc1, const void* enc2, const void* ga
     else
         hipLaunchKernelGGL(gate_fuse<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)enc1,
                            (const float*)enc2, (const float*)gates, (const float*)mask_pad, rows, d, inv, (float*)out);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+extern "C" int grit_kv_append(const void* old_k, const void* old_v, const int64_t* src_beam, int B, int cur_beam, int beam, int t_old,
+                              int row_bytes, const void* new_k, const void* new_v, long new_row_stride_bytes, void* out_k,
+                              void* out_v, void* stream) {
+    if (!new_k || !new_v || !out_k || !out_v || B <= 0 || cur_beam <= 0 || beam <= 0 || t_old < 0 || row_bytes <= 0)
+        return GRIT_ERR_BAD_ARG;
+    if (t_old > 0 && (!old_k || !old_v)) return GRIT_ERR_BAD_ARG;
+    if (!src_beam && cur_beam != beam) return GRIT_ERR_BAD_ARG;
+    if (row_bytes % 16 || new_row_stride_bytes % 16 || !aligned16(old_k) || !aligned16(old_v) || !aligned16(new_k) ||
+        !aligned16(new_v) || !aligned16(out_k) || !aligned16(out_v))
+        return GRIT_ERR_UNSUPPORTED;
+    const long rows = (long)B * beam;
+    const long total = 2 * rows * (t_old + 1) * (row_bytes / 16);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(kv_append, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)old_k, (const uint4*)old_v, src_beam,
+                       cur_beam, beam, t_old, row_bytes / 16, (const uint4*)new_k, (const uint4*)new_v, new_row_stride_bytes / 16,
+                       rows, (uint4*)out_k, (uint4*)out_v);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }

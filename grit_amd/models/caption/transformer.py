@@ -137,6 +137,8 @@ class Transformer(BaseCaptioner):
         try:
             for att in cross:  # N1: project the visual memory once per beam layout instead of once per step
                 att.hoist_kv, att._kv = True, None
+            for m in self._kv_cached_modules():
+                m._kv_deferred, m._beam_src = False, None
             with self.statefulness(batch_size):
                 for t in range(max_len):
                     images, outputs = self.iter(timestep=t, samples=images, outputs=outputs, return_probs=return_probs,
@@ -222,6 +224,9 @@ class Transformer(BaseCaptioner):
 
         return fn
 
+    def _kv_cached_modules(self):
+        return [layer.self_att for layer in self.cap_generator.layers]
+
     def iter(self, timestep, samples, outputs, return_probs, batch_size, beam_size=5, eos_idx=3, **kwargs):
         cur_beam = 1 if timestep == 0 else beam_size
         word_logprob = self.step(timestep, self.selected_words, samples, None, mode='feedback', **kwargs)
@@ -253,6 +258,12 @@ class Transformer(BaseCaptioner):
         # visual states stay [B, ...]; Attention.forward groups the beams of an image onto its one copy.  Leaving them
         # untouched also keeps their identity, which is what the hoisted K/V projections are keyed on.
         visual = {id(getattr(self, n, None)) for n in ('gri_feat', 'gri_mask', 'reg_feat', 'reg_mask')} - {id(None)}
+        # Self-attention caches that update themselves (one launch: source beam's history + the new key / value, ops/kv_cache.py)
+        # only need to be told which beam each survivor continues; everything else is re-gathered as in the reference.
+        for m in self._kv_cached_modules():
+            if m._kv_deferred:
+                m._beam_src = selected_beam
+                visual.update((id(m.running_keys), id(m.running_values)))
         self.apply_to_states(lambda tensor: tensor if id(tensor) in visual else expand(tensor))
 
         beam_col = selected_beam.unsqueeze(-1)

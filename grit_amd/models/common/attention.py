@@ -15,6 +15,7 @@ from torch.nn import functional as F
 
 from grit_amd.models.caption.containers import Module
 from grit_amd.ops import backend
+from grit_amd.ops import kv_cache
 from grit_amd.ops.attention import attention as fused_attention
 from grit_amd.ops.layer_norm import add_layer_norm, linear_add_layer_norm
 from grit_amd.ops.linear import Linear
@@ -22,6 +23,8 @@ from grit_amd.ops.linear import Linear
 
 # GRIT_DECODE_KV_CACHE=0: step-wise decoding re-projects the raw key / value history on every step, as the reference does
 _KV_CACHE = os.environ.get('GRIT_DECODE_KV_CACHE', '1') != '0'
+# GRIT_DECODE_KV_APPEND=0: the cache grows by torch.cat and is re-gathered by the surviving beam like every other state
+_KV_FUSED_APPEND = os.environ.get('GRIT_DECODE_KV_APPEND', '1') != '0'
 
 
 def init_params(module):
@@ -111,6 +114,7 @@ class MultiHeadAttention(Module):
         self.dropout = nn.Dropout(p=dropout)
         self.layer_norm = nn.LayerNorm(d_model)
         self.can_be_stateful = can_be_stateful
+        self._kv_deferred, self._beam_src = False, None  # fused cache update: see forward / Transformer.iter
         if can_be_stateful:
             self.register_state('running_keys', torch.zeros((1, d_model)))
             self.register_state('running_values', torch.zeros((1, d_model)))
@@ -129,11 +133,22 @@ class MultiHeadAttention(Module):
                 d = queries.shape[-1]
                 qkv = F.linear(queries, w, b)
                 q_proj, keys, values = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
-            self.running_keys = torch.cat([self.running_keys, keys], 1)
-            self.running_values = torch.cat([self.running_values, values], 1)
-            if self.timestep == 0:  # drop the placeholder row the state was initialised with
-                self.running_keys = self.running_keys[:, 1:]
-                self.running_values = self.running_values[:, 1:]
+            self._kv_deferred = bool(cached and _KV_FUSED_APPEND)
+            if self._kv_deferred:
+                # one launch: history of the source beam (Transformer.iter hands over the surviving-beam index instead of
+                # re-gathering these two states) + the new token's projected key / value
+                first = self.timestep == 0
+                src = None if first else self._beam_src  # [B, beam] source beam of every surviving beam, or None: same rows
+                self.running_keys, self.running_values = kv_cache.append(
+                    None if first else self.running_keys, None if first else self.running_values, src, keys, values,
+                    beam=1 if src is None else src.shape[-1])
+                self._beam_src = None
+            else:
+                self.running_keys = torch.cat([self.running_keys, keys], 1)
+                self.running_values = torch.cat([self.running_values, values], 1)
+                if self.timestep == 0:  # drop the placeholder row the state was initialised with
+                    self.running_keys = self.running_keys[:, 1:]
+                    self.running_values = self.running_values[:, 1:]
             keys, values = self.running_keys, self.running_values
             if cached:
                 kv_proj = (keys, values)

@@ -37,10 +37,12 @@
  *   grit_topk_rows_f32   <- Transformer.select (models/caption/transformer.py:184-188): sort of beam x vocabulary candidates
  *   grit_beam_step_f32   <- the body of Transformer.iter after the word log-probabilities (models/caption/transformer.py:208-240):
  *                           finished-beam masking, candidate scores, selection, beam / word split, score / mask / log-prob gathers
+ *   grit_kv_append       <- running_keys / running_values of the stateful self-attention (models/common/attention.py:166-181) and
+ *                           their per-step re-gather by the surviving beam (models/caption/transformer.py:229)
  *   grit_gate_pack, grit_gate_fuse
  *                        <- the sigmoid-gated merge of the two cross-attentions at inference, ParallelAttentionLayer.forward
  *                           (models/caption/cap_generator.py:44-56): masks, concatenations, sigmoids, products, sum, scale
- * (none of the last ten groups has a native ancestor in the reference: they replace chains of torch / PIL ops)
+ * (none of the last eleven groups has a native ancestor in the reference: they replace chains of torch / PIL ops)
  */
 #ifndef GRIT_HIP_H
 #define GRIT_HIP_H
@@ -51,7 +53,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 22
+#define GRIT_ABI_VERSION 23
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -392,6 +394,20 @@ int grit_gate_pack(const void* self_att, const void* enc1, const void* enc2, con
                    void* X, void* stream);
 int grit_gate_fuse(const void* enc1, const void* enc2, const void* gates, const void* mask_pad, int rows, int d, float divisor,
                    int is_bf16, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Key / value cache of step-wise decoding under beam search (reference models/common/attention.py:166-181 appends with torch.cat,
+ * models/caption/transformer.py:229 re-gathers every state by the surviving beam): for B images with `beam` surviving beams each,
+ *     out[(b, j)][0 .. t_old) = old[(b, src_beam[b][j])][0 .. t_old)      (old holds cur_beam histories per image)
+ *     out[(b, j)][t_old]      = new[(b, j)]
+ * for keys and values in one launch.  old_* [B * cur_beam, t_old, row_bytes] contiguous (ignored when t_old == 0), new_* one row per
+ * (b, j) at new_row_stride_bytes (a slice of the fused q/k/v projection), out_* [B * beam, t_old + 1, row_bytes] contiguous.
+ * src_beam [B * beam] int64 (index of the source beam within the image) or NULL = identity (then cur_beam must equal beam).
+ * Byte copies: any dtype; row_bytes, strides and bases 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------------ */
+int grit_kv_append(const void* old_k, const void* old_v, const int64_t* src_beam, int B, int cur_beam, int beam, int t_old,
+                   int row_bytes, const void* new_k, const void* new_v, long new_row_stride_bytes, void* out_k, void* out_v,
+                   void* stream);
 
 #ifdef __cplusplus
 }

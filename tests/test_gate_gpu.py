@@ -53,3 +53,30 @@ def test_gated_merge_is_the_composed_form(dtype, rows, T):
         assert (full.float() - ref.float()).abs().max().item() <= tol
     with torch.enable_grad():
         assert not gate.supported(self_att, enc1, enc2, mask_pad, fc)  # training keeps the differentiable composed form
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,cur,beam,t_old", [(64, 5, 5, 7), (64, 1, 5, 1), (3, 5, 5, 19), (2, 3, 3, 4), (5, 1, 1, 0), (4, 5, 5, 0)])
+def test_kv_append_is_gather_plus_cat(dtype, B, cur, beam, t_old):
+    """grit_kv_append (grit_amd/ops/kv_cache.py) == re-gather of the cache by the surviving beam (transformer.py:229) followed by
+    the append of the new key / value (attention.py:166-181); byte copies, so exact."""
+    from grit_amd.ops import kv_cache
+    g = torch.Generator(device='cuda').manual_seed(B * 100 + t_old)
+    d = 512
+    qkv = torch.randn(B * beam, 1, 3 * d, device='cuda', generator=g).to(dtype)      # new k / v are slices of the fused projection
+    new_k, new_v = qkv[..., d:2 * d], qkv[..., 2 * d:]
+    if t_old == 0:
+        got_k, got_v = kv_cache.append(None, None, None, new_k, new_v, beam=1 if cur == beam == 1 else beam)
+        assert torch.equal(got_k, new_k) and torch.equal(got_v, new_v)
+        return
+    old_k = torch.randn(B * cur, t_old, d, device='cuda', generator=g).to(dtype)
+    old_v = torch.randn(B * cur, t_old, d, device='cuda', generator=g).to(dtype)
+    src = torch.randint(0, cur, (B, beam), device='cuda', generator=g)
+    got_k, got_v = kv_cache.append(old_k, old_v, src, new_k, new_v, beam=beam)
+    idx = src.view(B, beam, 1, 1).expand(B, beam, t_old, d)
+    want_k = torch.cat([torch.gather(old_k.view(B, cur, t_old, d), 1, idx).view(B * beam, t_old, d), new_k], 1)
+    want_v = torch.cat([torch.gather(old_v.view(B, cur, t_old, d), 1, idx).view(B * beam, t_old, d), new_v], 1)
+    assert torch.equal(got_k, want_k) and torch.equal(got_v, want_v)
+    if cur == beam:  # no index: every beam continues itself
+        same_k, same_v = kv_cache.append(old_k, old_v, None, new_k, new_v, beam=1)
+        assert torch.equal(same_k, torch.cat([old_k, new_k], 1)) and torch.equal(same_v, torch.cat([old_v, new_v], 1))

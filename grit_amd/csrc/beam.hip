@@ -103,6 +103,7 @@ __device__ __forceinline__ void wave_best(float& v, int& i, int& o) {
     }
 }
 
+template <int KL>  // per-thread list length: k <= KL <= kMaxK (5 for the usual beam of 5: 40 % fewer compare-swaps per insertion)
 __global__ __launch_bounds__(kBeamThreads)
 void beam_partial(const float* __restrict__ logp, long ld, const float* __restrict__ seq_lp, const float* __restrict__ seq_mask,
                   const int64_t* __restrict__ prev_words, int eos, int first_step, int cur, int V, int k, int parts,
@@ -119,15 +120,15 @@ void beam_partial(const float* __restrict__ logp, long ld, const float* __restri
     const float* row = logp + (size_t)row_id * ld;
     const int seg = ((V + parts - 1) / parts + 3) & ~3;
     const int v0 = part * seg, v1 = min(V, v0 + seg);
-    float bv[kMaxK];
-    int bi[kMaxK];
+    float bv[KL];
+    int bi[KL];
 #pragma unroll
-    for (int q = 0; q < kMaxK; ++q) { bv[q] = -INFINITY; bi[q] = 0x7fffffff; }
+    for (int q = 0; q < KL; ++q) { bv[q] = -INFINITY; bi[q] = 0x7fffffff; }
     auto push = [&](float v, int i) {
-        if (!better(v, i, bv[kMaxK - 1], bi[kMaxK - 1])) return;
-        bv[kMaxK - 1] = v; bi[kMaxK - 1] = i;
+        if (!better(v, i, bv[KL - 1], bi[KL - 1])) return;
+        bv[KL - 1] = v; bi[KL - 1] = i;
 #pragma unroll
-        for (int q = kMaxK - 1; q > 0; --q)
+        for (int q = KL - 1; q > 0; --q)
             if (better(bv[q], bi[q], bv[q - 1], bi[q - 1])) {
                 const float tv = bv[q]; bv[q] = bv[q - 1]; bv[q - 1] = tv;
                 const int ti = bi[q]; bi[q] = bi[q - 1]; bi[q - 1] = ti;
@@ -159,7 +160,7 @@ void beam_partial(const float* __restrict__ logp, long ld, const float* __restri
     for (int r = 0; r < k; ++r) {
         float v = -INFINITY; int i = 0x7fffffff;
 #pragma unroll
-        for (int q = 0; q < kMaxK; ++q)
+        for (int q = 0; q < KL; ++q)
             if (q == headp) { v = bv[q]; i = bi[q]; }
         int o = tid;
         wave_best(v, i, o);
@@ -234,8 +235,12 @@ extern "C" int grit_beam_step_f32(const float* logp, long ld, const float* seq_l
     if (workspace_bytes < grit_beam_step_workspace(B, cur_beam, k)) return GRIT_ERR_BAD_ARG;
     float* ws_val = reinterpret_cast<float*>(workspace);
     int* ws_idx = reinterpret_cast<int*>(ws_val + (size_t)B * cur_beam * parts * kMaxK);
-    hipLaunchKernelGGL(beam_partial, dim3(parts, cur_beam, B), dim3(kBeamThreads), 0, (hipStream_t)stream, logp, ld, seq_logprob,
-                       seq_mask, prev_words, eos, first_step, cur_beam, V, k, parts, ws_val, ws_idx);
+    if (k <= 5)
+        hipLaunchKernelGGL(beam_partial<5>, dim3(parts, cur_beam, B), dim3(kBeamThreads), 0, (hipStream_t)stream, logp, ld, seq_logprob,
+                           seq_mask, prev_words, eos, first_step, cur_beam, V, k, parts, ws_val, ws_idx);
+    else
+        hipLaunchKernelGGL(beam_partial<kMaxK>, dim3(parts, cur_beam, B), dim3(kBeamThreads), 0, (hipStream_t)stream, logp, ld,
+                           seq_logprob, seq_mask, prev_words, eos, first_step, cur_beam, V, k, parts, ws_val, ws_idx);
     hipLaunchKernelGGL(beam_merge, dim3(B), dim3(64), 0, (hipStream_t)stream, logp, ld, seq_mask, prev_words, eos, first_step,
                        cur_beam, V, k, parts, ws_val, ws_idx, sel_beam, sel_word, new_seq_logprob, new_seq_mask, picked_logprob);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;

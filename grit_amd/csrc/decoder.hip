@@ -126,7 +126,52 @@ void kv_append(const uint4* __restrict__ old_k, const uint4* __restrict__ old_v,
     }
 }
 
+// Inputs of one step of step-wise decoding (davidnvq/grit models/caption/cap_generator.py:116-137, get_seq_inputs in stateful mode +
+// the two embedding lookups of :148): for every row r with token tok,
+//     pos = ++running_seq[r];   x[r] = word_emb[tok] + pos_emb[pos];   mask_pad[r] = tok != pad
+//     new_mask[r] = (old_mask[r][0 .. t_old), tok == pad)                       -- the self-attention key mask grows by one column
+// Fourteen launches in the composed form (eq, not, float, triu of ones, or, cat, add_, two embeddings, add, casts), one here.
+template <typename T>
+__global__ __launch_bounds__(64)
+void decode_step_inputs(const int64_t* __restrict__ tokens, int64_t pad_idx, const T* __restrict__ word_emb,
+                        const T* __restrict__ pos_emb, int n_pos, int d, int64_t* __restrict__ running_seq,
+                        const uint8_t* __restrict__ old_mask, int t_old, T* __restrict__ x, T* __restrict__ mask_pad,
+                        uint8_t* __restrict__ new_mask) {
+#pragma clang fp contract(off)
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int64_t tok = tokens[r];
+    int64_t pos = running_seq[r] + 1;
+    __builtin_amdgcn_s_barrier();  // every lane has read the counter before lane 0 advances it (one wave per row)
+    if (tid == 0) {
+        running_seq[r] = pos;
+        mask_pad[r] = from_f<T>(tok != pad_idx ? 1.0f : 0.0f);
+        new_mask[(size_t)r * (t_old + 1) + t_old] = tok == pad_idx ? 1 : 0;
+    }
+    for (int i = tid; i < t_old; i += 64) new_mask[(size_t)r * (t_old + 1) + i] = old_mask[(size_t)r * t_old + i];
+    if (pos >= n_pos) pos = n_pos - 1;  // the host checks the step count against the table; never read out of bounds
+    const T* w = word_emb + (size_t)tok * d;
+    const T* p = pos_emb + (size_t)pos * d;
+    for (int c = tid; c < d; c += 64) x[(size_t)r * d + c] = from_f<T>(rnd<T>(to_f<T>(w[c]) + to_f<T>(p[c])));
+}
+
 }  // namespace
+
+extern "C" int grit_decode_step_inputs(const int64_t* tokens, int64_t pad_idx, const void* word_emb, int vocab, const void* pos_emb,
+                                       int n_pos, int d, int is_bf16, int64_t* running_seq, const uint8_t* old_mask, int t_old,
+                                       int rows, void* x, void* mask_pad, uint8_t* new_mask, void* stream) {
+    if (!tokens || !word_emb || !pos_emb || !running_seq || !x || !mask_pad || !new_mask || rows <= 0 || d <= 0 || vocab <= 0 ||
+        n_pos <= 0 || t_old < 0 || (t_old > 0 && !old_mask))
+        return GRIT_ERR_BAD_ARG;
+    if (is_bf16)
+        hipLaunchKernelGGL(decode_step_inputs<__bf16>, dim3(rows), dim3(64), 0, (hipStream_t)stream, tokens, pad_idx,
+                           (const __bf16*)word_emb, (const __bf16*)pos_emb, n_pos, d, running_seq, old_mask, t_old, (__bf16*)x,
+                           (__bf16*)mask_pad, new_mask);
+    else
+        hipLaunchKernelGGL(decode_step_inputs<float>, dim3(rows), dim3(64), 0, (hipStream_t)stream, tokens, pad_idx,
+                           (const float*)word_emb, (const float*)pos_emb, n_pos, d, running_seq, old_mask, t_old, (float*)x,
+                           (float*)mask_pad, new_mask);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
 
 extern "C" int grit_gate_pack(const void* self_att, const void* enc1, const void* enc2, const void* mask_pad, int rows, int d,
                               int is_bf16, void* X, void* stream) {

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -51,6 +51,7 @@ SIGNATURES = {
     "grit_attn_bwd_f32": _ATTN_IN + [_ptr] * 3 + [_int] * 5 + [_f32, _f32, _u64] + [_ptr] * 5,
     "grit_attn_bwd_bf16": _ATTN_IN + [_ptr] * 3 + [_int] * 5 + [_f32, _f32, _u64] + [_ptr] * 5,
     "grit_topk_rows_f32": [_ptr, _c.c_long, _int, _int, _int, _ptr, _ptr, _ptr],
+    "grit_decode_step_inputs": [_ptr, _c.c_int64, _ptr, _int, _ptr, _int, _int, _int, _ptr, _ptr, _int, _int, _ptr, _ptr, _ptr, _ptr],
     "grit_kv_append": [_ptr, _ptr, _ptr, _int, _int, _int, _int, _int, _ptr, _ptr, _c.c_long, _ptr, _ptr, _ptr],
     "grit_gate_pack": [_ptr] * 4 + [_int, _int, _int, _ptr, _ptr],
     "grit_gate_fuse": [_ptr] * 4 + [_int, _int, _f32, _int, _ptr, _ptr],

@@ -6,6 +6,8 @@ CaptionGenerator :90-175).  Reproduced on purpose:
   * only the 'parallel' layer exists on the reference's reachable path (Q2) -- 'concat' / 'sequential' raise;
   * stateful decoding grows `running_mask_x` / `running_seq` exactly like the reference (:134-142).
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -15,8 +17,13 @@ from grit_amd.models.caption.containers import Module, ModuleList
 from grit_amd.models.common.attention import MultiHeadAttention
 from grit_amd.models.common.pos_embed import FeedForward, sinusoid_encoding_table
 from grit_amd.ops import backend
+from grit_amd.ops import decode_inputs
 from grit_amd.ops import gate as gate_ops
 from grit_amd.ops.linear import Linear
+
+
+# GRIT_FUSED_STEP_INPUTS=0: masks, step counter and embedding sum of a decoding step as the reference's separate torch ops
+_FUSED_STEP_INPUTS = os.environ.get('GRIT_FUSED_STEP_INPUTS', '1') != '0'
 
 
 class GeneratorLayer(Module):
@@ -105,8 +112,20 @@ class CaptionGenerator(Module):
             seq = self.running_seq
         return self.word_emb(input) + self.pos_emb(seq), mask_x, mask_pad
 
+    def _step_inputs(self, input):
+        """get_seq_inputs + the embedding sum for ONE new token per row in stateful mode, as one launch (ops/decode_inputs.py)."""
+        w, p = self.word_emb.weight, self.pos_emb.weight
+        if not (_FUSED_STEP_INPUTS and self._is_stateful and input.dim() == 2 and input.shape[1] == 1
+                and decode_inputs.supported(input, w, p, self.running_seq, self.running_mask_x) and w.is_contiguous() and p.is_contiguous()):
+            return None
+        if self.layers[0].self_att.timestep + 1 >= p.shape[0]:
+            raise IndexError("decoding step %d exceeds the position table (%d rows)" % (self.layers[0].self_att.timestep + 1, p.shape[0]))
+        x, self.running_mask_x, mask_pad = decode_inputs.step_inputs(input, self.pad_idx, w, p, self.running_seq, self.running_mask_x)
+        return x, self.running_mask_x, mask_pad
+
     def forward(self, input, vis_inputs):
-        x, mask_x, mask_pad = self.get_seq_inputs(input)
+        fused = self._step_inputs(input)
+        x, mask_x, mask_pad = fused if fused is not None else self.get_seq_inputs(input)
         mask_pad = mask_pad.to(x.dtype)
         y1, y2 = vis_inputs['gri_feat'], vis_inputs['reg_feat']
         m1, m2 = vis_inputs['gri_mask'], vis_inputs['reg_mask']

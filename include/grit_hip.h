@@ -37,12 +37,14 @@
  *   grit_topk_rows_f32   <- Transformer.select (models/caption/transformer.py:184-188): sort of beam x vocabulary candidates
  *   grit_beam_step_f32   <- the body of Transformer.iter after the word log-probabilities (models/caption/transformer.py:208-240):
  *                           finished-beam masking, candidate scores, selection, beam / word split, score / mask / log-prob gathers
+ *   grit_decode_step_inputs <- CaptionGenerator.get_seq_inputs in stateful mode + the word / position embedding sum
+ *                           (models/caption/cap_generator.py:116-137,148)
  *   grit_kv_append       <- running_keys / running_values of the stateful self-attention (models/common/attention.py:166-181) and
  *                           their per-step re-gather by the surviving beam (models/caption/transformer.py:229)
  *   grit_gate_pack, grit_gate_fuse
  *                        <- the sigmoid-gated merge of the two cross-attentions at inference, ParallelAttentionLayer.forward
  *                           (models/caption/cap_generator.py:44-56): masks, concatenations, sigmoids, products, sum, scale
- * (none of the last eleven groups has a native ancestor in the reference: they replace chains of torch / PIL ops)
+ * (none of the last twelve groups has a native ancestor in the reference: they replace chains of torch / PIL ops)
  */
 #ifndef GRIT_HIP_H
 #define GRIT_HIP_H
@@ -53,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 23
+#define GRIT_ABI_VERSION 24
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -408,6 +410,18 @@ int grit_gate_fuse(const void* enc1, const void* enc2, const void* gates, const 
 int grit_kv_append(const void* old_k, const void* old_v, const int64_t* src_beam, int B, int cur_beam, int beam, int t_old,
                    int row_bytes, const void* new_k, const void* new_v, long new_row_stride_bytes, void* out_k, void* out_v,
                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Inputs of one step of step-wise decoding (reference models/caption/cap_generator.py:116-137 get_seq_inputs in stateful mode and the
+ * embedding sum of :148).  tokens [rows] int64; word_emb [vocab, d], pos_emb [n_pos, d] (is_bf16: bfloat16, else float32);
+ * running_seq [rows] int64 step counters, advanced in place; old_mask [rows, t_old] bytes (1 = masked key), ignored when t_old == 0.
+ *     pos = ++running_seq[r];  x[r] = word_emb[tokens[r]] + pos_emb[pos];  mask_pad[r] = tokens[r] != pad_idx (as 1 / 0 in the table dtype);
+ *     new_mask[r] = (old_mask[r], tokens[r] == pad_idx)            [rows, t_old + 1]
+ * The caller checks that the step count stays inside pos_emb (the kernel clamps instead of faulting).
+ * ------------------------------------------------------------------------------------------------------ */
+int grit_decode_step_inputs(const int64_t* tokens, int64_t pad_idx, const void* word_emb, int vocab, const void* pos_emb, int n_pos,
+                            int d, int is_bf16, int64_t* running_seq, const uint8_t* old_mask, int t_old, int rows, void* x,
+                            void* mask_pad, uint8_t* new_mask, void* stream);
 
 #ifdef __cplusplus
 }

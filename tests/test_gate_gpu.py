@@ -80,3 +80,32 @@ def test_kv_append_is_gather_plus_cat(dtype, B, cur, beam, t_old):
     if cur == beam:  # no index: every beam continues itself
         same_k, same_v = kv_cache.append(old_k, old_v, None, new_k, new_v, beam=1)
         assert torch.equal(same_k, torch.cat([old_k, new_k], 1)) and torch.equal(same_v, torch.cat([old_v, new_v], 1))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_decode_step_inputs_match_get_seq_inputs(dtype):
+    """grit_decode_step_inputs (CaptionGenerator._step_inputs) against the reference-order get_seq_inputs + embedding sum in stateful
+    mode, four consecutive steps with padding tokens in the stream: bit-exact embeddings, masks, step counters."""
+    import grit_amd.models.caption.cap_generator as CG
+    torch.manual_seed(3)
+    gen = CG.CaptionGenerator(vocab_size=1000, max_len=54, n_layers=1, pad_idx=1).cuda().to(dtype).eval()
+    ref = CG.CaptionGenerator(vocab_size=1000, max_len=54, n_layers=1, pad_idx=1).cuda().to(dtype).eval()
+    ref.load_state_dict(gen.state_dict())
+    R = 40
+    with torch.no_grad(), gen.statefulness(R), ref.statefulness(R):
+        for step in range(4):
+            tokens = torch.randint(0, 6, (R, 1), device='cuda')  # a sixth of the tokens are <pad> (index 1)
+            fused = gen._step_inputs(tokens)
+            assert fused is not None
+            x, mask_x, mask_pad = fused
+            wx, wmask_x, wmask_pad = ref.get_seq_inputs(tokens)
+            assert torch.equal(x, wx)
+            assert mask_x.dtype == torch.bool and torch.equal(mask_x, wmask_x) and mask_x.shape == (R, 1, 1, step + 1)
+            assert torch.equal(mask_pad.float(), wmask_pad.float())
+            assert torch.equal(gen.running_seq, ref.running_seq) and int(gen.running_seq[0]) == step + 1
+            # what Transformer.iter does between steps: every state re-gathered by the surviving beam (here: a permutation)
+            perm = torch.randperm(R, device='cuda')
+            for m in (gen, ref):
+                m.apply_to_states(lambda t: t[perm] if t.shape[0] == R else t)
+                for layer in m.layers:  # the step counter the fused path checks against the position table
+                    layer.self_att.timestep += 1

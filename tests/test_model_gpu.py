@@ -246,6 +246,8 @@ def test_device_decode_shortcuts_reproduce_the_reference_order_loop(g7_model, mo
     monkeypatch.setattr(T, "_FUSED_BEAM_STEP", False)
     monkeypatch.setattr(A, "_KV_CACHE", False)
     monkeypatch.setattr(A, "_KV_FUSED_APPEND", False)
+    import grit_amd.models.caption.cap_generator as CG
+    monkeypatch.setattr(CG, "_FUSED_STEP_INPUTS", False)
     monkeypatch.setattr(gate_ops, "supported", lambda *a, **k: False)
     slow_tokens, slow_lp = decode()
     assert torch.equal(fast_tokens, slow_tokens)

@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--caption-len", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--fp32", action="store_true", help="diagnostic: no autocast (not the metric's dtype)")
     ap.add_argument("--points", choices=("model", "spread"), default="model",
                     help="spread: MSDeformAttn sampling locations replaced by SURVEY 8d config 2's distribution (diagnostic)")

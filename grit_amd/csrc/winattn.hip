@@ -200,9 +200,10 @@ void winattn_fwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
         // ---- logits in the log2 domain: t = s*scale*log2e + bias*log2e (+ mask*log2e)
         const bool analytic = (mask == nullptr) && g.shift > 0 && (wy == g.nWh - 1 || wx == g.nWw - 1);
 #pragma unroll
-        for (int kt = 0; kt < kTiles; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[kt][r] = fmaf(acc[kt][r], c2, b2[kt][r]);
+        for (int kt = 0; kt < kTiles; ++kt) {  // two logits per instruction (v_pk_fma_f32 on the halves of the MFMA result quad)
+            const v2f lo = __builtin_elementwise_fma(v2f{acc[kt][0], acc[kt][1]}, v2f{c2, c2}, v2f{b2[kt][0], b2[kt][1]});
+            const v2f hi = __builtin_elementwise_fma(v2f{acc[kt][2], acc[kt][3]}, v2f{c2, c2}, v2f{b2[kt][2], b2[kt][3]});
+            acc[kt] = v4f{lo[0], lo[1], hi[0], hi[1]};
         }
         if (analytic) {
 #pragma unroll
@@ -230,15 +231,17 @@ void winattn_fwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
 #pragma unroll
             for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[kt][r]);
         m = xor_max(xor_max(m, 16), 32);
-        float sum = 0.f;
+        v2f sum2 = {0.f, 0.f};
+        const v2f m2 = {m, m};
 #pragma unroll
-        for (int kt = 0; kt < kTiles; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(acc[kt][r] - m);
-                acc[kt][r] = e;
-                sum += e;
-            }
+        for (int kt = 0; kt < kTiles; ++kt) {
+            const v2f d_lo = v2f{acc[kt][0], acc[kt][1]} - m2, d_hi = v2f{acc[kt][2], acc[kt][3]} - m2;
+            const v2f e_lo = {__builtin_amdgcn_exp2f(d_lo[0]), __builtin_amdgcn_exp2f(d_lo[1])};
+            const v2f e_hi = {__builtin_amdgcn_exp2f(d_hi[0]), __builtin_amdgcn_exp2f(d_hi[1])};
+            acc[kt] = v4f{e_lo[0], e_lo[1], e_hi[0], e_hi[1]};
+            sum2 += e_lo + e_hi;
+        }
+        float sum = sum2[0] + sum2[1];
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;

@@ -4,6 +4,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment makes this process a LAUNCHER: before any GPU call it checks that N
+devices are visible (exit code 2 otherwise -- it never prints an `n_gpus: 1` line for `--gpus 8`), starts N fresh worker processes
+of this file (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT in their environment, one per GPU), waits
+for them and exits with the first non-zero worker code.  Under torchrun (WORLD_SIZE set) the process IS a worker; `--gpus` must
+then equal WORLD_SIZE.
+
 Workload (BASELINE.json metric, configs[3] per GPU): full GRIT (Swin-B window 12 + 6 deformable decoder layers +
 3-layer grid net + 3-layer caption decoder, 161 M parameters, random init), 32 images of 3x640x640 per GPU,
 captions of 20 tokens, train mode (dropout / DropPath on), bf16 compute copies over fp32 master weights
@@ -26,7 +32,8 @@ One JSON line on rank 0.  Besides the contract keys:
   cpu_baseline  (N = 1 only) the same training step on the host CPU: this repo's modules with the oracle ops
                 (oracle/torch_ref.py) injected -- a port, not the reference -- on a bounded sample (batch 1, few steps).
 Diagnostic flags (recorded in config, never the default): --points spread (decoder sampling locations replaced by config 2's
-distribution), --ragged (images of different sizes: the general padding-mask path), --fp32, GRIT_MSDA_BWD_F32ACC=1.
+distribution), --ragged (images of different sizes: the general padding-mask path), --fp32, GRIT_MSDA_BWD_F32ACC=0 (value gradient of the
+deformable attention accumulated in bf16 by packed atomics instead of f32).
 """
 import argparse
 import json
@@ -190,21 +197,106 @@ def _enable_tuned_gemms():
     return load_tuned_gemms()
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(args):
+    """`--gpus N` without a launcher around it: start N worker processes of this file, one per GPU, and wait for them.
+    Nothing here touches the GPU (torch.cuda.device_count() only counts devices): the workers are fresh processes, not re-execs
+    of one that initialised HIP.  Exit code: 2 when fewer than N devices are visible (the contract backend needs one device per
+    rank), otherwise the first non-zero worker code."""
+    import subprocess
+    backend = os.environ.get("GRIT_BENCH_BACKEND", "nccl")
+    visible = torch.cuda.device_count()
+    if backend == "nccl" and visible < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d device(s) visible: refusing to run (an RCCL rank needs its own GPU)\n"
+                         % (args.gpus, visible))
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+                       "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    code, left = 0, set(range(args.gpus))
+    while left:
+        for r in sorted(left):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            left.discard(r)
+            if rc != 0 and code == 0:
+                code = rc
+                for o in left:  # a dead rank leaves the others waiting in a collective: end exactly the processes started here
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return code
+
+
+def mock_worker(args, rank, world, backend):
+    """GRIT_BENCH_MOCK=1: the launcher / rendezvous / timing / JSON plumbing with the training step replaced by a sleep and a
+    small all-reduce, so the N > 1 contract command can be tested where there is no GPU (tests/test_bench_launcher.py).  The
+    line it prints is labelled as a mock and carries no throughput claim."""
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    t = torch.zeros(4)
+    for _ in range(args.warmup):
+        dist.all_reduce(t)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002)
+        t += 1
+        dist.all_reduce(t)
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ids = [None] * world
+    dist.all_gather_object(ids, {"rank": rank, "pid": os.getpid(), "device": "cpu"})
+    if rank == 0:
+        print(json.dumps({"metric": "MOCK (launcher plumbing test, no training step ran)", "mock": True, "value": None,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(tmax) / args.steps * 1e3,
+                          "config": {"backend": backend, "ranks": dist.get_world_size(), "rank_devices": ids}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch(args)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required"
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the line would misreport n_gpus; refusing\n" % (args.gpus, world))
+        return 2
     # GRIT_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a 1-GPU box (ranks share the device); the
     # contract run uses 'nccl' (= RCCL over xGMI on ROCm), one rank per GPU
     backend = os.environ.get("GRIT_BENCH_BACKEND", "nccl")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if os.environ.get("GRIT_BENCH_MOCK") == "1":
+        return mock_worker(args, rank, world, backend)
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required"
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        sys.stderr.write("bench.py: %d ranks but %d device(s) visible\n" % (world, torch.cuda.device_count()))
+        return 2
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend, rank=rank, world_size=world)
+    rank_devices = [{"rank": rank, "device": device.index, "pid": os.getpid()}]
+    if world > 1:
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, {"rank": rank, "device": device.index, "pid": os.getpid()})
     _enable_tuned_gemms()
 
     from grit_amd.config import default_config
@@ -317,8 +409,10 @@ def main():
                     "points": args.points, "empty_event_pair_us": empty_pair_us}
         if bwd:  # informational: the backward is bound by the chip-wide memory-side atomic rate, not by HBM
             avg_b = sum(t for t, _ in bwd) / len(bwd)
-            msda_bwd = {"kernel": "msda_bwd_d64 (f32 atomics)" if (args.fp32 or msda_op.F32_ACCUMULATE)
-                        else "msda_bwd_d64_pk (packed-bf16 atomics, same-cell merges)", "launches": len(bwd), "avg_launch_us": avg_b * 1e6,
+            msda_bwd = {"kernel": "msda_bwd_d64 (f32 maps, f32 atomics)" if args.fp32 else
+                        ("msda_bwd_d64_pk<stage> + msda_stage_flush (f32 atomics into a staging map, one rounding to bf16 per touched cell)"
+                         if msda_op.F32_ACCUMULATE else "msda_bwd_d64_pk (packed-bf16 atomics, same-cell merges)"),
+                        "launches": len(bwd), "avg_launch_us": avg_b * 1e6,
                         "whole_map_bytes_per_launch": int(bwd[0][1])}
         # window attention against its compulsory HBM bytes (memory-bound at 72 flop/B; the MFMA fraction is informational)
         window_attention = {}
@@ -358,6 +452,9 @@ def main():
                                    f"caption length {args.caption_len}, Adam x2, dropout on",
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                        "parallelism": f"dp{world}",
+                       "backend": backend if world > 1 else None,
+                       "rccl_ranks": dist.get_world_size() if (world > 1 and backend == "nccl") else (1 if world == 1 else 0),
+                       "rank_devices": rank_devices,
                        "grad_allreduce": (("RCCL" if backend == "nccl" else backend + " (plumbing run, not the contract backend)")
                                           + " bucketed (64 MiB flat bf16 buckets, 8 MiB tail), overlapped with backward")
                        if world > 1 else "none (1 GPU)",
@@ -385,4 +482,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -23,6 +23,7 @@ import torch
 from torch import nn
 
 from grit_amd.ddp import BucketedDataParallel
+from grit_amd.ops import weights_epoch
 
 SLOT_ALIGN = 8  # elements: every parameter starts 16-byte aligned in the bf16 buffers, 32-byte in the fp32 ones
 
@@ -101,6 +102,7 @@ class FlatAdam(torch.optim.Optimizer):
                     ctypes.c_void_p(var[start:].data_ptr()), ctypes.c_void_p(compute[start:].data_ptr()), n, float(lr),
                     float(b1), float(b2), float(eps), bc1, bc2s, grad_scale, _lib.current_stream_ptr())
             _lib.check(st, "grit_adam_flat")
+        weights_epoch.bump()  # the compute weights were rewritten by a raw kernel: no version counter saw it
         return None
 
 
@@ -156,6 +158,7 @@ class Bf16Compute(nn.Module):
         # `wrapped.module.load_state_dict(ckpt['state_dict'])` (reference train_caption.py:131-132, before every self-critical
         # epoch) must reach the fp32 masters, not only the bf16 compute views the module's parameters are
         module._register_load_state_dict_pre_hook(self._on_module_load)
+        weights_epoch.bump()  # every parameter now lives in other storage
 
     # ------------------------------------------------------------------ what the engine calls
     def forward(self, *args, **kwargs):
@@ -208,6 +211,7 @@ class Bf16Compute(nn.Module):
         if not self.flat_optimizer:
             for b, compute_flat, master_flat, _, _, _ in self._pairs:
                 compute_flat.copy_(master_flat)  # fp32 -> bf16
+            weights_epoch.bump()  # the parameters are views of compute_flat: their version counters did not move
 
     def master_state_dict(self):
         """fp32 state dict under the reference's key names: masters for trainable tensors, the kept fp32 originals for frozen
@@ -225,6 +229,7 @@ class Bf16Compute(nn.Module):
         full precision; the regular load then writes the same values, rounded, into the bf16 compute views."""
         if prefix != '':
             return
+        weights_epoch.bump()
         with torch.no_grad():
             for name, m in self._masters:
                 v = state_dict.get(name)

@@ -563,12 +563,22 @@ void msda_bwd_d64(const VT* __restrict__ value, const int64_t* __restrict__ shap
 // parity path (f32 maps) and can be forced for bf16 maps (GRIT_MSDA_BWD_F32ACC=1).
 // Lane = channel PAIR: the two 32-lane halves of the wave walk the even / odd points of the row, so one wave instruction
 // gathers or scatters two 128-byte pixel-head rows; grad_loc / grad_w leave through the same 63-shuffle butterfly.
+//
+// STAGE = true: the same row walk (gathers, geometry, merges, grad_loc / grad_w) with the value gradient accumulated in
+// FLOAT32 -- the reference's atomicAdd precision (ms_deform_im2col_cuda.cuh:125-152) -- into a dense staging map
+// stage[B, S, M, 64] that arrives zeroed.  The scatter there is lane = channel with wave-uniform point and weight (one
+// 256-byte contiguous wave atomic per corner, the full-rate shape of msda_bwd_d64), the weights taken by v_readlane from the
+// lane that computed the point.  Every cell a row touches is marked in cell_flags[B, S, M] (plain byte stores of 1: all
+// writers write the same value), so msda_stage_flush visits the touched cells only: it rounds them once into the bf16
+// gradient map and leaves stage and flags zeroed for the next launch.
+template <bool STAGE>
 __global__ __launch_bounds__(kWave * kRowsPerBlock)
 void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __restrict__ shapes,
                      const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
                      const __hip_bfloat16* __restrict__ grad_out, int S, int M, int L, int Lq, int P,
                      __hip_bfloat16* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_aw,
-                     int nrows, int nblk, int images_interleaved, int merge_disabled, int pix_el) {
+                     int nrows, int nblk, int images_interleaved, int merge_disabled, int pix_el,
+                     float* __restrict__ stage, unsigned char* __restrict__ cell_flags) {
     constexpr int D = 64, kMaxLP = 16;
     typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
     typedef v2bf __attribute__((address_space(1))) * gv2bf_ptr;
@@ -604,6 +614,29 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
     const int e1 = pst + c.o1, e2 = pst + c.o2, e3 = pst + c.o3, e4 = pst + c.o4;
     const int flags = lane < LP ? ((c.k1 ? 1 : 0) | (c.k2 ? 2 : 0) | (c.k3 ? 4 : 0) | (c.k4 ? 8 : 0)) : 0;
     const float fW = (float)pW * pwt, fH = (float)pH * pwt;
+    // STAGE: channel = lane view of this row's output gradient and of the staging map; touched cells flagged by the lane
+    // that owns the point
+    float go_ch = 0.f;
+    float* shead = nullptr;
+    if constexpr (STAGE) {
+        go_ch = ldv(grad_out + (size_t)row * D + lane);
+        shead = stage + (size_t)b * S * M * D + (size_t)m * D + lane;
+        if (lane < LP) {
+            unsigned char* fl = cell_flags + (size_t)b * S * M + m;
+            if (flags & 1) fl[(size_t)e1 * M] = 1;
+            if (flags & 2) fl[(size_t)e2 * M] = 1;
+            if (flags & 4) fl[(size_t)e3 * M] = 1;
+            if (flags & 8) fl[(size_t)e4 * M] = 1;
+        }
+    }
+#define GRIT_RLF(x, p) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), (p)))
+#define GRIT_STAGE_ADD(f_, s1_, s2_, s3_, s4_, W1_, W2_, W3_, W4_)                                   \
+    do {                                                                                             \
+        if ((f_) & 1) atomic_add_fast(shead + (size_t)(s1_) * (M * D), (W1_) * go_ch);               \
+        if ((f_) & 2) atomic_add_fast(shead + (size_t)(s2_) * (M * D), (W2_) * go_ch);               \
+        if ((f_) & 4) atomic_add_fast(shead + (size_t)(s3_) * (M * D), (W3_) * go_ch);               \
+        if ((f_) & 8) atomic_add_fast(shead + (size_t)(s4_) * (M * D), (W4_) * go_ch);               \
+    } while (0)
 
     float part[64];  // [0,16): grad_attn_w per point, [16,48): grad_loc (x, y) per point, rest zero
 #pragma unroll
@@ -654,7 +687,10 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
                         W1 += hh * (1.f - lw); W2 += hh * lw; W3 += lhw * (1.f - lw); W4 += lhw * lw;
                     }
                     const int f = __builtin_amdgcn_readlane(flags, p0);
-                    if (!odd) {
+                    if constexpr (STAGE) {
+                        GRIT_STAGE_ADD(f, __builtin_amdgcn_readlane(e1, p0), __builtin_amdgcn_readlane(e2, p0),
+                                       __builtin_amdgcn_readlane(e3, p0), __builtin_amdgcn_readlane(e4, p0), W1, W2, W3, W4);
+                    } else if (!odd) {
                         __hip_bfloat16* g1 = ghead + (size_t)__builtin_amdgcn_readlane(e1, p0) * pix_stride;
                         __hip_bfloat16* g2 = ghead + (size_t)__builtin_amdgcn_readlane(e2, p0) * pix_stride;
                         __hip_bfloat16* g3 = ghead + (size_t)__builtin_amdgcn_readlane(e3, p0) * pix_stride;
@@ -683,8 +719,30 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
                                   __builtin_amdgcn_readlane(e3, 2 * i) == __builtin_amdgcn_readlane(e3, 2 * i + 1) &&
                                   __builtin_amdgcn_readlane(e4, 2 * i) == __builtin_amdgcn_readlane(e4, 2 * i + 1) &&
                                   __builtin_amdgcn_readlane(flags, 2 * i) == __builtin_amdgcn_readlane(flags, 2 * i + 1);
+                if constexpr (STAGE) {
+                    // wave-uniform weights of the step's two points (2i on the lower half, 2i + 1 on the upper)
+                    const int pa_ = 2 * i, pb_ = 2 * i + 1;
+                    const float lhA = GRIT_RLF(c.lh, pa_), lwA = GRIT_RLF(c.lw, pa_), wtA = GRIT_RLF(pwt, pa_);
+                    const float hA = (1.f - lhA) * wtA, lA = lhA * wtA;
+                    float A1 = hA * (1.f - lwA), A2 = hA * lwA, A3 = lA * (1.f - lwA), A4 = lA * lwA;
+                    const int fA = __builtin_amdgcn_readlane(flags, pa_);
+                    if (pb_ < LP) {
+                        const float lhB = GRIT_RLF(c.lh, pb_), lwB = GRIT_RLF(c.lw, pb_), wtB = GRIT_RLF(pwt, pb_);
+                        const float hB = (1.f - lhB) * wtB, lB = lhB * wtB;
+                        const float B1 = hB * (1.f - lwB), B2 = hB * lwB, B3 = lB * (1.f - lwB), B4 = lB * lwB;
+                        if (pair) {
+                            A1 += B1; A2 += B2; A3 += B3; A4 += B4;
+                        } else {
+                            GRIT_STAGE_ADD(__builtin_amdgcn_readlane(flags, pb_), __builtin_amdgcn_readlane(e1, pb_),
+                                           __builtin_amdgcn_readlane(e2, pb_), __builtin_amdgcn_readlane(e3, pb_),
+                                           __builtin_amdgcn_readlane(e4, pb_), B1, B2, B3, B4);
+                        }
+                    }
+                    GRIT_STAGE_ADD(fA, __builtin_amdgcn_readlane(e1, pa_), __builtin_amdgcn_readlane(e2, pa_),
+                                   __builtin_amdgcn_readlane(e3, pa_), __builtin_amdgcn_readlane(e4, pa_), A1, A2, A3, A4);
+                }
                 float u1 = w1 * wt, u2 = w2 * wt, u3 = w3 * wt, u4 = w4 * wt;
-                bool issue = true;
+                bool issue = !STAGE;
                 if (pair) {
                     // the other half's point: 2i + 1 for the lower half (the only one that issues)
                     const float olh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.lh), 2 * i + 1));
@@ -692,9 +750,9 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
                     const float owt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pwt), 2 * i + 1));
                     const float ohh = (1.f - olh) * owt, olhw = olh * owt;
                     u1 += ohh * (1.f - olw); u2 += ohh * olw; u3 += olhw * (1.f - olw); u4 += olhw * olw;
-                    issue = !odd;
+                    issue = !STAGE && !odd;
                 }
-                if (issue) {
+                if (!STAGE && issue) {
                     if (f & 1) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s1 * pix_stride), v2bf{(__bf16)(u1 * go0), (__bf16)(u1 * go1)});
                     if (f & 2) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s2 * pix_stride), v2bf{(__bf16)(u2 * go0), (__bf16)(u2 * go1)});
                     if (f & 4) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s3 * pix_stride), v2bf{(__bf16)(u3 * go0), (__bf16)(u3 * go1)});
@@ -720,6 +778,8 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
     }
 #undef GRIT_PICK_I
 #undef GRIT_PICK_F
+#undef GRIT_RLF
+#undef GRIT_STAGE_ADD
     halve_step<64>(part, lane, 32);
     halve_step<32>(part, lane, 16);
     halve_step<16>(part, lane, 8);
@@ -729,6 +789,50 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
     const int j = (int)(__brev((unsigned)lane) >> 26);  // index of the value this lane now owns
     if (j < LP) grad_aw[(size_t)row * LP + j] = part[0];
     else if (j >= 16 && j < 16 + 2 * LP) grad_loc[(size_t)row * 2 * LP + (j - 16)] = part[0];
+}
+
+// Second half of the f32-accumulating bf16 backward: every (image, pixel, head) cell whose flag is set gets its 64 staged
+// f32 sums rounded ONCE to bf16 and written to its place in the (possibly strided) gradient map; the staged row and the
+// flag are cleared, so stage / cell_flags leave the launch as they must enter the next one: all zero.  Untouched cells are
+// not read (the gradient map was zero-filled): at GRIT's shapes the gather reaches 20-45 % of the cells.
+// A wave owns 64 consecutive cells (lane = cell for the flag read, lane = channel for the rows), four rows in flight.
+__global__ __launch_bounds__(256)
+void msda_stage_flush(float* __restrict__ stage, unsigned char* __restrict__ cell_flags, __hip_bfloat16* __restrict__ grad_value,
+                      long ncells, int S, int M, int pix_el) {
+    const int lane = threadIdx.x & 63;
+    const long base = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (base >= ncells) return;
+    const long cell = base + lane;
+    const unsigned char fl = cell < ncells ? cell_flags[cell] : (unsigned char)0;
+    unsigned long long mask = __ballot(fl != 0);
+    if (fl) cell_flags[cell] = 0;
+    while (mask) {
+        long c[4];
+        float v[4];
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (mask) {
+                const int bit = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                c[k] = base + bit;
+                n = k + 1;
+            } else {
+                c[k] = -1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < n) v[k] = stage[c[k] * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < n) {
+                stage[c[k] * 64 + lane] = 0.f;
+                const long pix = c[k] / M;  // b * S + pixel
+                const int m = (int)(c[k] - pix * M);
+                grad_value[pix * pix_el + (long)m * 64 + lane] = __float2bfloat16(v[k]);
+            }
+    }
 }
 
 bool dims_ok(int B, int S, int M, int D, int L, int Lq, int P) {
@@ -912,9 +1016,39 @@ int grit_msda_bwd_bf16acc_strided(const void* value, long pixel_stride, const in
     static const bool interleave = !(getenv("GRIT_MSDA_BWD_INTERLEAVE") && atoi(getenv("GRIT_MSDA_BWD_INTERLEAVE")) == 0);
     const int images = (interleave && B > 1 && (Lq * M) % kRowsPerBlock == 0) ? B : 1;
     static const bool no_merge = getenv("GRIT_MSDA_BWD_MERGE") && atoi(getenv("GRIT_MSDA_BWD_MERGE")) == 0;  // A/B knob
-    hipLaunchKernelGGL(msda_bwd_d64_pk, dim3(nblk), dim3(kWave * kRowsPerBlock), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(msda_bwd_d64_pk<false>, dim3(nblk), dim3(kWave * kRowsPerBlock), 0, (hipStream_t)stream,
                        (const __hip_bfloat16*)value, spatial_shapes, level_start, loc, attn_w, (const __hip_bfloat16*)grad_out,
-                       S, M, L, Lq, P, (__hip_bfloat16*)grad_value, grad_loc, grad_attn_w, nrows, nblk, images, no_merge ? 1 : 0, (int)pixel_stride);
+                       S, M, L, Lq, P, (__hip_bfloat16*)grad_value, grad_loc, grad_attn_w, nrows, nblk, images, no_merge ? 1 : 0,
+                       (int)pixel_stride, (float*)nullptr, (unsigned char*)nullptr);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+int grit_msda_bwd_bf16_staged(const void* value, long pixel_stride, const int64_t* spatial_shapes,
+                              const int64_t* level_start, const float* loc, const float* attn_w, const void* grad_out,
+                              int B, int S, int M, int D, int L, int Lq, int P, float* stage, unsigned char* cell_flags,
+                              void* grad_value, float* grad_loc, float* grad_attn_w, void* stream) {
+    if (pixel_stride < (long)M * D || pixel_stride % 2 || pixel_stride > 0x3fffffffL) return GRIT_ERR_BAD_ARG;
+    if (!value || !spatial_shapes || !level_start || !loc || !attn_w || !grad_out || !grad_value || !grad_loc || !grad_attn_w ||
+        !stage || !cell_flags)
+        return GRIT_ERR_BAD_ARG;
+    if (!dims_ok(B, S, M, D, L, Lq, P)) return GRIT_ERR_BAD_ARG;
+    if (D != 64 || L * P > 16 || ((uintptr_t)value % 4) || ((uintptr_t)grad_out % 4) || ((uintptr_t)grad_value % 2) ||
+        ((uintptr_t)stage % 4))
+        return GRIT_ERR_UNSUPPORTED;
+    const int nrows = B * Lq * M;
+    const int nblk = (nrows + kRowsPerBlock - 1) / kRowsPerBlock;
+    static const bool interleave = !(getenv("GRIT_MSDA_BWD_INTERLEAVE") && atoi(getenv("GRIT_MSDA_BWD_INTERLEAVE")) == 0);
+    const int images = (interleave && B > 1 && (Lq * M) % kRowsPerBlock == 0) ? B : 1;
+    static const bool no_merge = getenv("GRIT_MSDA_BWD_MERGE") && atoi(getenv("GRIT_MSDA_BWD_MERGE")) == 0;
+    hipLaunchKernelGGL(msda_bwd_d64_pk<true>, dim3(nblk), dim3(kWave * kRowsPerBlock), 0, (hipStream_t)stream,
+                       (const __hip_bfloat16*)value, spatial_shapes, level_start, loc, attn_w, (const __hip_bfloat16*)grad_out,
+                       S, M, L, Lq, P, (__hip_bfloat16*)nullptr, grad_loc, grad_attn_w, nrows, nblk, images, no_merge ? 1 : 0,
+                       (int)pixel_stride, stage, cell_flags);
+    if (hipGetLastError() != hipSuccess) return GRIT_ERR_LAUNCH;
+    const long ncells = (long)B * S * M;
+    const long nwaves = (ncells + 63) / 64;
+    hipLaunchKernelGGL(msda_stage_flush, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, stage, cell_flags,
+                       (__hip_bfloat16*)grad_value, ncells, S, M, (int)pixel_stride);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 

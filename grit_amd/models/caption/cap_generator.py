@@ -19,6 +19,7 @@ from grit_amd.models.common.pos_embed import FeedForward, sinusoid_encoding_tabl
 from grit_amd.ops import backend
 from grit_amd.ops import decode_inputs
 from grit_amd.ops import gate as gate_ops
+from grit_amd.ops import weights_epoch
 from grit_amd.ops.linear import Linear
 
 
@@ -53,7 +54,11 @@ class ParallelAttentionLayer(GeneratorLayer):
 
     def _cross_query_weights(self):
         a, b = self.vis_att1.attention.fc_q, self.vis_att2.attention.fc_q
-        tag = tuple((p.data_ptr(), 0 if p.is_inference() else p._version, p.dtype) for p in (a.weight, a.bias, b.weight, b.bias))
+        if a.weight.is_cuda and torch.cuda.is_current_stream_capturing():  # part of the captured graph: see Attention.fused_weights
+            with torch.no_grad():
+                return torch.cat([a.weight, b.weight], 0), torch.cat([a.bias, b.bias], 0)
+        tag = (weights_epoch.current(),) + tuple((p.data_ptr(), 0 if p.is_inference() else p._version, p.dtype)
+                                                 for p in (a.weight, a.bias, b.weight, b.bias))
         if self._q12 is None or self._q12[0] != tag:
             with torch.no_grad():
                 self._q12 = (tag, torch.cat([a.weight, b.weight], 0), torch.cat([a.bias, b.bias], 0))

@@ -101,12 +101,19 @@ class Transformer(BaseCaptioner):
 
     def _beam_search_graphed(self, vis, max_len, eos_idx, beam_size, out_size):
         names = sorted(k for k, v in vis.items() if isinstance(v, torch.Tensor))
+        # The graph reads every parameter from its storage at replay time (derived weights are rebuilt inside the capture), so
+        # in-place writers -- optimizer steps, load_state_dict -- need no invalidation.  What does: parameter STORAGE being
+        # replaced (module.to(dtype), Bf16Compute wrapping): the addresses of the first and last decoder parameters are in the key.
+        probe = (self.grid_net.fc.weight, self.cap_generator.fc.weight)
         key = (max_len, eos_idx, beam_size, out_size, torch.is_inference_mode_enabled(), vis[names[0]].device.index) + \
+            tuple((p.data_ptr(), p.dtype) for p in probe) + \
             tuple((k, tuple(vis[k].shape), vis[k].dtype) for k in names)
-        entry = self._decode_graphs.get(key)
+        entry = self._decode_graphs.pop(key, None)
+        if entry is not None:
+            self._decode_graphs[key] = entry  # most recently used last
         if entry is None:
-            if len(self._decode_graphs) >= 8:  # a few live shapes at most (each graph keeps its activations)
-                self._decode_graphs.clear()
+            while len(self._decode_graphs) >= 8:  # a few live shapes at most (each graph keeps its activations): drop the
+                self._decode_graphs.pop(next(iter(self._decode_graphs)))  # least recently used one, not all of them
             static_in = {k: vis[k].clone() for k in names}
             cur = torch.cuda.current_stream()
             side = torch.cuda.Stream()

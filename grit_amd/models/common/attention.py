@@ -16,6 +16,7 @@ from torch.nn import functional as F
 from grit_amd.models.caption.containers import Module
 from grit_amd.ops import backend
 from grit_amd.ops import kv_cache
+from grit_amd.ops import weights_epoch
 from grit_amd.ops.attention import attention as fused_attention
 from grit_amd.ops.layer_norm import add_layer_norm, linear_add_layer_norm
 from grit_amd.ops.linear import Linear
@@ -61,9 +62,15 @@ class Attention(nn.Module):
 
     def fused_weights(self, names):
         """Concatenated weight / bias of the named projections (('fc_q', 'fc_k', 'fc_v'): one GEMM instead of three), rebuilt
-        when a parameter is replaced or written in place.  Inference only: the copies carry no gradient."""
+        when a parameter is replaced, written in place, or when grit_amd.ops.weights_epoch moved (flat optimizer steps and
+        checkpoint loads under Bf16Compute do not touch the views' version counters).  Inference only: no gradient."""
         params = [p for n in names for p in (getattr(self, n).weight, getattr(self, n).bias)]
-        tag = tuple((p.data_ptr(), 0 if p.is_inference() else p._version, p.dtype) for p in params)
+        if params[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            # inside a captured decode graph the concatenation is part of the graph: every replay reads the parameters as they
+            # are then (optimizer steps and load_state_dict write them in place), and the graph owns the tensor it reads
+            with torch.no_grad():
+                return torch.cat(params[0::2], 0), torch.cat(params[1::2], 0)
+        tag = (weights_epoch.current(),) + tuple((p.data_ptr(), 0 if p.is_inference() else p._version, p.dtype) for p in params)
         hit = self._fused.get(names)
         if hit is None or hit[0] != tag:
             with torch.no_grad():

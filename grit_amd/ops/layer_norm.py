@@ -1,8 +1,8 @@
 """LayerNorm over the last dimension on the gfx950 streaming kernels (grit_layernorm_{fwd,bwd}).
 
 Used by the Swin backbone (norm1 / norm2 / patch-merging / patch-embed norms): there LayerNorm is a pure HBM
-stream over maps of up to 819 200 tokens and torch's bf16 kernels run at a fraction of the bandwidth.  Channel
-counts the kernels do not cover fall through to torch.nn.functional.layer_norm (a library op like the GEMMs)."""
+stream over maps of up to 819 200 tokens and torch's bf16 kernels run at a fraction of the bandwidth.  A device tensor
+whose channel count / dtype the kernels do not cover RAISES (no silent library fallback on the hot path)."""
 import ctypes
 
 import torch
@@ -77,7 +77,12 @@ def layer_norm(x, weight, bias, eps=1e-5):
             and x.dtype in (torch.float32, torch.bfloat16) and weight.dtype == bias.dtype
             and (weight.dtype == x.dtype or (x.dtype == torch.bfloat16 and weight.dtype == torch.float32)))
     if not fits:
-        return F.layer_norm(x, (C,), weight, bias, eps)
+        if x.is_cuda:  # no silent library fallback on the device: a shape / dtype outside the kernels' range is a loud error
+            raise _lib.GritHipError(
+                "layer_norm: no HIP kernel for C = %d (supported: %s), x %s, weight %s, bias %s -- every LayerNorm of GRIT fits; "
+                "extend grit_layernorm_* or call torch.nn.functional.layer_norm explicitly" %
+                (C, SUPPORTED_C, x.dtype, None if weight is None else weight.dtype, None if bias is None else bias.dtype))
+        return F.layer_norm(x, (C,), weight, bias, eps)  # host tensors (config 1 plumbing on CPU): the library op
     return _LayerNormFn.apply(x, weight.contiguous(), bias.contiguous(), float(eps))
 
 

@@ -29,9 +29,39 @@ LOC_OVERRIDE = None
 # from which the cache lines the gather touches are counted afterwards (unique_lines_touched)
 PROFILE_RECORD_GEOMETRY = False
 
-# GRIT_MSDA_BWD_F32ACC=1: bf16 maps keep an f32 staging map for grad_value (f32 atomics + one final rounding) instead of
-# accumulating in bf16 with packed atomics
-F32_ACCUMULATE = os.environ.get("GRIT_MSDA_BWD_F32ACC", "0") == "1"
+# bf16 value maps: grad_value is accumulated in f32 (float atomics into a staging map, ONE rounding to bf16 per touched cell:
+# the precision of the reference's atomicAdd, ms_deform_im2col_cuda.cuh:125-152) -- grit_msda_bwd_bf16_staged.
+# GRIT_MSDA_BWD_F32ACC=0 opts into accumulation IN bf16 by packed atomics (grit_msda_bwd_bf16acc*: twice the atomic rate, but
+# every add rounds to 8 mantissa bits and the result depends on the arrival order more strongly).
+F32_ACCUMULATE = os.environ.get("GRIT_MSDA_BWD_F32ACC", "1") != "0"
+
+_STAGE = {}  # (device, B, S, M) -> [stage f32 [B,S,M,64], cell flags u8 [B,S,M], dirty]: zero on entry AND exit of every call
+
+
+def _staging(device, B, S, M):
+    key = (str(device), B, S, M)
+    ent = _STAGE.get(key)
+    if ent is None:
+        if len(_STAGE) >= 4:  # shapes change with the batch / image size: keep the scratch of the last few only
+            _STAGE.clear()
+        ent = _STAGE[key] = [torch.zeros((B, S, M, 64), dtype=torch.float32, device=device),
+                             torch.zeros((B, S, M), dtype=torch.uint8, device=device), False]
+    elif ent[2]:  # a previous call died between its two launches: the invariant (all zero) has to be re-established
+        ent[0].zero_()
+        ent[1].zero_()
+        ent[2] = False
+    return ent
+
+
+def _bwd_staged(value_ptr, pixel_stride, shapes, lsi, loc, aw, go, B, S, M, D, L, Lq, P, gv_ptr, gl, ga, device):
+    ent = _staging(device, B, S, M)
+    ent[2] = True
+    with _lib.device_guard(device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 4)):
+        st = _lib.load().grit_msda_bwd_bf16_staged(value_ptr, pixel_stride, _ptr(shapes), _ptr(lsi), _ptr(loc), _ptr(aw), _ptr(go),
+                                                   B, S, M, D, L, Lq, P, _ptr(ent[0]), _ptr(ent[1]), gv_ptr, _ptr(gl), _ptr(ga),
+                                                   _lib.current_stream_ptr())
+    _lib.check(st, "grit_msda_bwd_bf16_staged")
+    ent[2] = False
 
 
 def _ptr(t):
@@ -165,14 +195,11 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     if _bf16_fast_path(value, D, L, P):
         loc, aw = sampling_loc.float(), attn_weight.float()
         go = grad_output.to(torch.bfloat16).contiguous()
-        gv = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
+        gv = torch.zeros(value.shape, dtype=torch.bfloat16, device=value.device)
         gl, ga = torch.empty_like(loc), torch.empty_like(aw)
-        with _lib.device_guard(value.device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 4)):
-            st = _lib.load().grit_msda_bwd_bf16(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc),
-                                                _ptr(aw), _ptr(go), B, S, M, D, L, Lq, P, _ptr(gv), _ptr(gl), _ptr(ga),
-                                                _lib.current_stream_ptr())
-        _lib.check(st, "grit_msda_bwd_bf16")
-        return [gv.to(torch.bfloat16), gl.to(sampling_loc.dtype), ga.to(attn_weight.dtype)]
+        _bwd_staged(_ptr(value), M * D, spatial_shapes, level_start_index, loc, aw, go, B, S, M, D, L, Lq, P, _ptr(gv), gl, ga,
+                    value.device)
+        return [gv, gl.to(sampling_loc.dtype), ga.to(attn_weight.dtype)]
     cdt = _compute_dtype(value)
     v, loc, aw = value.to(cdt), sampling_loc.to(cdt), attn_weight.to(cdt)
     go = grad_output.to(cdt).contiguous()
@@ -237,12 +264,16 @@ class _StackedMSDAFn(Function):
             maps.grad = torch.zeros_like(stacked)  # one fill for all layers; the kernels add into their slices
         go = grad_output.to(torch.bfloat16).contiguous()
         gl, ga = torch.empty_like(loc), torch.empty_like(aw)
-        with _lib.device_guard(stacked.device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 2)):
-            st = _lib.load().grit_msda_bwd_bf16acc_strided(maps.layer_ptr(stacked, layer), n * M * D, _ptr(shapes), _ptr(lsi),
-                                                           _ptr(loc), _ptr(aw), _ptr(go), B, S, M, D, L, Lq, P,
-                                                           maps.layer_ptr(maps.grad, layer), _ptr(gl), _ptr(ga),
-                                                           _lib.current_stream_ptr())
-        _lib.check(st, "grit_msda_bwd_bf16acc_strided")
+        if F32_ACCUMULATE:
+            _bwd_staged(maps.layer_ptr(stacked, layer), n * M * D, shapes, lsi, loc, aw, go, B, S, M, D, L, Lq, P,
+                        maps.layer_ptr(maps.grad, layer), gl, ga, stacked.device)
+        else:
+            with _lib.device_guard(stacked.device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 2)):
+                st = _lib.load().grit_msda_bwd_bf16acc_strided(maps.layer_ptr(stacked, layer), n * M * D, _ptr(shapes), _ptr(lsi),
+                                                               _ptr(loc), _ptr(aw), _ptr(go), B, S, M, D, L, Lq, P,
+                                                               maps.layer_ptr(maps.grad, layer), _ptr(gl), _ptr(ga),
+                                                               _lib.current_stream_ptr())
+            _lib.check(st, "grit_msda_bwd_bf16acc_strided")
         maps.pending -= 1
         gstacked = None
         if maps.pending == 0:  # every layer has added its part
@@ -252,7 +283,7 @@ class _StackedMSDAFn(Function):
 
 def stacked_fast_path(stacked, L, P):
     return (stacked.is_cuda and stacked.dtype == torch.bfloat16 and stacked.shape[-1] == 64 and L * P <= 16
-            and not F32_ACCUMULATE and stacked.numel() * 2 < (1 << 32))
+            and stacked.numel() * 2 < (1 << 32))
 
 
 def ms_deform_attn_stacked(maps, layer, shapes, lsi, loc, aw):

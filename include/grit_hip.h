@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 24
+#define GRIT_ABI_VERSION 25
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -132,6 +132,17 @@ int grit_msda_bwd_bf16acc_strided(const void* value, long pixel_stride, const in
                                   const int64_t* level_start, const float* loc, const float* attn_w, const void* grad_out,
                                   int B, int S, int M, int D, int L, int Lq, int P, void* grad_value, float* grad_loc,
                                   float* grad_attn_w, void* stream);
+/* bf16 maps, value gradient ACCUMULATED IN f32 (the precision of the reference's atomicAdd on its fp32 grad_value,
+ * ms_deform_im2col_cuda.cuh:125-152) and rounded to bf16 once: the default of the training step.  `stage` [B, S, M, 64] f32 and
+ * `cell_flags` [B, S, M] u8 are scratch that must ARRIVE ZEROED and is RETURNED ZEROED (the second launch of the call visits the
+ * cells the scatter touched -- flagged by the first -- rounds them into grad_value and clears stage and flags), so one
+ * allocation serves every layer and every step.  grad_value: bf16 map with `pixel_stride` elements between pixels, zero-filled
+ * by the caller (untouched cells are not written).  Same row walk, same-cell merges and grad_loc / grad_attn_w arithmetic as
+ * grit_msda_bwd_bf16acc_strided.  D = 64, L*P <= 16. */
+int grit_msda_bwd_bf16_staged(const void* value, long pixel_stride, const int64_t* spatial_shapes,
+                              const int64_t* level_start, const float* loc, const float* attn_w, const void* grad_out,
+                              int B, int S, int M, int D, int L, int Lq, int P, float* stage, unsigned char* cell_flags,
+                              void* grad_value, float* grad_loc, float* grad_attn_w, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Scaled-dot attention core, fp32 arithmetic, head_dim D = 64 (also the 150-query

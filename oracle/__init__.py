@@ -9,4 +9,9 @@ leg may import this package; nothing under grit_amd/ does (tests/test_layout.py 
 
 Parity status: PINNED -- every oracle is checked against golden vectors generated in the build
 container from the imported reference (tests/golden/make_golden.py, fixtures in tests/golden/*.npz).
+
+Exception, stated where it applies: the PTB tokenizer of the self-critical reward (grit_amd/datasets/caption/metrics/tokenizer.py,
+a product-side restatement of a third-party Java program that is absent from the reference tree and cannot run here) is checked
+against tests/golden/ptb_rules_table.json -- a hand-checked TABLE of published PTB / CoreNLP conventions, not output of the jar:
+"parity unpinned" against the Java program itself.
 """

@@ -43,6 +43,19 @@ def test_ptb_style_tokenizer_conventions():
     assert PTBTokenizer.tokenize({7: ["Hello, world"]}) == {7: ["hello world"]}
 
 
+def test_ptb_tokenizer_against_the_hand_checked_rule_table():
+    """tests/golden/ptb_rules_table.json: 43 rows of published PTB / CoreNLP-3.4.1 conventions (clitics, quotes, brackets,
+    hyphens, numbers with separators, slash escaping, the punctuation the CIDEr pipeline strips), each with the rule it
+    illustrates.  A table checked by hand -- not output of the Java tokenizer, which cannot run in the build image."""
+    from grit_amd.datasets.caption.metrics import PTBTokenizer
+    from grit_amd.datasets.caption.metrics.tokenizer import ptb_tokens
+    table = json.load(open(os.path.join(GOLDEN, "ptb_rules_table.json")))
+    assert len(table["rows"]) >= 40
+    for row in table["rows"]:
+        assert ptb_tokens(row["text"]) == row["tokens"], row["rule"]
+        assert PTBTokenizer.tokenize([row["text"]])[0][0] == row["after_punctuation_filter"], row["rule"]
+
+
 def test_cider_reward_fn_default_tokenizer():
     """engine.caption_engine.cider_reward_fn with the native tokenizer: tokens -> decode -> tokenise -> CIDEr -> [B, beam]."""
     from grit_amd.datasets.caption.metrics import Cider, PTBTokenizer

@@ -252,3 +252,59 @@ def test_device_decode_shortcuts_reproduce_the_reference_order_loop(g7_model, mo
     slow_tokens, slow_lp = decode()
     assert torch.equal(fast_tokens, slow_tokens)
     assert torch.allclose(fast_lp, slow_lp, rtol=1e-4, atol=1e-4)
+
+
+def test_eval_after_flat_adam_steps_sees_the_new_weights(monkeypatch):
+    """the inference-side derived weights (concatenated q/k/v of the decoder self-attention, the two cross
+    query projections) and the captured decode graph must follow FlatAdam's raw in-place updates of the flat bf16 compute
+    weights, which no tensor version counter records.  eval -> 4 large optimizer steps -> eval: the second evaluation must equal
+    the one a model WITHOUT any cache / graph / fusion computes from the updated weights, and differ from the first."""
+    import grit_amd.models.caption.cap_generator as CG
+    import grit_amd.models.caption.transformer as T
+    import grit_amd.models.common.attention as A
+    from grit_amd.amp import Bf16Compute
+    from grit_amd.engine.caption_engine import build_optimizers, train_xe_step
+    from grit_amd.ops import gate as gate_ops
+    from grit_amd.utils.misc import NestedTensor
+    g = load("step_g8.npz")
+    model, cfg = build_model(3, **{'model.dropout': 0.0, 'model.detector.dropout': 0.0, 'optimizer.xe_lr': 2e-3,
+                                   'optimizer.xe_backbone_lr': 2e-4})
+    model.train().to(DEV)
+    disable_drop_path(model)
+    wrapped = Bf16Compute(model)
+    opts = build_optimizers(wrapped, cfg, mode='xe')
+    loss_fn = torch.nn.NLLLoss(ignore_index=1)
+    batch = {'samples': NestedTensor(t(g["images"], device=DEV), t(g["mask"], device=DEV)), 'captions': t(g["caps"], device=DEV)}
+
+    def evaluate():
+        model.eval()
+        with torch.no_grad():
+            tokens, lp = model(batch['samples'], seq=None, use_beam_search=True, max_len=12, eos_idx=3, beam_size=3, out_size=1)
+            tf = model(batch['samples'], batch['captions'])
+        model.train()
+        return tokens.clone(), lp.float().clone(), tf.float().clone()
+
+    first = evaluate()
+    first_again = evaluate()  # graph replay + cache hits
+    assert torch.equal(first[0], first_again[0]) and torch.equal(first[1], first_again[1])
+    for _ in range(4):
+        train_xe_step(wrapped, batch, opts, loss_fn)
+    second = evaluate()
+    # the reference point: same weights, every cache / graph / inference fusion off
+    monkeypatch.setattr(T, "_GRAPH_DECODE", False)
+    monkeypatch.setattr(T, "_FUSED_BEAM_STEP", False)
+    monkeypatch.setattr(A, "_KV_CACHE", False)
+    monkeypatch.setattr(A, "_KV_FUSED_APPEND", False)
+    monkeypatch.setattr(CG, "_FUSED_STEP_INPUTS", False)
+    monkeypatch.setattr(gate_ops, "supported", lambda *a, **k: False)
+    plain = evaluate()
+    assert (second[2] - first[2]).abs().max() > 0.5, "the optimizer steps must have moved the model for this test to mean anything"
+    # teacher forcing in eval mode also goes through the cached cross-query weights; fused vs composed bf16 arithmetic differ by
+    # rounding only (log-probs ~ -9: 5e-2 is a few bf16 ulps of the logits), stale weights by the 0.5+ asserted above
+    assert (second[2] - plain[2]).abs().max() < 5e-2
+    # beam search in bf16: the fused and the composed arithmetic round differently, so compare scores, not bits; stale weights
+    # would be off by the distance between `first` and `second` (several nats)
+    assert (second[1].sum(-1) - plain[1].sum(-1)).abs().max() < 0.15 * max(1.0, float(plain[1].sum(-1).abs().max()))
+    stale_gap = (first[1].sum(-1) - plain[1].sum(-1)).abs().max()
+    fresh_gap = (second[1].sum(-1) - plain[1].sum(-1)).abs().max()
+    assert fresh_gap < 0.25 * stale_gap, (float(fresh_gap), float(stale_gap))

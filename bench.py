@@ -18,7 +18,10 @@ forward + backward + gradient all-reduce (RCCL, bucketed, overlapped with backwa
 the order of reference engine/caption_engine.py:312-350.  Weak scaling: the per-GPU batch is fixed.
 
 One JSON line on rank 0.  Besides the contract keys:
-  roofline      MSDeformAttn forward kernel (HBM-bound gather) as it runs INSIDE the step: algorithmic bytes per launch /
+  roofline      the dominant hand-written kernel of the step by ms/step -- the window-attention backward -- against its compulsory
+                HBM bytes (7 bf16 [144, 32] slices per window-head), launch times from HIP events on the launch stream inside the
+                timed region, `traffic` = PMC bytes per launch of the same kernel read from profiles/r03/pmc_in_step.txt.
+  roofline_msda MSDeformAttn forward kernel (HBM-bound gather) as it runs INSIDE the step: algorithmic bytes per launch /
                 average launch time measured with HIP events on the launch stream inside the timed region, against 8 TB/s.
                 Algorithmic bytes = the distinct 128-byte lines of the value map that the launch's sampling points touch (counted
                 from the recorded sampling locations after the timed region) + locations + weights + output, each once -- so the
@@ -30,7 +33,9 @@ One JSON line on rank 0.  Besides the contract keys:
   gemm          aggregate rate of the GEMMs of the long token maps (library and own), timed per launch in extra steps after the
                 timed region (an event pair per GEMM inside it would cost ~2 ms per step).
   cpu_baseline  (N = 1 only) the same training step on the host CPU: this repo's modules with the oracle ops
-                (oracle/torch_ref.py) injected -- a port, not the reference -- on a bounded sample (batch 1, few steps).
+                (oracle/torch_ref.py) injected -- a port, not the reference -- on a bounded sample (batch 1
+                on the physical cores, median of 5; a small matrix with batch 4 and N = 8; capped at 60 s).
+  decode_config5  (N = 1 only) BASELINE config 5 on one GPU after the timed region: beam-5 x 20-step captions/s at batch 64.
 Diagnostic flags (recorded in config, never the default): --points spread (decoder sampling locations replaced by config 2's
 distribution), --ragged (images of different sizes: the general padding-mask path), --fp32, GRIT_MSDA_BWD_F32ACC=0 (value gradient of the
 deformable attention accumulated in bf16 by packed atomics instead of f32).
@@ -50,12 +55,27 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_BF16 = 2.5e15
-# HBM-side bytes per launch at B = 32 (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes), per kernel, from profiles/r01/ (fp32) and profiles/r02/ (bf16)
-# (bf16: measured on this benchmark's own launches -- value maps in the stacked layout, randomly initialised model)
-MSDA_FWD_TRAFFIC_B32 = {"fwd": int((2 * 130045.19 + 9600.0) * 1024), "fwd_bf16": int((2 * 31856.0 + 4800.0) * 1024)}
-MSDA_FWD_TRAFFIC_SOURCE = {"fwd": "profiles/r01/msda_pmc_b32.txt", "fwd_bf16": "profiles/r02/pmc_in_step.txt"}
 MSDA_FWD_KERNEL = {"fwd": "msda_fwd_vec4<16,4> (MSDeformAttn forward, fp32 value map)",
                    "fwd_bf16": "msda_fwd_bf16_rows4<2> (MSDeformAttn forward, bf16 value map, fp32 sampling geometry)"}
+# HBM-side bytes per launch come from the committed PMC summary of THIS command (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+# passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), read at run time: no figure is typed in here
+PMC_SUMMARIES = ("profiles/r03/pmc_in_step.txt", "profiles/r02/pmc_in_step.txt")
+
+
+def pmc_traffic(kernel_substring):
+    """(bytes per launch, source file) of the first PMC summary row whose kernel name contains `kernel_substring`; (None, None)
+    when no summary has it.  Rows: `<kernel> launches N  FETCH_SIZE f  WRITE_SIZE w  HBM-side bytes/launch b`."""
+    for rel in PMC_SUMMARIES:
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                for line in f:
+                    if kernel_substring in line and "HBM-side bytes/launch" in line:
+                        return float(line.rsplit("HBM-side bytes/launch", 1)[1].split()[0]), rel
+        except OSError:
+            continue
+    return None, None
+
+
 FLOP_PER_IMAGE_FWD_BWD = 955.8e9  # SURVEY 8d: measured on the reference with torch.utils.flop_counter (640^2, T = 20)
 
 
@@ -77,7 +97,7 @@ def parse():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--caption-len", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed steps of the cpu_baseline headline sample (median)")
     ap.add_argument("--fp32", action="store_true", help="diagnostic: no autocast (not the metric's dtype)")
     ap.add_argument("--points", choices=("model", "spread"), default="model",
                     help="spread: MSDeformAttn sampling locations replaced by SURVEY 8d config 2's distribution (diagnostic)")
@@ -165,29 +185,102 @@ def build(device, config):
     return model
 
 
-def cpu_baseline(config, size, caption_len, steps):
-    """Bounded CPU sample of the same step: batch 1, fp32, oracle ops injected (kind = 'port')."""
+def _physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo; os.cpu_count() when that cannot be read."""
+    try:
+        pairs, phys = set(), None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    pairs.add((phys, line.split(":")[1].strip()))
+        return len(pairs) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(config, size, caption_len, steps, budget_s=60.0):
+    """Bounded CPU sample of the same step: this repo's modules with the oracle ops injected (kind =
+    'port'), fp32, dropout on.  Headline: batch 1 on N = physical cores, 1 warm-up + median of `steps` timed steps; `matrix`
+    adds batch 4 at the same N and batch 1 at N = 8 (the survey container's thread count) with fewer timed steps, each cut
+    short once the whole leg has used `budget_s` seconds."""
     from grit_amd.data import synthetic_batch
     from grit_amd.engine.caption_engine import build_optimizers, train_xe_step
     from grit_amd.ops.backend import use_reference_ops
     from oracle import torch_ref  # checker / CPU baseline only
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
+    logical, physical = os.cpu_count() or 1, _physical_cores()
     model = build(torch.device("cpu"), config).train()
     opts = build_optimizers(model, config, mode="xe")
     loss_fn = torch.nn.NLLLoss(ignore_index=1)
-    batch = synthetic_batch(1, size, size, caption_len, device="cpu", seed=0)
-    times = []
-    with use_reference_ops(torch_ref):
-        for i in range(steps + 1):
-            t0 = time.perf_counter()
-            train_xe_step(model, batch, opts, loss_fn)
-            times.append(time.perf_counter() - t0)
-    timed = times[1:]
-    return {"value": len(timed) / sum(timed), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"batch 1, {size}x{size}, T={caption_len}, fp32, 1 warm-up + {steps} timed steps, "
-                      f"torch {threads} threads on a {cores}-cpu host"}
+    t_leg = time.perf_counter()
+
+    def sample(bs, threads, timed):
+        torch.set_num_threads(threads)
+        batch = synthetic_batch(bs, size, size, caption_len, device="cpu", seed=0)
+        times = []
+        with use_reference_ops(torch_ref):
+            for i in range(timed + 1):
+                if i > 1 and time.perf_counter() - t_leg > budget_s:
+                    break
+                t0 = time.perf_counter()
+                train_xe_step(model, batch, opts, loss_fn)
+                times.append(time.perf_counter() - t0)
+        timed_steps = sorted(times[1:])
+        if not timed_steps:
+            return None
+        med = timed_steps[len(timed_steps) // 2]
+        return {"batch": bs, "threads": threads, "timed_steps": len(timed_steps), "median_s_per_step": med,
+                "images_per_sec": bs / med}
+
+    head = sample(1, physical, steps)
+    matrix = [head]
+    for bs, threads, timed in ((4, physical, 2), (1, min(8, logical), 2)):
+        if time.perf_counter() - t_leg < budget_s:
+            r = sample(bs, threads, timed)
+            if r is not None:
+                matrix.append(r)
+    return {"value": head["images_per_sec"], "unit": "images/sec", "cores": physical, "kind": "port",
+            "sample": f"batch 1, {size}x{size}, T={caption_len}, fp32, 1 warm-up + median of {head['timed_steps']} timed steps, "
+                      f"torch {physical} threads (physical cores) on a {logical}-cpu host; matrix: batch 4 at the same N and "
+                      f"batch 1 at N = 8, 1 warm-up + up to 2 timed steps each, the leg capped at {budget_s:.0f} s",
+            "matrix": matrix, "leg_seconds": time.perf_counter() - t_leg}
+
+
+def decode_config5(device, config, batch=64, iters=2):
+    """BASELINE config 5 on this GPU (the code path of tools/bench_decode.py): beam search, beam 5, 20 steps, batch 64 of
+    synthetic 640x640 images, eval mode, bf16 weights with fp32 logits / log-softmax / beam arithmetic; detector and decode
+    timed separately between device syncs, sequentially (no overlap between batches).  Tokens are hashed so that runs can be
+    compared bit for bit."""
+    import hashlib
+    from grit_amd.data import synthetic_batch
+    torch.manual_seed(config.exp.seed)
+    model = build(device, config).eval().to(torch.bfloat16)
+    data = synthetic_batch(batch, 640, 640, device=device, seed=1)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        return out, time.perf_counter() - t0
+
+    det, dec, tokens = [], [], None
+    with torch.no_grad():
+        for it in range(iters + 1):  # iteration 0 warms up and captures the decode graph
+            vis, t_det = timed(lambda: model.detector(data['samples']))
+            model.cached_features = True
+            (tokens, _), t_dec = timed(lambda: model(vis, seq=None, use_beam_search=True, max_len=20, eos_idx=3, beam_size=5,
+                                                     out_size=1))
+            model.cached_features = False
+            if it:
+                det.append(t_det)
+                dec.append(t_dec)
+    t_det, t_dec = min(det), min(dec)
+    return {"workload": "beam search, beam 5, 20 steps, batch %d, synthetic 640x640, eval, bf16 weights / fp32 decoder tail" % batch,
+            "captions_per_sec_sequential": batch / (t_det + t_dec), "detector_ms": t_det * 1e3, "decode_20_steps_ms": t_dec * 1e3,
+            "batch": batch, "beam": 5, "iterations": iters, "n_gpus": 1,
+            "tokens_sha1": hashlib.sha1(tokens.cpu().numpy().tobytes()).hexdigest(), "tokens_shape": list(tokens.shape)}
 
 
 def _enable_tuned_gemms():
@@ -291,6 +384,18 @@ def main():
         return 2
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
+    # RCCL channel budget: every channel is one workgroup (one CU) taken from the backward GEMMs while a collective is in flight.
+    # GRIT_RCCL_MAX_CHANNELS=n caps it (RCCL reads NCCL_MAX_NCHANNELS at communicator creation); unset = RCCL's own choice.
+    # Recorded in config.rccl_env together with every NCCL_* / RCCL_* variable the run saw.
+    if os.environ.get("GRIT_RCCL_MAX_CHANNELS"):
+        os.environ["NCCL_MAX_NCHANNELS"] = os.environ["GRIT_RCCL_MAX_CHANNELS"]
+    rccl_env = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))}
+    # GRIT_GRAD_SYNC=allreduce (default): bucketed all-reduce, every rank steps every master.  GRIT_GRAD_SYNC=shard: reduce-scatter,
+    # every rank's FlatAdam steps its 1/N slice, the bf16 compute weights are all-gathered (grit_amd.amp shard_optimizer)
+    grad_sync = os.environ.get("GRIT_GRAD_SYNC", "allreduce")
+    if grad_sync not in ("allreduce", "shard"):
+        sys.stderr.write("bench.py: GRIT_GRAD_SYNC must be allreduce or shard\n")
+        return 2
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(backend, rank=rank, world_size=world)
     rank_devices = [{"rank": rank, "device": device.index, "pid": os.getpid()}]
@@ -313,7 +418,7 @@ def main():
     if args.fp32:
         wrapped = BucketedDataParallel(model, bucket_mb=64)
     else:  # bf16 compute copies + fp32 master weights; gradients are produced, all-reduced and unscaled in flat bf16 buckets
-        wrapped = Bf16Compute(model, bucket_mb=64)
+        wrapped = Bf16Compute(model, bucket_mb=64, shard_optimizer=(grad_sync == "shard" and world > 1))
     optimizers = build_optimizers(wrapped, config, mode="xe")
     loss_fn = torch.nn.NLLLoss(ignore_index=1)
     # inputs resident in HBM before the timed region; 4 distinct batches per rank, cycled
@@ -396,12 +501,13 @@ def main():
             # HBM-side bytes per launch of this kernel at this shape from the committed PMC profile (separate
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 note); PMC collection
             # cannot run inside the timed benchmark, so the figure is quoted only for the shape it was measured on
-            traffic = MSDA_FWD_TRAFFIC_B32[fwd_kind] if (args.batch == 32 and args.size == 640 and args.points == "model"
-                                                         and not args.ragged) else None
+            traffic, traffic_src = (pmc_traffic("msda_fwd_bf16_rows4") if (not args.fp32 and args.batch == 32 and args.size == 640
+                                                                           and args.points == "model" and not args.ragged)
+                                    else (None, None))
             achieved = (nbytes if nbytes is not None else (traffic or 0)) / avg_t / 1e9
             roof = {"bound": "hbm", "kernel": MSDA_FWD_KERNEL[fwd_kind] + ", in the training step", "achieved": achieved,
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                    "traffic_source": MSDA_FWD_TRAFFIC_SOURCE[fwd_kind] if traffic else None,
+                    "traffic_source": traffic_src,
                     "traffic_frac": (traffic / avg_t / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                     "launches": len(fwd), "avg_launch_us": avg_t * 1e6,
                     "algorithmic_bytes_per_launch": int(nbytes) if nbytes is not None else None,
@@ -422,7 +528,13 @@ def main():
                 tt, ff = sum(t for t, _ in ev), sum(f for _, f in ev)
                 units = ff / (products * 2 * 144 * 144 * 32)             # (window, head) pairs over all launches
                 nbytes = units * tensors * 144 * 32 * 2
+                wa_traffic, wa_src = pmc_traffic(name) if (not args.fp32 and args.batch == 32 and args.size == 640
+                                                           and not args.ragged) else (None, None)
                 window_attention[name] = {"bound": "hbm", "kernel": name, "launches_per_step": len(ev) / args.steps,
+                                          "traffic": wa_traffic, "traffic_source": wa_src,
+                                          "traffic_note": "PMC bytes per launch, mean over the launches of a step (stages differ)",
+                                          "algorithmic_bytes_per_launch": int(nbytes / len(ev)),
+                                          "traffic_frac": (wa_traffic / (tt / len(ev)) / 1e9 / HBM_PEAK_GBPS) if wa_traffic else None,
                                           "ms_per_step": tt / args.steps * 1e3, "avg_launch_us": tt / len(ev) * 1e6,
                                           "algorithmic_bytes_per_step": int(nbytes / args.steps),
                                           "algorithmic_bytes_basis": "%d bf16 [144, 32] slices per (window, head)" % tensors,
@@ -456,13 +568,18 @@ def main():
                        "rccl_ranks": dist.get_world_size() if (world > 1 and backend == "nccl") else (1 if world == 1 else 0),
                        "rank_devices": rank_devices,
                        "grad_allreduce": (("RCCL" if backend == "nccl" else backend + " (plumbing run, not the contract backend)")
-                                          + " bucketed (64 MiB flat bf16 buckets, 8 MiB tail), overlapped with backward")
+                                          + (" bucketed all-reduce" if grad_sync == "allreduce" or args.fp32 else
+                                             " bucketed reduce-scatter + sharded FlatAdam + all-gather of the bf16 weights")
+                                          + " (64 MiB flat bf16 buckets, 8 MiB tail), overlapped with backward")
                        if world > 1 else "none (1 GPU)",
+                       "grad_sync": grad_sync if world > 1 else None, "rccl_env": rccl_env,
                        "points": args.points, "ragged": bool(args.ragged),
                        "msda_backward_accumulation": "f32" if (args.fp32 or msda_op.F32_ACCUMULATE) else "bf16 (packed atomics)"},
             "mfma_roofline_frac_bf16": value / world * FLOP_PER_IMAGE_FWD_BWD / MFMA_PEAK_BF16,
             "final_loss": final_loss,
-            "roofline": roof,
+            # the dominant hand-written kernel of the step by ms/step (profiles/r03/*steady_state.txt): the window-attention backward
+            "roofline": window_attention.get("winattn_bwd") or roof,
+            "roofline_msda": roof,
             "msda_backward": msda_bwd,
             "roofline_winattn_bwd": window_attention.get("winattn_bwd"),
             "roofline_winattn_fwd": window_attention.get("winattn_fwd"),
@@ -472,6 +589,9 @@ def main():
             del wrapped, optimizers, model
             torch.cuda.empty_cache()
             out["roofline_msda_spread"] = msda_spread_microbench(device)
+            if world == 1:  # config 5 on one GPU, driver-visible (after the timed region, training state released)
+                out["decode_config5"] = decode_config5(device, config)
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(config, args.size, args.caption_len, args.cpu_steps)

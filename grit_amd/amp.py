@@ -32,7 +32,15 @@ class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam (amsgrad off, weight decay 0) over the flat training state of Bf16Compute: one grit_adam_flat
     launch per contiguous run of this optimizer's parameters in each bucket reads the bf16 gradients as reduced,
     updates fp32 master + moments and rewrites the bf16 compute copy.  `state` / `param_groups` / `state_dict()` have
-    torch.optim.Adam's layout (exp_avg / exp_avg_sq are views into the flat moment buffers, `step` one shared tensor)."""
+    torch.optim.Adam's layout (exp_avg / exp_avg_sq are views into the flat moment buffers).
+
+    Step counts are kept PER PARAMETER, as torch.optim.Adam does (state['step'] advances only when the parameter has a
+    gradient): a parameter that joins the live set later -- the detector when cached_features flips to False
+    (train_caption.py:105-107) -- starts its bias corrections at step 1 instead of inheriting the optimizer's age.  A run
+    never mixes parameters of different ages (Bf16Compute._runs splits on the count).
+
+    With Bf16Compute(shard_optimizer=True) a run is clipped to this rank's slice of its bucket: every rank steps 1/world of
+    the masters and moments, and Bf16Compute.after_optimizer_step all-gathers the rewritten bf16 compute weights."""
 
     def __init__(self, owner, params, lr, betas=(0.9, 0.999), eps=1e-8):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
@@ -41,28 +49,35 @@ class FlatAdam(torch.optim.Optimizer):
         self._owner = owner
         mine = {p for g in self.param_groups for p in g['params']}
         self._mine = mine
-        self._runs = owner._runs(mine)
-        self._layout_version = owner.ddp.layout_version
-        self._t = 0
-        self._step_tensor = torch.tensor(0.0)
+        self._steps = {p: 0 for p in mine}       # optimizer steps each parameter has taken
+        self._step_tensors = {}                  # age -> the tensor the parameters of that age share as state['step']
         for p in mine:  # a NEW optimizer starts from zero moments (build_optimizers is called again when the phase changes)
             m, v = owner._moment_views[p]
             m.zero_()
             v.zero_()
+        self._derive_runs()
+
+    def _derive_runs(self):
+        """(run, parameters, steps taken) for every contiguous range of live parameters of one age, clipped to this rank's
+        slice when the optimizer is sharded."""
+        self._runs = self._owner._runs(self._mine, key=self._steps.get)
+        self._layout_version = self._owner.ddp.layout_version
         self._link_state()
 
     def _link_state(self):
         for g in self.param_groups:
             for p in g['params']:
                 m, v = self._owner._moment_views[p]
-                self.state[p] = {'step': self._step_tensor, 'exp_avg': m, 'exp_avg_sq': v}
+                n = self._steps[p]
+                if n not in self._step_tensors:
+                    self._step_tensors[n] = torch.tensor(float(n))
+                self.state[p] = {'step': self._step_tensors[n], 'exp_avg': m, 'exp_avg_sq': v}
 
     def zero_grad(self, set_to_none=True):
         pass  # gradients live in the bf16 buckets, which backward overwrites; the masters never carry .grad
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        steps = []
         for g in self.param_groups:
             for p in g['params']:
                 st = self.state.get(p, {})
@@ -70,14 +85,14 @@ class FlatAdam(torch.optim.Optimizer):
                 if 'exp_avg' in st:
                     m.copy_(st['exp_avg'])
                     v.copy_(st['exp_avg_sq'])
-                    steps.append(int(float(st['step'])))
-        self._t = max(steps) if steps else 0
-        self._step_tensor.fill_(float(self._t))
-        self._link_state()
+                    self._steps[p] = int(float(st['step']))
+        self._step_tensors = {}
+        self._derive_runs()
 
     @torch.no_grad()
     def step(self, closure=None):
         from grit_amd import lib as _lib
+        from grit_amd.ops import backend
         hyper = {(g['lr'], tuple(g['betas']), g['eps'], g['weight_decay'], g['amsgrad'], g['maximize']) for g in self.param_groups}
         if len(hyper) != 1:
             raise NotImplementedError("FlatAdam: the parameter groups of one optimizer must share lr / betas / eps "
@@ -86,15 +101,23 @@ class FlatAdam(torch.optim.Optimizer):
         if wd != 0 or amsgrad or maximize:
             raise NotImplementedError("FlatAdam implements Adam with weight_decay = 0, amsgrad = False, maximize = False")
         if self._layout_version != self._owner.ddp.layout_version:  # the live parameter set changed: parameters without a
-            self._runs = self._owner._runs(self._mine)                # gradient are not stepped (torch.optim.Adam skips them)
-            self._layout_version = self._owner.ddp.layout_version
-        self._t += 1
-        self._step_tensor.fill_(float(self._t))
-        bc1, bc2s = 1.0 - b1 ** self._t, math.sqrt(1.0 - b2 ** self._t)
+            self._derive_runs()                                       # gradient are not stepped (torch.optim.Adam skips them)
         grad_scale = 1.0 / self._owner.ddp.world  # the buckets hold the SUM over ranks: the average is folded in here
-        lib = _lib.load()
-        for bucket, compute, master, mom, var, start, end in self._runs:
+        ov = backend.override()
+        kernel = getattr(ov, 'adam_flat', None) if ov is not None else None  # tests on CPU inject the torch restatement
+        lib = _lib.load() if kernel is None else None
+        ages = set()
+        for (bucket, compute, master, mom, var, start, end), params, age in self._runs:
+            t = age + 1
+            ages.add(age)
+            bc1, bc2s = 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)
             n = end - start
+            if n <= 0:
+                continue
+            if kernel is not None:
+                kernel(master[start:end], bucket.flat[start:end], mom[start:end], var[start:end], compute[start:end], float(lr),
+                       float(b1), float(b2), float(eps), bc1, bc2s, grad_scale)
+                continue
             with _lib.device_guard(master.device):
                 st = lib.grit_adam_flat(
                     ctypes.c_void_p(master[start:].data_ptr()), ctypes.c_void_p(bucket.flat[start:].data_ptr()),
@@ -102,13 +125,33 @@ class FlatAdam(torch.optim.Optimizer):
                     ctypes.c_void_p(var[start:].data_ptr()), ctypes.c_void_p(compute[start:].data_ptr()), n, float(lr),
                     float(b1), float(b2), float(eps), bc1, bc2s, grad_scale, _lib.current_stream_ptr())
             _lib.check(st, "grit_adam_flat")
+        # every stepped parameter is one step older; the runs stay valid because the ages of a run move together
+        for i, (run, params, age) in enumerate(self._runs):
+            for p in params:
+                self._steps[p] = age + 1
+            self._runs[i] = (run, params, age + 1)
+        tensors = {}
+        for age in ages:  # state['step'] tensors move with their parameters
+            tnsr = self._step_tensors.pop(age, None)
+            if tnsr is not None:
+                tnsr.fill_(float(age + 1))
+                tensors[age + 1] = tnsr
+        merged = any(a in self._step_tensors for a in tensors)
+        self._step_tensors.update(tensors)
+        if merged:
+            self._link_state()
+        self._owner._masters_current = False
         weights_epoch.bump()  # the compute weights were rewritten by a raw kernel: no version counter saw it
         return None
 
 
 class Bf16Compute(nn.Module):
 
-    def __init__(self, module, bucket_mb=64, process_group=None, flat_optimizer=None):
+    def __init__(self, module, bucket_mb=64, process_group=None, flat_optimizer=None, shard_optimizer=False):
+        """shard_optimizer=True (needs the flat optimizer): gradients are reduce-scattered, every rank's FlatAdam steps only its
+        1/world slice of each bucket's masters and moments, and after_optimizer_step() all-gathers the rewritten bf16 compute
+        weights (waited for at the start of the next forward).  Masters / moments outside a rank's slice go stale until
+        consolidate() -- a collective every rank must enter -- which the engine calls before checkpoints are written."""
         super().__init__()
         import torch.distributed as dist
         names = {p: n for n, p in module.named_parameters()}
@@ -125,8 +168,15 @@ class Bf16Compute(nn.Module):
         # flat Adam (grit_adam_flat) when the state lives on a GPU; on the CPU (gloo tests) torch's Adam steps the masters
         # from fp32 copies of the gradients and the compute weights are refreshed by a copy
         self.flat_optimizer = all(p.is_cuda for p in fp32) if flat_optimizer is None else flat_optimizer
+        if shard_optimizer and not self.flat_optimizer:
+            raise ValueError("shard_optimizer needs the flat optimizer (FlatAdam): torch.optim.Adam steps whole parameters")
+        self.shard_optimizer = bool(shard_optimizer)
+        self.group = process_group
         self.ddp = BucketedDataParallel(module, bucket_mb=bucket_mb, process_group=process_group, repack_unused=False,
-                                        broadcast_parameters=False, slot_align=SLOT_ALIGN, average=not self.flat_optimizer)
+                                        broadcast_parameters=False, slot_align=SLOT_ALIGN, average=not self.flat_optimizer,
+                                        shard_grads=self.shard_optimizer)
+        self._gather_work = []         # all-gathers of the compute weights in flight (shard_optimizer)
+        self._masters_current = True   # False between a sharded optimizer step and consolidate()
         self.module = module
         self._masters, self._pairs, self._moment_views, self._slots = [], [], {}, []
         for b in self.ddp.buckets:
@@ -158,11 +208,22 @@ class Bf16Compute(nn.Module):
         # `wrapped.module.load_state_dict(ckpt['state_dict'])` (reference train_caption.py:131-132, before every self-critical
         # epoch) must reach the fp32 masters, not only the bf16 compute views the module's parameters are
         module._register_load_state_dict_pre_hook(self._on_module_load)
+        if self.shard_optimizer:  # also direct calls of wrapped.module(...) must not read weights whose all-gather is in flight
+            module.register_forward_pre_hook(lambda mod, args: self.wait_for_weights())
         weights_epoch.bump()  # every parameter now lives in other storage
 
     # ------------------------------------------------------------------ what the engine calls
     def forward(self, *args, **kwargs):
+        self.wait_for_weights()
         return self.ddp(*args, **kwargs)  # resets .grad to None first: backward assigns, one packed copy per bucket
+
+    def wait_for_weights(self):
+        """Sharded optimizer: the all-gathers of the compute weights issued by after_optimizer_step() must have landed before
+        anything reads the weights.  On RCCL `wait()` makes the current stream wait for the collective's stream (no host
+        block); the gathers were issued in the order the forward pass needs the buckets."""
+        for w in self._gather_work:
+            w.wait()
+        self._gather_work = []
 
     def named_master_parameters(self):
         return list(self._masters)
@@ -171,27 +232,33 @@ class Bf16Compute(nn.Module):
         """Optimizer factory for build_optimizers: Adam over `params` (masters, or Adam-style groups of them)."""
         return FlatAdam(self, params, lr=lr, betas=betas, eps=eps)
 
-    def _runs(self, masters):
-        """Maximal contiguous slot ranges of each bucket whose parameters all belong to `masters`."""
+    def _runs(self, masters, key=None):
+        """[(run, parameters, key value)]: maximal contiguous slot ranges of each bucket whose parameters all belong to
+        `masters`, are live and share `key(parameter)` (FlatAdam: the number of steps taken).  run = (bucket, compute, master,
+        mom, var, start, end) in elements of the bucket's flat buffers, clipped to this rank's slice under shard_optimizer."""
         runs, cur = [], None
         dead = self.ddp._dead
         for m, bi, start, end, p in self._slots:
+            k = key(m) if key is not None else None
             if m in masters and p not in dead:
-                if cur is not None and cur[0] == bi and cur[2] == start:
+                if cur is not None and cur[0] == bi and cur[2] == start and cur[4] == k:
                     cur[2] = end
+                    cur[3].append(m)
                 else:
                     if cur is not None:
                         runs.append(cur)
-                    cur = [bi, start, end]
+                    cur = [bi, start, end, [m], k]
             elif cur is not None:
                 runs.append(cur)
                 cur = None
         if cur is not None:
             runs.append(cur)
         out = []
-        for bi, start, end in runs:
+        for bi, start, end, params, k in runs:
             b, compute, master, _, mom, var = self._pairs[bi]
-            out.append((b, compute, master, mom, var, start, end))
+            if self.shard_optimizer:
+                start, end = max(start, b.lo), min(end, b.hi)  # empty (end <= start) when the run lies in other ranks' slices
+            out.append(((b, compute, master, mom, var, start, end), params, k))
         return out
 
     def finish_gradient_sync(self):
@@ -212,10 +279,33 @@ class Bf16Compute(nn.Module):
             for b, compute_flat, master_flat, _, _, _ in self._pairs:
                 compute_flat.copy_(master_flat)  # fp32 -> bf16
             weights_epoch.bump()  # the parameters are views of compute_flat: their version counters did not move
+        elif self.shard_optimizer and self.ddp.world > 1:
+            import torch.distributed as dist
+            # each rank rewrote the compute weights of its slice: gather the others'.  In place (the input is the rank's slice
+            # of the output: the layout RCCL's in-place all-gather defines), asynchronous, LAST bucket first -- buckets are
+            # laid out in reverse registration order, so the last one holds the parameters the next forward touches first
+            for b, compute_flat, _, _, _, _ in reversed(self._pairs):
+                self._gather_work.append(dist.all_gather_into_tensor(compute_flat, compute_flat[b.lo:b.hi], group=self.group,
+                                                                     async_op=True))
+
+    def consolidate(self):
+        """COLLECTIVE (every rank): bring the fp32 masters and Adam moments of all slices to every rank, so that
+        master_state_dict() / optimizer.state_dict() describe the whole model.  No-op unless the optimizer is sharded."""
+        self.wait_for_weights()
+        if self.shard_optimizer and self.ddp.world > 1 and not self._masters_current:
+            import torch.distributed as dist
+            for b, _, master_flat, _, mom, var in self._pairs:
+                for buf in (master_flat, mom, var):
+                    dist.all_gather_into_tensor(buf, buf[b.lo:b.hi], group=self.group)
+        self._masters_current = True
 
     def master_state_dict(self):
         """fp32 state dict under the reference's key names: masters for trainable tensors, the kept fp32 originals for frozen
         ones, upcast copies for floating buffers that only exist in bf16 (beam caches)."""
+        if self.shard_optimizer and self.ddp.world > 1 and not self._masters_current:
+            raise RuntimeError("sharded optimizer: the masters outside this rank's slice are stale -- call consolidate() on "
+                               "EVERY rank first (the engine does at the end of an epoch)")
+        self.wait_for_weights()
         sd = {k: (v.float() if v.is_floating_point() else v).clone() for k, v in self.module.state_dict().items()}
         for name, v in self._frozen_fp32.items():
             if name in sd and sd[name].shape == v.shape:

@@ -65,13 +65,12 @@ void colsum_kernel(const T* __restrict__ x, int M, int N, int rows_per_slab, flo
 // out[g][i] = cast(sum_s partial[g][s][i]).  One launch replaces torch's reduce + dtype-cast pair (~350 launches a step).
 // A workgroup covers CW float4 column groups x (256 / CW) interleaved slab lanes, 4 slabs in flight per thread, LDS fold.
 template <typename OT>
-__global__ __launch_bounds__(256)
-void slab_sum_kernel(const float* __restrict__ partial, long group_stride, int slabs, long n, int cw_log2, OT* __restrict__ out) {
-    __shared__ float4 red[256];
+__device__ __forceinline__ void slab_sum_body(const float* __restrict__ partial, long group_stride, int slabs, long n, int cw_log2,
+                                              OT* __restrict__ out, unsigned bx, unsigned by, float4* red) {
     const int cw = 1 << cw_log2, sg_count = 256 >> cw_log2;
     const int c = threadIdx.x & (cw - 1), sg = threadIdx.x >> cw_log2;
-    const long col = ((long)blockIdx.x * cw + c) * 4;
-    const float* src = partial + (long)blockIdx.y * group_stride + col;
+    const long col = ((long)bx * cw + c) * 4;
+    const float* src = partial + (long)by * group_stride + col;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < n) {
         int s = sg;
@@ -95,7 +94,7 @@ void slab_sum_kernel(const float* __restrict__ partial, long group_stride, int s
             const float4 a = red[(j << cw_log2) + c];
             acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
         }
-        OT* dst = out + (long)blockIdx.y * n + col;
+        OT* dst = out + (long)by * n + col;
         if constexpr (sizeof(OT) == 4) {
             *reinterpret_cast<float4*>(dst) = acc;
         } else {
@@ -107,7 +106,75 @@ void slab_sum_kernel(const float* __restrict__ partial, long group_stride, int s
     }
 }
 
+template <typename OT>
+__global__ __launch_bounds__(256)
+void slab_sum_kernel(const float* __restrict__ partial, long group_stride, int slabs, long n, int cw_log2, OT* __restrict__ out) {
+    __shared__ float4 red[256];
+    slab_sum_body<OT>(partial, group_stride, slabs, n, cw_log2, out, blockIdx.x, blockIdx.y, red);
+}
+
+// Several slab sums in ONE launch: a backward node that produced k sets of partials (split-M weight gradients, bias-gradient
+// column sums, LayerNorm dgamma / dbeta, the GELU-epilogue column sums) reduces them together instead of with k dependent
+// launches at the ~6 us launch floor each.  The job table travels by value in the kernel arguments (no device table to fill).
+struct GroupedArgs {
+    grit_slab_job job[GRIT_SLAB_GROUP_MAX];
+    unsigned first_block[GRIT_SLAB_GROUP_MAX + 1];  // workgroups [first_block[j], first_block[j + 1]) belong to job j
+    unsigned blocks_x[GRIT_SLAB_GROUP_MAX];         // column blocks per group of job j
+    int cw_log2[GRIT_SLAB_GROUP_MAX];
+    int n_jobs;
+};
+
+__global__ __launch_bounds__(256)
+void slab_sum_grouped_kernel(const GroupedArgs a) {
+    __shared__ float4 red[256];
+    int j = 0;
+    while (j + 1 < a.n_jobs && blockIdx.x >= a.first_block[j + 1]) ++j;
+    const unsigned local = blockIdx.x - a.first_block[j];
+    const unsigned by = local / a.blocks_x[j], bx = local - by * a.blocks_x[j];
+    const grit_slab_job& jb = a.job[j];
+    if (jb.out_is_bf16)
+        slab_sum_body<__hip_bfloat16>(jb.partial, jb.group_stride, jb.slabs, jb.n, a.cw_log2[j], (__hip_bfloat16*)jb.out, bx, by, red);
+    else
+        slab_sum_body<float>(jb.partial, jb.group_stride, jb.slabs, jb.n, a.cw_log2[j], (float*)jb.out, bx, by, red);
+}
+
+// column width (log2 of float4 groups per workgroup row) for a job: see grit_slab_sum
+int pick_cw_log2(long groups4, int groups, int slabs) {
+    int cw_log2 = 0;
+    while (cw_log2 < 6 && (1L << cw_log2) < groups4) ++cw_log2;
+    // tall, narrow partials (LayerNorm: 1024 slabs x 512 columns) would leave the chip to a handful of workgroups that
+    // each walk hundreds of slabs: trade column width (>= 128 contiguous bytes per slab row) for slab lanes
+    while (cw_log2 > 3 && (((groups4 + (1L << cw_log2) - 1) >> cw_log2) * groups) < 256 && slabs >= 8 * (256 >> (cw_log2 - 1)))
+        --cw_log2;
+    return cw_log2;
+}
+
 }  // namespace
+
+extern "C" int grit_slab_sum_grouped(const grit_slab_job* jobs, int n_jobs, void* stream) {
+    if (!jobs || n_jobs <= 0 || n_jobs > GRIT_SLAB_GROUP_MAX) return GRIT_ERR_BAD_ARG;
+    GroupedArgs a;
+    a.n_jobs = n_jobs;
+    unsigned long long total = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const grit_slab_job& jb = jobs[j];
+        if (!jb.partial || !jb.out || jb.groups <= 0 || jb.slabs <= 0 || jb.n <= 0 || jb.group_stride < 0) return GRIT_ERR_BAD_ARG;
+        if (jb.n % 4 != 0 || jb.group_stride % 4 != 0 || ((uintptr_t)jb.partial % 16) != 0 || ((uintptr_t)jb.out % 8) != 0)
+            return GRIT_ERR_UNSUPPORTED;
+        if (!jb.out_is_bf16 && ((uintptr_t)jb.out % 16) != 0) return GRIT_ERR_UNSUPPORTED;
+        const long groups4 = jb.n / 4;
+        a.job[j] = jb;
+        a.cw_log2[j] = pick_cw_log2(groups4, jb.groups, jb.slabs);
+        const long bx = (groups4 + (1L << a.cw_log2[j]) - 1) >> a.cw_log2[j];
+        a.blocks_x[j] = (unsigned)bx;
+        a.first_block[j] = (unsigned)total;
+        total += (unsigned long long)bx * (unsigned)jb.groups;
+        if (total > 0x7fffffffULL) return GRIT_ERR_UNSUPPORTED;
+    }
+    a.first_block[n_jobs] = (unsigned)total;
+    hipLaunchKernelGGL(slab_sum_grouped_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
 
 extern "C" int grit_slab_sum(const float* partial, int groups, long group_stride, int slabs, long n, void* out,
                              int out_is_bf16, void* stream) {
@@ -115,12 +182,7 @@ extern "C" int grit_slab_sum(const float* partial, int groups, long group_stride
     if (n % 4 != 0 || group_stride % 4 != 0 || ((uintptr_t)partial % 16) != 0 || ((uintptr_t)out % 16) != 0 || groups > 65535)
         return GRIT_ERR_UNSUPPORTED;
     const long groups4 = n / 4;
-    int cw_log2 = 0;
-    while (cw_log2 < 6 && (1L << cw_log2) < groups4) ++cw_log2;
-    // tall, narrow partials (LayerNorm: 1024 slabs x 512 columns) would leave the chip to a handful of workgroups that
-    // each walk hundreds of slabs: trade column width (>= 128 contiguous bytes per slab row) for slab lanes
-    while (cw_log2 > 3 && (((groups4 + (1L << cw_log2) - 1) >> cw_log2) * groups) < 256 && slabs >= 8 * (256 >> (cw_log2 - 1)))
-        --cw_log2;
+    const int cw_log2 = pick_cw_log2(groups4, groups, slabs);
     const long blocks = (groups4 + (1L << cw_log2) - 1) >> cw_log2;
     if (blocks > 0x7fffffffL) return GRIT_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)blocks, groups), block(256);

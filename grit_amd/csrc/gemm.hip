@@ -429,7 +429,9 @@ void gemm_nt_bf16(const GemmArgs g) {
                 v += __shfl_xor(v, 8, 64);
                 cs[j][r] = v;
             }
-        if (l15 == 0) {
+        // (a wave whose rows all lie past M has no slab in colsum [ceil(M / 128), N]: found in round 3 as 4 KB of zeros written
+        // behind the partials of a 37-row problem)
+        if (l15 == 0 && mw < g.M) {
             float* dst = g.colsum + (size_t)(mw / WTM) * g.N + nw + 4 * lq;
 #pragma unroll
             for (int j = 0; j < NTL; ++j) *reinterpret_cast<v4f*>(dst + 16 * j) = cs[j];
@@ -635,7 +637,7 @@ void gemm_pp_bf16(const GemmArgs g) {
                     v += __shfl_xor(v, 8, 64);
                     cs[j][r] = v;
                 }
-            if (l15 == 0) {
+            if (l15 == 0 && mw < g.M) {
                 float* dst = g.colsum + (size_t)(mw / 128) * g.N + nw + 4 * lq;
 #pragma unroll
                 for (int j = 0; j < NTL; ++j) *reinterpret_cast<v4f*>(dst + 16 * j) = cs[j];

@@ -28,6 +28,12 @@ broadcast_buffers=False) and lets NCCL's ring all-reduce 25 MB buckets.  This is
   * slots of live parameters that got no gradient in a step are zeroed, so an optimizer that steps whole flat
     runs never sees the previous step's values;
   * optional bf16 transport halves the bytes on the wire (sum in bf16 over <= 8 ranks, master grads fp32);
+  * `shard_grads=True` ("prefer reduce-scatter + all-gather across all 7 xGMI links"): a bucket is REDUCE-SCATTERED
+    instead of all-reduced -- rank r receives the sum of slice r (1/world of the bucket, slices aligned to `slot_align`) -- and
+    only that slice of the flat buffer holds reduced values afterwards.  It is the first half of the sharded optimizer step
+    of grit_amd.amp.Bf16Compute(shard_optimizer=True): each rank's FlatAdam updates the masters of its slice (Adam's HBM
+    traffic and state divide by world) and the bf16 compute weights are all-gathered, the second half of what an all-reduce
+    would have moved, now overlappable with the start of the next forward;
   * buffers are never broadcast (the beam-search caches are registered buffers; reference passes
     broadcast_buffers=False for the same reason).  Parameters are broadcast from rank 0 once.
 
@@ -38,12 +44,16 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
+from grit_amd.ops import linear as _linear_ops
+
 
 class _Bucket(object):
-    __slots__ = ('params', 'views', 'flat', 'pending', 'expected', 'work', 'wire', 'packed')
+    __slots__ = ('params', 'views', 'flat', 'pending', 'expected', 'work', 'wire', 'packed', 'lo', 'hi', 'rs_out')
 
-    def __init__(self, params, views, flat):
+    def __init__(self, params, views, flat, lo=0, hi=None):
         self.params, self.views, self.flat = params, views, flat
+        self.lo, self.hi = lo, flat.numel() if hi is None else hi  # this rank's slice (the whole bucket unless sharded)
+        self.rs_out = None
         self.expected = len(params)
         self.pending = self.expected
         self.work = None
@@ -54,11 +64,13 @@ class _Bucket(object):
 class BucketedDataParallel(nn.Module):
 
     def __init__(self, module, bucket_mb=64, process_group=None, wire_dtype=None, broadcast_parameters=True,
-                 repack_unused=True, slot_align=1, tail_mb=8, average=True, agree_every_step=False):
+                 repack_unused=True, slot_align=1, tail_mb=8, average=True, agree_every_step=False, shard_grads=False):
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.shard_grads = bool(shard_grads)
         self.bucket_bytes = int(bucket_mb * 2**20)
         self.tail_bytes = int(min(tail_mb, bucket_mb) * 2**20)
         self.wire_dtype = wire_dtype
@@ -116,6 +128,9 @@ class BucketedDataParallel(nn.Module):
         al = self.slot_align
         for plist in groups:
             total = sum(-(-p.numel() // al) * al for p in plist)
+            if self.shard_grads:  # equal slices per rank, each a multiple of the slot alignment (padding is reduced as zeros)
+                unit = al * self.world
+                total = -(-total // unit) * unit
             flat = torch.zeros(total, dtype=plist[0].dtype, device=plist[0].device)
             off, views = 0, []
             for p in plist:
@@ -125,7 +140,11 @@ class BucketedDataParallel(nn.Module):
                     p.grad = view
                 views.append(view)
                 off += -(-p.numel() // al) * al  # padding stays zero: it is reduced and optimised as zeros
-            b = _Bucket(plist, views, flat)
+            if self.shard_grads:
+                k = total // self.world
+                b = _Bucket(plist, views, flat, self.rank * k, (self.rank + 1) * k)
+            else:
+                b = _Bucket(plist, views, flat)
             for p, view in zip(plist, views):
                 self._where[p] = b
                 self._view_of[p] = view
@@ -154,6 +173,7 @@ class BucketedDataParallel(nn.Module):
         parameters without a gradient are zeroed (the flat buffer still holds the previous step's values there)."""
         if b.packed:
             return
+        _linear_ops.wait_deferred()  # small-map weight gradients computed beside the backward chain (grit_amd/ops/linear.py)
         src, dst, stale = [], [], []
         for p, view in zip(b.params, b.views):
             if p.grad is None:
@@ -174,15 +194,21 @@ class BucketedDataParallel(nn.Module):
     def _launch(self, b):
         if self.world == 1 or b.work is not None:
             return
+        src = b.flat
         if self.wire_dtype is not None and self.wire_dtype != b.flat.dtype:
-            b.wire = b.flat.to(self.wire_dtype)
-            b.work = dist.all_reduce(b.wire, group=self.group, async_op=True)
+            src = b.wire = b.flat.to(self.wire_dtype)
+        if self.shard_grads:
+            # out of place: the slice arrives in its own buffer and is copied over flat[lo:hi] once the collective is done
+            if b.rs_out is None or b.rs_out.dtype != src.dtype or b.rs_out.numel() != b.hi - b.lo:
+                b.rs_out = torch.empty(b.hi - b.lo, dtype=src.dtype, device=src.device)
+            b.work = dist.reduce_scatter_tensor(b.rs_out, src, group=self.group, async_op=True)
         else:
-            b.work = dist.all_reduce(b.flat, group=self.group, async_op=True)
+            b.work = dist.all_reduce(src, group=self.group, async_op=True)
 
     def finish_gradient_sync(self):
         """Launch what is still pending, agree on the used / late parameters, wait, reduce late gradients, average,
         and re-derive the live set if it changed."""
+        _linear_ops.end_deferral()
         for b in self.buckets:
             if b.expected == 0 and self._decided:
                 continue  # every parameter of the bucket is outside the live set (agreed by all ranks): nothing to send
@@ -204,9 +230,11 @@ class BucketedDataParallel(nn.Module):
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
-                if b.wire is not None:
+                if self.shard_grads:
+                    b.flat[b.lo:b.hi].copy_(b.rs_out)  # only this slice holds the sum over the ranks from here on
+                elif b.wire is not None:
                     b.flat.copy_(b.wire)
-                    b.wire = None
+                b.wire = None
                 b.work = None
         if flag_work is not None:
             flag_work.wait()
@@ -232,7 +260,7 @@ class BucketedDataParallel(nn.Module):
                 p.grad = g.mul_(scale) if (self.average and self.world > 1) else g
         if self.average and self.world > 1:
             for b in self.buckets:
-                b.flat.mul_(scale)
+                b.flat[b.lo:b.hi].mul_(scale)
         # live set = parameters that received a gradient on some rank in this step
         dead = {p for i, p in enumerate(self._params) if not flags[i] & 1}
         if dead != self._dead or not self._decided:
@@ -259,6 +287,9 @@ class BucketedDataParallel(nn.Module):
 
     def forward(self, *args, **kwargs):
         self.release_gradients()
+        # from here to finish_gradient_sync() this wrapper is the only consumer of parameter gradients: nodes may leave the
+        # weight gradients of small maps running on a side stream until _pack / finish_gradient_sync wait for it
+        _linear_ops.begin_deferral()
         return self.module(*args, **kwargs)
 
     def release_gradients(self):

@@ -28,6 +28,15 @@ def _unwrap(model):
     return getattr(model, 'module', model)
 
 
+def _consolidate(model):
+    """End of a training epoch, EVERY rank: with a sharded optimizer (grit_amd.amp.Bf16Compute(shard_optimizer=True)) the fp32
+    masters and Adam moments of the other ranks' slices are gathered, so that the checkpoints rank 0 (and the evaluation ranks,
+    reference train_caption.py:149-204) write afterwards hold the whole model.  No-op for every other wrapper."""
+    fn = getattr(model, 'consolidate', None)
+    if fn is not None:
+        fn()
+
+
 def build_optimizers(model, config, mode='xe'):
     # grit_amd.amp.Bf16Compute exposes fp32 masters under the module's parameter names; otherwise the module's own
     masters = getattr(model, 'named_master_parameters', None)
@@ -161,6 +170,7 @@ def train_xe(model, dataloaders, optimizers, text_field, epoch, rank=0, config=N
         if rank == 0 and writer is not None:
             writer.add_scalar('backbone_lr', optimizers['backbone'].param_groups[0]['lr'], epoch * n + it)
             writer.add_scalar('model_lr', optimizers['model'].param_groups[0]['lr'], epoch * n + it)
+    _consolidate(model)
     val_loss = evaluate_loss(model, dataloaders['valid'], loss_fn, text_field, epoch, writer) \
         if evaluate and 'valid' in dataloaders else 0.0
     if rank == 0 and checkpoint:
@@ -280,6 +290,7 @@ def train_sc(model, dataloaders, optimizers, cider, text_field, tokenizer_pool, 
             writer.add_scalar('backbone_lr', optimizers['backbone'].param_groups[0]['lr'], epoch * n + it)
             writer.add_scalar('model_lr', optimizers['model'].param_groups[0]['lr'], epoch * n + it)
     loss_fn = NLLLoss(ignore_index=_pad_index(text_field))
+    _consolidate(model)
     val_loss = evaluate_loss(model, dataloaders['valid'], loss_fn, text_field, epoch, writer) \
         if evaluate and 'valid' in dataloaders else 0.0
     if rank == 0 and checkpoint:

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -47,6 +47,9 @@ SIGNATURES = {
     "grit_image_batch_fwd": [_ptr] * 5 + [_int] * 6 + [_ptr] * 3,
     "grit_colsum": [_ptr, _int, _int, _int, _int, _ptr, _ptr],
     "grit_slab_sum": [_ptr, _int, _c.c_long, _int, _c.c_long, _ptr, _int, _ptr],
+    "grit_slab_sum_grouped": [_ptr, _int, _ptr],
+    "grit_wgrad_small_splits": [_int, _int, _int],
+    "grit_wgrad_small": [_ptr, _c.c_long, _ptr, _c.c_long, _int, _int, _int, _int, _ptr, _ptr, _ptr],
     "grit_attn_fwd_f32": _ATTN_IN + [_int] * 5 + [_f32, _f32, _u64, _ptr, _ptr, _ptr, _ptr],
     "grit_attn_fwd_bf16": _ATTN_IN + [_int] * 5 + [_f32, _f32, _u64, _ptr, _ptr, _ptr, _ptr],
     "grit_attn_bwd_f32": _ATTN_IN + [_ptr] * 3 + [_int] * 5 + [_f32, _f32, _u64] + [_ptr] * 5,
@@ -61,6 +64,15 @@ SIGNATURES = {
                            _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "grit_gemm_bf16_nt": [_ptr, _c.c_long] * 3 + [_int] * 4 + [_ptr, _ptr, _c.c_long, _ptr, _int, _ptr],
 }
+
+SLAB_GROUP_MAX = 16  # GRIT_SLAB_GROUP_MAX
+
+
+class SlabJob(_c.Structure):
+    """grit_slab_job of include/grit_hip.h."""
+    _fields_ = [("partial", _c.c_void_p), ("group_stride", _c.c_long), ("groups", _c.c_int), ("slabs", _c.c_int),
+                ("n", _c.c_long), ("out", _c.c_void_p), ("out_is_bf16", _c.c_int)]
+
 
 _lib = None
 

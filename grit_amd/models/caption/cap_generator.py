@@ -20,7 +20,7 @@ from grit_amd.ops import backend
 from grit_amd.ops import decode_inputs
 from grit_amd.ops import gate as gate_ops
 from grit_amd.ops import weights_epoch
-from grit_amd.ops.linear import Linear
+from grit_amd.ops.linear import Linear, mark_single_use
 
 
 # GRIT_FUSED_STEP_INPUTS=0: masks, step counter and embedding sum of a decoding step as the reference's separate torch ops
@@ -46,6 +46,10 @@ class ParallelAttentionLayer(GeneratorLayer):
         self.activation = activation
         self._q12 = None
         self.init_weights()
+        # teacher forcing applies every Linear of the layer once per forward pass -- except fc_alpha1, which gates both
+        # cross-attentions (two gradients that autograd adds).  Step-wise decoding with gradient suspends the declaration
+        # (Transformer.beam_search, grit_amd/ops/linear.py suspend_single_use)
+        mark_single_use(self.self_att, self.vis_att1, self.vis_att2, self.pwff)
 
     def init_weights(self):
         for fc in (self.fc_alpha1, self.fc_alpha2):

@@ -14,7 +14,7 @@ from torch import nn
 
 from grit_amd.models.common.attention import MultiHeadAttention
 from grit_amd.models.common.pos_embed import FeedForward
-from grit_amd.ops.linear import Linear
+from grit_amd.ops.linear import Linear, mark_single_use
 
 
 class TransformerLayer(nn.Module):
@@ -40,6 +40,7 @@ class GridFeatureNetwork(nn.Module):
         self.layer_norm = nn.LayerNorm(d_model)
         stack = (TransformerLayer(d_model, n_heads, d_ff, dropout, n_memories=n_memories) for _ in range(n_layers))
         self.layers = nn.ModuleList(stack)
+        mark_single_use(self)  # every Linear here runs once per forward pass: weight gradients beside the backward chain
 
     def embed(self, tokens):
         """The input stage: project to d_model, ReLU, dropout, LayerNorm."""

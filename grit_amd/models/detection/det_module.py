@@ -24,7 +24,7 @@ from grit_amd.models.common.swin_model import DropPath
 from grit_amd.models.ops.modules import MSDeformAttn
 from grit_amd.ops.attention import attention as fused_attention
 from grit_amd.ops.layer_norm import linear_add_layer_norm
-from grit_amd.ops.linear import Linear, linear, shared_input_linears
+from grit_amd.ops.linear import Linear, linear, mark_single_use, shared_input_linears
 from grit_amd.ops.msda import StackedValueMaps
 
 _SHARED_VALUE_PROJ = os.environ.get('GRIT_SHARED_VALUE_PROJ', '1') != '0'  # A/B knobs
@@ -145,6 +145,11 @@ class DetectionModule(nn.Module):
         layer = DeformableTransformerDecoderLayer(d_model, dim_feedforward, dropout, activation, num_feature_levels,
                                                   nhead, dec_n_points, drop_path=drop_path)
         self.decoder_layers = _get_clones(layer, num_decoder_layers)
+        # every Linear of a decoder layer is applied once per forward pass (the value projections go through project_values
+        # and are long maps anyway): their weight gradients may run beside the backward chain (grit_amd/ops/linear.py)
+        for l in self.decoder_layers:
+            mark_single_use(l.linear1, l.linear2, l.self_attn.out_proj, l.cross_attn.sampling_offsets,
+                            l.cross_attn.attention_weights, l.cross_attn.output_proj)
         self.num_decoder_layers = num_decoder_layers
         self.return_intermediate = return_intermediate_dec
         self.reference_points = nn.Linear(d_model, 2)

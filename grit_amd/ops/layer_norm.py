@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 
 from grit_amd import lib as _lib
 from grit_amd.ops import backend
-from grit_amd.ops.linear import slab_sum
+from grit_amd.ops.linear import SlabGroup, fork, join, on_stream, single_use_now, slab_sum
 from grit_amd.ops.profiling import timed
 
 SUPPORTED_C = (128, 256, 512, 1024, 2048, 4096)
@@ -120,9 +120,10 @@ class _AddLayerNormFn(Function):
         return dx.view(ctx.shape), d_branch.view(ctx.shape), None, sums[0], sums[1], None
 
 
-def _add_layer_norm_backward(x2, weight, mean, rstd, scale, gx, gy, batch, branch_colsum, drop_p, seed_dev):
+def _add_layer_norm_backward(x2, weight, mean, rstd, scale, gx, gy, batch, branch_colsum, drop_p, seed_dev, group=None):
     """(dx, d_branch, sums): sums[0] = dgamma, sums[1] = dbeta, and with branch_colsum sums[2] = column sums of d_branch
-    (the bias gradient of the Linear that produced the branch), all from the one grit_add_layernorm_bwd launch."""
+    (the bias gradient of the Linear that produced the branch), all from the one grit_add_layernorm_bwd launch.  With `group`
+    (a SlabGroup) the per-workgroup partials are summed by the group's launch: `sums` is filled by group.run()."""
     rows, C = x2.shape
     if gy is None:
         gy = torch.zeros_like(x2)
@@ -149,6 +150,8 @@ def _add_layer_norm_backward(x2, weight, mean, rstd, scale, gx, gy, batch, branc
             _ptr(seed_dev) if drop_p > 0 else None, rows, C, xb, wb, _ptr(dx), _ptr(d_branch) if own_branch else None,
             _ptr(base[0]), _ptr(base[1]), _ptr(base[2]) if branch_colsum else None, _lib.current_stream_ptr())
     _lib.check(st, "grit_add_layernorm_bwd")
+    if group is not None:
+        return dx, d_branch, group.add(base, weight.dtype, slabs=nblk)
     return dx, d_branch, slab_sum(base, weight.dtype, slabs=nblk)
 
 
@@ -158,7 +161,8 @@ class _LinearAddLayerNormFn(Function):
     LayerNorm backward kernel, which already streams the branch gradient, also delivers the Linear's bias gradient."""
 
     @staticmethod
-    def forward(ctx, inp, lin_w, lin_b, shortcut, scale, weight, bias, eps, drop_p, seed_dev):
+    def forward(ctx, inp, lin_w, lin_b, shortcut, scale, weight, bias, eps, drop_p, seed_dev, single_use=False):
+        ctx.single_use = single_use
         with timed("gemm_lib", flops=2.0 * inp.numel() * lin_w.shape[0]):
             branch = F.linear(inp, lin_w, lin_b)
         C = shortcut.shape[-1]
@@ -188,23 +192,34 @@ class _LinearAddLayerNormFn(Function):
     def backward(ctx, gx, gy):
         from grit_amd.ops.linear import weight_grad
         x2, weight, mean, rstd, scale, inp, lin_w, seed_dev = ctx.saved_tensors
+        group = SlabGroup()  # LayerNorm sums + the projection's weight gradient: one reduction launch for the node
         dx, d_branch, sums = _add_layer_norm_backward(x2, weight, mean, rstd, scale, gx, gy, ctx.shape[0], True, ctx.drop_p,
-                                                      seed_dev)
+                                                      seed_dev, group)
         inp2 = inp.reshape(-1, inp.shape[-1])
         if not inp2.is_contiguous():
             inp2 = inp2.contiguous()
-        d_inp = None
+        d_inp = d_lin_w = None
+        # small maps inside a deferral scope: the projection's weight gradient beside the chain (grit_amd/ops/linear.py fork)
+        side = fork(d_branch, inp2, rows=d_branch.shape[0], single_use=ctx.single_use) \
+            if (ctx.needs_input_grad[0] and ctx.needs_input_grad[1]) else None
+        if side is not None and getattr(side, "deferred", False):
+            group.run()  # the LayerNorm sums stay on this stream; the weight gradient of a small map has no partials (S = 1)
+            with on_stream(side):
+                d_lin_w = weight_grad(d_branch, inp2)
         if ctx.needs_input_grad[0]:
             with timed("gemm_lib", flops=2.0 * d_branch.numel() * lin_w.shape[1]):
                 d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
-        d_lin_w = weight_grad(d_branch, inp2) if ctx.needs_input_grad[1] else None
-        return d_inp, d_lin_w, sums[2].to(lin_w.dtype), dx.view(ctx.shape), None, sums[0], sums[1], None, None, None
+        if d_lin_w is None:
+            d_lin_w = weight_grad(d_branch, inp2, group) if ctx.needs_input_grad[1] else None
+            group.run()
+        join(side, d_lin_w)
+        return d_inp, d_lin_w, sums[2].to(lin_w.dtype), dx.view(ctx.shape), None, sums[0], sums[1], None, None, None, None
 
 
 MIN_ROWS_FUSED = 512  # below this torch's own chain is as good
 
 
-def linear_add_layer_norm(inp, linear, shortcut, scale, weight, bias, eps=1e-5, dropout_p=0.0, training=False):
+def linear_add_layer_norm(inp, linear, shortcut, scale, weight, bias, eps=1e-5, dropout_p=0.0, training=False, single_use=False):
     """x = shortcut + scale[b] * dropout(linear(inp));  returns (x, layer_norm(x)).  `linear`: an nn.Linear-like module
     with bias; scale: per-sample stochastic-depth factors or None; dropout_p applies (in training) between the projection
     and the residual add, as nn.Dropout does in the post-norm decoder layers."""
@@ -225,7 +240,7 @@ def linear_add_layer_norm(inp, linear, shortcut, scale, weight, bias, eps=1e-5, 
         scale = scale.reshape(-1).float().contiguous()
     seed_dev = backend.dropout_seed(inp.device) if p > 0 else None
     return _LinearAddLayerNormFn.apply(inp, linear.weight, linear.bias, shortcut, scale, weight.contiguous(), bias.contiguous(),
-                                       float(eps), p, seed_dev)
+                                       float(eps), p, seed_dev, single_use_now(single_use or getattr(linear, 'single_use', False)))
 
 
 def add_layer_norm(shortcut, branch, scale, weight, bias, eps=1e-5):

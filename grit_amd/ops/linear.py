@@ -31,10 +31,73 @@ WGRAD_STREAM = os.environ.get("GRIT_WGRAD_STREAM", "0") == "1"
 _side_streams = {}
 
 
-def fork(*inputs):
+# Small maps (the two decoders and the grid net: 640 .. 4 800 rows) are another matter: their GEMMs fill a few dozen CUs for
+# 10-30 us each and the backward pass is one long dependent chain of them, so the weight / bias gradients -- nothing downstream
+# in backward reads them -- can run BESIDE the chain on a second stream.  MEASURED SLOWER in the benchmark step (65.0 -> 65.7 ms,
+# two alternating passes on one box, profiles/r03/negative_results.txt): that part of the step is bound by how fast the host
+# enqueues its tiny kernels, and every fork adds two cross-stream event operations.  GRIT_WGRAD_STREAM_SMALL=1 (default 0) enables
+# it for nodes with fewer than SMALL_ROWS rows, and only while a gradient-bucket wrapper has declared a deferral scope
+# (grit_amd.ddp: begin_deferral in forward, wait_deferred before it packs or hands out gradients): the main stream then does not
+# wait for the side stream at the end of the node but when the gradients are first consumed.  A parameter used twice in one
+# forward pass would have its two gradients added by autograd on the main stream before that point, so the deferral is opt-in
+# per call site (`single_use=True`: the caller guarantees the weight receives exactly one gradient per backward pass).
+WGRAD_STREAM_SMALL = os.environ.get("GRIT_WGRAD_STREAM_SMALL", "0") == "1"
+SMALL_ROWS = int(os.environ.get("GRIT_WGRAD_SMALL_ROWS", "16384"))
+_deferral = {"active": False, "pending": set()}
+
+
+def mark_single_use(*modules):
+    """Declare that every Linear inside `modules` is applied exactly once per forward pass (its weight receives exactly one
+    gradient per backward pass).  Model constructors call this for the layers of the two decoders and the grid net."""
+    for mod in modules:
+        for m in mod.modules():
+            if isinstance(m, nn.Linear):
+                m.single_use = True
+
+
+class suspend_single_use(object):
+    """`with suspend_single_use():` -- the declarations above do not hold inside (step-wise decoding WITH gradient applies the
+    caption decoder once per generated token: self-critical training)."""
+
+    def __enter__(self):
+        self.prev = _deferral.get("suspended", False)
+        _deferral["suspended"] = True
+
+    def __exit__(self, *exc):
+        _deferral["suspended"] = self.prev
+
+
+def single_use_now(flag):
+    """The declaration as it holds for the forward call being recorded (nodes store this in their context: the backward pass
+    runs outside any suspend_single_use block)."""
+    return bool(flag) and not _deferral.get("suspended", False)
+
+
+def begin_deferral():
+    _deferral["active"] = True
+
+
+def wait_deferred():
+    """The current stream waits for every side stream that still runs deferred weight-gradient work."""
+    for side in _deferral["pending"]:
+        torch.cuda.current_stream(side.device).wait_stream(side)
+    _deferral["pending"].clear()
+
+
+def end_deferral():
+    wait_deferred()
+    _deferral["active"] = False
+
+
+def fork(*inputs, rows=None, single_use=False):
     """Side stream ordered after everything enqueued so far on the current stream (None when the knob is off / on CPU).
-    `inputs` are the tensors the side work reads: their memory is not handed out again before that work has run."""
-    if not (WGRAD_STREAM and inputs and inputs[0].is_cuda):
+    `inputs` are the tensors the side work reads: their memory is not handed out again before that work has run.
+    rows / single_use: the small-map deferral described above."""
+    if not (inputs and inputs[0].is_cuda):
+        return None
+    small = (WGRAD_STREAM_SMALL and single_use and rows is not None and rows < SMALL_ROWS and _deferral["active"]
+             and not torch.cuda.is_current_stream_capturing())
+    if not (WGRAD_STREAM or small):
         return None
     dev = inputs[0].device
     side = _side_streams.get(dev)
@@ -43,18 +106,23 @@ def fork(*inputs):
     side.wait_stream(torch.cuda.current_stream(dev))
     for t in inputs:
         t.record_stream(side)
+    side.deferred = bool(small and not WGRAD_STREAM)
     return side
 
 
 def join(side, *outputs):
-    """The current stream waits for the side work; `outputs` (allocated on the side stream) are consumed on the current one."""
+    """The current stream waits for the side work; `outputs` (allocated on the side stream) are consumed on the current one.
+    In a deferral scope (small maps) the wait is left to wait_deferred()."""
     if side is None:
         return
     main = torch.cuda.current_stream(side.device)
-    main.wait_stream(side)
     for t in outputs:
         if t is not None:
             t.record_stream(main)
+    if getattr(side, "deferred", False):
+        _deferral["pending"].add(side)
+        return
+    main.wait_stream(side)
 
 
 class on_stream:
@@ -88,8 +156,48 @@ def slab_sum(partial, out_dtype, slabs=None):
     return out
 
 
-def column_sum(x2d, out_dtype=torch.float32):
-    """[M, N] (bf16 / f32, contiguous, N % 8 == 0) -> [N] in out_dtype (f32 accumulation)."""
+class SlabGroup(object):
+    """The slab sums a backward node owes, reduced by ONE grit_slab_sum_grouped launch at the end of the node instead of one
+    dependent ~6 us launch each (split-M weight gradients, bias-gradient column sums, LayerNorm dgamma / dbeta ...).
+    `add` allocates and returns the output tensor right away; it holds the result only after `run()`."""
+
+    ENABLED = os.environ.get("GRIT_SLAB_GROUP", "1") != "0"  # A/B knob: 0 = one grit_slab_sum launch per job, as before
+
+    def __init__(self):
+        self.jobs, self.keep = [], []
+
+    def add(self, partial, out_dtype, slabs=None):
+        """partial f32 [groups, slabs_allocated, n...] contiguous -> out [groups, n...] (sum over the first `slabs` slabs)."""
+        if not SlabGroup.ENABLED:
+            return slab_sum(partial, out_dtype, slabs)
+        slabs = partial.shape[1] if slabs is None else slabs
+        tail = tuple(partial.shape[2:])
+        n = 1
+        for d in tail:
+            n *= d
+        out = torch.empty((partial.shape[0],) + tail, dtype=out_dtype, device=partial.device)
+        self.jobs.append((partial.data_ptr(), partial.stride(0), partial.shape[0], slabs, n, out.data_ptr(),
+                          int(out_dtype == torch.bfloat16)))
+        self.keep.append(partial)  # the partials must outlive the launch; outputs are owned by the caller
+        self.device = partial.device
+        return out
+
+    def run(self):
+        if not self.jobs:
+            return
+        lib = _lib.load()
+        with _lib.device_guard(self.device):
+            for i in range(0, len(self.jobs), _lib.SLAB_GROUP_MAX):
+                chunk = self.jobs[i:i + _lib.SLAB_GROUP_MAX]
+                table = (_lib.SlabJob * len(chunk))(*[_lib.SlabJob(*j) for j in chunk])
+                st = lib.grit_slab_sum_grouped(table, len(chunk), _lib.current_stream_ptr())
+                _lib.check(st, "grit_slab_sum_grouped")
+        self.jobs, self.keep = [], []
+
+
+def column_sum(x2d, out_dtype=torch.float32, group=None):
+    """[M, N] (bf16 / f32, contiguous, N % 8 == 0) -> [N] in out_dtype (f32 accumulation).  With `group` (a SlabGroup) the
+    second stage is left to the group's launch: the returned tensor is filled by group.run()."""
     M, N = x2d.shape
     strips = max(1, (N + 511) // 512)
     slabs = max(1, min(256, (M * N) // (1 << 18), 2048 // strips))
@@ -100,6 +208,8 @@ def column_sum(x2d, out_dtype=torch.float32):
         st = _lib.load().grit_colsum(ctypes.c_void_p(x2d.data_ptr()), M, N, int(x2d.dtype == torch.bfloat16), slabs,
                                      ctypes.c_void_p(partial.data_ptr()), _lib.current_stream_ptr())
     _lib.check(st, "grit_colsum")
+    if group is not None:
+        return group.add(partial.unsqueeze(0), out_dtype)[0]
     return slab_sum(partial.unsqueeze(0), out_dtype)[0]
 
 
@@ -118,23 +228,78 @@ def split_k(M):
     return s
 
 
-def weight_grad(dy2, x2):
-    """dW [N, K] = dy2^T [N, M] @ x2 [M, K], split over M into one batched GEMM with fp32 partial sums."""
+# GRIT_WGRAD_SMALL=1: weight + bias gradient of short maps (decoders, grid net) from ONE own launch, grit_wgrad_small, instead
+# of the library's transposed GEMM + column-sum kernel.  Stand-alone the kernel wins (6-25 us against 25-31 + 13 us,
+# tools/bench_small_wgrad.py); INSIDE the training step it averages 31 us per call -- operands cold in HBM, 3 workgroups per CU --
+# and the step gets 0.9-1.5 ms SLOWER (65.2 -> 66.1 / 66.8 ms, two alternating passes on one box; a one-split variant that writes
+# finished bf16 gradients without a reduction launch: 63.5 -> 64.8 ms): default off, profiles/r03/negative_results.txt.
+WGRAD_SMALL = os.environ.get("GRIT_WGRAD_SMALL", "0") == "1"
+WGRAD_SMALL_MAX_ROWS = 16384
+
+
+def small_weight_bias_grad(dy2, x2, need_db, out_dtype, group=None):
+    """(dW [N, K], db [N] or None) of a Linear on a short map from ONE grit_wgrad_small launch (split-M partials of both) plus
+    the reduction -- the caller's SlabGroup when given -- or None when the kernel does not cover the problem."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    if not (WGRAD_SMALL and dy2.is_cuda and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and M < WGRAD_SMALL_MAX_ROWS
+            and N % 64 == 0 and K % 64 == 0 and dy2.stride(1) == 1 and x2.stride(1) == 1 and dy2.stride(0) % 8 == 0
+            and x2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0):
+        return None
+    lib = _lib.load()
+    S = lib.grit_wgrad_small_splits(M, N, K)
+    if S <= 0:
+        return None
+    direct = S == 1 and out_dtype == torch.bfloat16  # the kernel rounds once and writes the finished gradients
+    if direct:
+        wpart = torch.empty((N, K), dtype=torch.bfloat16, device=dy2.device)
+        bpart = torch.empty((N,), dtype=torch.bfloat16, device=dy2.device) if need_db else None
+    elif S == 1:
+        return None  # f32 gradients of a short map: the library GEMM (parity path, not a throughput one)
+    else:
+        wpart = torch.empty((1, S, N, K), dtype=torch.float32, device=dy2.device)
+        bpart = torch.empty((1, S, N), dtype=torch.float32, device=dy2.device) if need_db else None
+    with _lib.device_guard(dy2.device), timed("gemm_own", flops=2.0 * M * N * K):
+        st = lib.grit_wgrad_small(ctypes.c_void_p(dy2.data_ptr()), dy2.stride(0), ctypes.c_void_p(x2.data_ptr()), x2.stride(0), M, N, K,
+                                  S, ctypes.c_void_p(wpart.data_ptr()), ctypes.c_void_p(bpart.data_ptr()) if need_db else None,
+                                  _lib.current_stream_ptr())
+    _lib.check(st, "grit_wgrad_small")
+    if direct:
+        return wpart, bpart
+    own = group is None
+    if own:
+        group = SlabGroup()
+    dw = group.add(wpart, out_dtype)[0]
+    db = group.add(bpart, out_dtype)[0] if need_db else None
+    if own:
+        group.run()
+    return dw, db
+
+
+def weight_grad(dy2, x2, group=None):
+    """dW [N, K] = dy2^T [N, M] @ x2 [M, K], split over M into one batched GEMM with fp32 partial sums.  With `group` (a
+    SlabGroup) the sum over the partials is left to the group's launch."""
+    small = small_weight_bias_grad(dy2, x2, False, dy2.dtype, group)
+    if small is not None:
+        return small[0]
     M, N = dy2.shape
     S = split_k(M) if (dy2.is_cuda and dy2.dtype == torch.bfloat16) else 1
     with timed("gemm_lib", flops=2.0 * M * N * x2.shape[1]):
         if S == 1:
             return torch.mm(dy2.t(), x2)
         part = torch.bmm(dy2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, x2.shape[1]), out_dtype=torch.float32)
+    if group is not None:
+        return group.add(part.unsqueeze(0), dy2.dtype)[0]
     return slab_sum(part.unsqueeze(0), dy2.dtype)[0]
 
 
 class _LinearFn(Function):
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, single_use=False):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.single_use = single_use
         with timed("gemm_lib", flops=2.0 * x.numel() * weight.shape[0]):
             return F.linear(x, weight, bias)
 
@@ -150,17 +315,25 @@ class _LinearFn(Function):
             x2 = x2.contiguous()
         dx = dw = db = None
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
-        side = fork(dy2, x2) if (ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or need_b)) else None
+        side = fork(dy2, x2, rows=dy2.shape[0], single_use=ctx.single_use) \
+            if (ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or need_b)) else None
+        group = SlabGroup() if dy2.is_cuda else None  # dW's and db's partial sums: one reduction launch
         with on_stream(side):
-            if ctx.needs_input_grad[1]:
-                dw = weight_grad(dy2, x2)
-            if need_b:
-                db = column_sum(dy2, weight.dtype)
+            both = small_weight_bias_grad(dy2, x2, need_b, weight.dtype, group) if ctx.needs_input_grad[1] else None
+            if both is not None:  # short map: dW and db partials from one launch
+                dw, db = both
+            else:
+                if ctx.needs_input_grad[1]:
+                    dw = weight_grad(dy2, x2, group)
+                if need_b:
+                    db = column_sum(dy2, weight.dtype, group)
+            if group is not None:
+                group.run()
         if ctx.needs_input_grad[0]:
             with timed("gemm_lib", flops=2.0 * dy2.numel() * weight.shape[1]):
                 dx = torch.mm(dy2, weight).view(x.shape)
         join(side, dw, db)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 class _SharedInputLinearsFn(Function):
@@ -185,6 +358,7 @@ class _SharedInputLinearsFn(Function):
         x2 = x.reshape(-1, x.shape[-1])
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
         dx2, dws, dbs = None, [None] * n, [None] * n
+        group = SlabGroup() if x2.is_cuda else None
         for l in range(n):
             if dys[l] is None:
                 continue
@@ -197,9 +371,11 @@ class _SharedInputLinearsFn(Function):
                     else:
                         dx2.addmm_(dy2, weights[l])
             if ctx.needs_input_grad[2 + l]:
-                dws[l] = weight_grad(dy2, x2)
+                dws[l] = weight_grad(dy2, x2, group)
             if ctx.needs_input_grad[2 + n + l]:
-                dbs[l] = column_sum(dy2, weights[l].dtype)
+                dbs[l] = column_sum(dy2, weights[l].dtype, group)
+        if group is not None:
+            group.run()
         dx = None if dx2 is None else dx2.view(x.shape)
         return (dx, None) + tuple(dws) + tuple(dbs)
 
@@ -217,7 +393,9 @@ def shared_input_linears(x, linears):
     return list(_SharedInputLinearsFn.apply(x, len(linears), *[lin.weight for lin in linears], *[lin.bias for lin in linears]))
 
 
-def linear(x, weight, bias):
+def linear(x, weight, bias, single_use=False):
+    """F.linear with the backward of this module.  single_use=True: the caller guarantees `weight` / `bias` receive exactly one
+    gradient per backward pass (not shared between call sites), which lets small maps compute them beside the chain (fork)."""
     fits = (backend.override() is None and x.is_cuda and torch.is_grad_enabled()
             and not torch.is_autocast_enabled()
             and (x.requires_grad or weight.requires_grad) and x.dtype == weight.dtype
@@ -225,11 +403,13 @@ def linear(x, weight, bias):
             and x.numel() // x.shape[-1] >= MIN_ROWS)
     if not fits:
         return F.linear(x, weight, bias)
-    return _LinearFn.apply(x, weight, bias)
+    return _LinearFn.apply(x, weight, bias, single_use_now(single_use))
 
 
 class Linear(nn.Linear):
-    """Same parameters / state-dict keys as nn.Linear."""
+    """Same parameters / state-dict keys as nn.Linear.  `single_use` (plain attribute, not part of the state): see linear()."""
+
+    single_use = False
 
     def forward(self, input):
-        return linear(input, self.weight, self.bias)
+        return linear(input, self.weight, self.bias, self.single_use)

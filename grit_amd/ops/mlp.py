@@ -20,7 +20,7 @@ from grit_amd import lib as _lib
 from grit_amd.ops import backend
 from grit_amd.ops import gemm as G
 from grit_amd.ops import layer_norm as LN
-from grit_amd.ops.linear import column_sum, fork, join, on_stream, slab_sum, weight_grad
+from grit_amd.ops.linear import SlabGroup, column_sum, fork, join, on_stream, slab_sum, weight_grad
 from grit_amd.ops.profiling import timed
 
 MIN_ROWS = 2048
@@ -35,27 +35,33 @@ def _rows(t):
     return t2 if t2.is_contiguous() else t2.contiguous()
 
 
-def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False):
+def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=None):
     """Gradients of branch = fc2(gelu(fc1(n2))) w.r.t. (n2, w1, b1, w2[, b2]) given d_branch [M, C].  The chain of input
-    gradients runs on the current stream, the weight / bias gradients beside it on the side stream (linear.fork)."""
+    gradients runs on the current stream, the weight / bias gradients beside it on the side stream (linear.fork).  `group`:
+    the caller's SlabGroup -- every partial sum of the node (dW2, db1, dW1[, db2]) is then reduced by the caller's one launch
+    (not combined with the side stream: the knob that enables it is an A/B diagnostic)."""
     need_x, need_w1, need_b1, need_w2 = needs
     d_n2 = d_w1 = d_b1 = d_w2 = d_b2 = None
     chain = need_x or need_w1 or need_b1
     side = fork(d_branch, act) if (chain and (need_w2 or need_b2)) else None
+    if side is not None:
+        group = None
     with on_stream(side):
         if need_w2:
-            d_w2 = weight_grad(d_branch, act)
+            d_w2 = weight_grad(d_branch, act, group)
         if need_b2:
-            d_b2 = column_sum(d_branch, w2.dtype)
+            d_b2 = column_sum(d_branch, w2.dtype, group)
     if chain:
         d_pre, partial = G.input_grad_dgelu(d_branch, w2.t().contiguous(), pre)
         join(side, d_w2, d_b2)
         side = fork(d_pre, partial, n2) if (need_x and (need_w1 or need_b1)) else None
+        if side is not None:
+            group = None
         with on_stream(side):
             if need_b1:
-                d_b1 = slab_sum(partial.unsqueeze(0), w1.dtype)[0]
+                d_b1 = (group.add(partial.unsqueeze(0), w1.dtype) if group is not None else slab_sum(partial.unsqueeze(0), w1.dtype))[0]
             if need_w1:
-                d_w1 = weight_grad(d_pre, n2)
+                d_w1 = weight_grad(d_pre, n2, group)
         if need_x:
             with timed("gemm_lib", flops=2.0 * d_pre.numel() * w1.shape[1]):
                 d_n2 = torch.mm(d_pre, w1)
@@ -82,7 +88,9 @@ class _MlpFn(Function):
         x2, w1, pre, act, w2 = ctx.saved_tensors
         d_branch = _rows(dy)
         ni = ctx.needs_input_grad
-        d_x, d_w1, d_b1, d_w2, d_b2 = _mlp_backward(d_branch, x2, w1, pre, act, w2, (ni[0], ni[1], ni[2], ni[3]), ni[4])
+        group = SlabGroup()
+        d_x, d_w1, d_b1, d_w2, d_b2 = _mlp_backward(d_branch, x2, w1, pre, act, w2, (ni[0], ni[1], ni[2], ni[3]), ni[4], group)
+        group.run()
         return (None if d_x is None else d_x.view(ctx.shape)), d_w1, d_b1, d_w2, d_b2
 
 
@@ -117,9 +125,11 @@ class _MlpAddLayerNormFn(Function):
     @once_differentiable
     def backward(ctx, gx, gy):
         x, weight, mean, rstd, scale, x2, w1, pre, act, w2 = ctx.saved_tensors
-        dx, d_branch, sums = LN._add_layer_norm_backward(x, weight, mean, rstd, scale, gx, gy, ctx.shape[0], True, 0.0, None)
+        group = SlabGroup()  # LayerNorm sums, dW2, db1, dW1: one reduction launch for the whole node
+        dx, d_branch, sums = LN._add_layer_norm_backward(x, weight, mean, rstd, scale, gx, gy, ctx.shape[0], True, 0.0, None, group)
         ni = ctx.needs_input_grad
-        d_x, d_w1, d_b1, d_w2, _ = _mlp_backward(d_branch, x2, w1, pre, act, w2, (ni[0], ni[1], ni[2], ni[3]))
+        d_x, d_w1, d_b1, d_w2, _ = _mlp_backward(d_branch, x2, w1, pre, act, w2, (ni[0], ni[1], ni[2], ni[3]), group=group)
+        group.run()
         return ((None if d_x is None else d_x.view(ctx.in_shape)), d_w1, d_b1, d_w2, sums[2].to(w2.dtype), dx.view(ctx.shape),
                 None, sums[0], sums[1], None)
 

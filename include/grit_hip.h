@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 25
+#define GRIT_ABI_VERSION 26
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -301,6 +301,37 @@ int grit_colsum(const void* x, int M, int N, int x_is_bf16, int slabs, float* pa
  * ------------------------------------------------------------------------------------------------------ */
 int grit_slab_sum(const float* partial, int groups, long group_stride, int slabs, long n, void* out, int out_is_bf16,
                   void* stream);
+
+/* Up to GRIT_SLAB_GROUP_MAX slab sums in ONE launch (same arithmetic per job as grit_slab_sum, job table passed by value): the
+ * reductions a backward node owes -- split-M weight gradients, bias-gradient column sums, LayerNorm dgamma / dbeta -- done together
+ * instead of as dependent launches of a few microseconds each.  bf16 outputs need 8-byte, f32 outputs 16-byte alignment. */
+#define GRIT_SLAB_GROUP_MAX 16
+typedef struct grit_slab_job {
+    const float* partial;   /* group g at partial + g * group_stride, slab s of a group at + s * n */
+    long group_stride;
+    int groups;
+    int slabs;
+    long n;
+    void* out;              /* [groups, n] */
+    int out_is_bf16;
+} grit_slab_job;
+int grit_slab_sum_grouped(const grit_slab_job* jobs, int n_jobs, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Weight + bias gradient of nn.Linear on SHORT token maps (the decoders and the grid net, M = 640 .. 4 800 rows; autograd of
+ * the Linear layers of models/detection/det_module.py:313-349, models/caption/grid_net.py:9-42, models/common/attention.py:51-88,
+ * models/common/pos_embed.py:34-48):     dW[n, k] = sum_m dY[m, n] * X[m, k]        db[n] = sum_m dY[m, n]
+ * dY [M, N], X [M, K] bf16 row-major with leading dimensions ldy / ldx (elements, multiples of 8; 16-byte aligned bases);
+ * N % 64 == 0, K % 64 == 0.  splits = grit_wgrad_small_splits(M, N, K) (0: shape not supported):
+ *   splits == 1  (M <= 4 800): dW_out is the finished gradient, bf16 [N, K], db_out bf16 [N] (or NULL: not wanted) -- ONE launch
+ *                replaces the library's transposed GEMM (24-47 us for these 2.5 GFLOP problems), the column-sum kernel and the
+ *                reduction launch behind it;
+ *   splits  > 1  dW_out = f32 partials [splits, N, K], db_out = f32 partials [splits, N] (or NULL), fully overwritten; the
+ *                caller sums over the splits (grit_slab_sum / grit_slab_sum_grouped).
+ * ------------------------------------------------------------------------------------------------------ */
+int grit_wgrad_small_splits(int M, int N, int K);
+int grit_wgrad_small(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, void* dW_out,
+                     void* db_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Adam step on one flat range of the fp32-master / bf16-compute training state (torch.optim.Adam as configured by the

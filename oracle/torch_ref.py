@@ -129,3 +129,17 @@ def attention(q, k, v, mask=None, scale=None, dropout_p=0.0, training=False):
 def layer_norm(x, weight, bias, eps=1e-5):
     """torch.nn.functional.layer_norm over the last dimension (what nn.LayerNorm does in the reference)."""
     return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Flat Adam step (grit_adam_flat): torch.optim.Adam's arithmetic (torch/optim/adam.py _single_tensor_adam, amsgrad off,
+# weight decay 0, the reference's optimizer: engine/caption_engine.py:59-69) on slices of the flat training state, so that
+# the sharded / per-parameter-age logic of grit_amd.amp.FlatAdam can be exercised on CPU (gloo tests).
+# ---------------------------------------------------------------------------------------------------
+def adam_flat(master, grad, mom, var, compute, lr, b1, b2, eps, bc1, bc2s, grad_scale):
+    g = grad.float() * grad_scale
+    mom.mul_(b1).add_(g, alpha=1.0 - b1)
+    var.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+    denom = (var.sqrt() / bc2s).add_(eps)
+    master.addcdiv_(mom, denom, value=-lr / bc1)
+    compute.copy_(master)

@@ -87,7 +87,7 @@ def test_bucketed_allreduce_world2(wire_bf16):
     assert abs(ret["avg_loss"] - loss.item()) < 1e-5
 
 
-def _amp_worker(rank, world, port, ret, device="cpu"):
+def _amp_worker(rank, world, port, ret, device="cpu", shard=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from grit_amd.amp import Bf16Compute
@@ -95,7 +95,7 @@ def _amp_worker(rank, world, port, ret, device="cpu"):
     from grit_amd.engine.caption_engine import build_optimizers
     torch.manual_seed(100 + rank)
     model = Toy().to(device)
-    wrapped = Bf16Compute(model, bucket_mb=0.0005)
+    wrapped = Bf16Compute(model, bucket_mb=0.0005, shard_optimizer=shard)
     ret["flat_%d" % rank] = bool(wrapped.flat_optimizer)
     cfg = default_config()
     # the engine's optimizer builder must pick up the fp32 masters (names of the module's parameters)
@@ -114,8 +114,9 @@ def _amp_worker(rank, world, port, ret, device="cpu"):
         opts['backbone'].step()
         wrapped.after_optimizer_step()
         losses.append(loss.item())
+    wrapped.consolidate()
     sd = {k: v.cpu() for k, v in wrapped.master_state_dict().items()}
-    flat = torch.cat([v.flatten().float() for v in sd.values()])
+    flat = torch.cat([v.flatten().float() for v in sd.values()] + [v.flatten().float().cpu() for v in model.state_dict().values()])
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     if rank == 0:
@@ -125,6 +126,7 @@ def _amp_worker(rank, world, port, ret, device="cpu"):
         ret["losses"] = losses
         ret["n_master"] = n_master
         ret["keys"] = sorted(sd.keys())
+        ret["sd"] = sd
     dist.barrier()
     dist.destroy_process_group()
 
@@ -147,16 +149,23 @@ def test_bf16_compute_fp32_masters_world2():
 @pytest.mark.gpu
 def test_bf16_compute_flat_adam_world2_on_gpu():
     """The same two-rank step on the GPU (both gloo ranks share cuda:0): here Bf16Compute takes the FlatAdam path
-    (grit_adam_flat reading the all-reduced bf16 buckets); masters must stay identical across the ranks."""
-    port = _free_port()
-    with mp.Manager() as mgr:
-        ret = mgr.dict()
-        mp.spawn(_amp_worker, args=(2, port, ret, "cuda"), nprocs=2, join=True)
-        ret = dict(ret)
-    assert ret["flat_0"] and ret["flat_1"]
-    assert ret["same_weights"]
-    assert ret["dtypes"] == ["torch.float32"] and ret["compute_dtype"] == "torch.bfloat16"
-    assert ret["losses"][-1] < ret["losses"][0]
+    (grit_adam_flat reading the all-reduced bf16 buckets); masters must stay identical across the ranks.  Then the sharded mode
+    (reduce-scatter, each rank's grit_adam_flat on its slice, all-gather of the compute weights, consolidate()): the same
+    masters bit for bit (two-term bf16 sums do not depend on the order)."""
+    rets = []
+    for shard in (False, True):
+        port = _free_port()
+        with mp.Manager() as mgr:
+            ret = mgr.dict()
+            mp.spawn(_amp_worker, args=(2, port, ret, "cuda", shard), nprocs=2, join=True)
+            ret = dict(ret)
+        assert ret["flat_0"] and ret["flat_1"]
+        assert ret["same_weights"]
+        assert ret["dtypes"] == ["torch.float32"] and ret["compute_dtype"] == "torch.bfloat16"
+        assert ret["losses"][-1] < ret["losses"][0]
+        rets.append(ret)
+    for k, v in rets[0]["sd"].items():
+        assert torch.equal(v, rets[1]["sd"][k]), k
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -300,3 +309,121 @@ def test_real_model_bucket_layout_world4():
     assert ret["n_unused"] == 78  # the static unused set of the reference (80 at three decoder layers: fixture G8)
     assert ret["final_sizes"][-1] <= 8 * 2**20 and max(ret["final_sizes"]) <= 64 * 2**20 and len(ret["final_sizes"]) >= 3
     assert all(ret["launched"])  # second step: nothing left to send when backward returns
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# reduce-scatter -> shard-local FlatAdam -> all-gather of the bf16 compute weights (Bf16Compute(shard_optimizer=True)) against
+# the all-reduce mode and against ONE process on the concatenated batch; FlatAdam's arithmetic on CPU is the oracle's adam_flat
+# (the HIP kernel is covered on the GPU: tests/test_stream_kernels_gpu.py), injected through the test seam
+class Wide(nn.Module):
+    """Several odd-sized parameters so that slices cut through parameters, plus a never-used one and a frozen one."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 24)
+        self.b = nn.Linear(24, 13)
+        self.c = nn.Linear(13, 4)
+        self.dead = nn.Linear(3, 5)
+        self.frozen = nn.Linear(8, 8)
+        for p in self.frozen.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        return self.c(torch.tanh(self.b(torch.relu(self.a(self.frozen(x))))))
+
+
+def _shard_worker(rank, world, port, shard, steps, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grit_amd.amp import Bf16Compute
+    from grit_amd.config import default_config
+    from grit_amd.engine.caption_engine import build_optimizers
+    from tests.helpers import oracle_ops
+    torch.manual_seed(3)
+    model = Wide()
+    wrapped = Bf16Compute(model, bucket_mb=0.0007, flat_optimizer=True, shard_optimizer=shard)
+    cfg = default_config(**{'optimizer.xe_lr': 1e-2})
+    with oracle_ops():
+        opts = build_optimizers(wrapped, cfg, mode='xe')
+        g = torch.Generator().manual_seed(7)
+        total = 8  # the same 8 samples whatever the world size
+        data, target = torch.randn(total, 8, generator=g), torch.randn(total, 4, generator=g)
+        n = total // world
+        xs, ys = data[rank * n:(rank + 1) * n].bfloat16(), target[rank * n:(rank + 1) * n]
+        losses = []
+        for it in range(steps):
+            loss = ((wrapped(xs).float() - ys) ** 2).mean()
+            loss.backward()
+            wrapped.finish_gradient_sync()
+            opts['model'].step()
+            opts['backbone'].step()
+            wrapped.after_optimizer_step()
+            losses.append(loss.item())
+        stale_raises = False
+        if shard and world > 1:
+            try:
+                wrapped.master_state_dict()
+            except RuntimeError:
+                stale_raises = True
+        wrapped.consolidate()
+        sd = wrapped.master_state_dict()
+        osd = opts['model'].state_dict()
+    compute = {k: v.clone() for k, v in model.state_dict().items()}
+    if world > 1:
+        flat = torch.cat([v.flatten().float() for v in sd.values()] + [v.flatten().float() for v in compute.values()])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        same = all(torch.equal(gathered[0], t) for t in gathered[1:])
+    else:
+        same = True
+    if rank == 0:
+        ret["sd"] = sd
+        ret["compute"] = compute
+        ret["same"] = same
+        ret["stale_raises"] = stale_raises
+        ret["steps_in_state"] = sorted({float(s['step']) for s in osd['state'].values()})
+        ret["moments"] = {i: (s['exp_avg'].clone(), s['exp_avg_sq'].clone()) for i, s in osd['state'].items()}
+        ret["n_buckets"] = len(wrapped.ddp.buckets)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run_shard(world, shard, steps=3):
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        if world == 1:
+            _shard_worker(0, 1, port, shard, steps, ret)
+        else:
+            mp.spawn(_shard_worker, args=(world, port, shard, steps, ret), nprocs=world, join=True)
+        return dict(ret)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_optimizer_equals_allreduce_and_single_process(world):
+    """After 3 steps: masters, bf16 compute weights and Adam moments of the sharded mode (reduce-scatter, every rank steps its
+    slice, all-gather of the compute weights, consolidate()) equal those of the all-reduce mode and of ONE process that saw the
+    whole batch -- up to the bf16 rounding of the gradient sum on the wire (mean of per-rank means vs one mean)."""
+    single = _run_shard(1, False)
+    allred = _run_shard(world, False)
+    shard = _run_shard(world, True)
+    assert shard["same"] and allred["same"]            # every rank holds the same model after consolidate()
+    assert shard["stale_raises"]                       # exporting before consolidate() is refused, not silently wrong
+    assert shard["n_buckets"] > 1
+    assert shard["steps_in_state"] == [0.0, 3.0] or shard["steps_in_state"] == [3.0]  # dead.* never stepped
+    # world 2: sharded == all-reduce EXACTLY (a two-term bf16 sum does not depend on the order; the same reduced gradients reach
+    # the same Adam arithmetic, only on another rank).  world 4: the two collectives add the four bf16 terms in different orders
+    # (Adam turns a last-bit difference of a near-zero gradient into a step of up to lr: most elements agree to 2e-3, none
+    # differs by more than 3 steps x lr)
+    def close(a, b):
+        d = (a.float() - b.float()).abs()
+        return float((d <= 2e-3 + 2e-2 * b.float().abs()).float().mean()) >= 0.9 and float(d.max()) <= 3.2e-2
+    same = (lambda a, b: torch.equal(a, b)) if world == 2 else close
+    for k, v in single["sd"].items():
+        assert same(shard["sd"][k], allred["sd"][k]), k
+        assert same(shard["compute"][k].float(), allred["compute"][k].float()), k
+        assert close(shard["sd"][k], v), k
+    for i, (m, v) in allred["moments"].items():
+        assert same(shard["moments"][i][0], m) and same(shard["moments"][i][1], v), i

@@ -46,8 +46,13 @@ def test_gemm_epilogues(M, N, K, variant):
     _close(G.gemm_nt(x, w, G.BIAS_GELU, bias=b, variant=variant), F.gelu(ref + b.float()))  # no pre-activation kept
     # GELU' epilogue + column sums (rows past M must not leak into the sums)
     aux = torch.randn(M, N, device='cuda').bfloat16()
-    part = torch.full((-(-M // 128), N), float('nan'), device='cuda')
+    # the partials sit between two canary rows: a wave whose rows all lie past M must not write a slab (round 3: a 37-row
+    # problem wrote 4 KB of zeros behind its one slab, into whatever the allocator had placed there)
+    slabs = -(-M // 128)
+    fenced = torch.full((slabs + 2, N), float('nan'), device='cuda')
+    part = fenced[1:1 + slabs]
     d = G.gemm_nt(x, w, G.DGELU, aux=aux, colsum=part, variant=variant)
+    assert torch.isnan(fenced[0]).all() and torch.isnan(fenced[-1]).all()
     a32 = aux.float().requires_grad_(True)
     F.gelu(a32).backward(ref)
     _close(d, a32.grad)
@@ -119,3 +124,64 @@ def test_fused_mlp_matches_module(with_norm):
         _close(a, b, 2.0 ** -6)
     for a, b in zip(grads_f, grads_r):
         _close(a, b, 2.0 ** -5)
+
+
+@pytest.mark.parametrize("M,N,K", [(4800, 512, 512), (4800, 128, 512), (4800, 1024, 512), (640, 512, 512), (3200, 2048, 512),
+                                   (777, 64, 192), (33, 128, 64), (16000, 256, 1024), (4801, 64, 64)])
+@pytest.mark.parametrize("strided", [False, True])
+def test_small_map_weight_and_bias_gradient(M, N, K, strided):
+    """grit_wgrad_small (dW = dY^T X and db = colsum(dY) of a short map in one launch: finished bf16 gradients up to 4 800 rows,
+    f32 split partials + the grouped reduction beyond), against the same contraction in float64 on the bf16 inputs; ragged M
+    (tail rows zero-filled), operands that are column slices of wider tensors (leading dimension > width), canary rows around
+    both outputs."""
+    import ctypes
+    from grit_amd import lib as _lib
+    from grit_amd.ops.linear import SlabGroup, small_weight_bias_grad
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    if strided:
+        dy = torch.randn(M, N + 64, device='cuda', generator=g).bfloat16()[:, 32:32 + N]
+        x = torch.randn(M, K + 8, device='cuda', generator=g).bfloat16()[:, 8:]
+    else:
+        dy = torch.randn(M, N, device='cuda', generator=g).bfloat16()
+        x = torch.randn(M, K, device='cuda', generator=g).bfloat16()
+    ref_w = (dy.double().t() @ x.double()).float()
+    ref_b = dy.double().sum(0).float()
+    dw, db = small_weight_bias_grad(dy, x, True, torch.bfloat16)
+    assert dw.dtype == db.dtype == torch.bfloat16 and dw.shape == (N, K) and db.shape == (N,)
+    _close(dw, ref_w)
+    _close(db, ref_b)
+    group = SlabGroup()  # through a caller's group, weight gradient alone
+    dw2, none = small_weight_bias_grad(dy, x, False, torch.bfloat16, group)
+    group.run()
+    assert none is None and torch.equal(dw2, dw)
+    # the raw entry point between canaries: nothing is written outside the outputs
+    lib = _lib.load()
+    S = lib.grit_wgrad_small_splits(M, N, K)
+    assert S == -(-M // 4800)
+    wdt = torch.bfloat16 if S == 1 else torch.float32
+    wfence = torch.full((S + 2, N, K), float('nan'), device='cuda', dtype=wdt)
+    bfence = torch.full((S + 2, N), float('nan'), device='cuda', dtype=wdt)
+    st = lib.grit_wgrad_small(ctypes.c_void_p(dy.data_ptr()), dy.stride(0), ctypes.c_void_p(x.data_ptr()), x.stride(0), M, N, K, S,
+                              ctypes.c_void_p(wfence[1].data_ptr()), ctypes.c_void_p(bfence[1].data_ptr()), _lib.current_stream_ptr())
+    assert st == 0
+    assert torch.isnan(wfence[0]).all() and torch.isnan(wfence[-1]).all() and torch.isfinite(wfence[1:-1]).all()
+    assert torch.isnan(bfence[0]).all() and torch.isnan(bfence[-1]).all() and torch.isfinite(bfence[1:-1]).all()
+    if S > 1:  # f32 partials: their sum is the contraction to fp32 accuracy
+        scale = ref_w.abs().max().item()
+        assert (wfence[1:-1].double().sum(0) - ref_w.double()).abs().max().item() <= 1e-5 * scale + 1e-4
+        assert (bfence[1:-1].double().sum(0) - ref_b.double()).abs().max().item() <= 1e-5 * ref_b.abs().max().item() + 1e-4
+    else:
+        assert torch.equal(wfence[1], dw) and torch.equal(bfence[1], db)
+
+
+def test_small_map_gradient_rejects_what_it_does_not_cover():
+    from grit_amd import lib as _lib
+    lib = _lib.load()
+    assert lib.grit_wgrad_small_splits(4800, 10201, 512) == 0  # vocabulary projection: N % 64 != 0 -> the library GEMM
+    assert lib.grit_wgrad_small_splits(4800, 512, 100) == 0
+    from grit_amd.ops.linear import small_weight_bias_grad
+    dy = torch.randn(100, 10201, device='cuda').bfloat16()
+    x = torch.randn(100, 512, device='cuda').bfloat16()
+    assert small_weight_bias_grad(dy, x, True, torch.bfloat16) is None
+    dy = torch.randn(100, 128, device='cuda')  # fp32 gradients: the parity path stays on the library
+    assert small_weight_bias_grad(dy, x, True, torch.float32) is None

@@ -308,3 +308,49 @@ def test_eval_after_flat_adam_steps_sees_the_new_weights(monkeypatch):
     stale_gap = (first[1].sum(-1) - plain[1].sum(-1)).abs().max()
     fresh_gap = (second[1].sum(-1) - plain[1].sum(-1)).abs().max()
     assert fresh_gap < 0.25 * stale_gap, (float(fresh_gap), float(stale_gap))
+
+
+def test_config3_step_at_640_batch16_equals_microbatch_accumulation():
+    """BASELINE config 3 with an assertion (the 640^2 workload ran only inside bench.py): full GRIT, bf16 weights,
+    16 synthetic 640x640 images, T = 20, dropout / drop-path off.  The loss and the gradients of ONE step on the batch of 16
+    must equal the average over eight micro-batches of 2 (every kernel of the path is per-image: batching must not change
+    the mathematics), within the bf16 tolerance of re-associated reductions; everything finite."""
+    from grit_amd.data import synthetic_batch
+    model, cfg = build_model(3, fill=False, **{'model.dropout': 0.0, 'model.detector.dropout': 0.0})
+    torch.manual_seed(0)
+    model.train().to(DEV).to(torch.bfloat16)
+    disable_drop_path(model)
+    loss_fn = torch.nn.NLLLoss(ignore_index=1)
+    batch = synthetic_batch(16, 640, 640, 20, device=DEV, seed=11)
+    picks = ('cap_generator.fc.weight', 'grid_net.fc.weight', 'detector.det_module.decoder_layers.5.cross_attn.value_proj.weight',
+             'detector.det_module.decoder_layers.0.cross_attn.sampling_offsets.weight',
+             'detector.backbone.layers.2.blocks.17.attn.qkv.weight', 'detector.backbone.layers.2.blocks.0.mlp.fc1.weight',
+             'detector.backbone.layers.1.blocks.0.attn.relative_position_bias_table', 'detector.input_proj.0.0.weight')
+    params = dict(model.named_parameters())
+
+    def step(images, mask, caps):
+        from grit_amd.utils.misc import NestedTensor
+        out = model(NestedTensor(images, mask), caps)
+        loss = loss_fn(out[:, :-1].reshape(-1, out.shape[-1]).float(), caps[:, 1:].reshape(-1))
+        loss.backward()
+        return float(loss)
+
+    s = batch['samples']
+    full = step(s.tensors, s.mask, batch['captions'])
+    g_full = {n: params[n].grad.float().clone() for n in picks}
+    assert np.isfinite(full) and 8.0 < full < 10.5  # ~ log(10201) = 9.23 for a randomly initialised decoder
+    for n, p in params.items():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n
+    micro, acc = [], {n: 0 for n in picks}
+    for i in range(0, 16, 2):
+        model.zero_grad(set_to_none=True)
+        micro.append(step(s.tensors[i:i + 2], s.mask[i:i + 2], batch['captions'][i:i + 2]))
+        for n in picks:
+            acc[n] = acc[n] + params[n].grad.float() / 8  # the micro-batch gradients averaged in fp32
+    assert abs(full - sum(micro) / 8) < 3e-3 * full, (full, micro)
+    rels = {n: float(torch.linalg.norm(g_full[n] - acc[n]) / torch.linalg.norm(acc[n])) for n in picks}
+    for n, rel in rels.items():
+        # gradients that pass through the deformable attention of a randomly initialised decoder are sums of many cancelling
+        # terms (value gradient rounded to bf16 per cell, f32 atomics in another arrival order for another batch): looser
+        assert rel < (0.15 if 'cross_attn' in n else 6e-2), rels

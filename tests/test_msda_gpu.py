@@ -308,7 +308,10 @@ def test_staged_f32_accumulation_rounds_once_and_leaves_scratch_zeroed():
     ulp = want.float().abs() * 2.0 ** -7 + 1e-6
     assert bool((diff <= ulp).all()), float((diff / ulp).max())
     assert float((gv != want).float().mean()) < 1e-2   # order-dependent last-bit flips are rare
-    assert bool((gv[dense == 0] == 0).all())
+    # cells no sampling point reaches stay exactly zero (per CELL: inside a touched cell an element may cancel to exactly 0.0 in
+    # one summation order and to 2^-27 in another -- seen on hardware)
+    untouched = dense.abs().sum(-1) == 0
+    assert bool(untouched.any()) and bool((gv[untouched] == 0).all())
     torch.testing.assert_close(gl, gl2, rtol=1e-3, atol=2e-4)  # two kernels, two summation orders over the 64 channels
     torch.testing.assert_close(ga, ga2, rtol=1e-3, atol=2e-4)
     ent = msda_op._STAGE[(str(v16.device), B, S, M)]

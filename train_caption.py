@@ -85,8 +85,10 @@ def main(gpu, config, dataloaders=None, text_field=None, cider=None, tokenizer_p
     raw.cached_features = bool(getattr(config.exp, 'cached_features', False))
     # precision: bf16 compute copies + fp32 master weights on the GPU (grit_amd/amp.py; gradients are produced and
     # all-reduced in flat bf16 buckets), plain fp32 with exp.bf16=False or on CPU
+    # exp.grad_sync = 'shard' (or GRIT_GRAD_SYNC=shard): reduce-scatter + sharded FlatAdam + all-gather instead of all-reduce
+    grad_sync = getattr(config.exp, 'grad_sync', os.environ.get('GRIT_GRAD_SYNC', 'allreduce'))
     if getattr(config.exp, 'bf16', use_cuda):
-        model = Bf16Compute(model)
+        model = Bf16Compute(model, shard_optimizer=(grad_sync == 'shard' and use_cuda and world > 1))
     else:
         model = BucketedDataParallel(model)
     optimizers = build_optimizers(model, config, mode='xe')

@@ -555,6 +555,292 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     }
 }
 
+// DMA-staged variant (the default): LDS plan, 161 808 of the 163 840 bytes of the CU:
+//   bias slab, TRANSPOSED [key][query], as bf16 with a 152-element pitch (conflict-free 8-byte reads per half-wave): 43 776 B.  The
+//     slab is the output of grit_relbias_fwd on a bf16 table in the training step, so the conversion is exact there; with an
+//     fp32 table it rounds the bias to bf16 inside this kernel only (2^-9 relative on an O(0.1) logit term, below the bf16
+//     resolution of P / dS that the products run in);
+//   dS^T [key][query] bf16, pitch 148: 42 624 B;  Q / dO / K tiles [144][32] bf16, DOUBLE buffered: 55 296 B;  V and O tiles,
+//     single (consumed at the top of their window): 18 432 B;  statistics 1 680 B.
+constexpr int kBP2 = 152;
+constexpr size_t kBwdDmaLds = (size_t)kN * kBP2 * 2 + (size_t)kN * kSP * 2 + 8 * (size_t)kN * kTP * 2 + 2 * kN * 4 + 3 * kHd * 4 + kN;
+static_assert(kBwdDmaLds <= 160 * 1024, "one workgroup per CU");
+
+template <bool kExplicitMask>
+__global__ __launch_bounds__(kThreads)
+void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ rel_bias, const __bf16* __restrict__ pad_qkv,
+                 const float* __restrict__ mask, Geom g, const __bf16* __restrict__ out, const __bf16* __restrict__ dout,
+                 const float* __restrict__ lse2, __bf16* __restrict__ dqkv, float* __restrict__ dbias,
+                 float* __restrict__ dpad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* bT = reinterpret_cast<__bf16*>(smem_raw);                       // [144][kBP2]  bias^T, bf16 (see header comment)
+    __bf16* dSt = bT + kN * kBP2;                                           // [144][kSP]   [key][query]
+    __bf16* tiles = dSt + kN * kSP;                                         // Q, dO, K of buffer 0, then of buffer 1: [144][kTP] each
+    __bf16* Vs1 = tiles + 6 * kN * kTP;                                     // V and O of the window being STARTED (read at its
+    __bf16* Os1 = Vs1 + kN * kTP;                                           //   top only: single buffers)
+    float* lse_s = reinterpret_cast<float*>(Os1 + kN * kTP);                // [144]
+    float* delta_s = lse_s + kN;                                            // [144]
+    float* pad_s = delta_s + kN;                                            // [96]
+    uint8_t* rid = reinterpret_cast<uint8_t*>(pad_s + 3 * kHd);             // [144]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int trq = l15 >> 2, trp = l15 & 3;
+    int h, grp;
+    head_and_group(g, h, grp);
+    const int ngrp = gridDim.x / g.nH;
+    const int NW = g.B * g.nWh * g.nWw;
+    const int C3 = 3 * g.C;
+    const int hoff = h * kHd;
+    const float c2 = g.scale * kLog2e;
+
+    // one-time: bias slab (transposed, log2 domain) and the pad-gradient accumulator
+    for (int i = tid; i < kN * kN; i += kThreads) {
+        const int qi = i / kN, ki = i - qi * kN;
+        bT[ki * kBP2 + qi] = (__bf16)rel_bias[(size_t)h * kN * kN + i];
+    }
+    if (tid < 3 * kHd) pad_s[tid] = 0.f;
+
+    v4f dB[kTiles];  // d(bias)[query 16qt + 4lg + r][key 16w + l15], summed over this workgroup's windows
+#pragma unroll
+    for (int qt = 0; qt < kTiles; ++qt) dB[qt] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    const v4s z4s = {0, 0, 0, 0};
+    const int sn = tid >> 2, sc = tid & 3;
+    // Operands of a window travel global -> LDS by DMA (global_load_lds, 16 bytes per lane, lane-linear: thread (token sn,
+    // chunk sc) of a [144][32] bf16 tile IS byte 16 tid of it), issued at the TOP of the previous window -- a whole window of
+    // compute hides them, and no register holds them meanwhile (the register-staged version could only issue them after phase
+    // 1, its register peak: ~20 % of the kernel was exposed load latency, profiles/r01/winattn_bwd_notes.txt).  Window-padding
+    // tokens: q / k / v come from pad_qkv, dO / O rows are zero-filled by the owning thread.
+    struct Next { float lse_v; int reg, tkk, kreg, wy, wx; size_t img; };
+    auto dma16 = [&](const __bf16* src, __bf16* tile) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(tile) + w * 1024), 16, 0, 0);
+    };
+    auto prefetch = [&](int win, int buf) {
+        Next f;
+        const int b = win / (g.nWh * g.nWw), wrem = win - b * (g.nWh * g.nWw);
+        f.wy = wrem / g.nWw; f.wx = wrem - f.wy * g.nWw;
+        f.img = (size_t)b * g.T;
+        const int tk = token_of(sn, f.wy, f.wx, g, f.reg);
+        const __bf16* src = tk >= 0 ? qkv + (f.img + tk) * C3 + hoff + sc * 8 : pad_qkv + hoff + sc * 8;
+        __bf16* tb = tiles + buf * 3 * kN * kTP;
+        dma16(src, tb);                              // Q
+        dma16(src + g.C, tb + 2 * kN * kTP);         // K
+        dma16(src + 2 * g.C, Vs1);                   // V
+        if (tk >= 0) {
+            dma16(dout + (f.img + tk) * g.C + hoff + sc * 8, tb + kN * kTP);   // dO
+            dma16(out + (f.img + tk) * g.C + hoff + sc * 8, Os1);              // O
+        } else {
+            *reinterpret_cast<uint4*>(&tb[kN * kTP + sn * kTP + sc * 8]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(&Os1[sn * kTP + sc * 8]) = make_uint4(0, 0, 0, 0);
+        }
+        f.tkk = token_of(16 * w + l15, f.wy, f.wx, g, f.kreg);  // this lane's key in phase 1 / query in phase 2
+        f.lse_v = 0.f;
+        if (tid < kN) f.lse_v = lse2[((size_t)win * g.nH + h) * kN + tid];
+        return f;
+    };
+    Next nxt;
+    int cur = 0;
+    if (grp < NW) nxt = prefetch(grp, 0);
+    for (int win = grp; win < NW; win += ngrp, cur ^= 1) {
+        const int wy = nxt.wy, wx = nxt.wx, reg = nxt.reg, tkk = nxt.tkk, kreg = nxt.kreg;
+        const size_t img = nxt.img;
+        const float lse_v = nxt.lse_v;
+        __bf16* Qs = tiles + cur * 3 * kN * kTP;
+        __bf16* dOs = Qs + kN * kTP;
+        __bf16* Ks = dOs + kN * kTP;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs (and its stores of the previous window) are done
+        __syncthreads();  // ... everybody's: the tiles of this window are complete (first time: so is the bias slab)
+        float dpart = 0.f;  // delta = rowsum(dO * O): 8 channels per thread, 4 threads per token
+        {
+            const v8bf a = as_v8bf(*reinterpret_cast<const uint4*>(&dOs[sn * kTP + sc * 8]));
+            const v8bf c = as_v8bf(*reinterpret_cast<const uint4*>(&Os1[sn * kTP + sc * 8]));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dpart = fmaf((float)a[e], (float)c[e], dpart);
+            dpart += __shfl_xor(dpart, 1, 64);
+            dpart += __shfl_xor(dpart, 2, 64);
+        }
+        if (sc == 0) { rid[sn] = (uint8_t)reg; delta_s[sn] = dpart; }
+        if (tid < kN) lse_s[tid] = lse_v;
+        // this lane's K / V fragments (B operands of phase 1): key 16 w + l15, channels 8 lg ..
+        const v8bf kf = as_v8bf(*reinterpret_cast<const uint4*>(&Ks[(16 * w + l15) * kTP + lg * 8]));
+        const v8bf vf = as_v8bf(*reinterpret_cast<const uint4*>(&Vs1[(16 * w + l15) * kTP + lg * 8]));
+        __syncthreads();  // statistics visible; the V / O tiles and the other tile buffer are free for the next window's DMA
+        if (win + ngrp < NW) nxt = prefetch(win + ngrp, cur ^ 1);  // lands under phases 1 and 2 of this window
+
+        // Per-lane LDS offsets, made opaque once per window: without this hipcc hoists ~90 loop-invariant LDS
+        // addresses out of the window loop, runs out of registers and reloads them from scratch before every read.
+        int oRow = l15 * kTP + lg * 8;                   // row reads of Qs / dOs      (+ 16 qt kTP)
+        int oTr = (4 * lg + trq) * kTP + 4 * trp;        // transposing reads, phase 1 (+ 32 s kTP)
+        int oB = (16 * w + l15) * kBP2 + 4 * lg;         // bias slab (bf16)           (+ 16 qt)
+        int oSt = 4 * lg;                                // lse / delta                (+ 16 qt)
+        int oW = (16 * w + l15) * kSP + 4 * lg;          // dS^T writes                (+ 16 qt)
+        asm volatile("" : "+v"(oRow), "+v"(oTr), "+v"(oB), "+v"(oSt), "+v"(oW));
+
+        // ================= phase 1: wave w = key tile w =================
+        // S[q][k] = Q K^T, dP[q][k] = dO V^T on tiles (qt, w); after each PAIR of query tiles (one 32-deep k-step of
+        // the products that sum over queries) the packed P / dS feed dV^T += dO^T P and dK^T += Q^T dS at once.
+        const bool analytic = !kExplicitMask && g.shift > 0 && (wy == g.nWh - 1 || wx == g.nWw - 1);
+        v4f dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
+        v4bf pprev, sprev;
+        // software pipeline by one query tile: the S / dP MFMAs of tile qt+1 (and the LDS reads feeding them) are issued
+        // before the element-wise work of tile qt, so their latency hides under ~60 VALU instructions instead of parking the
+        // wave (PMC: 52 % of the wave cycles were s_waitcnt / barrier waits, 26 % issue stalls on MFMA results)
+        auto score_tiles = [&](int qt, v4f& s_out, v4f& dp_out) {
+            const v8bf qa = as_v8bf(*reinterpret_cast<const uint4*>(&Qs[oRow + 16 * qt * kTP]));
+            const v8bf da = as_v8bf(*reinterpret_cast<const uint4*>(&dOs[oRow + 16 * qt * kTP]));
+            s_out = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            dp_out = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        };
+        v4f s_cur, dp_cur;
+        score_tiles(0, s_cur, dp_cur);
+#pragma unroll
+        for (int qt = 0; qt < kTiles; ++qt) {
+            const v4f s = s_cur, dp = dp_cur;
+            if (qt + 1 < kTiles) {  // next tile's MFMAs and LDS reads fly under this tile's element-wise work
+                score_tiles(qt + 1, s_cur, dp_cur);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // element-wise part, two score elements per instruction: the loop is instruction-issue bound and hipcc does not
+            // form packed-fp32 operations from this code by itself, so the fma / sub / mul / add pairs are spelled out
+            // (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 on 64-bit register pairs, which the halves of an MFMA result are)
+            const uint2 braw = *reinterpret_cast<const uint2*>(&bT[oB + 16 * qt]);  // 4 bf16 biases: exact in f32, scaled here
+            const v2f b_lo = v2f{__uint_as_float(braw.x << 16), __uint_as_float(braw.x & 0xffff0000u)} * v2f{kLog2e, kLog2e};
+            const v2f b_hi = v2f{__uint_as_float(braw.y << 16), __uint_as_float(braw.y & 0xffff0000u)} * v2f{kLog2e, kLog2e};
+            const v4f bq = {b_lo[0], b_lo[1], b_hi[0], b_hi[1]};
+            const v4f lq = *reinterpret_cast<const v4f*>(&lse_s[oSt + 16 * qt]);
+            const v4f dl = *reinterpret_cast<const v4f*>(&delta_s[oSt + 16 * qt]);
+            const v2f c2v = {c2, c2};
+            // first consumers of the two MFMA results: compiler-visible
+            v2f t_lo = __builtin_elementwise_fma(v2f{s[0], s[1]}, c2v, v2f{bq[0], bq[1]});
+            v2f t_hi = __builtin_elementwise_fma(v2f{s[2], s[3]}, c2v, v2f{bq[2], bq[3]});
+            const v2f d_lo = v2f{dp[0], dp[1]} - v2f{dl[0], dl[1]}, d_hi = v2f{dp[2], dp[3]} - v2f{dl[2], dl[3]};
+            if (kExplicitMask) {
+                const float* mrow = mask + ((size_t)(win % g.nWm) * kN + 16 * qt + 4 * lg) * kN + 16 * w + l15;
+                t_lo[0] = fmaf(mrow[0], kLog2e, t_lo[0]); t_lo[1] = fmaf(mrow[kN], kLog2e, t_lo[1]);
+                t_hi[0] = fmaf(mrow[2 * kN], kLog2e, t_hi[0]); t_hi[1] = fmaf(mrow[3 * kN], kLog2e, t_hi[1]);
+            }
+            if (analytic) {
+                // wave-uniform branch, kept a real branch (the empty asm cannot be speculated): the analytic shift mask is
+                // 3 VALU instructions per element and only the last window row / column of shifted blocks needs it
+                asm volatile("" ::: "memory");
+                const uint32_t ids = *reinterpret_cast<const uint32_t*>(&rid[oSt + 16 * qt]);
+                if ((int)(ids & 0xff) != kreg) t_lo[0] += -100.0f * kLog2e;
+                if ((int)((ids >> 8) & 0xff) != kreg) t_lo[1] += -100.0f * kLog2e;
+                if ((int)((ids >> 16) & 0xff) != kreg) t_hi[0] += -100.0f * kLog2e;
+                if ((int)((ids >> 24) & 0xff) != kreg) t_hi[1] += -100.0f * kLog2e;
+            }
+            const v2f e_lo = pk_sub_asm(t_lo, v2f{lq[0], lq[1]}), e_hi = pk_sub_asm(t_hi, v2f{lq[2], lq[3]});
+            const v2f p_lo = {__builtin_amdgcn_exp2f(e_lo[0]), __builtin_amdgcn_exp2f(e_lo[1])};
+            const v2f p_hi = {__builtin_amdgcn_exp2f(e_hi[0]), __builtin_amdgcn_exp2f(e_hi[1])};
+            // p comes out of the transcendental unit (v_exp_f32): TRANS -> VALU is a software hazard as well, so this product
+            // stays a C++ expression too
+            const v2f ds_lo = p_lo * d_lo, ds_hi = p_hi * d_hi;
+            {
+                const v2f a = pk_add_asm(v2f{dB[qt][0], dB[qt][1]}, ds_lo), b = pk_add_asm(v2f{dB[qt][2], dB[qt][3]}, ds_hi);
+                dB[qt] = v4f{a[0], a[1], b[0], b[1]};
+            }
+            const v4bf pp = {(__bf16)p_lo[0], (__bf16)p_lo[1], (__bf16)p_hi[0], (__bf16)p_hi[1]};
+            const v4bf sp = {(__bf16)ds_lo[0], (__bf16)ds_lo[1], (__bf16)ds_hi[0], (__bf16)ds_hi[1]};
+            *reinterpret_cast<v4bf*>(&dSt[oW + 16 * qt]) = sp;
+            if ((qt & 1) || qt == kTiles - 1) {
+                const bool single = !(qt & 1);  // last, unpaired tile: upper 16 k-slots are zero
+                const v8bf pf = single ? v8bf{pp[0], pp[1], pp[2], pp[3], 0, 0, 0, 0}
+                                       : v8bf{pprev[0], pprev[1], pprev[2], pprev[3], pp[0], pp[1], pp[2], pp[3]};
+                const v8bf sf = single ? v8bf{sp[0], sp[1], sp[2], sp[3], 0, 0, 0, 0}
+                                       : v8bf{sprev[0], sprev[1], sprev[2], sprev[3], sp[0], sp[1], sp[2], sp[3]};
+                const int r0 = 16 * (single ? qt : qt - 1);  // queries 32s + 4lg + (0..3) | +16
+                const __bf16* dlo = &dOs[oTr + r0 * kTP];
+                const __bf16* qlo = &Qs[oTr + r0 * kTP];
+                const v4s d_hi0 = single ? z4s : tr_read(dlo + 16 * kTP), d_hi1 = single ? z4s : tr_read(dlo + 16 * kTP + 16);
+                const v4s q_hi0 = single ? z4s : tr_read(qlo + 16 * kTP), q_hi1 = single ? z4s : tr_read(qlo + 16 * kTP + 16);
+                dv0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(dlo), d_hi0), pf, dv0, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(dlo + 16), d_hi1), pf, dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(qlo), q_hi0), sf, dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(qlo + 16), q_hi1), sf, dk1, 0, 0, 0);
+            }
+            pprev = pp;
+            sprev = sp;
+        }
+        if (tkk >= 0) {
+            __bf16* base = dqkv + (img + tkk) * C3 + hoff + 4 * lg;
+            v4bf a, c, e, f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a[r] = (__bf16)(dk0[r] * g.scale); c[r] = (__bf16)(dk1[r] * g.scale);
+                e[r] = (__bf16)dv0[r]; f[r] = (__bf16)dv1[r];
+            }
+            GRIT_ST4(base + g.C, a);
+            GRIT_ST4(base + g.C + 16, c);
+            GRIT_ST4(base + 2 * g.C, e);
+            GRIT_ST4(base + 2 * g.C + 16, f);
+        }
+        if (__any(tkk < 0)) {  // gradient of window-padding tokens flows to pad_qkv: reduce over the tile first
+            const float keep = tkk < 0 ? 1.f : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = sum16(dk0[r] * keep) * g.scale, c = sum16(dk1[r] * keep) * g.scale;
+                const float e = sum16(dv0[r] * keep), f = sum16(dv1[r] * keep);
+                if (l15 == 0) {
+                    atomicAdd(&pad_s[kHd + 4 * lg + r], a);
+                    atomicAdd(&pad_s[kHd + 16 + 4 * lg + r], c);
+                    atomicAdd(&pad_s[2 * kHd + 4 * lg + r], e);
+                    atomicAdd(&pad_s[2 * kHd + 16 + 4 * lg + r], f);
+                }
+            }
+        }
+        __syncthreads();  // dSt complete
+
+        // ================= phase 2: wave w = query tile w : dQ^T[d][q] = scale * sum_k K^T[d][k] dS^T[k][q]
+        // k-slot (lg, j) = key 32s + 8lg + j; the last step covers keys 128..143 only (lanes lg >= 2 contribute zeros)
+        v4f dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
+        int oS2 = (8 * lg + trq) * kSP + 16 * w + 4 * trp, oK2 = (8 * lg + trq) * kTP + 4 * trp;
+        int oS2d = trq * kSP + 16 * w + 4 * trp - 128 * kSP, oK2d = trq * kTP + 4 * trp - 128 * kTP;  // dead lanes, s5 = 4
+        asm volatile("" : "+v"(oS2), "+v"(oK2), "+v"(oS2d), "+v"(oK2d));
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            const bool live = (s5 < 4) || (lg < 2);  // dead lanes read a valid address (EXEC stays full), then zero
+            const __bf16* slo = &dSt[(live ? oS2 : oS2d) + 32 * s5 * kSP];
+            const __bf16* klo = &Ks[(live ? oK2 : oK2d) + 32 * s5 * kTP];
+            v8bf sf = join(tr_read(slo), tr_read(slo + 4 * kSP));
+            if (!live) sf = v8bf{0, 0, 0, 0, 0, 0, 0, 0};
+            dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(klo), tr_read(klo + 4 * kTP)), sf, dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(klo + 16), tr_read(klo + 4 * kTP + 16)), sf, dq1, 0, 0, 0);
+        }
+        if (tkk >= 0) {
+            __bf16* base = dqkv + (img + tkk) * C3 + hoff + 4 * lg;
+            v4bf a, c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = (__bf16)(dq0[r] * g.scale); c[r] = (__bf16)(dq1[r] * g.scale); }
+            GRIT_ST4(base, a);
+            GRIT_ST4(base + 16, c);
+        }
+        if (__any(tkk < 0)) {
+            const float keep = tkk < 0 ? 1.f : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = sum16(dq0[r] * keep) * g.scale, c = sum16(dq1[r] * keep) * g.scale;
+                if (l15 == 0) {
+                    atomicAdd(&pad_s[4 * lg + r], a);
+                    atomicAdd(&pad_s[16 + 4 * lg + r], c);
+                }
+            }
+        }
+    }
+    // ---- flush the register-resident d(bias) of this workgroup's windows and the padded-token gradient
+#pragma unroll
+    for (int qt = 0; qt < kTiles; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            atomicAdd(&dbias[((size_t)h * kN + 16 * qt + 4 * lg + r) * kN + 16 * w + l15], dB[qt][r]);
+    __syncthreads();
+    if (tid < 3 * kHd) {
+        const float v = pad_s[tid];
+        if (v != 0.f) atomicAdd(&dpad[(tid / kHd) * g.C + hoff + (tid % kHd)], v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // fp32 arithmetic (the parity path: fp32 weights -> the reference's fp32 WindowAttention within 1e-4, swin_model.py:155-186)
 // ---------------------------------------------------------------------------------------------------
@@ -794,9 +1080,24 @@ int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pa
     static bool lds_attr_set = false;  // idempotent attribute, racing first calls set the same value
     if (!lds_attr_set) {
         if (hipFuncSetAttribute((const void*)winattn_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)winattn_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds) != hipSuccess)
+            hipFuncSetAttribute((const void*)winattn_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)winattn_bwd_dma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdDmaLds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)winattn_bwd_dma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdDmaLds) != hipSuccess)
             return GRIT_ERR_LAUNCH;
         lds_attr_set = true;
+    }
+    // GRIT_WINATTN_BWD_DMA=0: the register-staged kernel of rounds 1-2 (A/B knob)
+    static const bool use_dma = !(getenv("GRIT_WINATTN_BWD_DMA") && atoi(getenv("GRIT_WINATTN_BWD_DMA")) == 0);
+    if (use_dma) {
+        if (mask)
+            hipLaunchKernelGGL(winattn_bwd_dma<true>, dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdDmaLds, (hipStream_t)stream,
+                               (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
+                               (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad);
+        else
+            hipLaunchKernelGGL(winattn_bwd_dma<false>, dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdDmaLds, (hipStream_t)stream,
+                               (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
+                               (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad);
+        return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
     }
     if (mask)
         hipLaunchKernelGGL(winattn_bwd<true>, dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdLds, (hipStream_t)stream,

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -48,6 +48,13 @@ SIGNATURES = {
     "grit_colsum": [_ptr, _int, _int, _int, _int, _ptr, _ptr],
     "grit_slab_sum": [_ptr, _int, _c.c_long, _int, _c.c_long, _ptr, _int, _ptr],
     "grit_slab_sum_grouped": [_ptr, _int, _ptr],
+    "grit_msda_geometry_fwd": [_ptr, _ptr, _int, _ptr, _int, _ptr, _c.c_long, _int, _int, _int, _ptr, _ptr, _ptr],
+    "grit_msda_geometry_bwd": [_ptr, _ptr, _ptr, _ptr, _int, _ptr, _c.c_long, _int, _int, _int, _int, _ptr, _ptr, _ptr],
+    "grit_box_refine": [_ptr, _int, _ptr, _int, _c.c_long, _ptr, _ptr],
+    "grit_relu_dropout_fwd": [_ptr, _c.c_long, _f32, _ptr, _int, _ptr, _ptr],
+    "grit_relu_dropout_bwd": [_ptr, _ptr, _c.c_long, _f32, _ptr, _int, _ptr, _ptr],
+    "grit_gate_bwd_a": [_ptr, _ptr, _ptr, _ptr, _ptr, _c.c_long, _int, _f32, _int, _ptr, _ptr],
+    "grit_gate_bwd_b": [_ptr, _ptr, _ptr, _ptr, _c.c_long, _int, _f32, _int, _ptr, _ptr, _ptr, _ptr],
     "grit_wgrad_small_splits": [_int, _int, _int],
     "grit_wgrad_small": [_ptr, _c.c_long, _ptr, _c.c_long, _int, _int, _int, _int, _ptr, _ptr, _ptr],
     "grit_attn_fwd_f32": _ATTN_IN + [_int] * 5 + [_f32, _f32, _u64, _ptr, _ptr, _ptr, _ptr],

@@ -19,6 +19,7 @@ from grit_amd.models.common.pos_embed import FeedForward, sinusoid_encoding_tabl
 from grit_amd.ops import backend
 from grit_amd.ops import decode_inputs
 from grit_amd.ops import gate as gate_ops
+from grit_amd.ops import glue
 from grit_amd.ops import weights_epoch
 from grit_amd.ops.linear import Linear, mark_single_use
 
@@ -77,8 +78,18 @@ class ParallelAttentionLayer(GeneratorLayer):
             enc1 = self.vis_att1(self_att, y1, y1, mask_y1, q_proj=q12[..., :d])
             enc2 = self.vis_att2(self_att, y2, y2, mask_y2, q_proj=q12[..., d:])
             return self.pwff(gate_ops.gated_merge(self_att, enc1, enc2, mask_pad, self.fc_alpha1)) * mask_pad
-        enc1 = self.vis_att1(self_att, y1, y1, mask_y1) * mask_pad  # grid branch
-        enc2 = self.vis_att2(self_att, y2, y2, mask_y2) * mask_pad  # region branch
+        if self.training and torch.is_grad_enabled() and self_att.is_cuda:
+            # training step on the device: masks, concatenations, sigmoids, products, sum and scale of the merge below as pack /
+            # ONE fc_alpha1 GEMM / fuse forward and two launches + the GEMMs backward (grit_amd/ops/glue.py)
+            e1 = self.vis_att1(self_att, y1, y1, mask_y1)
+            e2 = self.vis_att2(self_att, y2, y2, mask_y2)
+            merged = glue.gated_merge_train(self_att, e1, e2, mask_pad, self.fc_alpha1)
+            if merged is not None:
+                return self.pwff(merged) * mask_pad
+            enc1, enc2 = e1 * mask_pad, e2 * mask_pad
+        else:
+            enc1 = self.vis_att1(self_att, y1, y1, mask_y1) * mask_pad  # grid branch
+            enc2 = self.vis_att2(self_att, y2, y2, mask_y2) * mask_pad  # region branch
         gate1 = torch.sigmoid(self.fc_alpha1(torch.cat([self_att, enc1], -1)))
         gate2 = torch.sigmoid(self.fc_alpha1(torch.cat([self_att, enc2], -1)))  # fc_alpha1 again, as in the reference
         fused = (enc1 * gate1 + enc2 * gate2) / np.sqrt(2)

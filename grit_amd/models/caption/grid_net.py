@@ -46,6 +46,14 @@ class GridFeatureNetwork(nn.Module):
         """The input stage: project to d_model, ReLU, dropout, LayerNorm."""
         return self.layer_norm(self.dropout(F.relu(self.fc(tokens))))
 
+    def last(self, input, mask=None):
+        """Output of the LAST layer only, [B, N, d_model] -- all the captioner consumes (reference transformer.py:69 takes
+        out[:, -1]): the training step skips the [B, n_layers, N, d_model] collection and the slice / copy gradients behind it."""
+        x = self.embed(input)
+        for layer in self.layers:
+            x = layer(x, x, x, mask)
+        return x
+
     def forward(self, input, mask=None):
         """-> (outs [B, n_layers, N, d_model], mask), outs[:, i] being the output of layer i."""
         x = self.embed(input)

@@ -63,8 +63,11 @@ class Transformer(BaseCaptioner):
         vis = images if self.cached_features else self.detector(images)
         vis = dict(vis)
         if self.config.model.use_gri_feat:
-            grid, _ = self.grid_net(vis['gri_feat'], vis['gri_mask'])
-            vis['gri_feat'] = grid[:, -1]
+            if len(self.grid_net.layers) > 0 and type(self.grid_net).forward is GridFeatureNetwork.forward:
+                vis['gri_feat'] = self.grid_net.last(vis['gri_feat'], vis['gri_mask'])  # == grid_net(...)[0][:, -1]
+            else:
+                grid, _ = self.grid_net(vis['gri_feat'], vis['gri_mask'])
+                vis['gri_feat'] = grid[:, -1]
         return vis
 
     def forward(self, images, seq, use_beam_search=False, max_len=20, eos_idx=3, beam_size=5, out_size=1,

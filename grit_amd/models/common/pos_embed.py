@@ -2,6 +2,7 @@
 import torch
 from torch import nn
 from torch.nn import functional as F
+from grit_amd.ops.glue import relu_dropout
 from grit_amd.ops.layer_norm import add_layer_norm, linear_add_layer_norm
 from grit_amd.ops.linear import Linear
 
@@ -35,7 +36,10 @@ class FeedForward(nn.Module):
         self.layer_norm = nn.LayerNorm(d_model)
 
     def forward(self, input):
-        hidden = self.dropout_2(F.relu(self.fc1(input)))
+        if self.training and torch.is_grad_enabled() and input.is_cuda:
+            hidden = relu_dropout(self.fc1(input), self.dropout_2.p, True)  # ReLU + dropout: one launch each way
+        else:
+            hidden = self.dropout_2(F.relu(self.fc1(input)))
         if self.training and torch.is_grad_enabled() and input.is_cuda:
             ln = self.layer_norm  # fc2 + dropout + residual + LayerNorm as one autograd node
             return linear_add_layer_norm(hidden, self.fc2, input, None, ln.weight, ln.bias, ln.eps, self.dropout.p, True)[1]

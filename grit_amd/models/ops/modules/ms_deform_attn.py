@@ -11,6 +11,7 @@ from torch.nn.init import constant_, xavier_uniform_
 
 from grit_amd.ops.linear import Linear
 
+from grit_amd.ops.glue import sampling_geometry
 from grit_amd.ops.msda import ms_deform_attn_stacked
 
 from ..functions.ms_deform_attn_func import deformable_sample
@@ -74,6 +75,20 @@ class MSDeformAttn(nn.Module):
             value = value.view(N, Len_in, M, self.d_model // M)
         # the (tiny) query-side arithmetic runs in fp32 whatever the projections' dtype: locations need sub-pixel precision
         cdt = torch.float64 if (stacked is None and value.dtype == torch.float64) else torch.float32
+        fused = None
+        if cdt == torch.float32 and reference_points.shape[-1] in (2, 4):
+            # offsets / softmax / reference-point arithmetic below as ONE launch forward and one backward (grit_amd/ops/glue.py)
+            fused = sampling_geometry(self.sampling_offsets(query), self.attention_weights(query), reference_points,
+                                      input_spatial_shapes, M, L, P)
+        if fused is not None:
+            locations, weights = fused
+            if stacked is not None:
+                sampled = ms_deform_attn_stacked(stacked[0], stacked[1], input_spatial_shapes, input_level_start_index,
+                                                 locations, weights)
+            else:
+                sampled = deformable_sample(value, input_spatial_shapes, input_level_start_index, locations, weights,
+                                            self.im2col_step).to(value.dtype)
+            return self.output_proj(sampled) if project else sampled
         offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2).to(cdt)
         weights = F.softmax(self.attention_weights(query).view(N, Len_q, M, L * P).to(cdt), -1).view(N, Len_q, M, L, P)
         reference_points = reference_points.to(cdt)

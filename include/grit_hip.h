@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 26
+#define GRIT_ABI_VERSION 27
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -438,6 +438,39 @@ int grit_gate_pack(const void* self_att, const void* enc1, const void* enc2, con
                    void* X, void* stream);
 int grit_gate_fuse(const void* enc1, const void* enc2, const void* gates, const void* mask_pad, int rows, int d, float divisor,
                    int is_bf16, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Element-wise glue of the decoders in the TRAINING step, one launch each instead of a chain of 4-14 torch launches at the ~6 us
+ * dependent-launch floor (grit_amd/csrc/glue.hip).  fp32 arithmetic in the reference's operation order, outputs rounded once.
+ *
+ * grit_msda_geometry_fwd / _bwd -- MSDeformAttn.forward's query-side arithmetic, models/ops/modules/ms_deform_attn.py:97-113:
+ *   offsets [rows, M, L, P, 2], logits [rows, M, L*P] (bf16 or f32: the outputs of sampling_offsets / attention_weights; rows =
+ *   B * Lq), ref [rows, L, ref_dim] f32 (ref_dim 4: box cx, cy, w, h -> loc = ref_xy + offset / P * wh * 0.5; ref_dim 2: point ->
+ *   loc = ref_xy + offset / (W_l, H_l), spatial_shapes [L, 2] int64 (H, W)), L*P <= 64
+ *     -> loc [rows, M, L, P, 2] f32, attn_w [rows, M, L*P] f32 = softmax(logits) over the L*P points.
+ *   backward: grad_offsets / grad_logits (bf16 or f32) from grad_loc, grad_attn_w, attn_w; ref receives no gradient (the
+ *   reference detaches it: det_module.py:52).
+ * grit_box_refine -- DetectionModule.bbox_refine, det_module.py:40-53: out [rows, 4] f32 = sigmoid(delta + inverse_sigmoid(ref))
+ *   (ref_dim 4) or sigmoid(cat(delta[:2] + inverse_sigmoid(ref), delta[2:])) (ref_dim 2); delta [rows, 4] bf16 / f32.
+ * grit_relu_dropout_fwd / _bwd -- dropout(relu(x)) of the position-wise FFNs (det_module.py:302-304, pos_embed.py:44-48), n
+ *   elements; the keep mask is a counter hash of (element index, *seed_dev) regenerated in the backward (dx = dy * keep / (1 - p)
+ *   where x > 0); p = 0: plain ReLU and its gradient.
+ * grit_gate_bwd_a / _b -- backward of the gated merge of models/caption/cap_generator.py:44-56 around the fc_alpha1 GEMMs (forward:
+ *   grit_gate_pack, GEMM, grit_gate_fuse): a: d_gates [2 rows, d] from d_out, enc1, enc2, gates, mask_pad; b: d_self, d_enc1,
+ *   d_enc2 [rows, d] from d_out, gates, mask_pad and dX [2 rows, 2 d] = d_gates @ W.  One dtype (bf16 / f32) for all tensors.
+ * ------------------------------------------------------------------------------------------------------ */
+int grit_msda_geometry_fwd(const void* offsets, const void* logits, int in_is_bf16, const float* ref, int ref_dim,
+                           const int64_t* spatial_shapes, long rows, int M, int L, int P, float* loc, float* attn_w, void* stream);
+int grit_msda_geometry_bwd(const float* grad_loc, const float* grad_attn_w, const float* attn_w, const float* ref, int ref_dim,
+                           const int64_t* spatial_shapes, long rows, int M, int L, int P, int out_is_bf16, void* grad_offsets,
+                           void* grad_logits, void* stream);
+int grit_box_refine(const void* delta, int delta_is_bf16, const float* ref, int ref_dim, long rows, float* out, void* stream);
+int grit_relu_dropout_fwd(const void* x, long n, float p, const uint64_t* seed_dev, int is_bf16, void* y, void* stream);
+int grit_relu_dropout_bwd(const void* x, const void* dy, long n, float p, const uint64_t* seed_dev, int is_bf16, void* dx, void* stream);
+int grit_gate_bwd_a(const void* d_out, const void* enc1, const void* enc2, const void* gates, const void* mask_pad, long rows, int d,
+                    float divisor, int is_bf16, void* d_gates, void* stream);
+int grit_gate_bwd_b(const void* d_out, const void* gates, const void* mask_pad, const void* dX, long rows, int d, float divisor,
+                    int is_bf16, void* d_self, void* d_enc1, void* d_enc2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Key / value cache of step-wise decoding under beam search (reference models/common/attention.py:166-181 appends with torch.cat,

@@ -1,6 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r03
-python tools/bench_small_wgrad.py 2>&1 | tail -12
-bash tools/micro/prof_step.sh 2>&1 | grep -E "wgrad_small|slab_sum|colsum|GPU busy"
-bash tools/micro/ab_env.sh GRIT_WGRAD_SMALL 0 1
+GRIT_TEST_SEED_GUARD=1 timeout 2400 python -m pytest tests -q -m gpu > gpurun_out/r03/gpu_tests_guard.log 2>&1; echo "gpu tests rc=$?"
+grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/r03/gpu_tests_guard.log | tail -15
+grep -E "^E  " gpurun_out/r03/gpu_tests_guard.log | cut -c1-300 | head -20
+bash tools/micro/ab_env.sh GRIT_FUSED_GLUE 0 1

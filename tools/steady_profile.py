@@ -35,6 +35,34 @@ def main(out_dir, nwin=2):
           f"GPU busy {tot / 1e6 / nwin:.2f} ms/step, GEMM (hipBLASLt/rocBLAS) {gemm / 1e6 / nwin:.2f} ms/step")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
         print(f"{v[0] / 1e6 / nwin:8.2f} ms/step  calls/step {v[1] / nwin:7.1f}  avg {v[0] / v[1] / 1e3:9.1f} us  {k[:140]}")
+    # the decoder phase of a step: from the first MSDeformAttn forward launch (decoder layer 0) to the end of the last MSDeformAttn
+    # backward work (decoder layer 0 again): deformable decoder forward after its first sampling, grid net, caption decoder, loss,
+    # and their backward passes -- thousands of small dependent kernels.  Busy time inside it, kernel count, and how much of the
+    # busy time belongs to kernels shorter than 20 us.
+    win_rows = [r for r in rows if start <= int(r["Start_Timestamp"]) < end]
+    spans, cur_first, last_bwd = [], None, None
+    for r in win_rows:
+        nm, s0, e0 = r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if "msda_fwd" in nm and (cur_first is None or s0 - cur_first[0] > 30e6):
+            if cur_first is not None and last_bwd is not None:
+                spans.append((cur_first[0], last_bwd))
+            cur_first, last_bwd = (s0,), None
+        if "msda_bwd" in nm or "msda_stage_flush" in nm:
+            last_bwd = e0
+    if cur_first is not None and last_bwd is not None:
+        spans.append((cur_first[0], last_bwd))
+    if spans:
+        tot_span = tot_busy = tot_small = n_k = 0
+        for a, b in spans:
+            ks = [r for r in win_rows if a <= int(r["Start_Timestamp"]) < b]
+            tot_span += b - a
+            tot_busy += sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ks)
+            tot_small += sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ks
+                             if int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) < 20000)
+            n_k += len(ks)
+        n = len(spans)
+        print(f"\ndecoder phase (first msda_fwd .. last msda_bwd), mean of {n}: span {tot_span / n / 1e6:.2f} ms, GPU busy "
+              f"{tot_busy / n / 1e6:.2f} ms in {n_k / n:.0f} kernels, of which {tot_small / n / 1e6:.2f} ms in kernels < 20 us")
     # where the GPU waits for the host: idle gaps between consecutive kernels inside the window
     win = [r for r in rows if start <= int(r["Start_Timestamp"]) < end]
     gaps, busy_until = [], int(win[0]["End_Timestamp"])

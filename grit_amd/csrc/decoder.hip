@@ -133,7 +133,7 @@ void kv_append(const uint4* __restrict__ old_k, const uint4* __restrict__ old_v,
 // Fourteen launches in the composed form (eq, not, float, triu of ones, or, cat, add_, two embeddings, add, casts), one here.
 template <typename T>
 __global__ __launch_bounds__(64)
-void decode_step_inputs(const int64_t* __restrict__ tokens, int64_t pad_idx, const T* __restrict__ word_emb,
+void decode_step_inputs(const int64_t* __restrict__ tokens, int64_t pad_idx, const T* __restrict__ word_emb, int vocab,
                         const T* __restrict__ pos_emb, int n_pos, int d, int64_t* __restrict__ running_seq,
                         const uint8_t* __restrict__ old_mask, int t_old, T* __restrict__ x, T* __restrict__ mask_pad,
                         uint8_t* __restrict__ new_mask) {
@@ -149,7 +149,10 @@ void decode_step_inputs(const int64_t* __restrict__ tokens, int64_t pad_idx, con
     }
     for (int i = tid; i < t_old; i += 64) new_mask[(size_t)r * (t_old + 1) + i] = old_mask[(size_t)r * t_old + i];
     if (pos >= n_pos) pos = n_pos - 1;  // the host checks the step count against the table; never read out of bounds
-    const T* w = word_emb + (size_t)tok * d;
+    // a token id outside the table (torch's embedding would raise) must never become an out-of-bounds read: such a row reads
+    // row 0; ids come from this library's own beam step, so this is a guard, not a code path
+    const int64_t tok_in = (tok >= 0 && tok < vocab) ? tok : 0;
+    const T* w = word_emb + (size_t)tok_in * d;
     const T* p = pos_emb + (size_t)pos * d;
     for (int c = tid; c < d; c += 64) x[(size_t)r * d + c] = from_f<T>(rnd<T>(to_f<T>(w[c]) + to_f<T>(p[c])));
 }
@@ -164,11 +167,11 @@ extern "C" int grit_decode_step_inputs(const int64_t* tokens, int64_t pad_idx, c
         return GRIT_ERR_BAD_ARG;
     if (is_bf16)
         hipLaunchKernelGGL(decode_step_inputs<__bf16>, dim3(rows), dim3(64), 0, (hipStream_t)stream, tokens, pad_idx,
-                           (const __bf16*)word_emb, (const __bf16*)pos_emb, n_pos, d, running_seq, old_mask, t_old, (__bf16*)x,
+                           (const __bf16*)word_emb, vocab, (const __bf16*)pos_emb, n_pos, d, running_seq, old_mask, t_old, (__bf16*)x,
                            (__bf16*)mask_pad, new_mask);
     else
         hipLaunchKernelGGL(decode_step_inputs<float>, dim3(rows), dim3(64), 0, (hipStream_t)stream, tokens, pad_idx,
-                           (const float*)word_emb, (const float*)pos_emb, n_pos, d, running_seq, old_mask, t_old, (float*)x,
+                           (const float*)word_emb, vocab, (const float*)pos_emb, n_pos, d, running_seq, old_mask, t_old, (float*)x,
                            (float*)mask_pad, new_mask);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }

@@ -555,7 +555,7 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     }
 }
 
-// DMA-staged variant (the default): LDS plan, 161 808 of the 163 840 bytes of the CU:
+// DMA-staged variant (opt-in, GRIT_WINATTN_BWD_DMA=1): LDS plan, 161 808 of the 163 840 bytes of the CU:
 //   bias slab, TRANSPOSED [key][query], as bf16 with a 152-element pitch (conflict-free 8-byte reads per half-wave): 43 776 B.  The
 //     slab is the output of grit_relbias_fwd on a bf16 table in the training step, so the conversion is exact there; with an
 //     fp32 table it rounds the bias to bf16 inside this kernel only (2^-9 relative on an O(0.1) logit term, below the bf16
@@ -1086,8 +1086,9 @@ int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pa
             return GRIT_ERR_LAUNCH;
         lds_attr_set = true;
     }
-    // GRIT_WINATTN_BWD_DMA=0: the register-staged kernel of rounds 1-2 (A/B knob)
-    static const bool use_dma = !(getenv("GRIT_WINATTN_BWD_DMA") && atoi(getenv("GRIT_WINATTN_BWD_DMA")) == 0);
+    // GRIT_WINATTN_BWD_DMA=1: the DMA-staged variant (measured: equal on stages 0 / 1, 3-9 % slower on stages 2 / 3, the step
+    // 0.25 ms slower -- profiles/r03/negative_results.txt); default: the register-staged kernel
+    static const bool use_dma = getenv("GRIT_WINATTN_BWD_DMA") && atoi(getenv("GRIT_WINATTN_BWD_DMA")) == 1;
     if (use_dma) {
         if (mask)
             hipLaunchKernelGGL(winattn_bwd_dma<true>, dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdDmaLds, (hipStream_t)stream,

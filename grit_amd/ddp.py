@@ -83,6 +83,8 @@ class BucketedDataParallel(nn.Module):
         # data, so every rank sees the change in the same step.  agree_every_step=True reduces the flags in every step
         # (safe for data-dependent graphs; costs a host read of the flags per step).
         self.agree_every_step = agree_every_step
+        import os
+        self.check_agreement = os.environ.get("GRIT_DDP_CHECK_AGREEMENT", "0") == "1"
         self._dead = set()        # agreed: parameters outside the live set (no gradient anywhere in the last step)
         self._used_now = set()    # parameters whose hook fired in the current backward pass
         self._late = set()        # ... and whose gradient is not part of a bucket reduction of this step
@@ -224,7 +226,17 @@ class BucketedDataParallel(nn.Module):
             flags[self._index[p]] = 3
         local_dead = {p for i, p in enumerate(self._params) if not flags[i] & 1}
         flag_work = flag_t = None
-        if self.world > 1 and (self.agree_every_step or not self._decided or self._late or local_dead != self._dead):
+        need_agreement = bool(self.agree_every_step or not self._decided or self._late or local_dead != self._dead)
+        if self.world > 1 and self.check_agreement:
+            # GRIT_DDP_CHECK_AGREEMENT=1 (debug): every rank must have come to the same decision, or the collectives below would
+            # not match up (a data-dependent graph on one rank).  One extra tiny all-reduce + host read per step.
+            probe = torch.tensor([int(need_agreement), -int(need_agreement)], dtype=torch.int32, device=self._params[0].device)
+            dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=self.group)
+            lo_hi = probe.cpu().tolist()
+            if lo_hi[0] != -lo_hi[1]:
+                raise RuntimeError("BucketedDataParallel: the ranks disagree on whether the used-parameter flags must be "
+                                   "exchanged in this step (the graph depends on the data): construct with agree_every_step=True")
+        if self.world > 1 and need_agreement:
             flag_t = torch.tensor(flags, dtype=torch.int32, device=self._params[0].device)
             flag_work = dist.all_reduce(flag_t, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         for b in self.buckets:

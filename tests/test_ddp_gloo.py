@@ -197,6 +197,7 @@ def _phase_worker(rank, world, port, mode, ret):
     torch.manual_seed(5)
     model = Phased()
     ddp = BucketedDataParallel(model, bucket_mb=0.0003, tail_mb=0.0001, repack_unused=(mode == "repack"))
+    ddp.check_agreement = True  # GRIT_DDP_CHECK_AGREEMENT=1: assert every step that the ranks took the same decision
     g = torch.Generator().manual_seed(7)
     data = torch.randn(world * 4, 8, generator=g)
     target = torch.randn(world * 4, 4, generator=g)

@@ -189,3 +189,34 @@ def test_small_map_gradient_rejects_what_it_does_not_cover(monkeypatch):
     assert small_weight_bias_grad(dy, x, True, torch.bfloat16) is None
     dy = torch.randn(100, 128, device='cuda')  # fp32 gradients: the parity path stays on the library
     assert small_weight_bias_grad(dy, x, True, torch.float32) is None
+
+
+def test_fused_gelu_epilogues_against_erf_gelu_over_the_whole_range():
+    """the BIAS_GELU / DGELU epilogues evaluate GELU as x * sigmoid(x * P(x^2)) fitted to the reference's exact erf
+    form (nn.GELU, models/common/swin_model.py:19-37).  Bound the deviation where it can be seen: an identity GEMM (K = N = 128,
+    weight = I) feeds every bf16 value of [-9, 9] through both epilogues; forward against torch's erf GELU and backward against
+    its autograd derivative, both evaluated in fp32 on the same bf16 inputs.  Tolerance: the fit's stated 2.6e-5 / 1.1e-4 absolute
+    plus the bf16 rounding of the stored result (2^-9 relative)."""
+    from grit_amd.ops import gemm as G
+    N = 128
+    vals = torch.linspace(-9, 9, 256 * 1024, device='cuda').bfloat16().unique()
+    M = (vals.numel() + N - 1) // N * N
+    x = torch.zeros(M, device='cuda', dtype=torch.bfloat16)
+    x[:vals.numel()] = vals
+    x = x.view(-1, N).contiguous()
+    eye = torch.eye(N, device='cuda', dtype=torch.bfloat16)
+    zero_b = torch.zeros(N, device='cuda', dtype=torch.bfloat16)
+    pre = torch.empty_like(x)
+    act = G.gemm_nt(x, eye, G.BIAS_GELU, bias=zero_b, aux=pre)
+    assert torch.equal(pre, x)
+    ref = F.gelu(x.float())
+    err = (act.float() - ref).abs()
+    assert float((err - ref.abs() * 2.0 ** -8).max()) <= 3e-5, float(err.max())
+    # derivative: d = (1 . I) * gelu'(x) with an all-ones accumulator operand
+    ones = torch.ones_like(x)
+    part = torch.empty((-(-x.shape[0] // 128), N), device='cuda')
+    d = G.gemm_nt(ones, eye, G.DGELU, aux=x, colsum=part)
+    xr = x.float().requires_grad_(True)
+    F.gelu(xr).sum().backward()
+    derr = (d.float() - xr.grad).abs()
+    assert float((derr - xr.grad.abs() * 2.0 ** -8).max()) <= 1.5e-4, float(derr.max())

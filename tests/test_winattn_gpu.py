@@ -172,3 +172,19 @@ def test_backward_conservation_at_benchmark_size():
     row = y.grad.sum(-1)                                              # [nH, 144]: sum over keys of d(bias)
     assert row.abs().max().item() < 2e-2 * y.grad.abs().sum(-1).max().item() + 1e-3
     assert torch.isfinite(x.grad.float()).all() and torch.isfinite(y.grad).all()
+
+
+def test_dma_staged_backward_variant_passes_the_same_tests():
+    """GRIT_WINATTN_BWD_DMA=1 selects winattn_bwd_dma (operands of the next window DMA'd into a second LDS tile buffer, bias slab
+    as bf16).  The library reads the knob once per process, so the backward tests of this file are re-run in a child process with
+    the knob set (the child never recurses into this test)."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("GRIT_WINATTN_BWD_DMA") == "1":
+        pytest.skip("already the child run")
+    env = dict(os.environ, GRIT_WINATTN_BWD_DMA="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "backward or explicit_mask or properties"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout

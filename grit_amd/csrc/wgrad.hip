@@ -40,16 +40,22 @@ __device__ __forceinline__ v8bf tr_pair(const __bf16* lo, const __bf16* hi) {
     return __builtin_bit_cast(v8bf, r);
 }
 
-__global__ __launch_bounds__(256)
-void wgrad_small(const __bf16* __restrict__ dY, long ldy, const __bf16* __restrict__ X, long ldx, int M, int N, int K, int S,
-                 int rows_per_split, float* __restrict__ dWp, float* __restrict__ dbp, __bf16* __restrict__ dW16,
-                 __bf16* __restrict__ db16) {
-    __shared__ __attribute__((aligned(16))) __bf16 Ys[2][kStep * kPitch];
-    __shared__ __attribute__((aligned(16))) __bf16 Xs[2][kStep * kPitch];
-    __shared__ float colred[4][kTile];
+struct WgradLds {
+    __bf16 Ys[2][kStep * kPitch];
+    __bf16 Xs[2][kStep * kPitch];
+    float colred[4][kTile];
+};
+
+__device__ __forceinline__
+void wgrad_body(const __bf16* __restrict__ dY, long ldy, const __bf16* __restrict__ X, long ldx, int M, int N, int K,
+                int rows_per_split, float* __restrict__ dWp, float* __restrict__ dbp, __bf16* __restrict__ dW16,
+                __bf16* __restrict__ db16, int block_id, WgradLds& lds) {
+    auto& Ys = lds.Ys;
+    auto& Xs = lds.Xs;
+    auto& colred = lds.colred;
 
     const int tiles_k = K / kTile, tiles_n = N / kTile;
-    int id = blockIdx.x;
+    int id = block_id;
     const int tk = id % tiles_k; id /= tiles_k;
     const int tn = id % tiles_n;
     const int s = id / tiles_n;
@@ -168,6 +174,35 @@ void wgrad_small(const __bf16* __restrict__ dY, long ldy, const __bf16* __restri
     }
 }
 
+__global__ __launch_bounds__(256)
+void wgrad_small(const __bf16* __restrict__ dY, long ldy, const __bf16* __restrict__ X, long ldx, int M, int N, int K, int S,
+                 int rows_per_split, float* __restrict__ dWp, float* __restrict__ dbp, __bf16* __restrict__ dW16,
+                 __bf16* __restrict__ db16) {
+    __shared__ __attribute__((aligned(16))) WgradLds lds;
+    wgrad_body(dY, ldy, X, ldx, M, N, K, rows_per_split, dWp, dbp, dW16, db16, (int)blockIdx.x, lds);
+}
+
+// Many problems, one launch: the weight / bias gradients of the short-map Linears of a whole decoder, collected while its
+// backward pass runs and executed together when their consumer (the gradient-bucket wrapper) asks for them.  One problem alone
+// leaves the chip to ~3 workgroups per CU that each crawl through ~13 latency-bound steps (31 us per call inside the step,
+// profiles/r03/negative_results.txt); dozens of problems in one grid fill every CU with independent workgroups.
+struct WgradGroupArgs {
+    grit_wgrad_job job[GRIT_WGRAD_GROUP_MAX];
+    unsigned first_block[GRIT_WGRAD_GROUP_MAX + 1];
+    int rows_per_split[GRIT_WGRAD_GROUP_MAX];
+    int n_jobs;
+};
+
+__global__ __launch_bounds__(256)
+void wgrad_small_grouped(const WgradGroupArgs a) {
+    __shared__ __attribute__((aligned(16))) WgradLds lds;
+    int j = 0;
+    while (j + 1 < a.n_jobs && blockIdx.x >= a.first_block[j + 1]) ++j;
+    const grit_wgrad_job& jb = a.job[j];
+    wgrad_body((const __bf16*)jb.dY, jb.ldy, (const __bf16*)jb.X, jb.ldx, jb.M, jb.N, jb.K, a.rows_per_split[j], jb.dW_partial,
+               jb.db_partial, (__bf16*)nullptr, (__bf16*)nullptr, (int)(blockIdx.x - a.first_block[j]), lds);
+}
+
 }  // namespace
 
 static int rows_per_split(int M, int splits) {
@@ -208,5 +243,33 @@ extern "C" int grit_wgrad_small(const void* dY, long ldy, const void* X, long ld
                        ldx, M, N, K, splits, rows_per_split(M, splits), direct ? (float*)nullptr : (float*)dW_out,
                        direct ? (float*)nullptr : (float*)db_out, direct ? (__bf16*)dW_out : (__bf16*)nullptr,
                        direct ? (__bf16*)db_out : (__bf16*)nullptr);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+extern "C" int grit_wgrad_group_splits(int M) {
+    // inside a grouped launch the other problems fill the chip: a split is simply one pass of the register ring (<= 416 rows)
+    return M <= 0 ? 0 : (M + kMaxSteps * kStep - 1) / (kMaxSteps * kStep);
+}
+
+extern "C" int grit_wgrad_small_grouped(const grit_wgrad_job* jobs, int n_jobs, void* stream) {
+    if (!jobs || n_jobs <= 0 || n_jobs > GRIT_WGRAD_GROUP_MAX) return GRIT_ERR_BAD_ARG;
+    WgradGroupArgs a;
+    a.n_jobs = n_jobs;
+    unsigned long long total = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const grit_wgrad_job& jb = jobs[j];
+        if (!jb.dY || !jb.X || !jb.dW_partial || jb.M <= 0 || jb.N <= 0 || jb.K <= 0) return GRIT_ERR_BAD_ARG;
+        if (jb.N % kTile || jb.K % kTile || jb.ldy % 8 || jb.ldx % 8 || jb.ldy < jb.N || jb.ldx < jb.K || ((uintptr_t)jb.dY % 16) ||
+            ((uintptr_t)jb.X % 16) || ((uintptr_t)jb.dW_partial % 16))
+            return GRIT_ERR_UNSUPPORTED;
+        if (jb.splits != grit_wgrad_group_splits(jb.M)) return GRIT_ERR_BAD_ARG;
+        a.job[j] = jb;
+        a.rows_per_split[j] = rows_per_split(jb.M, jb.splits);
+        a.first_block[j] = (unsigned)total;
+        total += (unsigned long long)(jb.N / kTile) * (jb.K / kTile) * jb.splits;
+        if (total > 0x7fffffffULL) return GRIT_ERR_UNSUPPORTED;
+    }
+    a.first_block[n_jobs] = (unsigned)total;
+    hipLaunchKernelGGL(wgrad_small_grouped, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -56,6 +56,8 @@ SIGNATURES = {
     "grit_gate_bwd_a": [_ptr, _ptr, _ptr, _ptr, _ptr, _c.c_long, _int, _f32, _int, _ptr, _ptr],
     "grit_gate_bwd_b": [_ptr, _ptr, _ptr, _ptr, _c.c_long, _int, _f32, _int, _ptr, _ptr, _ptr, _ptr],
     "grit_wgrad_small_splits": [_int, _int, _int],
+    "grit_wgrad_group_splits": [_int],
+    "grit_wgrad_small_grouped": [_ptr, _int, _ptr],
     "grit_wgrad_small": [_ptr, _c.c_long, _ptr, _c.c_long, _int, _int, _int, _int, _ptr, _ptr, _ptr],
     "grit_attn_fwd_f32": _ATTN_IN + [_int] * 5 + [_f32, _f32, _u64, _ptr, _ptr, _ptr, _ptr],
     "grit_attn_fwd_bf16": _ATTN_IN + [_int] * 5 + [_f32, _f32, _u64, _ptr, _ptr, _ptr, _ptr],
@@ -72,13 +74,20 @@ SIGNATURES = {
     "grit_gemm_bf16_nt": [_ptr, _c.c_long] * 3 + [_int] * 4 + [_ptr, _ptr, _c.c_long, _ptr, _int, _ptr],
 }
 
-SLAB_GROUP_MAX = 16  # GRIT_SLAB_GROUP_MAX
+SLAB_GROUP_MAX = 48  # GRIT_SLAB_GROUP_MAX
+WGRAD_GROUP_MAX = 32  # GRIT_WGRAD_GROUP_MAX
 
 
 class SlabJob(_c.Structure):
     """grit_slab_job of include/grit_hip.h."""
     _fields_ = [("partial", _c.c_void_p), ("group_stride", _c.c_long), ("groups", _c.c_int), ("slabs", _c.c_int),
                 ("n", _c.c_long), ("out", _c.c_void_p), ("out_is_bf16", _c.c_int)]
+
+
+class WgradJob(_c.Structure):
+    """grit_wgrad_job of include/grit_hip.h."""
+    _fields_ = [("dY", _c.c_void_p), ("ldy", _c.c_long), ("X", _c.c_void_p), ("ldx", _c.c_long), ("M", _c.c_int), ("N", _c.c_int),
+                ("K", _c.c_int), ("splits", _c.c_int), ("dW_partial", _c.c_void_p), ("db_partial", _c.c_void_p)]
 
 
 _lib = None

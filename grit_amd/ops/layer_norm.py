@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 
 from grit_amd import lib as _lib
 from grit_amd.ops import backend
-from grit_amd.ops.linear import SlabGroup, fork, join, on_stream, single_use_now, slab_sum
+from grit_amd.ops.linear import SlabGroup, defer_weight_bias_grad, fork, join, on_stream, single_use_now, slab_sum
 from grit_amd.ops.profiling import timed
 
 SUPPORTED_C = (128, 256, 512, 1024, 2048, 4096)
@@ -199,6 +199,14 @@ class _LinearAddLayerNormFn(Function):
         if not inp2.is_contiguous():
             inp2 = inp2.contiguous()
         d_inp = d_lin_w = None
+        deferred = defer_weight_bias_grad(d_branch, inp2, lin_w, None, ctx.needs_input_grad[1], False, ctx.single_use)
+        if deferred is not None:  # short map: the projection's weight gradient joins the scope's grouped launch
+            group.run()
+            if ctx.needs_input_grad[0]:
+                with timed("gemm_lib", flops=2.0 * d_branch.numel() * lin_w.shape[1]):
+                    d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
+            return (d_inp, deferred[0], sums[2].to(lin_w.dtype), dx.view(ctx.shape), None, sums[0], sums[1], None, None, None,
+                    None)
         # small maps inside a deferral scope: the projection's weight gradient beside the chain (grit_amd/ops/linear.py fork)
         side = fork(d_branch, inp2, rows=d_branch.shape[0], single_use=ctx.single_use) \
             if (ctx.needs_input_grad[0] and ctx.needs_input_grad[1]) else None

@@ -73,12 +73,84 @@ def single_use_now(flag):
     return bool(flag) and not _deferral.get("suspended", False)
 
 
+# GRIT_WGRAD_DEFER (default 1): inside a deferral scope the weight / bias gradients of single-use Linears on short maps are not
+# computed by their node at all.  The node returns EMPTY gradient tensors, remembers (dY, X, where the results go), and the
+# scope's owner -- the gradient-bucket wrapper, the only consumer of parameter gradients between backward and the optimizer --
+# has them all computed by ONE grouped launch (grit_wgrad_small_grouped + one grouped slab sum) right before it first reads them
+# (ddp._pack / finish_gradient_sync -> flush_deferred).  ~95 library GEMMs of 24-40 us, ~60 column-sum and ~90 reduction launches
+# per step become a handful of launches that fill the chip.  Safety: a job is only deferred when the parameter has no gradient
+# yet; at flush time the parameter's .grad must still be the very tensor the node returned (autograd keeps -- "steals" -- a fresh
+# contiguous gradient), otherwise the parameter received a second gradient and the run stops with an error instead of training
+# on garbage.
+WGRAD_DEFER = os.environ.get("GRIT_WGRAD_DEFER", "1") != "0"
+_deferral["jobs"] = []
+
+
+def defer_weight_bias_grad(dy2, x2, weight, bias, need_dw, need_db, single_use):
+    """(dW, db) as empty tensors that flush_deferred() will fill, or None when the job must be done by the node itself."""
+    if not (WGRAD_DEFER and single_use and need_dw and _deferral["active"] and dy2.is_cuda and dy2.dtype == torch.bfloat16
+            and x2.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.grad is None
+            and (not need_db or (bias is not None and bias.grad is None and bias.dtype == torch.bfloat16))
+            and not torch.cuda.is_current_stream_capturing()):
+        return None
+    M, N = dy2.shape
+    K = x2.shape[1]
+    if not (M < WGRAD_SMALL_MAX_ROWS and N % 64 == 0 and K % 64 == 0 and dy2.stride(1) == 1 and x2.stride(1) == 1
+            and dy2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0):
+        return None
+    dw = torch.empty((N, K), dtype=torch.bfloat16, device=dy2.device)
+    db = torch.empty((N,), dtype=torch.bfloat16, device=dy2.device) if need_db else None
+    # no reference to dw / db is kept (autograd only adopts a gradient tensor nobody else holds): addresses only
+    _deferral["jobs"].append((dy2, x2, weight, bias if need_db else None, dw.data_ptr(), db.data_ptr() if need_db else 0, M, N, K))
+    return dw, db
+
+
+def flush_deferred():
+    """Compute every deferred weight / bias gradient (one grouped GEMM launch + one grouped reduction per <= 32 problems)."""
+    jobs = _deferral["jobs"]
+    if not jobs:
+        return
+    _deferral["jobs"] = []
+    lib = _lib.load()
+    dev = jobs[0][0].device
+    with _lib.device_guard(dev):
+        for i in range(0, len(jobs), _lib.WGRAD_GROUP_MAX):
+            chunk = jobs[i:i + _lib.WGRAD_GROUP_MAX]
+            sizes, total = [], 0
+            for dy2, x2, w, b, pw, pb, M, N, K in chunk:
+                if w.grad is None or w.grad.data_ptr() != pw or (b is not None and (b.grad is None or b.grad.data_ptr() != pb)):
+                    raise _lib.GritHipError(
+                        "deferred weight gradient: a parameter declared single-use ([%d, %d]) no longer holds the gradient tensor its "
+                        "node returned -- it received a second gradient in the same backward pass; do not mark it single_use "
+                        "(grit_amd.ops.linear.mark_single_use) or run with GRIT_WGRAD_DEFER=0" % (N, K))
+                S = lib.grit_wgrad_group_splits(M)
+                sizes.append((S, total, total + S * N * K))
+                total += S * N * K + (S * N if b is not None else 0)
+            work = torch.empty(total, dtype=torch.float32, device=dev)
+            base = work.data_ptr()
+            table = (_lib.WgradJob * len(chunk))()
+            group = SlabGroup()
+            for t, (job, (S, woff, boff)) in enumerate(zip(chunk, sizes)):
+                dy2, x2, w, b, pw, pb, M, N, K = job
+                table[t] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, base + 4 * woff,
+                                         (base + 4 * boff) if b is not None else None)
+                group.add_raw(work[woff:], 1, 0, S, N * K, pw, True)
+                if b is not None:
+                    group.add_raw(work[boff:], 1, 0, S, N, pb, True)
+            with timed("gemm_own", flops=2.0 * sum(j[6] * j[7] * j[8] for j in chunk)):
+                st = lib.grit_wgrad_small_grouped(table, len(chunk), _lib.current_stream_ptr())
+            _lib.check(st, "grit_wgrad_small_grouped")
+            group.run()  # keeps `work` (and through `chunk` the operands) alive until the launches are enqueued
+
+
 def begin_deferral():
     _deferral["active"] = True
 
 
 def wait_deferred():
-    """The current stream waits for every side stream that still runs deferred weight-gradient work."""
+    """Deferred weight gradients are computed now, and the current stream waits for every side stream that still runs
+    weight-gradient work: call before anything reads parameter gradients."""
+    flush_deferred()
     for side in _deferral["pending"]:
         torch.cuda.current_stream(side.device).wait_stream(side)
     _deferral["pending"].clear()
@@ -181,6 +253,12 @@ class SlabGroup(object):
         self.keep.append(partial)  # the partials must outlive the launch; outputs are owned by the caller
         self.device = partial.device
         return out
+
+    def add_raw(self, partial, groups, group_stride, slabs, n, out_ptr, out_is_bf16):
+        """Same, for a partial block inside a larger workspace and an output that already exists (raw device address)."""
+        self.jobs.append((partial.data_ptr(), group_stride, groups, slabs, n, out_ptr, int(out_is_bf16)))
+        self.keep.append(partial)
+        self.device = partial.device
 
     def run(self):
         if not self.jobs:
@@ -300,6 +378,7 @@ class _LinearFn(Function):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.single_use = single_use
+        ctx.bias_param = bias if single_use else None  # the parameter itself: the deferred path checks its .grad
         with timed("gemm_lib", flops=2.0 * x.numel() * weight.shape[0]):
             return F.linear(x, weight, bias)
 
@@ -315,6 +394,13 @@ class _LinearFn(Function):
             x2 = x2.contiguous()
         dx = dw = db = None
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        deferred = defer_weight_bias_grad(dy2, x2, weight, ctx.bias_param, ctx.needs_input_grad[1], need_b, ctx.single_use)
+        if deferred is not None:  # short map inside a gradient-bucket scope: dW / db come from the scope's grouped launch
+            dw, db = deferred
+            if ctx.needs_input_grad[0]:
+                with timed("gemm_lib", flops=2.0 * dy2.numel() * weight.shape[1]):
+                    dx = torch.mm(dy2, weight).view(x.shape)
+            return dx, dw, db, None
         side = fork(dy2, x2, rows=dy2.shape[0], single_use=ctx.single_use) \
             if (ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or need_b)) else None
         group = SlabGroup() if dy2.is_cuda else None  # dW's and db's partial sums: one reduction launch

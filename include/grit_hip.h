@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 27
+#define GRIT_ABI_VERSION 28
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -305,7 +305,7 @@ int grit_slab_sum(const float* partial, int groups, long group_stride, int slabs
 /* Up to GRIT_SLAB_GROUP_MAX slab sums in ONE launch (same arithmetic per job as grit_slab_sum, job table passed by value): the
  * reductions a backward node owes -- split-M weight gradients, bias-gradient column sums, LayerNorm dgamma / dbeta -- done together
  * instead of as dependent launches of a few microseconds each.  bf16 outputs need 8-byte, f32 outputs 16-byte alignment. */
-#define GRIT_SLAB_GROUP_MAX 16
+#define GRIT_SLAB_GROUP_MAX 48
 typedef struct grit_slab_job {
     const float* partial;   /* group g at partial + g * group_stride, slab s of a group at + s * n */
     long group_stride;
@@ -332,6 +332,19 @@ int grit_slab_sum_grouped(const grit_slab_job* jobs, int n_jobs, void* stream);
 int grit_wgrad_small_splits(int M, int N, int K);
 int grit_wgrad_small(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, void* dW_out,
                      void* db_out, void* stream);
+/* Up to GRIT_WGRAD_GROUP_MAX such problems in ONE launch (job table by value): the deferred weight / bias gradients of a decoder's
+ * short-map Linears (grit_amd/ops/linear.py DeferredWgrads).  Every job writes f32 partials dW_partial [splits, N, K] and, when
+ * db_partial != NULL, [splits, N], splits = grit_wgrad_group_splits(M); the caller reduces them (grit_slab_sum_grouped). */
+#define GRIT_WGRAD_GROUP_MAX 32
+typedef struct grit_wgrad_job {
+    const void* dY; long ldy;
+    const void* X; long ldx;
+    int M, N, K, splits;
+    float* dW_partial;
+    float* db_partial;
+} grit_wgrad_job;
+int grit_wgrad_group_splits(int M);
+int grit_wgrad_small_grouped(const grit_wgrad_job* jobs, int n_jobs, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Adam step on one flat range of the fp32-master / bf16-compute training state (torch.optim.Adam as configured by the

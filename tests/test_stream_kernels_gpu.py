@@ -367,16 +367,16 @@ def test_small_map_weight_gradients_beside_the_chain_equal_the_inline_ones(monke
     class Net(torch.nn.Module):
         def __init__(self):
             super().__init__()
-            self.a = L.Linear(512, 1024)
-            self.b = torch.nn.Linear(1024, 512)
+            self.a = torch.nn.ModuleList(L.Linear(512, 1024) for _ in range(3))
+            self.b = torch.nn.ModuleList(torch.nn.Linear(1024, 512) for _ in range(3))
             self.norm = torch.nn.LayerNorm(512)
             self.twice = L.Linear(512, 512)
             L.mark_single_use(self.a, self.b)
 
         def forward(self, x):
-            for _ in range(3):
-                h = torch.relu(self.a(x))
-                x = linear_add_layer_norm(h, self.b, x, None, self.norm.weight, self.norm.bias, 1e-5, 0.0, True)[1]
+            for a, b in zip(self.a, self.b):
+                h = torch.relu(a(x))
+                x = linear_add_layer_norm(h, b, x, None, self.norm.weight, self.norm.bias, 1e-5, 0.0, True)[1]
                 x = self.twice(self.twice(x))
             return x
 
@@ -385,6 +385,7 @@ def test_small_map_weight_gradients_beside_the_chain_equal_the_inline_ones(monke
     x = torch.randn(8, 600, 512, device=DEV).bfloat16()
     cot = torch.randn(8, 600, 512, device=DEV).bfloat16()
     ddp = BucketedDataParallel(net, bucket_mb=1)
+    monkeypatch.setattr(L, "WGRAD_DEFER", False)  # this test is about the side-stream variant of the per-node path
     results = []
     for knob in (False, True, True):
         monkeypatch.setattr(L, "WGRAD_STREAM_SMALL", knob)
@@ -401,7 +402,67 @@ def test_small_map_weight_gradients_beside_the_chain_equal_the_inline_ones(monke
         results.append(({n: p.grad.clone() for n, p in net.named_parameters()}, deferred))
         monkeypatch.setattr(L, "fork", real_fork)
         monkeypatch.setattr(LNmod, "fork", real_fork)
-    # b three times, a twice (its first application reads the input, which needs no gradient: nothing to overlap with); `twice` never
+    # b[0..2], a[1..2] (a[0] reads the input, which needs no gradient: nothing to overlap with); `twice` never
     assert results[0][1] == 0 and results[1][1] == 5 and results[2][1] == 5
     for n, g in results[0][0].items():
         assert torch.equal(g, results[1][0][n]) and torch.equal(g, results[2][0][n]), n
+
+
+def test_deferred_grouped_weight_gradients(monkeypatch):
+    """GRIT_WGRAD_DEFER: inside a gradient-bucket wrapper's scope the single-use Linears of short maps return EMPTY weight / bias
+    gradients that the wrapper fills with one grouped launch before it packs them (grit_wgrad_small_grouped + one grouped slab
+    sum).  Same gradients as the per-node library path within bf16 accumulation-order noise; nothing pending afterwards; a
+    Linear that is (wrongly) declared single-use but applied twice stops the run with an error instead of a wrong gradient."""
+    from grit_amd.ddp import BucketedDataParallel
+    from grit_amd.lib import GritHipError
+    from grit_amd.ops import linear as L
+    from grit_amd.ops.layer_norm import linear_add_layer_norm
+
+    class Net(torch.nn.Module):
+        def __init__(self, lie=False):
+            super().__init__()
+            self.a = L.Linear(512, 1024)
+            self.b = torch.nn.Linear(1024, 512)
+            self.c = L.Linear(512, 128)
+            self.norm = torch.nn.LayerNorm(512)
+            self.twice = L.Linear(512, 512)
+            L.mark_single_use(self.a, self.b, self.c)
+            if lie:
+                L.mark_single_use(self.twice)
+
+        def forward(self, x):
+            h = torch.relu(self.a(x))
+            x = linear_add_layer_norm(h, self.b, x, None, self.norm.weight, self.norm.bias, 1e-5, 0.0, True)[1]
+            x = self.twice(torch.tanh(self.twice(x)))
+            return x, self.c(x)
+
+    torch.manual_seed(0)
+    net = Net().to(DEV).bfloat16()
+    x = torch.randn(8, 600, 512, device=DEV).bfloat16().requires_grad_(True)
+    cot = torch.randn(8, 600, 512, device=DEV).bfloat16()
+    cot2 = torch.randn(8, 600, 128, device=DEV).bfloat16()
+    ddp = BucketedDataParallel(net, bucket_mb=1)
+    results = []
+    for knob in (False, True):
+        monkeypatch.setattr(L, "WGRAD_DEFER", knob)
+        x.grad = None
+        y, z = ddp(x)
+        ((y.float() * cot.float()).sum() + (z.float() * cot2.float()).sum()).backward()
+        if knob:
+            assert len(L._deferral["jobs"]) + sum(b.packed for b in ddp.buckets) > 0  # something was deferred (or already flushed)
+        ddp.finish_gradient_sync()
+        assert not L._deferral["jobs"] and not L._deferral["active"]
+        torch.cuda.synchronize()
+        results.append({n: p.grad.float().clone() for n, p in net.named_parameters()})
+    for n, g in results[0].items():
+        scale = g.abs().max().item()
+        assert (g - results[1][n]).abs().max().item() <= 2e-2 * scale + 1e-6, n
+    # the lie: `twice` is applied twice but declared single-use
+    monkeypatch.setattr(L, "WGRAD_DEFER", True)
+    bad = BucketedDataParallel(Net(lie=True).to(DEV).bfloat16(), bucket_mb=1)
+    y, z = bad(x)
+    with pytest.raises(GritHipError, match="second gradient"):
+        ((y.float() * cot.float()).sum() + (z.float() * cot2.float()).sum()).backward()
+        bad.finish_gradient_sync()
+    L._deferral["jobs"] = []
+    L.end_deferral()

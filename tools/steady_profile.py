@@ -63,6 +63,15 @@ def main(out_dir, nwin=2):
         n = len(spans)
         print(f"\ndecoder phase (first msda_fwd .. last msda_bwd), mean of {n}: span {tot_span / n / 1e6:.2f} ms, GPU busy "
               f"{tot_busy / n / 1e6:.2f} ms in {n_k / n:.0f} kernels, of which {tot_small / n / 1e6:.2f} ms in kernels < 20 us")
+        inside = collections.defaultdict(lambda: [0, 0])
+        for a, b in spans:
+            for r in win_rows:
+                if a <= int(r["Start_Timestamp"]) < b:
+                    e = inside[r["Kernel_Name"]]
+                    e[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                    e[1] += 1
+        for k, v in sorted(inside.items(), key=lambda kv: -kv[1][1])[:40]:
+            print(f"    in phase: calls/step {v[1] / n:6.1f}  {v[0] / n / 1e6:6.3f} ms/step  avg {v[0] / v[1] / 1e3:7.1f} us  {k[:150]}")
     # where the GPU waits for the host: idle gaps between consecutive kernels inside the window
     win = [r for r in rows if start <= int(r["Start_Timestamp"]) < end]
     gaps, busy_until = [], int(win[0]["End_Timestamp"])

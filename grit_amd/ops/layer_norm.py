@@ -13,7 +13,8 @@ from torch.autograd.function import once_differentiable
 
 from grit_amd import lib as _lib
 from grit_amd.ops import backend
-from grit_amd.ops.linear import SlabGroup, defer_weight_bias_grad, fork, join, on_stream, single_use_now, slab_sum
+from grit_amd.ops.linear import (SlabGroup, defer_slab_group, defer_weight_bias_grad, fork, join, on_stream, single_use_now,
+                                 slab_sum)
 from grit_amd.ops.profiling import timed
 
 SUPPORTED_C = (128, 256, 512, 1024, 2048, 4096)
@@ -163,6 +164,7 @@ class _LinearAddLayerNormFn(Function):
     @staticmethod
     def forward(ctx, inp, lin_w, lin_b, shortcut, scale, weight, bias, eps, drop_p, seed_dev, single_use=False):
         ctx.single_use = single_use
+        ctx.sum_params = (weight, bias, lin_b) if single_use else None  # the parameters whose gradients the node's sums are
         with timed("gemm_lib", flops=2.0 * inp.numel() * lin_w.shape[0]):
             branch = F.linear(inp, lin_w, lin_b)
         C = shortcut.shape[-1]
@@ -201,7 +203,12 @@ class _LinearAddLayerNormFn(Function):
         d_inp = d_lin_w = None
         deferred = defer_weight_bias_grad(d_branch, inp2, lin_w, None, ctx.needs_input_grad[1], False, ctx.single_use)
         if deferred is not None:  # short map: the projection's weight gradient joins the scope's grouped launch
-            group.run()
+            esz = sums.element_size() * sums.shape[-1]
+            if not (ctx.sum_params is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[5] and ctx.needs_input_grad[6]
+                    and sums.dtype == lin_w.dtype
+                    and defer_slab_group(group, [(ctx.sum_params[0], sums.data_ptr()), (ctx.sum_params[1], sums.data_ptr() + esz),
+                                                 (ctx.sum_params[2], sums.data_ptr() + 2 * esz)])):
+                group.run()  # ... and so do the node's LayerNorm / bias sums when all three gradients are wanted
             if ctx.needs_input_grad[0]:
                 with timed("gemm_lib", flops=2.0 * d_branch.numel() * lin_w.shape[1]):
                     d_inp = torch.mm(d_branch, lin_w).view(inp.shape)

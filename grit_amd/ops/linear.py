@@ -84,6 +84,7 @@ def single_use_now(flag):
 # on garbage.
 WGRAD_DEFER = os.environ.get("GRIT_WGRAD_DEFER", "1") != "0"
 _deferral["jobs"] = []
+_deferral["slabs"] = []
 
 
 def defer_weight_bias_grad(dy2, x2, weight, bias, need_dw, need_db, single_use):
@@ -105,10 +106,64 @@ def defer_weight_bias_grad(dy2, x2, weight, bias, need_dw, need_db, single_use):
     return dw, db
 
 
-def flush_deferred():
-    """Compute every deferred weight / bias gradient (one grouped GEMM launch + one grouped reduction per <= 32 problems)."""
+def defer_slab_group(group, checks):
+    """Leave the pending reductions of `group` (a SlabGroup whose outputs are parameter gradients of a single-use node: LayerNorm
+    dgamma / dbeta, a projection's bias gradient) to flush_deferred() instead of launching them now.  checks: [(parameter, device
+    address its gradient must have at flush time)].  False (nothing deferred) when the deferral does not apply."""
+    if not (WGRAD_DEFER and _deferral["active"] and group.jobs and not torch.cuda.is_current_stream_capturing()
+            and all(p is not None and p.grad is None for p, _ in checks)):
+        return False
+    _deferral["slabs"].append((group.jobs, group.keep, checks))
+    group.jobs, group.keep = [], []
+    return True
+
+
+_SECOND_GRADIENT = ("deferred %s: a parameter of a node declared single-use %s hold the gradient tensor the node returned (it "
+                    "received a second gradient in the same backward pass, or none at all); do not mark the module single_use "
+                    "(grit_amd.ops.linear.mark_single_use) or run with GRIT_WGRAD_DEFER=0")
+_deferral["unverified"] = []
+
+
+def _verify(p, ptr, what, final):
+    """The parameter's .grad must be the very tensor the node returned.  A flush is triggered from a parameter's post-accumulate
+    hook, i.e. possibly BETWEEN the deliveries of two gradients of one node: a gradient the engine has not delivered yet (it
+    holds the tensor, the memory is valid) is written anyway and checked at the next flush -- before anything can have replaced
+    it, because every bucket pack starts with a flush -- and at the final flush (backward is over) it must be there."""
+    if p.grad is None and not final:
+        _deferral["unverified"].append((p, ptr, what))
+    elif p.grad is None or p.grad.data_ptr() != ptr:
+        raise _lib.GritHipError(_SECOND_GRADIENT % (what, "does not" if p.grad is None else "no longer"))
+
+
+def _verify_earlier(final):
+    earlier, _deferral["unverified"] = _deferral["unverified"], []
+    for p, ptr, what in earlier:
+        _verify(p, ptr, what, final)
+
+
+def _flush_deferred_slabs(into=None, final=False):
+    slabs = _deferral["slabs"]
+    if not slabs:
+        return
+    _deferral["slabs"] = []
+    group = into if into is not None else SlabGroup()
+    for jobs, keep, checks in slabs:
+        for p, ptr in checks:
+            _verify(p, ptr, "reduction", final)
+        group.jobs.extend(jobs)
+        group.keep.extend(keep)
+        group.device = keep[0].device
+    if into is None:
+        group.run()
+
+
+def flush_deferred(final=False):
+    """Compute every deferred weight / bias gradient (one grouped GEMM launch + one grouped reduction per <= 32 problems) and
+    every deferred reduction.  final: backward is over (finish_gradient_sync), every gradient must have been delivered."""
+    _verify_earlier(final)
     jobs = _deferral["jobs"]
     if not jobs:
+        _flush_deferred_slabs(final=final)
         return
     _deferral["jobs"] = []
     lib = _lib.load()
@@ -118,11 +173,9 @@ def flush_deferred():
             chunk = jobs[i:i + _lib.WGRAD_GROUP_MAX]
             sizes, total = [], 0
             for dy2, x2, w, b, pw, pb, M, N, K in chunk:
-                if w.grad is None or w.grad.data_ptr() != pw or (b is not None and (b.grad is None or b.grad.data_ptr() != pb)):
-                    raise _lib.GritHipError(
-                        "deferred weight gradient: a parameter declared single-use ([%d, %d]) no longer holds the gradient tensor its "
-                        "node returned -- it received a second gradient in the same backward pass; do not mark it single_use "
-                        "(grit_amd.ops.linear.mark_single_use) or run with GRIT_WGRAD_DEFER=0" % (N, K))
+                _verify(w, pw, "weight gradient [%d, %d]" % (N, K), final)
+                if b is not None:
+                    _verify(b, pb, "bias gradient [%d]" % N, final)
                 S = lib.grit_wgrad_group_splits(M)
                 sizes.append((S, total, total + S * N * K))
                 total += S * N * K + (S * N if b is not None else 0)
@@ -140,25 +193,36 @@ def flush_deferred():
             with timed("gemm_own", flops=2.0 * sum(j[6] * j[7] * j[8] for j in chunk)):
                 st = lib.grit_wgrad_small_grouped(table, len(chunk), _lib.current_stream_ptr())
             _lib.check(st, "grit_wgrad_small_grouped")
+            if i + _lib.WGRAD_GROUP_MAX >= len(jobs):
+                _flush_deferred_slabs(into=group, final=final)  # the nodes' own deferred reductions ride in the last chunk's launch
             group.run()  # keeps `work` (and through `chunk` the operands) alive until the launches are enqueued
 
 
 def begin_deferral():
+    if not _deferral["active"]:  # leftovers of a pass that ended with an exception
+        abandon_deferred()
     _deferral["active"] = True
 
 
-def wait_deferred():
+def abandon_deferred():
+    """Forget every pending job (after an exception: the gradients of that pass are void anyway)."""
+    _deferral["jobs"], _deferral["slabs"], _deferral["unverified"] = [], [], []
+
+
+def wait_deferred(final=False):
     """Deferred weight gradients are computed now, and the current stream waits for every side stream that still runs
     weight-gradient work: call before anything reads parameter gradients."""
-    flush_deferred()
+    flush_deferred(final)
     for side in _deferral["pending"]:
         torch.cuda.current_stream(side.device).wait_stream(side)
     _deferral["pending"].clear()
 
 
 def end_deferral():
-    wait_deferred()
-    _deferral["active"] = False
+    try:
+        wait_deferred(final=True)
+    finally:
+        _deferral["active"] = False
 
 
 def fork(*inputs, rows=None, single_use=False):

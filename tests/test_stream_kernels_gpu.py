@@ -451,7 +451,7 @@ def test_deferred_grouped_weight_gradients(monkeypatch):
         if knob:
             assert len(L._deferral["jobs"]) + sum(b.packed for b in ddp.buckets) > 0  # something was deferred (or already flushed)
         ddp.finish_gradient_sync()
-        assert not L._deferral["jobs"] and not L._deferral["active"]
+        assert not L._deferral["jobs"] and not L._deferral["slabs"] and not L._deferral["unverified"] and not L._deferral["active"]
         torch.cuda.synchronize()
         results.append({n: p.grad.float().clone() for n, p in net.named_parameters()})
     for n, g in results[0].items():
@@ -464,5 +464,6 @@ def test_deferred_grouped_weight_gradients(monkeypatch):
     with pytest.raises(GritHipError, match="second gradient"):
         ((y.float() * cot.float()).sum() + (z.float() * cot2.float()).sum()).backward()
         bad.finish_gradient_sync()
-    L._deferral["jobs"] = []
+    L.abandon_deferred()
     L.end_deferral()
+    assert not L._deferral["unverified"] and not L._deferral["slabs"]

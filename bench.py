@@ -367,10 +367,21 @@ def mock_worker(args, rank, world, backend):
     return 0
 
 
+def _keep_stdout_for_the_json_line():
+    """RCCL prints a version banner with C stdio (seen: five lines that reach stdout when the process exits, i.e. AFTER the JSON
+    line).  Whoever reads this program's stdout wants exactly one line: native code gets stderr as its fd 1, Python's sys.stdout
+    keeps the real one."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(real, "w", buffering=1)
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch(args)
+    _keep_stdout_for_the_json_line()
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -402,7 +413,12 @@ def main():
     if grad_sync not in ("allreduce", "shard"):
         sys.stderr.write("bench.py: GRIT_GRAD_SYNC must be allreduce or shard\n")
         return 2
-    if world > 1 and not dist.is_initialized():
+    # GRIT_BENCH_SELF_COLLECTIVES=1 (N = 1 only): a one-rank process group whose gradient sync is still issued collective by
+    # collective (grit_amd/ddp.py GRIT_DDP_SELF_COLLECTIVES) -- what the RCCL path costs on the one GPU a box has, wire excluded
+    self_coll = world == 1 and os.environ.get("GRIT_BENCH_SELF_COLLECTIVES") == "1"
+    if self_coll:
+        os.environ["GRIT_DDP_SELF_COLLECTIVES"] = "1"
+    if (world > 1 or self_coll) and not dist.is_initialized():
         dist.init_process_group(backend, rank=rank, world_size=world)
     rank_devices = [{"rank": rank, "device": device.index, "pid": os.getpid()}]
     if world > 1:
@@ -424,7 +440,7 @@ def main():
     if args.fp32:
         wrapped = BucketedDataParallel(model, bucket_mb=64)
     else:  # bf16 compute copies + fp32 master weights; gradients are produced, all-reduced and unscaled in flat bf16 buckets
-        wrapped = Bf16Compute(model, bucket_mb=64, shard_optimizer=(grad_sync == "shard" and world > 1))
+        wrapped = Bf16Compute(model, bucket_mb=64, shard_optimizer=(grad_sync == "shard" and (world > 1 or self_coll)))
     optimizers = build_optimizers(wrapped, config, mode="xe")
     loss_fn = torch.nn.NLLLoss(ignore_index=1)
     # inputs resident in HBM before the timed region; 4 distinct batches per rank, cycled
@@ -577,8 +593,11 @@ def main():
                                           + (" bucketed all-reduce" if grad_sync == "allreduce" or args.fp32 else
                                              " bucketed reduce-scatter + sharded FlatAdam + all-gather of the bf16 weights")
                                           + " (64 MiB flat bf16 buckets, 8 MiB tail), overlapped with backward")
-                       if world > 1 else "none (1 GPU)",
-                       "grad_sync": grad_sync if world > 1 else None, "rccl_env": rccl_env,
+                       if world > 1 else ("none (1 GPU)" if not self_coll else
+                                          backend + " SELF-collectives of a one-rank group (" + grad_sync + "): the sync path "
+                                          "without a wire, not a multi-GPU number"),
+                       "grad_sync": grad_sync if (world > 1 or self_coll) else None, "self_collectives": bool(self_coll),
+                       "rccl_env": rccl_env,
                        "points": args.points, "ragged": bool(args.ragged),
                        "msda_backward_accumulation": "f32" if (args.fp32 or msda_op.F32_ACCUMULATE) else "bf16 (packed atomics)"},
             "mfma_roofline_frac_bf16": value / world * FLOP_PER_IMAGE_FWD_BWD / MFMA_PEAK_BF16,
@@ -604,6 +623,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -279,7 +279,7 @@ class Bf16Compute(nn.Module):
             for b, compute_flat, master_flat, _, _, _ in self._pairs:
                 compute_flat.copy_(master_flat)  # fp32 -> bf16
             weights_epoch.bump()  # the parameters are views of compute_flat: their version counters did not move
-        elif self.shard_optimizer and self.ddp.world > 1:
+        elif self.shard_optimizer and self.ddp.collective:
             import torch.distributed as dist
             # each rank rewrote the compute weights of its slice: gather the others'.  In place (the input is the rank's slice
             # of the output: the layout RCCL's in-place all-gather defines), asynchronous, LAST bucket first -- buckets are
@@ -292,7 +292,7 @@ class Bf16Compute(nn.Module):
         """COLLECTIVE (every rank): bring the fp32 masters and Adam moments of all slices to every rank, so that
         master_state_dict() / optimizer.state_dict() describe the whole model.  No-op unless the optimizer is sharded."""
         self.wait_for_weights()
-        if self.shard_optimizer and self.ddp.world > 1 and not self._masters_current:
+        if self.shard_optimizer and self.ddp.collective and not self._masters_current:
             import torch.distributed as dist
             for b, _, master_flat, _, mom, var in self._pairs:
                 for buf in (master_flat, mom, var):
@@ -302,7 +302,7 @@ class Bf16Compute(nn.Module):
     def master_state_dict(self):
         """fp32 state dict under the reference's key names: masters for trainable tensors, the kept fp32 originals for frozen
         ones, upcast copies for floating buffers that only exist in bf16 (beam caches)."""
-        if self.shard_optimizer and self.ddp.world > 1 and not self._masters_current:
+        if self.shard_optimizer and self.ddp.collective and not self._masters_current:
             raise RuntimeError("sharded optimizer: the masters outside this rank's slice are stale -- call consolidate() on "
                                "EVERY rank first (the engine does at the end of an epoch)")
         self.wait_for_weights()

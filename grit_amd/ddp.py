@@ -71,6 +71,11 @@ class BucketedDataParallel(nn.Module):
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.shard_grads = bool(shard_grads)
+        # GRIT_DDP_SELF_COLLECTIVES=1 (measurement aid): with a process group of ONE rank still issue every collective of the
+        # gradient sync (RCCL runs them as device copies).  Exercises the hooks, the bucket launches on the process group's
+        # stream, the waits and the sharded optimizer on hardware that has a single GPU; the arithmetic is unchanged.
+        import os
+        self.collective = self.world > 1 or (dist.is_initialized() and os.environ.get("GRIT_DDP_SELF_COLLECTIVES") == "1")
         self.bucket_bytes = int(bucket_mb * 2**20)
         self.tail_bytes = int(min(tail_mb, bucket_mb) * 2**20)
         self.wire_dtype = wire_dtype
@@ -83,7 +88,6 @@ class BucketedDataParallel(nn.Module):
         # data, so every rank sees the change in the same step.  agree_every_step=True reduces the flags in every step
         # (safe for data-dependent graphs; costs a host read of the flags per step).
         self.agree_every_step = agree_every_step
-        import os
         self.check_agreement = os.environ.get("GRIT_DDP_CHECK_AGREEMENT", "0") == "1"
         self._dead = set()        # agreed: parameters outside the live set (no gradient anywhere in the last step)
         self._used_now = set()    # parameters whose hook fired in the current backward pass
@@ -194,7 +198,7 @@ class BucketedDataParallel(nn.Module):
         b.packed = True
 
     def _launch(self, b):
-        if self.world == 1 or b.work is not None:
+        if not self.collective or b.work is not None:
             return
         src = b.flat
         if self.wire_dtype is not None and self.wire_dtype != b.flat.dtype:
@@ -227,7 +231,7 @@ class BucketedDataParallel(nn.Module):
         local_dead = {p for i, p in enumerate(self._params) if not flags[i] & 1}
         flag_work = flag_t = None
         need_agreement = bool(self.agree_every_step or not self._decided or self._late or local_dead != self._dead)
-        if self.world > 1 and self.check_agreement:
+        if self.collective and self.check_agreement:
             # GRIT_DDP_CHECK_AGREEMENT=1 (debug): every rank must have come to the same decision, or the collectives below would
             # not match up (a data-dependent graph on one rank).  One extra tiny all-reduce + host read per step.
             probe = torch.tensor([int(need_agreement), -int(need_agreement)], dtype=torch.int32, device=self._params[0].device)
@@ -236,7 +240,7 @@ class BucketedDataParallel(nn.Module):
             if lo_hi[0] != -lo_hi[1]:
                 raise RuntimeError("BucketedDataParallel: the ranks disagree on whether the used-parameter flags must be "
                                    "exchanged in this step (the graph depends on the data): construct with agree_every_step=True")
-        if self.world > 1 and need_agreement:
+        if self.collective and need_agreement:
             flag_t = torch.tensor(flags, dtype=torch.int32, device=self._params[0].device)
             flag_work = dist.all_reduce(flag_t, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         for b in self.buckets:
@@ -263,7 +267,7 @@ class BucketedDataParallel(nn.Module):
             view = self._view_of.get(p)
             in_bucket = view is not None and p.grad is not None and p.grad.data_ptr() == view.data_ptr()
             g = torch.zeros_like(p) if (p.grad is None or in_bucket) else p.grad
-            if self.world > 1:
+            if self.collective:
                 dist.all_reduce(g, group=self.group)
             if view is not None:
                 view.add_(g)

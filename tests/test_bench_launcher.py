@@ -22,6 +22,8 @@ def test_gpus_2_spawns_two_ranks_on_gloo():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout  # rank 0 only
+    # ... and nothing else: native libraries of the workers (RCCL's version banner) get stderr as their fd 1
+    assert r.stdout.strip().splitlines() == lines, r.stdout
     out = json.loads(lines[0])
     assert out["mock"] is True and out["n_gpus"] == 2 and out["steps"] == 3
     devs = out["config"]["rank_devices"]
@@ -43,3 +45,12 @@ def test_refuses_world_size_mismatch():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "4"], env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_native_stdout_of_a_worker_goes_to_stderr():
+    """A C-level write to fd 1 inside a worker (what RCCL's banner is) must not land on the stdout the JSON line goes to."""
+    code = ("import os, sys; sys.argv = ['bench.py']; sys.path.insert(0, %r); import bench; bench._keep_stdout_for_the_json_line(); "
+            "os.write(1, b'native banner\\n'); print('{\"json\": 1}')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip() == '{"json": 1}' and "native banner" in r.stderr

@@ -428,3 +428,73 @@ def test_sharded_optimizer_equals_allreduce_and_single_process(world):
         assert close(shard["sd"][k], v), k
     for i, (m, v) in allred["moments"].items():
         assert same(shard["moments"][i][0], m) and same(shard["moments"][i][1], v), i
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the collectives of the gradient sync on RCCL itself: a one-rank nccl group with GRIT_DDP_SELF_COLLECTIVES=1 issues every
+# all-reduce / reduce-scatter / all-gather the N-rank run would (they degenerate to device copies), on the process group's
+# stream, from the same hooks.  What a 1-GPU box can show of the contract backend.
+def _self_collectives_worker(rank, port, shard, selfc, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if selfc:
+        os.environ["GRIT_DDP_SELF_COLLECTIVES"] = "1"
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    from grit_amd.amp import Bf16Compute
+    from grit_amd.config import default_config
+    from grit_amd.engine.caption_engine import build_optimizers
+    torch.manual_seed(3)
+    model = Wide().cuda()
+    wrapped = Bf16Compute(model, bucket_mb=0.0007, shard_optimizer=shard)
+    assert wrapped.flat_optimizer and wrapped.ddp.collective == selfc
+    opts = build_optimizers(wrapped, default_config(**{'optimizer.xe_lr': 1e-2}), mode='xe')
+    g = torch.Generator().manual_seed(7)
+    xs, ys = torch.randn(8, 8, generator=g).cuda().bfloat16(), torch.randn(8, 4, generator=g).cuda()
+    issued = []
+    if selfc:
+        for name in ("all_reduce", "reduce_scatter_tensor", "all_gather_into_tensor"):
+            def spy(*a, _f=getattr(dist, name), _n=name, **k):
+                issued.append(_n)
+                return _f(*a, **k)
+            setattr(dist, name, spy)
+    losses = []
+    for it in range(3):
+        loss = ((wrapped(xs).float() - ys) ** 2).mean()
+        loss.backward()
+        wrapped.finish_gradient_sync()
+        opts['model'].step()
+        opts['backbone'].step()
+        wrapped.after_optimizer_step()
+        losses.append(loss.item())
+    wrapped.consolidate()
+    torch.cuda.synchronize()
+    ret["sd"] = {k: v.cpu() for k, v in wrapped.master_state_dict().items()}
+    ret["compute"] = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    ret["losses"] = losses
+    ret["issued"] = sorted(set(issued))
+    if selfc:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shard", [False, True])
+def test_gradient_sync_collectives_on_rccl_one_rank(shard):
+    """nccl (= RCCL) backend, one rank, every collective issued: same masters / compute weights / losses, bit for bit, as the run
+    without a process group; the collectives that ran are the mode's own."""
+    out = []
+    for selfc in (False, True):
+        port = _free_port()
+        with mp.Manager() as mgr:
+            ret = mgr.dict()
+            mp.spawn(_self_collectives_worker, args=(port, shard, selfc, ret), nprocs=1, join=True)
+            out.append(dict(ret))
+    plain, rccl = out
+    assert rccl["losses"] == plain["losses"] and rccl["losses"][-1] < rccl["losses"][0]
+    for k, v in plain["sd"].items():
+        assert torch.equal(v, rccl["sd"][k]), k
+    for k, v in plain["compute"].items():
+        assert torch.equal(v, rccl["compute"][k]), k
+    if shard:
+        assert "reduce_scatter_tensor" in rccl["issued"] and "all_gather_into_tensor" in rccl["issued"]
+    else:
+        assert "all_reduce" in rccl["issued"] and "reduce_scatter_tensor" not in rccl["issued"]

@@ -71,7 +71,19 @@ struct Geom {
     int B, H, W, C, nH, shift, nWh, nWw, Hp, Wp, T, nWm;
     float scale;
     int xcd_pairs;  // 1: workgroup id -> (head, window group) keeps heads 2j / 2j+1 on one XCD (head_and_group)
+    float inv_img, inv_nww;  // 1 / (windows per image), 1 / nWw: window_of
 };
+
+// window id -> (image, window row, window column).  Once per (window, head) and wave, on the issue-bound path of both MFMA
+// kernels: two 32-bit integer divisions by launch constants are ~50 instructions, the float form is 8 (same-box A/B,
+// profiles/r03/winattn_window_index.txt: forward -2..3 %, backward -0.5..1 %, nothing visible in the step).  Exact while
+// win < 2^21 (checked on the host): (win + 0.5) / n is at least 0.5 / n from an integer, the float error stays below that.
+__device__ __forceinline__ void window_of(int win, const Geom& g, int& b, int& wy, int& wx) {
+    b = (int)(((float)win + 0.5f) * g.inv_img);
+    const int wrem = win - b * (g.nWh * g.nWw);
+    wy = (int)(((float)wrem + 0.5f) * g.inv_nww);
+    wx = wrem - wy * g.nWw;
+}
 
 // Workgroups are dealt to the 8 XCDs round-robin by id and every XCD has its own L2.  A head's q / k / v slice of a token
 // is 64 bytes, so heads 2j and 2j+1 share each 128-byte line: with head = id % nH the two always sit on different XCDs
@@ -164,8 +176,8 @@ void winattn_fwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     struct Fetch { uint4 kq, vq, qf; int reg, tq, qreg, wy, wx; size_t img; };
     auto fetch = [&](int win) {
         Fetch f;
-        const int b = win / (g.nWh * g.nWw), wrem = win - b * (g.nWh * g.nWw);
-        f.wy = wrem / g.nWw; f.wx = wrem - f.wy * g.nWw;
+        int b;
+        window_of(win, g, b, f.wy, f.wx);
         f.img = (size_t)b * g.T;
         const int tk = token_of(sn, f.wy, f.wx, g, f.reg);
         const __bf16* src = tk >= 0 ? qkv + (f.img + tk) * C3 + hoff + sc * 8 : pad_qkv + hoff + sc * 8;
@@ -341,8 +353,8 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     struct Fetch { uint4 q_c, k_c, do_c, o_c, kf, vf; float lse_v; int reg, tkk, kreg, wy, wx; size_t img; };
     auto fetch = [&](int win) {
         Fetch f;
-        const int b = win / (g.nWh * g.nWw), wrem = win - b * (g.nWh * g.nWw);
-        f.wy = wrem / g.nWw; f.wx = wrem - f.wy * g.nWw;
+        int b;
+        window_of(win, g, b, f.wy, f.wx);
         f.img = (size_t)b * g.T;
         const int tk = token_of(sn, f.wy, f.wx, g, f.reg);
         const __bf16* src = tk >= 0 ? qkv + (f.img + tk) * C3 + hoff + sc * 8 : pad_qkv + hoff + sc * 8;
@@ -619,8 +631,8 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     };
     auto prefetch = [&](int win, int buf) {
         Next f;
-        const int b = win / (g.nWh * g.nWw), wrem = win - b * (g.nWh * g.nWw);
-        f.wy = wrem / g.nWw; f.wx = wrem - f.wy * g.nWw;
+        int b;
+        window_of(win, g, b, f.wy, f.wx);
         f.img = (size_t)b * g.T;
         const int tk = token_of(sn, f.wy, f.wx, g, f.reg);
         const __bf16* src = tk >= 0 ? qkv + (f.img + tk) * C3 + hoff + sc * 8 : pad_qkv + hoff + sc * 8;
@@ -1018,6 +1030,7 @@ int check_geom(int B, int H, int W, int C, int nH, int window, int shift) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || nH <= 0) return GRIT_ERR_BAD_ARG;
     if (window != kWs || C != nH * kHd || shift < 0 || shift >= kWs) return GRIT_ERR_UNSUPPORTED;
     if ((long long)B * H * W * 3 * C >= (1LL << 40)) return GRIT_ERR_BAD_ARG;
+    if ((long long)B * ((H + kWs - 1) / kWs) * ((W + kWs - 1) / kWs) >= (1LL << 21)) return GRIT_ERR_UNSUPPORTED;  // window_of
     return GRIT_OK;
 }
 
@@ -1027,6 +1040,7 @@ Geom make_geom(int B, int H, int W, int C, int nH, int shift, float scale, int n
     g.nWh = (H + kWs - 1) / kWs; g.nWw = (W + kWs - 1) / kWs;
     g.Hp = g.nWh * kWs; g.Wp = g.nWw * kWs; g.T = H * W; g.nWm = nWm > 0 ? nWm : 1; g.scale = scale;
     g.xcd_pairs = 0;
+    g.inv_img = 1.0f / (float)(g.nWh * g.nWw); g.inv_nww = 1.0f / (float)g.nWw;
     return g;
 }
 

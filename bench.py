@@ -538,7 +538,10 @@ def main():
         if bwd:  # informational: the backward is bound by the chip-wide memory-side atomic rate, not by HBM
             avg_b = sum(t for t, _ in bwd) / len(bwd)
             msda_bwd = {"kernel": "msda_bwd_d64 (f32 maps, f32 atomics)" if args.fp32 else
-                        ("msda_bwd_d64_pk<stage> + msda_stage_flush (f32 atomics into a staging map, one rounding to bf16 per touched cell)"
+                        (("msda_bwd_index + msda_bwd_d64_pk<no scatter> + msda_bwd_gather (gather form: contributions binned by cell in "
+                          "LDS, f32 sums in registers, one rounding to bf16, no atomics on memory)"
+                          if msda_op.F32_METHOD == "sorted" else
+                          "msda_bwd_d64_pk<stage> + msda_stage_flush (f32 atomics into a staging map, one rounding to bf16 per touched cell)")
                          if msda_op.F32_ACCUMULATE else "msda_bwd_d64_pk (packed-bf16 atomics, same-cell merges)"),
                         "launches": len(bwd), "avg_launch_us": avg_b * 1e6,
                         "whole_map_bytes_per_launch": int(bwd[0][1])}
@@ -599,7 +602,8 @@ def main():
                        "grad_sync": grad_sync if (world > 1 or self_coll) else None, "self_collectives": bool(self_coll),
                        "rccl_env": rccl_env,
                        "points": args.points, "ragged": bool(args.ragged),
-                       "msda_backward_accumulation": "f32" if (args.fp32 or msda_op.F32_ACCUMULATE) else "bf16 (packed atomics)"},
+                       "msda_backward_accumulation": ("f32" if args.fp32 else ("f32 (" + msda_op.F32_METHOD + ")") if msda_op.F32_ACCUMULATE
+                                                      else "bf16 (packed atomics)")},
             "mfma_roofline_frac_bf16": value / world * FLOP_PER_IMAGE_FWD_BWD / MFMA_PEAK_BF16,
             "final_loss": final_loss,
             # the dominant hand-written kernel of the step by ms/step (profiles/r03/*steady_state.txt): the window-attention backward

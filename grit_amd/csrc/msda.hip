@@ -571,7 +571,10 @@ void msda_bwd_d64(const VT* __restrict__ value, const int64_t* __restrict__ shap
 // lane that computed the point.  Every cell a row touches is marked in cell_flags[B, S, M] (plain byte stores of 1: all
 // writers write the same value), so msda_stage_flush visits the touched cells only: it rounds them once into the bf16
 // gradient map and leaves stage and flags zeroed for the next launch.
-template <bool STAGE>
+// MODE 0: packed-bf16 atomics into grad_value; MODE 1 (STAGE): f32 atomics into the staging map; MODE 2: NO scatter at all --
+// the row walk only produces grad_loc / grad_attn_w, the value gradient comes from the gather-form kernels further down
+// (msda_bwd_index / msda_bwd_gather).
+template <int MODE>
 __global__ __launch_bounds__(kWave * kRowsPerBlock)
 void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __restrict__ shapes,
                      const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
@@ -580,6 +583,7 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
                      int nrows, int nblk, int images_interleaved, int merge_disabled, int pix_el,
                      float* __restrict__ stage, unsigned char* __restrict__ cell_flags) {
     constexpr int D = 64, kMaxLP = 16;
+    constexpr bool STAGE = MODE == 1, PACKED = MODE == 0;
     typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
     typedef v2bf __attribute__((address_space(1))) * gv2bf_ptr;
     const int lane = threadIdx.x & (kWave - 1);
@@ -661,7 +665,7 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
     // per level with wave-uniform compares and the bilinear weights are summed first -- 4 half-wave atomics per level
     // instead of 8 full-wave ones, and a quarter of the same-address traffic.  Levels whose points differ take the
     // per-point path unchanged.
-    const bool mergeable = P == 4 && LP == kMaxLP && !merge_disabled;
+    const bool mergeable = MODE != 2 && P == 4 && LP == kMaxLP && !merge_disabled;
     bool merged = false;
 #pragma unroll
     for (int i = 0; i < kMaxLP / 2; ++i) {
@@ -690,7 +694,7 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
                     if constexpr (STAGE) {
                         GRIT_STAGE_ADD(f, __builtin_amdgcn_readlane(e1, p0), __builtin_amdgcn_readlane(e2, p0),
                                        __builtin_amdgcn_readlane(e3, p0), __builtin_amdgcn_readlane(e4, p0), W1, W2, W3, W4);
-                    } else if (!odd) {
+                    } else if (PACKED && !odd) {
                         __hip_bfloat16* g1 = ghead + (size_t)__builtin_amdgcn_readlane(e1, p0) * pix_stride;
                         __hip_bfloat16* g2 = ghead + (size_t)__builtin_amdgcn_readlane(e2, p0) * pix_stride;
                         __hip_bfloat16* g3 = ghead + (size_t)__builtin_amdgcn_readlane(e3, p0) * pix_stride;
@@ -742,7 +746,7 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
                                    __builtin_amdgcn_readlane(e3, pa_), __builtin_amdgcn_readlane(e4, pa_), A1, A2, A3, A4);
                 }
                 float u1 = w1 * wt, u2 = w2 * wt, u3 = w3 * wt, u4 = w4 * wt;
-                bool issue = !STAGE;
+                bool issue = PACKED;
                 if (pair) {
                     // the other half's point: 2i + 1 for the lower half (the only one that issues)
                     const float olh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.lh), 2 * i + 1));
@@ -750,9 +754,9 @@ void msda_bwd_d64_pk(const __hip_bfloat16* __restrict__ value, const int64_t* __
                     const float owt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pwt), 2 * i + 1));
                     const float ohh = (1.f - olh) * owt, olhw = olh * owt;
                     u1 += ohh * (1.f - olw); u2 += ohh * olw; u3 += olhw * (1.f - olw); u4 += olhw * olw;
-                    issue = !STAGE && !odd;
+                    issue = PACKED && !odd;
                 }
-                if (!STAGE && issue) {
+                if (PACKED && issue) {
                     if (f & 1) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s1 * pix_stride), v2bf{(__bf16)(u1 * go0), (__bf16)(u1 * go1)});
                     if (f & 2) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s2 * pix_stride), v2bf{(__bf16)(u2 * go0), (__bf16)(u2 * go1)});
                     if (f & 4) __builtin_amdgcn_global_atomic_fadd_v2bf16((gv2bf_ptr)(ghead + (size_t)s3 * pix_stride), v2bf{(__bf16)(u3 * go0), (__bf16)(u3 * go1)});
@@ -832,6 +836,213 @@ void msda_stage_flush(float* __restrict__ stage, unsigned char* __restrict__ cel
                 const int m = (int)(c[k] - pix * M);
                 grad_value[pix * pix_el + (long)m * 64 + lane] = __float2bfloat16(v[k]);
             }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Gather-form value gradient (bf16 maps, D = 64): no atomics on memory at all.
+//
+// The scatter of the reference (atomicAdd per corner and channel, ms_deform_im2col_cuda.cuh:125-152) is bound on gfx950 by
+// the memory-side atomic units (~323 G f32 adds/s chip-wide, tools/micro/atomic_rate.hip): 157 M channel-adds per launch are
+// ~460 us whatever the kernel does around them.  But WHERE every contribution goes is known from the sampling locations
+// alone, and per (image, head) there are only Lq*L*P*4 of them (9 600 at GRIT's shapes) over S cells, reading Lq rows of
+// grad_out (19 KB): the whole problem of one (image, head) fits the LDS of one CU.  msda_bwd_value, one 1024-thread workgroup
+// per (image, head) -- 256 of them at B = 32, M = 8: one per CU --
+//   1. loads its Lq rows of grad_out into LDS; bins the (query, point, corner) contributions by cell with LDS counters (the
+//      value an LDS atomic returns is the contribution's position inside its cell's run);
+//   2. scans the S counters in LDS (exclusive offsets);
+//   3. writes the contributions, ordered by cell, into an LDS array {query, attention weight x bilinear weight};
+//   4. walks the cells: eight lanes per cell (8 channels each), eight cells per wave instruction; a cell's lanes sum
+//      w_i * grad_out[q_i][channels] in f32 registers, round ONCE to bf16 and store their 128-byte row -- every cell, zeros
+//      included, so the gradient map needs no zero fill, no f32 staging copy and no flush, and nothing but the final rows
+//      ever goes to memory.
+// grad_loc / grad_attn_w come from the unchanged row walk with its scatter compiled out (msda_bwd_d64_pk<2>).
+// f32 accumulation like the reference's atomicAdd; the order of the terms inside a cell follows the order in which the LDS
+// counters were taken (like atomics, not fixed run to run, but the sum is rounded to bf16 once, after the last term).
+constexpr int kValueThreads = 1024, kValuePts = 4;   // up to 4 096 (query, point) pairs per (image, head)
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf_m __attribute__((ext_vector_type(8)));
+typedef short v4s_m __attribute__((ext_vector_type(4)));
+typedef short v8s_m __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) v4s_m lds_v4s_m;
+
+__device__ __forceinline__ float bf16_round(float x) {  // x rounded to the nearest bf16 (ties to even), as a float
+    return __bfloat162float(__float2bfloat16(x));
+}
+
+__host__ __device__ inline size_t value_lds_bytes(int S, int L, int Lq, int P) {
+    const size_t counters = ((size_t)S + 2) / 2 * 2 * 4;          // S + 1 offsets, padded to 8 bytes
+    return counters + (size_t)Lq * L * P * 4 * 8 + ((size_t)Lq + 1) * 128 + 64;  // + one all-zero row of grad_out
+}
+
+__global__ __launch_bounds__(kValueThreads)
+void msda_bwd_value(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+                    const float* __restrict__ aw, const __hip_bfloat16* __restrict__ grad_out,
+                    __hip_bfloat16* __restrict__ grad_value, int S, int M, int L, int Lq, int P, int pix_el) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int LP = L * P, npts = Lq * LP, cap = npts * 4;
+    int* cnt = reinterpret_cast<int*>(smem);                                     // [S + 1] counters, then exclusive offsets
+    uint2* recs = reinterpret_cast<uint2*>(smem + ((size_t)S + 2) / 2 * 2 * 4);  // [cap] {query, weight}
+    unsigned char* gol = reinterpret_cast<unsigned char*>(recs + cap);           // [Lq][128 B] rows of grad_out
+    int* wsum = reinterpret_cast<int*>(gol + ((size_t)Lq + 1) * 128);            // [16] wave totals of the scan
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg = blockIdx.x, b = seg / M, m = seg - b * M;
+
+    // ---- 1. counters to zero, grad_out rows of this (image, head) into LDS, contributions binned
+    for (int i = tid; i <= S; i += kValueThreads) cnt[i] = 0;
+    if (tid < 32) reinterpret_cast<unsigned*>(gol + (size_t)Lq * 128)[tid] = 0u;  // row Lq: zeros (k slots past a run)
+    for (int i = tid; i < Lq * 8; i += kValueThreads) {
+        const int q = i >> 3, piece = i & 7;
+        *reinterpret_cast<uint4*>(gol + (size_t)q * 128 + piece * 16) =
+            *reinterpret_cast<const uint4*>(grad_out + ((size_t)(b * Lq + q) * M + m) * 64 + piece * 8);
+    }
+    __syncthreads();
+    int cell[kValuePts][4], rank[kValuePts][4], qid[kValuePts];
+    float wgt[kValuePts][4];
+#pragma unroll
+    for (int j = 0; j < kValuePts; ++j) {
+        const int i = tid + j * kValueThreads;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cell[j][k] = -1;
+        if (i < npts) {
+            const int q = i / LP, p = i - q * LP, l = p / P;
+            const size_t row = (size_t)(b * Lq + q) * M + m;
+            qid[j] = q;
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)lsi[l];
+            const float x = loc[row * 2 * LP + 2 * p], y = loc[row * 2 * LP + 2 * p + 1];
+            const float a = aw[row * LP + p];
+            const Corners<float> c = make_corners<float>(x, y, H, W);
+            if (c.k1) { cell[j][0] = st + c.o1; wgt[j][0] = c.w1 * a; }
+            if (c.k2) { cell[j][1] = st + c.o2; wgt[j][1] = c.w2 * a; }
+            if (c.k3) { cell[j][2] = st + c.o3; wgt[j][2] = c.w3 * a; }
+            if (c.k4) { cell[j][3] = st + c.o4; wgt[j][3] = c.w4 * a; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (cell[j][k] >= 0) rank[j][k] = atomicAdd(&cnt[cell[j][k]], 1);  // position inside the cell's run
+        }
+    }
+    __syncthreads();
+    // ---- 2. exclusive scan of the S counters: a contiguous chunk per thread, wave scans of the chunk sums, 16 wave totals
+    const int CH = (S + kValueThreads - 1) / kValueThreads, c0 = tid * CH;
+    int local = 0;
+    for (int k = 0; k < CH; ++k)
+        if (c0 + k < S) local += cnt[c0 + k];
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        const int v = lane < kValueThreads / 64 ? wsum[lane] : 0;
+        int iv = v;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int t = __shfl_up(iv, o, 64);
+            if (lane >= o) iv += t;
+        }
+        if (lane < kValueThreads / 64) wsum[lane] = iv - v;  // exclusive
+    }
+    __syncthreads();
+    int run = incl - local + wsum[wave];
+    for (int k = 0; k < CH; ++k)
+        if (c0 + k < S) {
+            const int c = cnt[c0 + k];
+            cnt[c0 + k] = run;
+            run += c;
+        }
+    if (tid == kValueThreads - 1) cnt[S] = run;  // the last thread's running total is the segment's record count
+    __syncthreads();
+    // ---- 3. contributions ordered by cell.  A record is 8 bytes: query (12 bits), cell within its 16-cell tile (4 bits) and the
+    // weight as THREE bf16 terms hi + mid + lo (24 mantissa bits: the f32 weight exactly), the form step 4 feeds to the MFMA
+#pragma unroll
+    for (int j = 0; j < kValuePts; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (cell[j][k] >= 0) {
+                const float w = wgt[j][k];
+                const unsigned hi = __float_as_uint(bf16_round(w)) >> 16;
+                const float r1 = w - __uint_as_float(hi << 16);
+                const unsigned mid = __float_as_uint(bf16_round(r1)) >> 16;
+                const float r2 = r1 - __uint_as_float(mid << 16);
+                const unsigned lo = __float_as_uint(bf16_round(r2)) >> 16;
+                recs[cnt[cell[j][k]] + rank[j][k]] =
+                    make_uint2((unsigned)qid[j] | ((unsigned)(cell[j][k] & 15) << 12) | (hi << 16), mid | (lo << 16));
+            }
+    __syncthreads();
+    // ---- 4. tiles of 16 consecutive cells:  Out^T[64 channels x 16 cells] = G^T[64 x n] . W[n x 16]  on the matrix cores, where
+    // the n contributions of the tile are one contiguous run of records, G^T their grad_out rows (bf16, exact) read straight from
+    // the LDS rows by transposing reads (every lane addresses the row of ITS record), and W[k][c] = weight of record k if it
+    // belongs to cell c, else 0 -- three bf16 terms, three MFMAs into the same f32 accumulator.  No loop over cells, no
+    // divergence between hot and empty cells; a wave takes a contiguous range of tiles of equal estimated cost.
+    const int l15 = lane & 15, lg = lane >> 4, trq = l15 >> 2, trp = l15 & 3;
+    const int T = (S + 15) >> 4, nwave = kValueThreads / 64;
+    const int total = cnt[S] + 8 * T;  // cost model: a record ~ 1, a tile's fixed part ~ 8
+    auto first_tile_at = [&](int target) {  // smallest t with cnt[16 t] + 8 t >= target (monotone in t)
+        int lo = 0, hi = T;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cnt[min(16 * mid, S)] + 8 * mid >= target) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    const int tlo = wave == 0 ? 0 : first_tile_at((int)((long)total * wave / nwave));
+    const int thi = wave == nwave - 1 ? T : first_tile_at((int)((long)total * (wave + 1) / nwave));
+    __hip_bfloat16* gbase = grad_value + (size_t)b * S * pix_el + (size_t)m * 64 + 4 * lg;
+    const unsigned char* grow = gol + 8 * trp;  // + q * 128 + 32 * cb
+    for (int t = tlo; t < thi; ++t) {
+        const int beg = __builtin_amdgcn_readfirstlane(cnt[16 * t]);
+        const int end = __builtin_amdgcn_readfirstlane(cnt[min(16 * t + 16, S)]);
+        v4f acc[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int k0 = beg; k0 < end; k0 += 32) {
+            // k slots of this lane (the order the transposing reads define): e < 4: k0 + 4 lg + e,  e >= 4: k0 + 16 + 4 lg + e - 4
+            unsigned whi[8], wmid[8], wlo[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + 4 * lg + (e & 3) + (e >> 2) * 16;
+                const uint2 r = recs[min(k, cap - 1)];
+                const bool mine = k < end && ((r.x >> 12) & 15u) == (unsigned)l15;
+                whi[e] = mine ? (r.x >> 16) : 0u;
+                wmid[e] = mine ? (r.y & 0xffffu) : 0u;
+                wlo[e] = mine ? (r.y >> 16) : 0u;
+            }
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+            const u4v ph = {whi[0] | (whi[1] << 16), whi[2] | (whi[3] << 16), whi[4] | (whi[5] << 16), whi[6] | (whi[7] << 16)};
+            const u4v pm = {wmid[0] | (wmid[1] << 16), wmid[2] | (wmid[3] << 16), wmid[4] | (wmid[5] << 16), wmid[6] | (wmid[7] << 16)};
+            const u4v pl = {wlo[0] | (wlo[1] << 16), wlo[2] | (wlo[3] << 16), wlo[4] | (wlo[5] << 16), wlo[6] | (wlo[7] << 16)};
+            const v8bf_m bh = __builtin_bit_cast(v8bf_m, ph), bm = __builtin_bit_cast(v8bf_m, pm), bl = __builtin_bit_cast(v8bf_m, pl);
+            // rows this lane addresses for the transposing reads: records k0 + 4 lg + trq and + 16 (past the run: the zero row)
+            const int ka = k0 + 4 * lg + trq, kb = ka + 16;
+            const unsigned qa = ka < end ? (recs[min(ka, cap - 1)].x & 0xfffu) : (unsigned)Lq;
+            const unsigned qb = kb < end ? (recs[min(kb, cap - 1)].x & 0xfffu) : (unsigned)Lq;
+            const unsigned char* ra = grow + (size_t)qa * 128;
+            const unsigned char* rb = grow + (size_t)qb * 128;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const v4s_m x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_m*)(ra + 32 * cb));
+                const v4s_m x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_m*)(rb + 32 * cb));
+                const v8s_m xs = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                const v8bf_m a = __builtin_bit_cast(v8bf_m, xs);
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bm, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl, acc[cb], 0, 0, 0);
+            }
+        }
+        // acc[cb][r] = Out[cell 16 t + l15][channel 16 cb + 4 lg + r]
+        const int cellw = 16 * t + l15;
+        if (cellw < S) {
+            __hip_bfloat16* dst = gbase + (size_t)cellw * pix_el;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                typedef __bf16 v4bf_m __attribute__((ext_vector_type(4)));
+                const v4bf_m o = {(__bf16)acc[cb][0], (__bf16)acc[cb][1], (__bf16)acc[cb][2], (__bf16)acc[cb][3]};
+                *reinterpret_cast<v4bf_m*>(dst + 16 * cb) = o;
+            }
+        }
     }
 }
 
@@ -1016,7 +1227,7 @@ int grit_msda_bwd_bf16acc_strided(const void* value, long pixel_stride, const in
     static const bool interleave = !(getenv("GRIT_MSDA_BWD_INTERLEAVE") && atoi(getenv("GRIT_MSDA_BWD_INTERLEAVE")) == 0);
     const int images = (interleave && B > 1 && (Lq * M) % kRowsPerBlock == 0) ? B : 1;
     static const bool no_merge = getenv("GRIT_MSDA_BWD_MERGE") && atoi(getenv("GRIT_MSDA_BWD_MERGE")) == 0;  // A/B knob
-    hipLaunchKernelGGL(msda_bwd_d64_pk<false>, dim3(nblk), dim3(kWave * kRowsPerBlock), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(msda_bwd_d64_pk<0>, dim3(nblk), dim3(kWave * kRowsPerBlock), 0, (hipStream_t)stream,
                        (const __hip_bfloat16*)value, spatial_shapes, level_start, loc, attn_w, (const __hip_bfloat16*)grad_out,
                        S, M, L, Lq, P, (__hip_bfloat16*)grad_value, grad_loc, grad_attn_w, nrows, nblk, images, no_merge ? 1 : 0,
                        (int)pixel_stride, (float*)nullptr, (unsigned char*)nullptr);
@@ -1040,7 +1251,7 @@ int grit_msda_bwd_bf16_staged(const void* value, long pixel_stride, const int64_
     static const bool interleave = !(getenv("GRIT_MSDA_BWD_INTERLEAVE") && atoi(getenv("GRIT_MSDA_BWD_INTERLEAVE")) == 0);
     const int images = (interleave && B > 1 && (Lq * M) % kRowsPerBlock == 0) ? B : 1;
     static const bool no_merge = getenv("GRIT_MSDA_BWD_MERGE") && atoi(getenv("GRIT_MSDA_BWD_MERGE")) == 0;
-    hipLaunchKernelGGL(msda_bwd_d64_pk<true>, dim3(nblk), dim3(kWave * kRowsPerBlock), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(msda_bwd_d64_pk<1>, dim3(nblk), dim3(kWave * kRowsPerBlock), 0, (hipStream_t)stream,
                        (const __hip_bfloat16*)value, spatial_shapes, level_start, loc, attn_w, (const __hip_bfloat16*)grad_out,
                        S, M, L, Lq, P, (__hip_bfloat16*)nullptr, grad_loc, grad_attn_w, nrows, nblk, images, no_merge ? 1 : 0,
                        (int)pixel_stride, stage, cell_flags);
@@ -1049,6 +1260,45 @@ int grit_msda_bwd_bf16_staged(const void* value, long pixel_stride, const int64_
     const long nwaves = (ncells + 63) / 64;
     hipLaunchKernelGGL(msda_stage_flush, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, stage, cell_flags,
                        (__hip_bfloat16*)grad_value, ncells, S, M, (int)pixel_stride);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+int grit_msda_bwd_sorted_supported(int B, int S, int M, int L, int Lq, int P) {
+    if (B <= 0 || S <= 0 || M <= 0 || L <= 0 || Lq <= 0 || P <= 0) return GRIT_ERR_BAD_ARG;
+    if ((long)Lq * L * P > (long)kValueThreads * kValuePts || Lq > 4095) return GRIT_ERR_UNSUPPORTED;
+    if (value_lds_bytes(S, L, Lq, P) > 160 * 1024) return GRIT_ERR_UNSUPPORTED;
+    return GRIT_OK;
+}
+
+int grit_msda_bwd_bf16_sorted(const void* value, long pixel_stride, const int64_t* spatial_shapes,
+                              const int64_t* level_start, const float* loc, const float* attn_w, const void* grad_out,
+                              int B, int S, int M, int D, int L, int Lq, int P, void* grad_value, float* grad_loc,
+                              float* grad_attn_w, void* stream) {
+    if (pixel_stride < (long)M * D || pixel_stride % 8 || pixel_stride > 0x3fffffffL) return GRIT_ERR_BAD_ARG;
+    if (!value || !spatial_shapes || !level_start || !loc || !attn_w || !grad_out || !grad_value || !grad_loc || !grad_attn_w)
+        return GRIT_ERR_BAD_ARG;
+    if (!dims_ok(B, S, M, D, L, Lq, P)) return GRIT_ERR_BAD_ARG;
+    const int ok = grit_msda_bwd_sorted_supported(B, S, M, L, Lq, P);
+    if (ok != GRIT_OK) return ok;
+    if (D != 64 || L * P > 16 || ((uintptr_t)value % 4) || ((uintptr_t)grad_out % 16) || ((uintptr_t)grad_value % 16))
+        return GRIT_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    static bool lds_attr_set = false;  // idempotent attribute
+    if (!lds_attr_set) {
+        if (hipFuncSetAttribute((const void*)msda_bwd_value, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return GRIT_ERR_LAUNCH;
+        lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(msda_bwd_value, dim3(B * M), dim3(kValueThreads), value_lds_bytes(S, L, Lq, P), st, spatial_shapes,
+                       level_start, loc, attn_w, (const __hip_bfloat16*)grad_out, (__hip_bfloat16*)grad_value, S, M, L, Lq, P,
+                       (int)pixel_stride);
+    if (hipGetLastError() != hipSuccess) return GRIT_ERR_LAUNCH;
+    const int nrows = B * Lq * M;
+    const int nblk = (nrows + kRowsPerBlock - 1) / kRowsPerBlock;
+    hipLaunchKernelGGL(msda_bwd_d64_pk<2>, dim3(nblk), dim3(kWave * kRowsPerBlock), 0, st, (const __hip_bfloat16*)value,
+                       spatial_shapes, level_start, loc, attn_w, (const __hip_bfloat16*)grad_out, S, M, L, Lq, P,
+                       (__hip_bfloat16*)nullptr, grad_loc, grad_attn_w, nrows, nblk, 1, 1, (int)pixel_stride, (float*)nullptr,
+                       (unsigned char*)nullptr);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 

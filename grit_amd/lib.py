@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -30,6 +30,8 @@ SIGNATURES = {
     "grit_msda_fwd_bf16_strided": [_ptr, _c.c_long] + [_ptr] * 4 + [_int] * 7 + [_ptr, _ptr],
     "grit_msda_bwd_bf16acc_strided": [_ptr, _c.c_long] + [_ptr] * 5 + [_int] * 7 + [_ptr] * 4,
     "grit_msda_bwd_bf16_staged": [_ptr, _c.c_long] + [_ptr] * 5 + [_int] * 7 + [_ptr] * 6,
+    "grit_msda_bwd_sorted_supported": [_int] * 6,
+    "grit_msda_bwd_bf16_sorted": [_ptr, _c.c_long] + [_ptr] * 5 + [_int] * 7 + [_ptr] * 4,
     "grit_winattn_fwd_bf16": [_ptr] * 4 + [_int] * 8 + [_f32, _ptr, _ptr, _ptr],
     "grit_winattn_bwd_bf16": [_ptr] * 4 + [_int] + [_ptr] * 3 + [_int] * 7 + [_f32] + [_ptr] * 4,
     "grit_winattn_fwd_f32": [_ptr] * 4 + [_int] * 8 + [_f32, _ptr, _ptr, _ptr],

@@ -34,6 +34,12 @@ PROFILE_RECORD_GEOMETRY = False
 # GRIT_MSDA_BWD_F32ACC=0 opts into accumulation IN bf16 by packed atomics (grit_msda_bwd_bf16acc*: twice the atomic rate, but
 # every add rounds to 8 mantissa bits and the result depends on the arrival order more strongly).
 F32_ACCUMULATE = os.environ.get("GRIT_MSDA_BWD_F32ACC", "1") != "0"
+# How the f32 accumulation is done.  "sorted" (default): gather form -- contributions binned by cell in LDS, every cell summed in
+# f32 registers, all inside the LDS of one CU per (image, head): no atomics on memory, dense output (grit_msda_bwd_bf16_sorted).  "staged": f32 atomics into a staging map + flush
+# (grit_msda_bwd_bf16_staged; also the fallback where the sorted path does not apply: S or Lq*L*P beyond one workgroup's LDS).
+F32_METHOD = os.environ.get("GRIT_MSDA_BWD_METHOD", "sorted")
+if F32_METHOD not in ("sorted", "staged"):
+    raise ValueError("GRIT_MSDA_BWD_METHOD must be 'sorted' or 'staged'")
 
 _STAGE = {}  # (device, B, S, M) -> [stage f32 [B,S,M,64], cell flags u8 [B,S,M], dirty]: zero on entry AND exit of every call
 
@@ -62,6 +68,19 @@ def _bwd_staged(value_ptr, pixel_stride, shapes, lsi, loc, aw, go, B, S, M, D, L
                                                    _lib.current_stream_ptr())
     _lib.check(st, "grit_msda_bwd_bf16_staged")
     ent[2] = False
+
+
+def sorted_applies(B, S, M, L, Lq, P):
+    """True when the gather-form backward handles the shape (one (image, head) problem must fit the LDS of a CU)."""
+    return F32_METHOD == "sorted" and _lib.load().grit_msda_bwd_sorted_supported(B, S, M, L, Lq, P) == 0
+
+
+def _bwd_sorted(value_ptr, pixel_stride, shapes, lsi, loc, aw, go, B, S, M, D, L, Lq, P, gv_ptr, gl, ga, device):
+    """Value gradient in gather form; writes EVERY cell of the [B, S, M, 64] slice behind gv_ptr."""
+    with _lib.device_guard(device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 2)):
+        st = _lib.load().grit_msda_bwd_bf16_sorted(value_ptr, pixel_stride, _ptr(shapes), _ptr(lsi), _ptr(loc), _ptr(aw), _ptr(go),
+                                                   B, S, M, D, L, Lq, P, gv_ptr, _ptr(gl), _ptr(ga), _lib.current_stream_ptr())
+    _lib.check(st, "grit_msda_bwd_bf16_sorted")
 
 
 def _ptr(t):
@@ -195,10 +214,15 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     if _bf16_fast_path(value, D, L, P):
         loc, aw = sampling_loc.float(), attn_weight.float()
         go = grad_output.to(torch.bfloat16).contiguous()
-        gv = torch.zeros(value.shape, dtype=torch.bfloat16, device=value.device)
         gl, ga = torch.empty_like(loc), torch.empty_like(aw)
-        _bwd_staged(_ptr(value), M * D, spatial_shapes, level_start_index, loc, aw, go, B, S, M, D, L, Lq, P, _ptr(gv), gl, ga,
-                    value.device)
+        if sorted_applies(B, S, M, L, Lq, P):
+            gv = torch.empty(value.shape, dtype=torch.bfloat16, device=value.device)  # every cell is written
+            _bwd_sorted(_ptr(value), M * D, spatial_shapes, level_start_index, loc.contiguous(), aw.contiguous(), go,
+                        B, S, M, D, L, Lq, P, _ptr(gv), gl, ga, value.device)
+        else:
+            gv = torch.zeros(value.shape, dtype=torch.bfloat16, device=value.device)
+            _bwd_staged(_ptr(value), M * D, spatial_shapes, level_start_index, loc, aw, go, B, S, M, D, L, Lq, P, _ptr(gv), gl,
+                        ga, value.device)
         return [gv, gl.to(sampling_loc.dtype), ga.to(attn_weight.dtype)]
     cdt = _compute_dtype(value)
     v, loc, aw = value.to(cdt), sampling_loc.to(cdt), attn_weight.to(cdt)
@@ -225,6 +249,7 @@ class StackedValueMaps(object):
         assert stacked.dim() == 5 and stacked.is_contiguous() and stacked.dtype == torch.bfloat16
         self.stacked, self.layers = stacked, layers
         self.pending, self.grad = 0, None
+        self.layers_seen = set()
 
     def layer_ptr(self, tensor, layer):
         B, S, n, M, D = self.stacked.shape
@@ -251,6 +276,7 @@ class _StackedMSDAFn(Function):
         ctx.save_for_backward(stacked, shapes, lsi, loc, aw)
         ctx.maps, ctx.layer = maps, layer
         maps.pending += 1
+        maps.layers_seen.add(layer)
         return out
 
     @staticmethod
@@ -260,11 +286,18 @@ class _StackedMSDAFn(Function):
         maps, layer = ctx.maps, ctx.layer
         B, S, n, M, D = stacked.shape
         _, Lq, _, L, P, _ = loc.shape
+        use_sorted = F32_ACCUMULATE and sorted_applies(B, S, M, L, Lq, P)
         if maps.grad is None:
-            maps.grad = torch.zeros_like(stacked)  # one fill for all layers; the kernels add into their slices
+            # sorted path: every layer's kernel writes its whole slice, so the buffer needs no fill -- provided every slice has
+            # a sampling node waiting (all layers of the decoder ran); otherwise one fill for all layers
+            every_slice = use_sorted and maps.layers_seen == set(range(n)) and maps.pending == n
+            maps.grad = torch.empty_like(stacked) if every_slice else torch.zeros_like(stacked)
         go = grad_output.to(torch.bfloat16).contiguous()
         gl, ga = torch.empty_like(loc), torch.empty_like(aw)
-        if F32_ACCUMULATE:
+        if use_sorted:
+            _bwd_sorted(maps.layer_ptr(stacked, layer), n * M * D, shapes, lsi, loc, aw, go, B, S, M, D, L, Lq, P,
+                        maps.layer_ptr(maps.grad, layer), gl, ga, stacked.device)
+        elif F32_ACCUMULATE:
             _bwd_staged(maps.layer_ptr(stacked, layer), n * M * D, shapes, lsi, loc, aw, go, B, S, M, D, L, Lq, P,
                         maps.layer_ptr(maps.grad, layer), gl, ga, stacked.device)
         else:

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 28
+#define GRIT_ABI_VERSION 29
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -143,6 +143,23 @@ int grit_msda_bwd_bf16_staged(const void* value, long pixel_stride, const int64_
                               const int64_t* level_start, const float* loc, const float* attn_w, const void* grad_out,
                               int B, int S, int M, int D, int L, int Lq, int P, float* stage, unsigned char* cell_flags,
                               void* grad_value, float* grad_loc, float* grad_attn_w, void* stream);
+
+/* bf16 maps, value gradient in GATHER form: the default of the training step.  No atomics on memory -- one workgroup per
+ * (image, head) keeps that pair's whole problem in the LDS of its CU: the Lq rows of grad_out, the Lq*L*P*4 corner contributions
+ * binned by cell (counting sort: LDS counters, LDS scan, LDS records {query, attention weight x bilinear weight}); every cell then
+ * sums its contributions w_i * grad_out[q_i, :] in f32 registers and is rounded to bf16 ONCE.  f32 accumulation like the
+ * reference's atomicAdd (ms_deform_im2col_cuda.cuh:125-152) without its rate limit (the memory-side atomic units of gfx950 do
+ * ~323 G f32 adds/s: ~460 us per launch at GRIT's shapes; this path: profiles/r03/msda_bwd_methods.txt).
+ * grad_value: bf16 map with `pixel_stride` elements between pixels (a multiple of 8, base 16-byte aligned); EVERY cell of the
+ * [B, S, M, 64] slice is written (zeros where nothing sampled), so the caller does not zero-fill it.  grad_loc / grad_attn_w: the
+ * row walk of grit_msda_bwd_bf16acc_strided with its scatter compiled out.  D = 64, L*P <= 16, Lq*L*P <= 4096 and
+ * 4 (S + 1) + 32 Lq L P + 128 Lq + 64 <= 160 KB of LDS (GRIT: 130 KB); grit_msda_bwd_sorted_supported says GRIT_OK /
+ * GRIT_ERR_UNSUPPORTED for a shape -- callers fall back to grit_msda_bwd_bf16_staged. */
+int grit_msda_bwd_sorted_supported(int B, int S, int M, int L, int Lq, int P);
+int grit_msda_bwd_bf16_sorted(const void* value, long pixel_stride, const int64_t* spatial_shapes,
+                              const int64_t* level_start, const float* loc, const float* attn_w, const void* grad_out,
+                              int B, int S, int M, int D, int L, int Lq, int P, void* grad_value, float* grad_loc,
+                              float* grad_attn_w, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Scaled-dot attention core, fp32 arithmetic, head_dim D = 64 (also the 150-query

@@ -166,8 +166,15 @@ def test_shim_module_name():
     assert out.shape == (1, 4, 512) and gv.shape == value.shape and gl.shape == loc.shape and ga.shape == aw.shape
 
 
-@pytest.mark.parametrize("f32_accumulate", [False, True])
-def test_bf16_value_maps_forward_backward(f32_accumulate):
+def _set_accumulation(msda_op, mode, monkeypatch):
+    """mode: False (packed bf16 atomics), "sorted" (gather form, the default) or "staged" (f32 atomics + flush)."""
+    monkeypatch.setattr(msda_op, "F32_ACCUMULATE", bool(mode))
+    if mode:
+        monkeypatch.setattr(msda_op, "F32_METHOD", mode)
+
+
+@pytest.mark.parametrize("f32_accumulate", [False, "sorted", "staged"])
+def test_bf16_value_maps_forward_backward(f32_accumulate, monkeypatch):
     """Training path: value / grad_out in bf16, oracle in fp32 on the same rounded inputs.  grad_value is accumulated
     in f32 with one final rounding (grit_msda_bwd_bf16_staged, the default: the reference's atomicAdd precision; relative L2
     error ~2e-3 = the bf16 rounding of the result) or, opt-in (GRIT_MSDA_BWD_F32ACC=0), in bf16 by packed atomics
@@ -176,11 +183,8 @@ def test_bf16_value_maps_forward_backward(f32_accumulate):
     value, shapes, lsi, loc, aw = _config2(B=2)
     v16 = value.bfloat16()
     cot = torch.randn(2, 150, 512, generator=torch.Generator().manual_seed(5)).bfloat16()
-    saved, msda_op.F32_ACCUMULATE = msda_op.F32_ACCUMULATE, f32_accumulate
-    try:
-        out, gv, gl, ga = _run(v16.to(DEV), shapes.to(DEV), lsi.to(DEV), loc.to(DEV), aw.to(DEV), cot.to(DEV))
-    finally:
-        msda_op.F32_ACCUMULATE = saved
+    _set_accumulation(msda_op, f32_accumulate, monkeypatch)
+    out, gv, gl, ga = _run(v16.to(DEV), shapes.to(DEV), lsi.to(DEV), loc.to(DEV), aw.to(DEV), cot.to(DEV))
     assert out.dtype == torch.bfloat16 and gv.dtype == torch.bfloat16
     vr, cr = v16.float().numpy(), cot.float().numpy()
     ref = omsda.msda_forward(vr, shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy())
@@ -195,7 +199,7 @@ def test_bf16_value_maps_forward_backward(f32_accumulate):
     np.testing.assert_allclose(gl.cpu().numpy(), ogl, rtol=1e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("f32_accumulate", [False, True])
+@pytest.mark.parametrize("f32_accumulate", [False, "sorted", "staged"])
 def test_bf16_backward_merges_points_that_share_a_cell(f32_accumulate, monkeypatch):
     """Freshly initialised model: the P points of a level sit in one pixel cell (tiny offsets).  The bf16-accumulating
     backward sums their bilinear weights and issues one update per corner; mixed here with levels whose points differ,
@@ -213,7 +217,7 @@ def test_bf16_backward_merges_points_that_share_a_cell(f32_accumulate, monkeypat
     loc[0, :10] = -0.2            # entirely outside: no update at all
     loc[1, :10, :, 3] = 0.999      # last cell of the coarsest level: right / bottom corners dead
     from grit_amd.ops import msda as msda_op
-    monkeypatch.setattr(msda_op, "F32_ACCUMULATE", f32_accumulate)
+    _set_accumulation(msda_op, f32_accumulate, monkeypatch)
     v16 = value.bfloat16()
     cot = torch.randn(2, 150, 512, generator=g).bfloat16()
     out, gv, gl, ga = _run(v16.to(DEV), shapes.to(DEV), lsi.to(DEV), loc.to(DEV), aw.to(DEV), cot.to(DEV))
@@ -280,7 +284,7 @@ def test_bf16_forward_kernels_layouts_and_dead_corners(shapes_l, M, Lq, P, B):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)
 
 
-def test_staged_f32_accumulation_rounds_once_and_leaves_scratch_zeroed():
+def test_staged_f32_accumulation_rounds_once_and_leaves_scratch_zeroed(monkeypatch):
     """grit_msda_bwd_bf16_staged at the benchmark's batch (B = 32, config-2 points): (1) against the dense f32-accumulating kernel
     grit_msda_bwd_bf16 followed by ONE rounding to bf16, the staged result differs by at most the last bf16 bit of a sum whose
     f32 atomics arrived in another order; (2) cells no sampling point reaches stay exactly zero; (3) the staging map and the
@@ -294,6 +298,7 @@ def test_staged_f32_accumulation_rounds_once_and_leaves_scratch_zeroed():
     shapes, lsi, loc, aw = shapes.to(DEV), lsi.to(DEV), loc.to(DEV), aw.to(DEV)
     cot = torch.randn(32, 150, 512, generator=torch.Generator().manual_seed(5)).bfloat16().to(DEV)
     assert msda_op.F32_ACCUMULATE  # the default
+    monkeypatch.setattr(msda_op, "F32_METHOD", "staged")
     gv, gl, ga = msda_op.ms_deform_attn_backward(v16, shapes, lsi, loc, aw, cot)
     assert gv.dtype == torch.bfloat16
     B, S, M, D = v16.shape
@@ -320,14 +325,93 @@ def test_staged_f32_accumulation_rounds_once_and_leaves_scratch_zeroed():
     assert float((gv_again != gv).float().mean()) < 1e-2 and bool(((gv_again.float() - gv.float()).abs() <= ulp).all())
 
 
-@pytest.mark.parametrize("f32_accumulate", [True, False])
+@pytest.mark.parametrize("points", ["config2", "one_cell"])
+def test_sorted_gather_form_backward(points):
+    """grit_msda_bwd_bf16_sorted at the benchmark's batch (B = 32), called through the C ABI on a STRIDED gradient map (layer 1
+    of 3) that arrives full of NaN (the kernel takes no scratch: everything between the inputs and the rows lives in LDS): (1) every cell of the layer's slice is written -- sums where points sampled, exact zeros
+    elsewhere -- and the other layers' slices are not touched; (2) against the dense f32-accumulating kernel grit_msda_bwd_bf16
+    followed by ONE rounding to bf16 the result differs by at most the last bf16 bit (another order of the same f32 terms);
+    (3) grad_loc / grad_attn_w equal the row walk of the other kernels; (4) "one_cell": every query of an image samples the same
+    cell of the coarsest level (runs of 600 contributions in four cells), others empty."""
+    import ctypes
+    from grit_amd import lib as _lib
+    from grit_amd.ops import msda as msda_op
+    value, shapes, lsi, loc, aw = _config2(B=32)
+    if points == "one_cell":
+        loc = loc.clone()
+        loc[:, :, :, 3] = 0.55 + 0.01 * torch.rand(loc[:, :, :, 3].shape, generator=torch.Generator().manual_seed(2))
+    v16 = value.bfloat16().to(DEV)
+    shapes, lsi, loc, aw = shapes.to(DEV), lsi.to(DEV), loc.to(DEV).contiguous(), aw.to(DEV).contiguous()
+    cot = torch.randn(32, 150, 512, generator=torch.Generator().manual_seed(5)).bfloat16().to(DEV)
+    B, S, M, D = v16.shape
+    L, Lq, P, n = 4, 150, 4, 3
+    assert msda_op.sorted_applies(B, S, M, L, Lq, P)
+    stacked_v = torch.zeros(B, S, n, M, D, dtype=torch.bfloat16, device=DEV)
+    stacked_v[:, :, 1] = v16
+    grad = torch.full((B, S, n, M, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    gl, ga = torch.empty_like(loc), torch.empty_like(aw)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    layer_off = 1 * M * D * 2
+    st = _lib.load().grit_msda_bwd_bf16_sorted(ctypes.c_void_p(stacked_v.data_ptr() + layer_off), n * M * D, p(shapes), p(lsi), p(loc),
+                                               p(aw), p(cot), B, S, M, D, L, Lq, P,
+                                               ctypes.c_void_p(grad.data_ptr() + layer_off), p(gl), p(ga), _lib.current_stream_ptr())
+    assert st == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(grad[:, :, 0]).all()) and bool(torch.isnan(grad[:, :, 2]).all())
+    gv = grad[:, :, 1]
+    assert not bool(torch.isnan(gv).any())
+    dense = torch.zeros(v16.shape, dtype=torch.float32, device=DEV)
+    gl2, ga2 = torch.empty_like(loc), torch.empty_like(aw)
+    st = _lib.load().grit_msda_bwd_bf16(p(v16), p(shapes), p(lsi), p(loc), p(aw), p(cot), B, S, M, D, L, Lq, P, p(dense), p(gl2),
+                                        p(ga2), _lib.current_stream_ptr())
+    assert st == 0
+    want = dense.to(torch.bfloat16)
+    diff = (gv.float() - want.float()).abs()
+    # the same f32 terms in another order: one_cell sums 600 terms of mixed sign per element (cancellation), so the bound is
+    # relative to the sum of magnitudes there
+    ulp = want.float().abs() * 2.0 ** -7 + (1e-6 if points == "config2" else 2e-4 * float(dense.abs().max()))
+    assert bool((diff <= ulp).all()), float((diff / ulp).max())
+    if points == "config2":
+        assert float((gv != want).float().mean()) < 1e-2
+    untouched = dense.abs().sum(-1) == 0
+    assert bool(untouched.any()) and bool((gv[untouched] == 0).all())
+    torch.testing.assert_close(gl, gl2, rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(ga, ga2, rtol=1e-3, atol=2e-4)
+
+
+def test_sorted_backward_limits_fall_back_to_the_staged_path(monkeypatch):
+    """Shapes beyond one workgroup's LDS (S cells) or register budget (Lq*L*P pairs): the workspace query says unsupported and
+    the op takes the staged path (same results within the f32-accumulation tolerance)."""
+    from grit_amd.ops import msda as msda_op
+    assert msda_op.sorted_applies(2, 8500, 8, 4, 150, 4)
+    assert not msda_op.sorted_applies(2, 20000, 8, 4, 150, 4)            # 80 KB of counters + 77 KB of records + rows
+    assert not msda_op.sorted_applies(2, 8500, 8, 4, 300, 4)             # 4 800 (query, point) pairs
+    monkeypatch.setattr(msda_op, "F32_METHOD", "staged")
+    assert not msda_op.sorted_applies(2, 8500, 8, 4, 150, 4)
+    monkeypatch.setattr(msda_op, "F32_METHOD", "sorted")
+    g = torch.Generator().manual_seed(3)
+    shapes = torch.tensor([[20, 20], [10, 10]])
+    lsi = torch.tensor([0, 400])
+    Lq = 300                                                              # 300 * 2 * 8 = 4 800 pairs: falls back
+    value = torch.randn(2, 500, 8, 64, generator=g).bfloat16().to(DEV)
+    loc = torch.rand(2, Lq, 8, 2, 8, 2, generator=g).to(DEV)
+    aw = torch.softmax(torch.randn(2, Lq, 8, 16, generator=g), -1).view(2, Lq, 8, 2, 8).to(DEV)
+    cot = torch.randn(2, Lq, 512, generator=g).bfloat16().to(DEV)
+    gv, gl, ga = msda_op.ms_deform_attn_backward(value, shapes.to(DEV), lsi.to(DEV), loc, aw, cot)
+    monkeypatch.setattr(msda_op, "F32_ACCUMULATE", False)
+    gv2, gl2, ga2 = msda_op.ms_deform_attn_backward(value, shapes.to(DEV), lsi.to(DEV), loc, aw, cot)
+    assert torch.linalg.norm(gv.float() - gv2.float()) / torch.linalg.norm(gv2.float()) < 1e-2
+    torch.testing.assert_close(gl, gl2, rtol=1e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("f32_accumulate", ["sorted", "staged", False])
 def test_stacked_value_maps_equal_per_layer_maps(f32_accumulate, monkeypatch):
     """Strided kernels (grit_msda_*_strided): three layers' value maps interleaved in one [B, S, 3, M, D] tensor.  Forward
     and the per-row gradients are those of the dense kernels bit for bit (same kernels, other pixel stride); the value
     gradients of all layers land in one buffer that only the node running last hands to autograd."""
     from grit_amd.ops.msda import MSDeformAttnFunction, StackedValueMaps, ms_deform_attn_stacked, stacked_fast_path
     from grit_amd.ops import msda as msda_op
-    monkeypatch.setattr(msda_op, "F32_ACCUMULATE", f32_accumulate)
+    _set_accumulation(msda_op, f32_accumulate, monkeypatch)
     value, shapes, lsi, loc, aw = _config2(B=2)
     g = torch.Generator().manual_seed(17)
     n = 3

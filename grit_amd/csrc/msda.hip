@@ -461,6 +461,115 @@ void msda_fwd_bf16_rows4(const __hip_bfloat16* __restrict__ value, const int64_t
     }
 }
 
+// grad_loc / grad_attn_w for bf16 maps, D = 64, L*P <= 16, in the shape of msda_fwd_bf16_rows4: a wave owns four rows, lane j
+// computes point (j & 15) of row r0 + (j >> 4) once and parks the corner offsets in LDS; each 16-lane row serves one (b, q, m)
+// row, its two 8-lane halves walk 8 points each with 8 channels (16 B) per lane.  Everything the two gradients need from the
+// value map are the four scalars  a_k = <grad_out row, corner k row>  per point (ms_deform_im2col_cuda.cuh:97-158 with the
+// channel sum pulled inside): 8 multiply-adds per gathered 16 bytes, then ONE 32-value butterfly over the 8 lanes of a half
+// (28 exchanges for four rows; the one-row-per-wave walk above spends 63 per row), after which lane j holds the four dots of
+// exactly the point whose geometry it computed.
+template <int BATCH>
+__global__ __launch_bounds__(256)
+void msda_bwd_rows4(const __hip_bfloat16* __restrict__ value, const int64_t* __restrict__ shapes,
+                    const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
+                    const __hip_bfloat16* __restrict__ grad_out, int S, int M, int L, int Lq, int P,
+                    float* __restrict__ grad_loc, float* __restrict__ grad_aw, int nrows, int nblk, int pix_el) {
+    constexpr int D = 64;
+    __shared__ uint4 geo[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = (xcd_logical_block(blockIdx.x, nblk) * 4 + wave) * 4;
+    if (r0 >= nrows) return;
+    const int LP = L * P;
+    const int row = r0 + (lane >> 4), p = lane & 15;
+    const bool valid = row < nrows && p < LP;
+    const int rc = min(row, nrows - 1), pc = min(p, LP - 1);
+    const float2 xy = *reinterpret_cast<const float2*>(loc + ((size_t)rc * LP + pc) * 2);
+    const float wt = valid ? aw[(size_t)rc * LP + pc] : 0.f;
+    const int l = pc / P;
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const Corners<float> c = make_corners<float>(xy.x, xy.y, H, W);
+    {
+        const uint32_t m = rc % M, b = (rc / M) / Lq;
+        const uint32_t pix = (uint32_t)pix_el * 2;
+        const uint32_t base = (b * (uint32_t)S + (uint32_t)lsi[l]) * pix + m * (D * 2);
+        // a dead corner keeps its clamped (legal) address; bit 0 of the byte offset marks it (offsets are multiples of 16)
+        geo[wave][lane] = make_uint4((base + c.o1 * pix) | (c.k1 ? 0u : 1u), (base + c.o2 * pix) | (c.k2 ? 0u : 1u),
+                                     (base + c.o3 * pix) | (c.k3 ? 0u : 1u), (base + c.o4 * pix) | (c.k4 ? 0u : 1u));
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int c8 = lane & 7;
+    const uint32_t cb = c8 * 16;
+    const uint4* g = &geo[wave][(lane & 48) + (lane & 8)];  // this half's 8 points of this row
+    const char* vb = reinterpret_cast<const char*>(value);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 go2[4];
+    {
+        const uint4 gq = *reinterpret_cast<const uint4*>(grad_out + (size_t)rc * D + c8 * 8);
+        const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) go2[j] = f2{__uint_as_float(gw[j] << 16), __uint_as_float(gw[j] & 0xffff0000u)};
+    }
+    float d[32];  // d[4 i + k]: this lane's 8 channels of <grad_out, corner k of this half's point i>
+#pragma unroll
+    for (int it0 = 0; it0 < 8; it0 += BATCH) {
+        uint4 v[BATCH][4];
+        uint4 o[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            o[i] = g[it0 + i];
+            v[i][0] = *reinterpret_cast<const uint4*>(vb + ((o[i].x & ~1u) + cb));
+            v[i][1] = *reinterpret_cast<const uint4*>(vb + ((o[i].y & ~1u) + cb));
+            v[i][2] = *reinterpret_cast<const uint4*>(vb + ((o[i].z & ~1u) + cb));
+            v[i][3] = *reinterpret_cast<const uint4*>(vb + ((o[i].w & ~1u) + cb));
+        }
+        __builtin_amdgcn_sched_barrier(0);  // every gather of the batch is in flight before the first one is consumed
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const uint32_t dead[4] = {o[i].x & 1u, o[i].y & 1u, o[i].z & 1u, o[i].w & 1u};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // a corner outside the map: whatever sits at its clamped address (even a NaN) contributes exactly nothing
+                const uint32_t w4[4] = {dead[k] ? 0u : v[i][k].x, dead[k] ? 0u : v[i][k].y, dead[k] ? 0u : v[i][k].z,
+                                        dead[k] ? 0u : v[i][k].w};
+                f2 a = {0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    a = __builtin_elementwise_fma(go2[j], f2{__uint_as_float(w4[j] << 16), __uint_as_float(w4[j] & 0xffff0000u)}, a);
+                d[4 * (it0 + i) + k] = a.x + a.y;
+            }
+        }
+    }
+    // 32 values over the 8 lanes of the half: three halving exchanges (lane bit 2 <-> point bit 2, ...), after which lane j of the
+    // half holds d[0..3] = the four dots of point j of the half, i.e. of point (lane & 15) of its row
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const bool hi = lane & 4;
+        const float keep = hi ? d[16 + i] : d[i], send = hi ? d[i] : d[16 + i];
+        d[i] = keep + __shfl_xor(send, 4, kWave);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool hi = lane & 2;
+        const float keep = hi ? d[8 + i] : d[i], send = hi ? d[i] : d[8 + i];
+        d[i] = keep + __shfl_xor(send, 2, kWave);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool hi = lane & 1;
+        const float keep = hi ? d[4 + i] : d[i], send = hi ? d[i] : d[4 + i];
+        d[i] = keep + __shfl_xor(send, 1, kWave);
+    }
+    if (valid) {
+        const float a1 = d[0], a2 = d[1], a3 = d[2], a4 = d[3];  // already zero for dead corners
+        const float gh = -c.hw * a1 - c.lw * a2 + c.hw * a3 + c.lw * a4;
+        const float gw = -c.hh * a1 + c.hh * a2 - c.lh * a3 + c.lh * a4;
+        const float val = c.w1 * a1 + c.w2 * a2 + c.w3 * a3 + c.w4 * a4;
+        grad_aw[(size_t)row * LP + p] = val;
+        *reinterpret_cast<float2*>(grad_loc + ((size_t)row * LP + p) * 2) = make_float2((float)W * wt * gw, (float)H * wt * gh);
+    }
+}
+
 __device__ __forceinline__ float ldv(const float* p) { return *p; }
 __device__ __forceinline__ float ldv(const __hip_bfloat16* p) { return __bfloat162float(*p); }
 
@@ -1000,20 +1109,26 @@ void msda_bwd_value(const int64_t* __restrict__ shapes, const int64_t* __restric
         for (int cb = 0; cb < 4; ++cb) acc[cb] = v4f{0.f, 0.f, 0.f, 0.f};
         for (int k0 = beg; k0 < end; k0 += 32) {
             // k slots of this lane (the order the transposing reads define): e < 4: k0 + 4 lg + e,  e >= 4: k0 + 16 + 4 lg + e - 4
-            unsigned whi[8], wmid[8], wlo[8];
+            // masked record words first (2 selects per record), then three byte permutes per PAIR of records gather the hi /
+            // mid / lo halves into the packed operand registers
+            unsigned rx[8], ry[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = k0 + 4 * lg + (e & 3) + (e >> 2) * 16;
                 const uint2 r = recs[min(k, cap - 1)];
                 const bool mine = k < end && ((r.x >> 12) & 15u) == (unsigned)l15;
-                whi[e] = mine ? (r.x >> 16) : 0u;
-                wmid[e] = mine ? (r.y & 0xffffu) : 0u;
-                wlo[e] = mine ? (r.y >> 16) : 0u;
+                rx[e] = mine ? r.x : 0u;
+                ry[e] = mine ? r.y : 0u;
             }
             typedef unsigned u4v __attribute__((ext_vector_type(4)));
-            const u4v ph = {whi[0] | (whi[1] << 16), whi[2] | (whi[3] << 16), whi[4] | (whi[5] << 16), whi[6] | (whi[7] << 16)};
-            const u4v pm = {wmid[0] | (wmid[1] << 16), wmid[2] | (wmid[3] << 16), wmid[4] | (wmid[5] << 16), wmid[6] | (wmid[7] << 16)};
-            const u4v pl = {wlo[0] | (wlo[1] << 16), wlo[2] | (wlo[3] << 16), wlo[4] | (wlo[5] << 16), wlo[6] | (wlo[7] << 16)};
+            u4v ph, pm, pl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // v_perm_b32(hi word, lo word, selector): selector bytes 0-3 index the low word, 4-7 the high word
+                ph[e] = __builtin_amdgcn_perm(rx[2 * e + 1], rx[2 * e], 0x07060302u);  // hi halves: x >> 16
+                pm[e] = __builtin_amdgcn_perm(ry[2 * e + 1], ry[2 * e], 0x05040100u);  // mid: y & 0xffff
+                pl[e] = __builtin_amdgcn_perm(ry[2 * e + 1], ry[2 * e], 0x07060302u);  // lo: y >> 16
+            }
             const v8bf_m bh = __builtin_bit_cast(v8bf_m, ph), bm = __builtin_bit_cast(v8bf_m, pm), bl = __builtin_bit_cast(v8bf_m, pl);
             // rows this lane addresses for the transposing reads: records k0 + 4 lg + trq and + 16 (past the run: the zero row)
             const int ka = k0 + 4 * lg + trq, kb = ka + 16;
@@ -1294,6 +1409,14 @@ int grit_msda_bwd_bf16_sorted(const void* value, long pixel_stride, const int64_
                        (int)pixel_stride);
     if (hipGetLastError() != hipSuccess) return GRIT_ERR_LAUNCH;
     const int nrows = B * Lq * M;
+    static const bool rows1 = getenv("GRIT_MSDA_BWD_ROWS1") && atoi(getenv("GRIT_MSDA_BWD_ROWS1")) != 0;  // A/B: one row per wave
+    if (!rows1 && (long)B * S * pixel_stride * 2 < (1LL << 32) && (uintptr_t)value % 16 == 0) {
+        const int nblk16 = (nrows + 15) / 16;
+        hipLaunchKernelGGL(msda_bwd_rows4<2>, dim3(nblk16), dim3(256), 0, st, (const __hip_bfloat16*)value, spatial_shapes,
+                           level_start, loc, attn_w, (const __hip_bfloat16*)grad_out, S, M, L, Lq, P, grad_loc, grad_attn_w,
+                           nrows, nblk16, (int)pixel_stride);
+        return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+    }
     const int nblk = (nrows + kRowsPerBlock - 1) / kRowsPerBlock;
     hipLaunchKernelGGL(msda_bwd_d64_pk<2>, dim3(nblk), dim3(kWave * kRowsPerBlock), 0, st, (const __hip_bfloat16*)value,
                        spatial_shapes, level_start, loc, attn_w, (const __hip_bfloat16*)grad_out, S, M, L, Lq, P,

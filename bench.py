@@ -538,13 +538,31 @@ def main():
         if bwd:  # informational: the backward is bound by the chip-wide memory-side atomic rate, not by HBM
             avg_b = sum(t for t, _ in bwd) / len(bwd)
             msda_bwd = {"kernel": "msda_bwd_d64 (f32 maps, f32 atomics)" if args.fp32 else
-                        (("msda_bwd_index + msda_bwd_d64_pk<no scatter> + msda_bwd_gather (gather form: contributions binned by cell in "
-                          "LDS, f32 sums in registers, one rounding to bf16, no atomics on memory)"
+                        (("msda_bwd_value + msda_bwd_rows4 (gather form: per (image, head) the corner contributions are binned by cell "
+                          "in one CU's LDS and every cell is summed on the matrix cores in f32, rounded to bf16 once; no atomics on "
+                          "memory, dense output)"
                           if msda_op.F32_METHOD == "sorted" else
                           "msda_bwd_d64_pk<stage> + msda_stage_flush (f32 atomics into a staging map, one rounding to bf16 per touched cell)")
                          if msda_op.F32_ACCUMULATE else "msda_bwd_d64_pk (packed-bf16 atomics, same-cell merges)"),
                         "launches": len(bwd), "avg_launch_us": avg_b * 1e6,
                         "whole_map_bytes_per_launch": int(bwd[0][1])}
+            if not args.fp32 and msda_op.F32_ACCUMULATE and msda_op.F32_METHOD == "sorted":
+                # the gather form IS an HBM-shaped kernel pair: its compulsory bytes are the dense gradient slice it writes plus
+                # locations, weights, grad_out (twice: both kernels) and the gathered corner rows of the row walk
+                ta, tb = pmc_traffic("msda_bwd_value"), pmc_traffic("msda_bwd_rows4")
+                on_config = args.batch == 32 and args.size == 640 and args.points == "model" and not args.ragged
+                traffic_b = (ta[0] + tb[0]) if (on_config and ta[0] and tb[0]) else None
+                Bm, Sm, Mm, Lm, Lqm, Pm = (int(v) for v in msda_op.LAST_BWD_SHAPE)
+                rows_m, lp_m = Bm * Lqm * Mm, Lm * Pm
+                compulsory = Bm * Sm * Mm * 64 * 2 + rows_m * (lp_m * 12 * 2 + 64 * 2 * 2)
+                msda_bwd.update({"bound": "hbm", "achieved": compulsory / avg_b / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": compulsory / avg_b / 1e9 / HBM_PEAK_GBPS,
+                                 "algorithmic_bytes_per_launch": int(compulsory),
+                                 "algorithmic_bytes_basis": "dense bf16 gradient slice written once + locations, weights and their "
+                                                            "gradients + grad_out read by both kernels; the gathered corner rows of the "
+                                                            "row walk are NOT counted (a lower bound on the bytes)",
+                                 "traffic": traffic_b, "traffic_source": ta[1] if traffic_b else None,
+                                 "traffic_frac": (traffic_b / avg_b / 1e9 / HBM_PEAK_GBPS) if traffic_b else None})
         # window attention against its compulsory HBM bytes (memory-bound at 72 flop/B; the MFMA fraction is informational)
         window_attention = {}
         for kind, name, products, tensors in (("fwd", "winattn_fwd", 2, 4), ("bwd", "winattn_bwd", 5, 7)):

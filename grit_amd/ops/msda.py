@@ -75,8 +75,13 @@ def sorted_applies(B, S, M, L, Lq, P):
     return F32_METHOD == "sorted" and _lib.load().grit_msda_bwd_sorted_supported(B, S, M, L, Lq, P) == 0
 
 
+LAST_BWD_SHAPE = None  # (B, S, M, L, Lq, P) of the last gather-form backward (bench.py prices its bytes with it)
+
+
 def _bwd_sorted(value_ptr, pixel_stride, shapes, lsi, loc, aw, go, B, S, M, D, L, Lq, P, gv_ptr, gl, ga, device):
     """Value gradient in gather form; writes EVERY cell of the [B, S, M, 64] slice behind gv_ptr."""
+    global LAST_BWD_SHAPE
+    LAST_BWD_SHAPE = (B, S, M, L, Lq, P)
     with _lib.device_guard(device), _Timed("bwd_bf16", _algorithmic_bytes("bwd", B, S, M, D, L, Lq, P, 2, 4, 2)):
         st = _lib.load().grit_msda_bwd_bf16_sorted(value_ptr, pixel_stride, _ptr(shapes), _ptr(lsi), _ptr(loc), _ptr(aw), _ptr(go),
                                                    B, S, M, D, L, Lq, P, gv_ptr, _ptr(gl), _ptr(ga), _lib.current_stream_ptr())

@@ -1,0 +1,225 @@
+// Weight gradient of nn.Linear on the LONG token maps of GRIT's Swin backbone (gfx950):
+//
+//     dW[N, K] = dY[M, N]^T . X[M, K]        bf16 in (row-major, the contraction index m is the SLOW index of both operands:
+//                                             "TN"), fp32 accumulation;  M = 51 200 tokens at stage 2, N / K = 512 .. 2 048
+//
+// reference: autograd of the Linear layers of every Swin block (models/common/swin_model.py:26-35 Mlp, :147-149 qkv / proj) --
+// half of the backbone's backward GEMM flops.  The library path is a batched GEMM over 16 row slices that writes 16 fp32 copies
+// of dW plus a reduction kernel that reads them back (3.6 GB per training step).
+//
+// Structure:
+//   * workgroup = 8 waves (2 x 4) on a 256 (n) x 256 (k) tile of dW over ONE slice of the rows; N/256 x K/256 tiles x S slices
+//     = one workgroup per CU, all co-resident, each with a main loop of ~100 steps of 32 rows (the K = 512 forward GEMMs have 8);
+//   * a step's operands are 32 rows x 512 bytes of dY and of X, row-major as they lie in memory: global_load_lds_dwordx4 into a
+//     four-stage LDS ring with a counted vmcnt (gemm.hip's pipeline).  The transpose the TN layout needs happens in the LDS READ:
+//     both MFMA operands come through ds_read_b64_tr_b16 (lane = output row n / output column k, k-slots = the 32 token rows);
+//   * the 16 rows a transposing read touches are 512 bytes apart -- the same banks.  The 32-byte groups of a row are XOR-ed with
+//     (row & 7) on the DMA's SOURCE address and on the read: 8 distinct bank groups, the 2-way remainder is the instruction's own
+//     512 bytes;
+//   * v_mfma_f32_16x16x32_bf16 with dY^T as the A operand: accumulator rows = n, lanes = 16 consecutive k.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "../../include/grit_hip.h"
+
+namespace {
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s lds_v4s;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int kT = 256, kBK = 32, kThreads = 512, kStages = 4;
+constexpr int kOpBytes = kBK * kT * 2;       // 16 KB: one operand of one step
+constexpr int kStageBytes = 2 * kOpBytes;    // 32 KB
+constexpr int kLoads = 4;                    // DMA instructions per thread and stage (2 per operand)
+
+struct TnArgs {
+    const __bf16* dY; long ldy;
+    const __bf16* X; long ldx;
+    float* partial;           // [S][N][K] fp32
+    int M, N, K, S, rows_per_split, tiles_n, tiles_k;
+};
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// The transposing reads are issued as inline asm.  Through the builtin, hipcc puts `s_waitcnt vmcnt(0)` in front of every one of
+// them (an LDS read it cannot prove disjoint from the LDS-DMA writes still in flight), which serialises the global loads of the
+// NEXT stages with the compute of this one (measured: 0.50 PFLOP/s).  As asm the compiler knows nothing about the reads, so the
+// waits are this file's: `lgkmcnt(0)` tied to the fragment registers before their first use, a counted `vmcnt` per stage.
+// addr: byte offset in LDS of rows 0..15 of the block; the second read takes rows 16..31 (+ 8 192 B).
+__device__ __forceinline__ v4i tr_pair(unsigned addr) {
+    v2i lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(hi) : "v"(addr));
+    return v4i{lo[0], lo[1], hi[0], hi[1]};
+}
+
+__global__ __launch_bounds__(kThreads, 2)
+void wgrad_tn_256(const TnArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    // XCD-aware order: the workgroups of one XCD (equal blockIdx % 8) take a contiguous band of (slice, tile) pairs, so a slice's
+    // rows of dY and X are fetched into one L2 and shared by the tiles that run next to each other
+    const int tiles = g.tiles_n * g.tiles_k, nwg = tiles * g.S;
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int qd = nwg >> 3, rm = nwg & 7;
+    const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    const int split = logical / tiles, tile = logical - split * tiles;
+    const int tn = tile / g.tiles_k, tk = tile - tn * g.tiles_k;
+    const int n0 = tn * kT, k0 = tk * kT;
+    const int m_begin = split * g.rows_per_split, m_end = min(g.M, m_begin + g.rows_per_split);
+    const int nsteps = (m_end - m_begin) / kBK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;  // wave tile: rows n [128 wm, +128), columns k [64 wn, +64)
+    const int l15 = lane & 15, lg = lane >> 4, trq = l15 >> 2, trp = l15 & 3;
+
+    // ---- DMA sources: round i covers rows 16 i + tid / 32; the 16-byte position p of the LDS row holds logical chunk
+    // (((p >> 1) ^ (row & 7)) << 1) | (p & 1)
+    const __bf16* ysrc[2];
+    const __bf16* xsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 16 * i + (tid >> 5), p = tid & 31;
+        const int c = ((((p >> 1) ^ (row & 7)) << 1) | (p & 1));
+        ysrc[i] = g.dY + (size_t)(m_begin + row) * g.ldy + n0 + c * 8;
+        xsrc[i] = g.X + (size_t)(m_begin + row) * g.ldx + k0 + c * 8;
+    }
+    const int wave_dst = wave * 1024;
+    auto dma_piece = [&](int slot, int step, int i) {  // i = 0, 1: dY rounds; 2, 3: X rounds
+        char* base = lds + slot * kStageBytes;
+        if (i < 2)
+            __builtin_amdgcn_global_load_lds((gptr_t)(ysrc[i & 1] + (size_t)step * kBK * g.ldy), (lptr_t)(base + (i & 1) * 8192 + wave_dst), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i & 1] + (size_t)step * kBK * g.ldx),
+                                             (lptr_t)(base + kOpBytes + (i & 1) * 8192 + wave_dst), 16, 0, 0);
+    };
+
+    // ---- fragment read offsets: row (half 16 + 4 lg + trq), 32-byte group (block ^ (row & 7)), 8 bytes at trp
+    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)lds;
+    const int r_lo = 4 * lg + trq, sr = r_lo & 7;
+    unsigned aoff[8], boff[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) aoff[i] = lds_base + r_lo * 512 + (((wm * 8 + i) ^ sr) * 32) + trp * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) boff[j] = lds_base + kOpBytes + r_lo * 512 + (((wn * 4 + j) ^ sr) * 32) + trp * 8;
+
+    v4f acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    // every stage issue is unconditional (past the last step it re-reads the last rows into a slot nobody reads any more): the
+    // vmcnt bookkeeping below has no branches
+    auto issue_stage_piece = [&](int step, int i) { dma_piece(step % kStages, min(step, nsteps - 1), i); };
+#pragma unroll
+    for (int st = 0; st < kStages - 1; ++st)
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) issue_stage_piece(st, i);
+
+    // Fragments are double-buffered in registers: the 24 transposing reads of step t + 1 are spread between the MFMAs of step t
+    // (an LDS round trip is ~2 MFMA groups long and both waves of a SIMD run the same schedule: nothing else would cover it).
+    // So a step needs its successor's stage landed: exactly ONE younger stage's DMAs (4 per thread) stay counted across the wait.
+    v4i fa[8], fb[4];
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage 0 landed
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j] = tr_pair(boff[j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = tr_pair(aoff[i]);
+    // One step: MFMAs on the fragments (ca, cb) that are complete, reads of the next step's fragments into (na, nb).  The loop is
+    // unrolled by two with the two register sets swapping roles: a register COPY of (na, nb) right after the reads were issued
+    // would copy whatever the registers held before the data arrived (the compiler cannot know: the reads are asm).
+    auto step = [&](int t, v4i (&ca)[8], v4i (&cb)[4], v4i (&na)[8], v4i (&nb)[4]) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // stage t + 1 landed (stage t + 2 may still be in flight)
+        __builtin_amdgcn_s_barrier();                      // ... for every wave; and every wave is done reading stage t - 1's slot
+        // the fragments of step t are complete: one lgkmcnt wait, tied to the registers so that no MFMA moves above it
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ca[0]), "+v"(ca[1]), "+v"(ca[2]), "+v"(ca[3]), "+v"(ca[4]), "+v"(ca[5]), "+v"(ca[6]), "+v"(ca[7]),
+                       "+v"(cb[0]), "+v"(cb[1]), "+v"(cb[2]), "+v"(cb[3])
+                     :: "memory");
+        const unsigned sn = (unsigned)(((t + 1) % kStages) * kStageBytes);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, ca[i]), __builtin_bit_cast(v8bf, cb[j]),
+                                                                    acc[i][j], 0, 0, 0);
+            na[i] = tr_pair(aoff[i] + sn);
+            if (i < 4) nb[i] = tr_pair(boff[i] + sn);
+            if (i >= 4) issue_stage_piece(t + kStages - 1, i - 4);  // slot (t + 3) % 4 = (t - 1) % 4: read during step t - 2
+        }
+    };
+    v4i ga[8], gb[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ga[i] = v4i{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gb[j] = v4i{0, 0, 0, 0};
+    int t = 0;
+    for (; t + 1 < nsteps; t += 2) {
+        step(t, fa, fb, ga, gb);
+        step(t + 1, ga, gb, fa, fb);
+    }
+    if (t < nsteps) step(t, fa, fb, ga, gb);
+    // Nothing of this workgroup may land in LDS after it is gone -- and the reads the last step issued into the (now unused)
+    // fragment registers must have landed before the compiler re-uses those registers: to the compiler an asm read is complete
+    // when it is issued, so the wait is tied to all 24 of them (seen: epilogue addresses overwritten by late LDS data).
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]),
+                   "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]),
+                   "+v"(ga[0]), "+v"(ga[1]), "+v"(ga[2]), "+v"(ga[3]), "+v"(ga[4]), "+v"(ga[5]), "+v"(ga[6]), "+v"(ga[7]),
+                   "+v"(gb[0]), "+v"(gb[1]), "+v"(gb[2]), "+v"(gb[3])
+                 :: "memory");
+
+    // ---- epilogue: acc[i][j][r] = dW[n0 + 128 wm + 16 i + 4 lg + r][k0 + 64 wn + 16 j + l15] of this slice
+    float* out = g.partial + ((size_t)split * g.N + n0 + 128 * wm + 4 * lg) * g.K + k0 + 64 * wn + l15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(size_t)(16 * i + r) * g.K + 16 * j] = acc[i][j][r];
+}
+
+}  // namespace
+
+extern "C" int grit_wgrad_tn_splits(int M, int N, int K) {
+    // one workgroup per CU: S slices of the rows such that tiles x S ~ 256, every slice a whole number of 32-row steps
+    if (M <= 0 || N <= 0 || K <= 0 || N % kT || K % kT || M % kBK) return 0;
+    const int tiles = (N / kT) * (K / kT);
+    int S = 256 / tiles;  // never a second round of workgroups
+    if (S < 1) S = 1;
+    const int steps = M / kBK;
+    if (S > steps) S = steps;
+    const int rows = ((steps + S - 1) / S) * kBK;
+    return (M + rows - 1) / rows;
+}
+
+extern "C" int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial,
+                             void* stream) {
+    if (!dY || !X || !partial || M <= 0 || N <= 0 || K <= 0 || splits <= 0) return GRIT_ERR_BAD_ARG;
+    if (N % kT || K % kT || M % kBK || ldy % 8 || ldx % 8 || ldy < N || ldx < K || ((uintptr_t)dY % 16) || ((uintptr_t)X % 16) ||
+        ((uintptr_t)partial % 16))
+        return GRIT_ERR_UNSUPPORTED;
+    if (splits != grit_wgrad_tn_splits(M, N, K)) return GRIT_ERR_BAD_ARG;
+    TnArgs a;
+    a.dY = (const __bf16*)dY; a.ldy = ldy; a.X = (const __bf16*)X; a.ldx = ldx; a.partial = partial;
+    a.M = M; a.N = N; a.K = K; a.S = splits;
+    const int steps = M / kBK;
+    a.rows_per_split = ((steps + splits - 1) / splits) * kBK;
+    a.tiles_n = N / kT; a.tiles_k = K / kT;
+    static bool attr_set = false;  // idempotent attribute
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)wgrad_tn_256, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes) != hipSuccess)
+            return GRIT_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_tn_256, dim3((unsigned)(a.tiles_n * a.tiles_k * splits)), dim3(kThreads), kStages * kStageBytes,
+                       (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}

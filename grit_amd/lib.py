@@ -30,6 +30,8 @@ SIGNATURES = {
     "grit_msda_fwd_bf16_strided": [_ptr, _c.c_long] + [_ptr] * 4 + [_int] * 7 + [_ptr, _ptr],
     "grit_msda_bwd_bf16acc_strided": [_ptr, _c.c_long] + [_ptr] * 5 + [_int] * 7 + [_ptr] * 4,
     "grit_msda_bwd_bf16_staged": [_ptr, _c.c_long] + [_ptr] * 5 + [_int] * 7 + [_ptr] * 6,
+    "grit_wgrad_tn_splits": [_int] * 3,
+    "grit_wgrad_tn": [_ptr, _c.c_long, _ptr, _c.c_long] + [_int] * 4 + [_ptr, _ptr],
     "grit_msda_bwd_sorted_supported": [_int] * 6,
     "grit_msda_bwd_bf16_sorted": [_ptr, _c.c_long] + [_ptr] * 5 + [_int] * 7 + [_ptr] * 4,
     "grit_winattn_fwd_bf16": [_ptr] * 4 + [_int] * 8 + [_f32, _ptr, _ptr, _ptr],

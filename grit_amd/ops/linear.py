@@ -418,6 +418,33 @@ def small_weight_bias_grad(dy2, x2, need_db, out_dtype, group=None):
     return dw, db
 
 
+# GRIT_WGRAD_TN (default 1): weight gradients of the long token maps by grit_wgrad_tn (grit_amd/csrc/wgrad_tn.hip: 256 x 256 tiles,
+# transposing LDS reads, one workgroup per CU) instead of the library's batched GEMM over 16 row slices -- 1.02-1.19 PFLOP/s
+# against 0.76-0.99 on the Swin shapes (profiles/r03/wgrad_tn.txt).  The slices' fp32 partials are summed by the grouped slab sum as
+# before.
+WGRAD_TN = os.environ.get("GRIT_WGRAD_TN", "1") != "0"
+
+
+def long_weight_grad_partials(dy2, x2):
+    """fp32 partials [S, N, K] of dW = dy2^T x2 from the own kernel, or None where it does not apply (the library path runs)."""
+    if not (WGRAD_TN and dy2.is_cuda and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16):
+        return None
+    M, N = dy2.shape
+    K = x2.shape[1]
+    if M < 8192 or dy2.stride(1) != 1 or x2.stride(1) != 1:  # shorter maps: the deferred grouped kernel / the library
+        return None
+    lib = _lib.load()
+    S = lib.grit_wgrad_tn_splits(M, N, K)
+    if S <= 0 or dy2.stride(0) % 8 or x2.stride(0) % 8 or dy2.data_ptr() % 16 or x2.data_ptr() % 16:
+        return None
+    part = torch.empty((S, N, K), dtype=torch.float32, device=dy2.device)
+    with _lib.device_guard(dy2.device), timed("gemm_own", flops=2.0 * M * N * K):
+        st = lib.grit_wgrad_tn(ctypes.c_void_p(dy2.data_ptr()), dy2.stride(0), ctypes.c_void_p(x2.data_ptr()), x2.stride(0), M, N, K, S,
+                               ctypes.c_void_p(part.data_ptr()), _lib.current_stream_ptr())
+    _lib.check(st, "grit_wgrad_tn")
+    return part
+
+
 def weight_grad(dy2, x2, group=None):
     """dW [N, K] = dy2^T [N, M] @ x2 [M, K], split over M into one batched GEMM with fp32 partial sums.  With `group` (a
     SlabGroup) the sum over the partials is left to the group's launch."""
@@ -425,6 +452,11 @@ def weight_grad(dy2, x2, group=None):
     if small is not None:
         return small[0]
     M, N = dy2.shape
+    own = long_weight_grad_partials(dy2, x2)
+    if own is not None:
+        if group is not None:
+            return group.add(own.unsqueeze(0), dy2.dtype)[0]
+        return slab_sum(own.unsqueeze(0), dy2.dtype)[0]
     S = split_k(M) if (dy2.is_cuda and dy2.dtype == torch.bfloat16) else 1
     with timed("gemm_lib", flops=2.0 * M * N * x2.shape[1]):
         if S == 1:

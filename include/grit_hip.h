@@ -363,6 +363,16 @@ typedef struct grit_wgrad_job {
 int grit_wgrad_group_splits(int M);
 int grit_wgrad_small_grouped(const grit_wgrad_job* jobs, int n_jobs, void* stream);
 
+/* Weight gradient of a Linear on a LONG token map (the Swin blocks): partial[s, N, K] (fp32) = dY[rows of slice s]^T . X[rows of
+ * slice s] for S = grit_wgrad_tn_splits(M, N, K) row slices (chosen so that tiles x S fills the chip with one 256 x 256-tile
+ * workgroup per CU); the caller sums the slices (grit_slab_sum_grouped).  The contraction runs over the slow index of both
+ * operands; the transpose happens in the LDS reads (ds_read_b64_tr_b16 on both MFMA operands, grit_amd/csrc/wgrad_tn.hip).
+ * Replaces the batched library GEMM over row slices of autograd's Linear backward (models/common/swin_model.py:26-35, 147-149).
+ * N, K multiples of 256, M a multiple of 32 (grit_wgrad_tn_splits returns 0 otherwise: use the library), 16-byte aligned bases,
+ * leading dimensions multiples of 8. */
+int grit_wgrad_tn_splits(int M, int N, int K);
+int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Adam step on one flat range of the fp32-master / bf16-compute training state (torch.optim.Adam as configured by the
  * reference's build_optimizers, engine/caption_engine.py:18-73: amsgrad off, weight decay 0).

@@ -220,3 +220,52 @@ def test_fused_gelu_epilogues_against_erf_gelu_over_the_whole_range():
     F.gelu(xr).sum().backward()
     derr = (d.float() - xr.grad).abs()
     assert float((derr - xr.grad.abs() * 2.0 ** -8).max()) <= 1.5e-4, float(derr.max())
+
+
+DEV = "cuda"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,pad", [(51200, 2048, 512, 0), (51200, 512, 512, 0), (51200, 1536, 512, 0), (12800, 1024, 4096, 0),
+                                       (2464 * 3 + 32, 256, 256, 8), (64, 256, 512, 0), (204800, 768, 256, 0)])
+def test_long_map_weight_gradient_tn(M, N, K, pad):
+    """grit_wgrad_tn: dW = dY^T X over row slices (fp32 partials) on the Swin shapes -- even and odd numbers of 32-row steps per
+    slice, a last slice shorter than the others, fewer workgroups than CUs, operands with a leading dimension larger than their
+    width -- against an fp64 reference of the same bf16 inputs; shapes outside the contract answer 0 slices."""
+    import ctypes
+    from grit_amd import lib as _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    dy_full = torch.randn(M, N + pad, device=DEV, generator=g).bfloat16()
+    x_full = torch.randn(M, K + pad, device=DEV, generator=g).bfloat16()
+    dy, x = dy_full[:, :N], x_full[:, :K]
+    S = lib.grit_wgrad_tn_splits(M, N, K)
+    assert S >= 1 and (N // 256) * (K // 256) * S <= 256
+    part = torch.full((S, N, K), float("nan"), dtype=torch.float32, device=DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = lib.grit_wgrad_tn(p(dy), dy.stride(0), p(x), x.stride(0), M, N, K, S, p(part), _lib.current_stream_ptr())
+    assert st == 0
+    got = part.double().sum(0)
+    ref = dy.double().t() @ x.double()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-5 * scale * max(1.0, M / 51200) + 1e-4
+    assert lib.grit_wgrad_tn_splits(51200, 384, 128) == 0 and lib.grit_wgrad_tn_splits(51201, 512, 512) == 0
+    assert lib.grit_wgrad_tn(p(dy), dy.stride(0), p(x), x.stride(0), M, N, K, S + 1, p(part), _lib.current_stream_ptr()) != 0
+
+
+@pytest.mark.gpu
+def test_weight_grad_routes_long_maps_to_the_own_kernel(monkeypatch):
+    """ops.linear.weight_grad: the long-map path (own kernel + grouped slab sum) and the library path (GRIT_WGRAD_TN=0) agree
+    within the bf16 rounding of the result."""
+    from grit_amd.ops import linear as L
+    g = torch.Generator(device=DEV).manual_seed(5)
+    dy = torch.randn(51200, 512, device=DEV, generator=g).bfloat16()
+    x = torch.randn(51200, 512, device=DEV, generator=g).bfloat16()
+    monkeypatch.setattr(L, "WGRAD_TN", True)
+    assert L.long_weight_grad_partials(dy, x) is not None
+    own = L.weight_grad(dy, x)
+    monkeypatch.setattr(L, "WGRAD_TN", False)
+    assert L.long_weight_grad_partials(dy, x) is None
+    lib_path = L.weight_grad(dy, x)
+    assert own.dtype == torch.bfloat16 and own.shape == (512, 512)
+    torch.testing.assert_close(own.float(), lib_path.float(), rtol=1e-2, atol=1e-2 * float(lib_path.float().abs().max()))

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from grit_amd.ops.layer_norm import LayerNorm, add_layer_norm, linear_add_layer_norm
-from grit_amd.ops.linear import Linear, linear
+from grit_amd.ops.linear import Linear, linear, mark_single_use
 from grit_amd.ops.mlp import hidden as fused_hidden, mlp as fused_mlp, mlp_add_layer_norm
 from grit_amd.ops.rel_bias import relative_position_bias
 from grit_amd.ops.window_attention import window_attention
@@ -184,6 +184,11 @@ class SwinTransformerBlock(nn.Module):
         self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        # these Linears run once per forward pass: inside a gradient-bucket scope the reductions of their backward nodes
+        # (weight-gradient partials, bias / LayerNorm sums) are left to the scope's grouped launch (grit_amd/ops/linear.py).
+        # NOT attn.qkv: its bias receives a second gradient in every pass (the q / k / v rows of the window-padding tokens ARE the
+        # bias: WindowAttention's pad_qkv) -- found by the deferral's own check on the first try
+        mark_single_use(self.attn.proj, self.mlp.fc1, self.mlp.fc2)
         self.H = None
         self.W = None
 

@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 
 from grit_amd import lib as _lib
 from grit_amd.ops import backend
-from grit_amd.ops.linear import (SlabGroup, defer_slab_group, defer_weight_bias_grad, fork, join, on_stream, single_use_now,
+from grit_amd.ops.linear import (SlabGroup, defer_slab_group, defer_weight_bias_grad, finish_group, fork, join, on_stream, single_use_now,
                                  slab_sum)
 from grit_amd.ops.profiling import timed
 
@@ -165,6 +165,7 @@ class _LinearAddLayerNormFn(Function):
     def forward(ctx, inp, lin_w, lin_b, shortcut, scale, weight, bias, eps, drop_p, seed_dev, single_use=False):
         ctx.single_use = single_use
         ctx.sum_params = (weight, bias, lin_b) if single_use else None  # the parameters whose gradients the node's sums are
+        ctx.lin_w_param = lin_w if single_use else None
         with timed("gemm_lib", flops=2.0 * inp.numel() * lin_w.shape[0]):
             branch = F.linear(inp, lin_w, lin_b)
         C = shortcut.shape[-1]
@@ -226,7 +227,11 @@ class _LinearAddLayerNormFn(Function):
                 d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
         if d_lin_w is None:
             d_lin_w = weight_grad(d_branch, inp2, group) if ctx.needs_input_grad[1] else None
-            group.run()
+            sp = ctx.sum_params
+            # long maps: the node's reductions (weight-gradient partials, LayerNorm / bias sums) join the scope's grouped launch
+            finish_group(group, side is None and sp is not None and sums.dtype == lin_w.dtype and ctx.needs_input_grad[2]
+                         and ctx.needs_input_grad[5] and ctx.needs_input_grad[6],
+                         [] if sp is None else [(ctx.lin_w_param, d_lin_w), (sp[0], sums[0]), (sp[1], sums[1]), (sp[2], sums[2])])
         join(side, d_lin_w)
         return d_inp, d_lin_w, sums[2].to(lin_w.dtype), dx.view(ctx.shape), None, sums[0], sums[1], None, None, None, None
 

@@ -141,6 +141,25 @@ def _verify_earlier(final):
         _verify(p, ptr, what, final)
 
 
+# GRIT_SLAB_DEFER_LONG=1 (default 0): also the LONG-map nodes (Swin blocks) leave their reductions to the scope's flush.  Measured
+# neutral (59.26 / 59.23 -> 59.43 / 59.10 ms, profiles/r03/negative_results.txt): summed right behind the GEMM the fp32 partials
+# are still in the Infinity Cache, summed a bucket later they come from HBM -- what the bigger launch saves, the colder data costs.
+FINISH_DEFER = os.environ.get("GRIT_SLAB_DEFER_LONG", "0") == "1"
+
+
+def finish_group(group, single_use, outputs):
+    """End of a backward node that owns a SlabGroup.  outputs: [(parameter, gradient tensor the group's launch will fill)].  Inside a
+    deferral scope, when every one of them belongs to a parameter declared single-use that holds no gradient yet, the launch is
+    left to the scope's flush (one grouped launch for the nodes of a whole gradient bucket instead of one small launch per node:
+    the long-map weight-gradient partials are then summed at streaming bandwidth); otherwise it runs now."""
+    if group is None or not group.jobs:
+        return
+    checks = [(p, t.data_ptr()) for p, t in outputs if t is not None]
+    if FINISH_DEFER and single_use and checks and all(p is not None for p, _ in checks) and defer_slab_group(group, checks):
+        return
+    group.run()
+
+
 def _flush_deferred_slabs(into=None, final=False):
     slabs = _deferral["slabs"]
     if not slabs:
@@ -475,6 +494,7 @@ class _LinearFn(Function):
         ctx.has_bias = bias is not None
         ctx.single_use = single_use
         ctx.bias_param = bias if single_use else None  # the parameter itself: the deferred path checks its .grad
+        ctx.weight_param = weight if single_use else None
         with timed("gemm_lib", flops=2.0 * x.numel() * weight.shape[0]):
             return F.linear(x, weight, bias)
 
@@ -509,7 +529,9 @@ class _LinearFn(Function):
                     dw = weight_grad(dy2, x2, group)
                 if need_b:
                     db = column_sum(dy2, weight.dtype, group)
-            if group is not None:
+            if side is None:
+                finish_group(group, ctx.single_use, [(ctx.weight_param, dw), (ctx.bias_param, db)])
+            elif group is not None:
                 group.run()
         if ctx.needs_input_grad[0]:
             with timed("gemm_lib", flops=2.0 * dy2.numel() * weight.shape[1]):

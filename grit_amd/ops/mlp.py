@@ -20,7 +20,8 @@ from grit_amd import lib as _lib
 from grit_amd.ops import backend
 from grit_amd.ops import gemm as G
 from grit_amd.ops import layer_norm as LN
-from grit_amd.ops.linear import SlabGroup, column_sum, fork, join, on_stream, slab_sum, weight_grad
+from grit_amd.ops.linear import (WGRAD_STREAM, SlabGroup, column_sum, finish_group, fork, join, on_stream, single_use_now, slab_sum,
+                                 weight_grad)
 from grit_amd.ops.profiling import timed
 
 MIN_ROWS = 2048
@@ -73,7 +74,8 @@ class _MlpFn(Function):
     """branch = fc2(gelu(fc1(x)))."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, single_use=False):
+        ctx.params = (w1, b1, w2, b2) if single_use else None
         x2 = _rows(x)
         pre, act = G.linear_bias_gelu(x2, w1, b1)
         with timed("gemm_lib", flops=2.0 * act.numel() * w2.shape[0]):
@@ -90,15 +92,18 @@ class _MlpFn(Function):
         ni = ctx.needs_input_grad
         group = SlabGroup()
         d_x, d_w1, d_b1, d_w2, d_b2 = _mlp_backward(d_branch, x2, w1, pre, act, w2, (ni[0], ni[1], ni[2], ni[3]), ni[4], group)
-        group.run()
-        return (None if d_x is None else d_x.view(ctx.shape)), d_w1, d_b1, d_w2, d_b2
+        ps = ctx.params
+        finish_group(group, ps is not None and not WGRAD_STREAM, [] if ps is None else
+                     [(ps[0], d_w1), (ps[1], d_b1), (ps[2], d_w2), (ps[3], d_b2)])
+        return (None if d_x is None else d_x.view(ctx.shape)), d_w1, d_b1, d_w2, d_b2, None
 
 
 class _MlpAddLayerNormFn(Function):
     """(x_in, shortcut, scale) -> (x, LayerNorm(x)) with x = shortcut + scale[b] * fc2(gelu(fc1(x_in)))."""
 
     @staticmethod
-    def forward(ctx, x_in, w1, b1, w2, b2, shortcut, scale, weight, bias, eps):
+    def forward(ctx, x_in, w1, b1, w2, b2, shortcut, scale, weight, bias, eps, single_use=False):
+        ctx.params = (w1, b1, w2, b2, weight, bias) if single_use else None
         x2 = _rows(x_in)
         pre, act = G.linear_bias_gelu(x2, w1, b1)
         with timed("gemm_lib", flops=2.0 * act.numel() * w2.shape[0]):
@@ -129,9 +134,13 @@ class _MlpAddLayerNormFn(Function):
         dx, d_branch, sums = LN._add_layer_norm_backward(x, weight, mean, rstd, scale, gx, gy, ctx.shape[0], True, 0.0, None, group)
         ni = ctx.needs_input_grad
         d_x, d_w1, d_b1, d_w2, _ = _mlp_backward(d_branch, x2, w1, pre, act, w2, (ni[0], ni[1], ni[2], ni[3]), group=group)
-        group.run()
+        ps = ctx.params
+        # (sums in another dtype than the parameters would be converted -- read -- below, before a deferred launch has run)
+        finish_group(group, ps is not None and not WGRAD_STREAM and sums.dtype == w2.dtype and ni[4] and ni[7] and ni[8],
+                     [] if ps is None else [(ps[0], d_w1), (ps[1], d_b1), (ps[2], d_w2), (ps[3], sums[2]), (ps[4], sums[0]),
+                                            (ps[5], sums[1])])
         return ((None if d_x is None else d_x.view(ctx.in_shape)), d_w1, d_b1, d_w2, sums[2].to(w2.dtype), dx.view(ctx.shape),
-                None, sums[0], sums[1], None)
+                None, sums[0], sums[1], None, None)
 
 
 def _fits(x, mlp):
@@ -155,7 +164,8 @@ def mlp(x, module):
     if not (torch.is_grad_enabled() and (x.requires_grad or fc1.weight.requires_grad or fc2.weight.requires_grad)):
         act = G.gemm_nt(_rows(x), fc1.weight, G.BIAS_GELU, bias=fc1.bias)  # frozen stage / inference: no pre-activation kept
         return F.linear(act, fc2.weight, fc2.bias).view(x.shape[:-1] + (fc2.weight.shape[0],))
-    return _MlpFn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+    return _MlpFn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias,
+                        single_use_now(getattr(fc1, "single_use", False) and getattr(fc2, "single_use", False)))
 
 
 def hidden(x, module):
@@ -181,4 +191,5 @@ def mlp_add_layer_norm(x_in, module, shortcut, scale, norm):
         scale = scale.reshape(-1).float().contiguous()
     fc1, fc2 = module.fc1, module.fc2
     return _MlpAddLayerNormFn.apply(x_in, fc1.weight, fc1.bias, fc2.weight, fc2.bias, shortcut, scale, norm.weight.contiguous(),
-                                    norm.bias.contiguous(), float(norm.eps))
+                                    norm.bias.contiguous(), float(norm.eps),
+                                    single_use_now(getattr(fc1, "single_use", False) and getattr(fc2, "single_use", False)))

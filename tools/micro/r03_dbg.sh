@@ -1,8 +1,8 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r03
-timeout 600 python tools/micro/bench_wgrad_tn.py 2>&1 | grep -v amdgpu > gpurun_out/r03/wgrad_tn.txt; cat gpurun_out/r03/wgrad_tn.txt
+
 GRIT_TEST_SEED_GUARD=1 timeout 2400 python -m pytest tests -q -m gpu > gpurun_out/r03/gpu_tests_guard.log 2>&1; echo "gpu tests rc=$?"
 grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/r03/gpu_tests_guard.log | tail -8
 grep -E "^E  " gpurun_out/r03/gpu_tests_guard.log | cut -c1-300 | head -12
-GRIT_AB_OUT=gpurun_out/r03/ab2 bash tools/micro/ab_env.sh GRIT_WGRAD_TN 0 1
+GRIT_AB_OUT=gpurun_out/r03/ab2 bash tools/micro/ab_env.sh GRIT_SLAB_DEFER_LONG 0 1

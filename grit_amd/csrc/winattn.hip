@@ -567,7 +567,7 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     }
 }
 
-// DMA-staged variant (opt-in, GRIT_WINATTN_BWD_DMA=1): LDS plan, 161 808 of the 163 840 bytes of the CU:
+// DMA-staged variant (the default; GRIT_WINATTN_BWD_DMA=0 selects the register-staged kernel above): LDS plan, 161 808 of the 163 840 bytes of the CU:
 //   bias slab, TRANSPOSED [key][query], as bf16 with a 152-element pitch (conflict-free 8-byte reads per half-wave): 43 776 B.  The
 //     slab is the output of grit_relbias_fwd on a bf16 table in the training step, so the conversion is exact there; with an
 //     fp32 table it rounds the bias to bf16 inside this kernel only (2^-9 relative on an O(0.1) logit term, below the bf16
@@ -625,9 +625,14 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     // 1, its register peak: ~20 % of the kernel was exposed load latency, profiles/r01/winattn_bwd_notes.txt).  Window-padding
     // tokens: q / k / v come from pad_qkv, dO / O rows are zero-filled by the owning thread.
     struct Next { float lse_v; int reg, tkk, kreg, wy, wx; size_t img; };
+    // Issued as inline asm: through __builtin_amdgcn_global_load_lds hipcc cannot tell which later LDS reads the transfer may
+    // alias (one dynamic LDS block) and puts `s_waitcnt vmcnt(0)` right behind the issue -- the prefetch then overlaps nothing
+    // (found in round 3 on the weight-gradient GEMM; it is why this variant measured no better than register staging).  The
+    // waits are this kernel's own: `vmcnt(0)` + barrier at the top of the window that consumes the tiles.
     auto dma16 = [&](const __bf16* src, __bf16* tile) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(tile) + w * 1024), 16, 0, 0);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(
+            (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(tile) + w * 1024));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory", "m0");
     };
     auto prefetch = [&](int win, int buf) {
         Next f;
@@ -1100,9 +1105,10 @@ int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pa
             return GRIT_ERR_LAUNCH;
         lds_attr_set = true;
     }
-    // GRIT_WINATTN_BWD_DMA=1: the DMA-staged variant (measured: equal on stages 0 / 1, 3-9 % slower on stages 2 / 3, the step
-    // 0.25 ms slower -- profiles/r03/negative_results.txt); default: the register-staged kernel
-    static const bool use_dma = getenv("GRIT_WINATTN_BWD_DMA") && atoi(getenv("GRIT_WINATTN_BWD_DMA")) == 1;
+    // The DMA-staged variant is the default since its transfers are issued as asm (before that the compiler's `vmcnt(0)` behind
+    // every issue made it 3-9 % SLOWER on stages 2 / 3, profiles/r03/negative_results.txt #3): -3 % on stages 0 / 1, -2 % on
+    // stage 2, equal on stage 3, step -0.1 ms (profiles/r03/winattn_dma_asm.txt).  GRIT_WINATTN_BWD_DMA=0: register staging.
+    static const bool use_dma = !(getenv("GRIT_WINATTN_BWD_DMA") && atoi(getenv("GRIT_WINATTN_BWD_DMA")) == 0);
     if (use_dma) {
         if (mask)
             hipLaunchKernelGGL(winattn_bwd_dma<true>, dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdDmaLds, (hipStream_t)stream,

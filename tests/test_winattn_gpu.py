@@ -174,16 +174,16 @@ def test_backward_conservation_at_benchmark_size():
     assert torch.isfinite(x.grad.float()).all() and torch.isfinite(y.grad).all()
 
 
-def test_dma_staged_backward_variant_passes_the_same_tests():
-    """GRIT_WINATTN_BWD_DMA=1 selects winattn_bwd_dma (operands of the next window DMA'd into a second LDS tile buffer, bias slab
-    as bf16).  The library reads the knob once per process, so the backward tests of this file are re-run in a child process with
-    the knob set (the child never recurses into this test)."""
+def test_register_staged_backward_variant_passes_the_same_tests():
+    """The default backward is winattn_bwd_dma (operands of the next window DMA'd into a second LDS tile buffer, bias slab as bf16);
+    GRIT_WINATTN_BWD_DMA=0 selects the register-staged winattn_bwd.  The library reads the knob once per process, so the backward
+    tests of this file are re-run in a child process with the knob set (the child never recurses into this test)."""
     import os
     import subprocess
     import sys
-    if os.environ.get("GRIT_WINATTN_BWD_DMA") == "1":
+    if os.environ.get("GRIT_WINATTN_BWD_DMA") == "0":
         pytest.skip("already the child run")
-    env = dict(os.environ, GRIT_WINATTN_BWD_DMA="1")
+    env = dict(os.environ, GRIT_WINATTN_BWD_DMA="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
                         "backward or explicit_mask or properties"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]

@@ -64,9 +64,47 @@ void colsum_kernel(const T* __restrict__ x, int M, int N, int rows_per_slab, flo
 // Second stage of every slab-wise reduction in the step (column sums, split-M weight gradients, LayerNorm dgamma/dbeta):
 // out[g][i] = cast(sum_s partial[g][s][i]).  One launch replaces torch's reduce + dtype-cast pair (~350 launches a step).
 // A workgroup covers CW float4 column groups x (256 / CW) interleaved slab lanes, 4 slabs in flight per thread, LDS fold.
+// Wide outputs with a moderate number of slabs (the weight-gradient slices: 16-85 slabs of 0.25-1 M elements): a thread owns one
+// float4 column group and walks ALL slabs, eight 16-byte loads in flight -- no LDS fold, no barrier.  (The shape below, 4 loads in
+// flight and an LDS fold, ran these sums at ~2 TB/s inside the training step.)
+template <typename OT>
+__device__ __forceinline__ void slab_sum_wide(const float* __restrict__ partial, long group_stride, int slabs, long n,
+                                              OT* __restrict__ out, unsigned bx, unsigned by) {
+    const long col = ((long)bx * 256 + threadIdx.x) * 4;
+    if (col >= n) return;
+    const float* src = partial + (long)by * group_stride + col;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 7 < slabs; s += 8) {  // read once: streamed past the caches' retention (nontemporal)
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(src + (long)(s + u) * n));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc4 += v[u];
+    }
+    for (; s < slabs; ++s) acc4 += __builtin_nontemporal_load(reinterpret_cast<const f4*>(src + (long)s * n));
+    const float4 acc = make_float4(acc4[0], acc4[1], acc4[2], acc4[3]);
+    OT* dst = out + (long)by * n + col;
+    if constexpr (sizeof(OT) == 4) {
+        *reinterpret_cast<float4*>(dst) = acc;
+    } else {
+        union { __hip_bfloat16 h[4]; uint2 u; } pk;
+        pk.h[0] = __float2bfloat16(acc.x); pk.h[1] = __float2bfloat16(acc.y);
+        pk.h[2] = __float2bfloat16(acc.z); pk.h[3] = __float2bfloat16(acc.w);
+        *reinterpret_cast<uint2*>(dst) = pk.u;
+    }
+}
+
+constexpr int kWideMark = 31;  // cw_log2 value that selects slab_sum_wide
+
 template <typename OT>
 __device__ __forceinline__ void slab_sum_body(const float* __restrict__ partial, long group_stride, int slabs, long n, int cw_log2,
                                               OT* __restrict__ out, unsigned bx, unsigned by, float4* red) {
+    if (cw_log2 == kWideMark) {  // workgroup-uniform
+        slab_sum_wide<OT>(partial, group_stride, slabs, n, out, bx, by);
+        return;
+    }
     const int cw = 1 << cw_log2, sg_count = 256 >> cw_log2;
     const int c = threadIdx.x & (cw - 1), sg = threadIdx.x >> cw_log2;
     const long col = ((long)bx * cw + c) * 4;
@@ -140,6 +178,8 @@ void slab_sum_grouped_kernel(const GroupedArgs a) {
 
 // column width (log2 of float4 groups per workgroup row) for a job: see grit_slab_sum
 int pick_cw_log2(long groups4, int groups, int slabs) {
+    static const bool wide_ok = !(getenv("GRIT_SLAB_WIDE") && atoi(getenv("GRIT_SLAB_WIDE")) == 0);
+    if (wide_ok && groups4 >= 16384 && slabs >= 4 && slabs <= 512) return kWideMark;  // >= 64 workgroups of 256 column groups
     int cw_log2 = 0;
     while (cw_log2 < 6 && (1L << cw_log2) < groups4) ++cw_log2;
     // tall, narrow partials (LayerNorm: 1024 slabs x 512 columns) would leave the chip to a handful of workgroups that
@@ -165,7 +205,7 @@ extern "C" int grit_slab_sum_grouped(const grit_slab_job* jobs, int n_jobs, void
         const long groups4 = jb.n / 4;
         a.job[j] = jb;
         a.cw_log2[j] = pick_cw_log2(groups4, jb.groups, jb.slabs);
-        const long bx = (groups4 + (1L << a.cw_log2[j]) - 1) >> a.cw_log2[j];
+        const long bx = a.cw_log2[j] == kWideMark ? (groups4 + 255) / 256 : (groups4 + (1L << a.cw_log2[j]) - 1) >> a.cw_log2[j];
         a.blocks_x[j] = (unsigned)bx;
         a.first_block[j] = (unsigned)total;
         total += (unsigned long long)bx * (unsigned)jb.groups;
@@ -183,7 +223,7 @@ extern "C" int grit_slab_sum(const float* partial, int groups, long group_stride
         return GRIT_ERR_UNSUPPORTED;
     const long groups4 = n / 4;
     const int cw_log2 = pick_cw_log2(groups4, groups, slabs);
-    const long blocks = (groups4 + (1L << cw_log2) - 1) >> cw_log2;
+    const long blocks = cw_log2 == kWideMark ? (groups4 + 255) / 256 : (groups4 + (1L << cw_log2) - 1) >> cw_log2;
     if (blocks > 0x7fffffffL) return GRIT_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)blocks, groups), block(256);
     if (out_is_bf16)

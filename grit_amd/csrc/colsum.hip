@@ -36,6 +36,19 @@ void colsum_kernel(const T* __restrict__ x, int M, int N, int rows_per_slab, flo
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (col < N) {
         int r = r0 + wave;
+        for (; r + 28 < r1; r += 32) {  // 8 rows of this wave in flight
+            float a[8], b[8], c[8], d[8], e[8], f[8], g[8], h[8];
+            load8(x + (size_t)r * N + col, a);
+            load8(x + (size_t)(r + 4) * N + col, b);
+            load8(x + (size_t)(r + 8) * N + col, c);
+            load8(x + (size_t)(r + 12) * N + col, d);
+            load8(x + (size_t)(r + 16) * N + col, e);
+            load8(x + (size_t)(r + 20) * N + col, f);
+            load8(x + (size_t)(r + 24) * N + col, g);
+            load8(x + (size_t)(r + 28) * N + col, h);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += ((a[i] + b[i]) + (c[i] + d[i])) + ((e[i] + f[i]) + (g[i] + h[i]));
+        }
         for (; r + 12 < r1; r += 16) {  // 4 rows of this wave in flight
             float a[8], b[8], c[8], d[8];
             load8(x + (size_t)r * N + col, a);

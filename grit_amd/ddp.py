@@ -154,6 +154,9 @@ class BucketedDataParallel(nn.Module):
             for p, view in zip(plist, views):
                 self._where[p] = b
                 self._view_of[p] = view
+                # backward nodes that produce this gradient with a kernel of their own may write it straight into its slot
+                # (grit_amd/ops/linear.py grad_slot): _pack then finds it in place and copies nothing
+                p._grit_grad_slot = (flat, view.storage_offset(), p.numel(), tuple(p.shape))
             self.buckets.append(b)
         self._refresh_expected()
 

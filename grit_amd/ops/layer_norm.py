@@ -226,7 +226,7 @@ class _LinearAddLayerNormFn(Function):
             with timed("gemm_lib", flops=2.0 * d_branch.numel() * lin_w.shape[1]):
                 d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
         if d_lin_w is None:
-            d_lin_w = weight_grad(d_branch, inp2, group) if ctx.needs_input_grad[1] else None
+            d_lin_w = weight_grad(d_branch, inp2, group, param=lin_w) if ctx.needs_input_grad[1] else None
             sp = ctx.sum_params
             # long maps: the node's reductions (weight-gradient partials, LayerNorm / bias sums) join the scope's grouped launch
             finish_group(group, side is None and sp is not None and sums.dtype == lin_w.dtype and ctx.needs_input_grad[2]

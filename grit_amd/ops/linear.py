@@ -295,15 +295,32 @@ class on_stream:
             self.ctx.__exit__(*a)
 
 
-def slab_sum(partial, out_dtype, slabs=None):
+GRAD_IN_PLACE = os.environ.get("GRIT_GRAD_IN_PLACE", "1") != "0"  # A/B knob of grad_slot
+
+
+def grad_slot(param, dtype, device):
+    """Inside a gradient-bucket scope: a FRESH view of `param`'s slot in its flat gradient bucket (grit_amd/ddp.py), for a backward
+    node to write the gradient into -- autograd adopts the view as .grad, the bucket pack finds it in place and skips its copy
+    (~400 MB of read + write per step for the Swin weight gradients).  None when it does not apply."""
+    slot = getattr(param, "_grit_grad_slot", None) if (GRAD_IN_PLACE and param is not None and _deferral["active"]) else None
+    if slot is None or param.grad is not None:
+        return None
+    flat, off, n, shape = slot
+    if flat.dtype != dtype or flat.device != device or (flat.data_ptr() + off * flat.element_size()) % 16:
+        return None
+    return flat[off:off + n].view(shape)
+
+
+def slab_sum(partial, out_dtype, slabs=None, out=None):
     """f32 partial sums [groups, slabs_allocated, n...] (contiguous) -> [groups, n...] in out_dtype: the sum over the first
-    `slabs` slabs of every group and the dtype cast in one launch (grit_slab_sum)."""
+    `slabs` slabs of every group and the dtype cast in one launch (grit_slab_sum).  out: where to (contiguous, same shape)."""
     slabs = partial.shape[1] if slabs is None else slabs
     tail = partial.shape[2:]
     n = 1
     for d in tail:
         n *= d
-    out = torch.empty((partial.shape[0],) + tuple(tail), dtype=out_dtype, device=partial.device)
+    if out is None:
+        out = torch.empty((partial.shape[0],) + tuple(tail), dtype=out_dtype, device=partial.device)
     with _lib.device_guard(partial.device):
         st = _lib.load().grit_slab_sum(ctypes.c_void_p(partial.data_ptr()), partial.shape[0], partial.stride(0), slabs, n,
                                        ctypes.c_void_p(out.data_ptr()), int(out_dtype == torch.bfloat16), _lib.current_stream_ptr())
@@ -321,16 +338,18 @@ class SlabGroup(object):
     def __init__(self):
         self.jobs, self.keep = [], []
 
-    def add(self, partial, out_dtype, slabs=None):
-        """partial f32 [groups, slabs_allocated, n...] contiguous -> out [groups, n...] (sum over the first `slabs` slabs)."""
+    def add(self, partial, out_dtype, slabs=None, out=None):
+        """partial f32 [groups, slabs_allocated, n...] contiguous -> out [groups, n...] (sum over the first `slabs` slabs);
+        out: an existing contiguous tensor of that shape and dtype to write to."""
         if not SlabGroup.ENABLED:
-            return slab_sum(partial, out_dtype, slabs)
+            return slab_sum(partial, out_dtype, slabs, out)
         slabs = partial.shape[1] if slabs is None else slabs
         tail = tuple(partial.shape[2:])
         n = 1
         for d in tail:
             n *= d
-        out = torch.empty((partial.shape[0],) + tail, dtype=out_dtype, device=partial.device)
+        if out is None:
+            out = torch.empty((partial.shape[0],) + tail, dtype=out_dtype, device=partial.device)
         self.jobs.append((partial.data_ptr(), partial.stride(0), partial.shape[0], slabs, n, out.data_ptr(),
                           int(out_dtype == torch.bfloat16)))
         self.keep.append(partial)  # the partials must outlive the launch; outputs are owned by the caller
@@ -464,18 +483,21 @@ def long_weight_grad_partials(dy2, x2):
     return part
 
 
-def weight_grad(dy2, x2, group=None):
+def weight_grad(dy2, x2, group=None, param=None):
     """dW [N, K] = dy2^T [N, M] @ x2 [M, K], split over M into one batched GEMM with fp32 partial sums.  With `group` (a
-    SlabGroup) the sum over the partials is left to the group's launch."""
+    SlabGroup) the sum over the partials is left to the group's launch.  param: the weight this is the gradient of -- inside a
+    gradient-bucket scope the sum is then written straight into the parameter's bucket slot (grad_slot)."""
     small = small_weight_bias_grad(dy2, x2, False, dy2.dtype, group)
     if small is not None:
         return small[0]
     M, N = dy2.shape
     own = long_weight_grad_partials(dy2, x2)
     if own is not None:
+        slot = grad_slot(param, dy2.dtype, dy2.device)
+        out = None if slot is None else slot.view(1, N, x2.shape[1])
         if group is not None:
-            return group.add(own.unsqueeze(0), dy2.dtype)[0]
-        return slab_sum(own.unsqueeze(0), dy2.dtype)[0]
+            return group.add(own.unsqueeze(0), dy2.dtype, out=out)[0]
+        return slab_sum(own.unsqueeze(0), dy2.dtype, out=out)[0]
     S = split_k(M) if (dy2.is_cuda and dy2.dtype == torch.bfloat16) else 1
     with timed("gemm_lib", flops=2.0 * M * N * x2.shape[1]):
         if S == 1:
@@ -526,7 +548,7 @@ class _LinearFn(Function):
                 dw, db = both
             else:
                 if ctx.needs_input_grad[1]:
-                    dw = weight_grad(dy2, x2, group)
+                    dw = weight_grad(dy2, x2, group, param=weight)
                 if need_b:
                     db = column_sum(dy2, weight.dtype, group)
             if side is None:

@@ -49,7 +49,7 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=No
         group = None
     with on_stream(side):
         if need_w2:
-            d_w2 = weight_grad(d_branch, act, group)
+            d_w2 = weight_grad(d_branch, act, group, param=w2)
         if need_b2:
             d_b2 = column_sum(d_branch, w2.dtype, group)
     if chain:
@@ -62,7 +62,7 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=No
             if need_b1:
                 d_b1 = (group.add(partial.unsqueeze(0), w1.dtype) if group is not None else slab_sum(partial.unsqueeze(0), w1.dtype))[0]
             if need_w1:
-                d_w1 = weight_grad(d_pre, n2, group)
+                d_w1 = weight_grad(d_pre, n2, group, param=w1)
         if need_x:
             with timed("gemm_lib", flops=2.0 * d_pre.numel() * w1.shape[1]):
                 d_n2 = torch.mm(d_pre, w1)

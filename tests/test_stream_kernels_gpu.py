@@ -467,3 +467,48 @@ def test_deferred_grouped_weight_gradients(monkeypatch):
     L.abandon_deferred()
     L.end_deferral()
     assert not L._deferral["unverified"] and not L._deferral["slabs"]
+
+
+def test_long_map_weight_gradients_are_written_into_their_bucket_slots(monkeypatch):
+    """Inside a gradient-bucket scope the weight gradients of long maps (own GEMM + slab sum) are summed straight into the parameter's
+    slot of the flat bucket (ops.linear.grad_slot): autograd adopts the view, the bucket pack finds the gradient in place and does
+    not copy it.  Same gradients as with the knob off; fewer elements through _pack's multi-tensor copy."""
+    from grit_amd.ddp import BucketedDataParallel
+    from grit_amd.ops import linear as L
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = L.Linear(512, 512)
+            self.b = L.Linear(512, 256)
+
+        def forward(self, x):
+            return self.b(torch.tanh(self.a(x)))
+
+    torch.manual_seed(0)
+    net = Net().to(DEV).bfloat16()
+    x = torch.randn(16, 1024, 512, device=DEV).bfloat16()          # 16 384 rows: a long map
+    cot = torch.randn(16, 1024, 256, device=DEV).bfloat16()
+    ddp = BucketedDataParallel(net, bucket_mb=64)
+    copied, results = [], []
+    real = torch._foreach_copy_
+
+    def spy(dst, src, *a, **k):
+        copied[-1] += sum(t.numel() for t in dst)
+        return real(dst, src, *a, **k)
+
+    monkeypatch.setattr(torch, "_foreach_copy_", spy)
+    for knob in (False, True):
+        monkeypatch.setattr(L, "GRAD_IN_PLACE", knob)
+        copied.append(0)
+        y = ddp(x)
+        (y.float() * cot.float()).sum().backward()
+        if knob:
+            slot = net.a.weight._grit_grad_slot
+            assert net.a.weight.grad.data_ptr() == slot[0].data_ptr() + slot[1] * 2  # already in its bucket before the pack
+        ddp.finish_gradient_sync()
+        torch.cuda.synchronize()
+        results.append({n: p.grad.float().clone() for n, p in net.named_parameters()})
+    for n, g in results[0].items():
+        assert torch.equal(g, results[1][n]), n
+    assert copied[1] <= copied[0] - net.a.weight.numel() - net.b.weight.numel()

@@ -442,3 +442,32 @@ def test_stacked_value_maps_equal_per_layer_maps(f32_accumulate, monkeypatch):
         assert (have - want).abs().max() < 3e-2 * want.abs().max()
         touched = want.abs().sum(-1) > 0  # (image, pixel, head) rows some point reached
         assert (have.abs().sum(-1)[~touched] == 0).all()
+
+
+@pytest.mark.parametrize("B,M,levels,P,Lq", [(3, 4, [[7, 9], [3, 5]], 3, 37), (1, 8, [[20, 20]], 4, 5), (5, 2, [[6, 6], [5, 4], [3, 3], [1, 2]], 4, 150),
+                                             (2, 8, [[80, 80], [40, 40], [20, 20], [10, 10]], 2, 301)])
+def test_sorted_backward_odd_shapes(B, M, levels, P, Lq, monkeypatch):
+    """Gather-form backward away from the benchmark's shape: row counts that are no multiple of 4, fewer than 16 points per row,
+    a single level, a level of two cells, B x M far from the number of CUs, points on and outside the border -- against the C
+    oracle on the bf16-rounded inputs, same tolerances as the config-2 test."""
+    from grit_amd.ops import msda as msda_op
+    g = torch.Generator().manual_seed(B * 1000 + Lq)
+    shapes = torch.tensor(levels)
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S, L = int(shapes.prod(1).sum()), len(levels)
+    value = torch.randn(B, S, M, 64, generator=g).bfloat16()
+    loc = (torch.rand(B, Lq, M, L, P, 2, generator=g) * 1.2 - 0.1)
+    loc[0, 0] = 0.0
+    loc[-1, -1] = 1.0
+    aw = torch.softmax(torch.randn(B, Lq, M, L * P, generator=g), -1).view(B, Lq, M, L, P)
+    cot = torch.randn(B, Lq, M * 64, generator=g).bfloat16()
+    assert msda_op.sorted_applies(B, S, M, L, Lq, P)
+    _set_accumulation(msda_op, "sorted", monkeypatch)
+    gv, gl, ga = msda_op.ms_deform_attn_backward(value.to(DEV), shapes.to(DEV), lsi.to(DEV), loc.to(DEV), aw.to(DEV), cot.to(DEV))
+    ogv, ogl, oga = omsda.msda_backward(value.float().numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy(), cot.float().numpy())
+    got = gv.float().cpu().numpy()
+    assert np.linalg.norm(got - ogv) / max(np.linalg.norm(ogv), 1e-20) < 3e-3
+    assert np.abs(got - ogv).max() < 1e-2 * np.abs(ogv).max()
+    assert (got[ogv == 0] == 0).all()
+    np.testing.assert_allclose(ga.cpu().numpy(), oga, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gl.cpu().numpy(), ogl, rtol=1e-3, atol=2e-3)

@@ -27,40 +27,70 @@ __device__ __forceinline__ void load8(const float* p, float (&f)[8]) {
 }
 
 template <typename T>
+__device__ __forceinline__ void colsum_body(const T* __restrict__ x, size_t ld, int M, int N, int rows_per_slab,
+                                            float* __restrict__ partial, unsigned bx, unsigned by, float (*red)[512]);
+
+template <typename T>
 __global__ __launch_bounds__(256)
 void colsum_kernel(const T* __restrict__ x, int M, int N, int rows_per_slab, float* __restrict__ partial) {
     __shared__ float red[4][512];
+    colsum_body<T>(x, (size_t)N, M, N, rows_per_slab, partial, blockIdx.x, blockIdx.y, red);
+}
+
+// Column sums of several bf16 matrices in ONE launch (job table by value): the bias gradients of the decoders' short-map Linears
+// whose weight gradients go through grit_wgrad_tn_grouped.
+struct ColsumGroupArgs {
+    grit_colsum_job job[GRIT_COLSUM_GROUP_MAX];
+    unsigned first_block[GRIT_COLSUM_GROUP_MAX + 1];
+    unsigned strips[GRIT_COLSUM_GROUP_MAX];
+    int n_jobs;
+};
+
+__global__ __launch_bounds__(256)
+void colsum_grouped_kernel(const ColsumGroupArgs a) {
+    __shared__ float red[4][512];
+    int j = 0;
+    while (j + 1 < a.n_jobs && blockIdx.x >= a.first_block[j + 1]) ++j;
+    const unsigned local = blockIdx.x - a.first_block[j];
+    const unsigned by = local / a.strips[j], bx = local - by * a.strips[j];
+    const grit_colsum_job& jb = a.job[j];
+    colsum_body<__hip_bfloat16>((const __hip_bfloat16*)jb.x, (size_t)jb.ld, jb.M, jb.N, (jb.M + jb.slabs - 1) / jb.slabs, jb.partial, bx, by, red);
+}
+
+template <typename T>
+__device__ __forceinline__ void colsum_body(const T* __restrict__ x, size_t ld, int M, int N, int rows_per_slab,
+                                            float* __restrict__ partial, unsigned bx, unsigned by, float (*red)[512]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = blockIdx.x * 512 + lane * 8;
-    const int r0 = blockIdx.y * rows_per_slab, r1 = min(M, r0 + rows_per_slab);
+    const int col = bx * 512 + lane * 8;
+    const int r0 = by * rows_per_slab, r1 = min(M, r0 + rows_per_slab);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (col < N) {
         int r = r0 + wave;
         for (; r + 28 < r1; r += 32) {  // 8 rows of this wave in flight
             float a[8], b[8], c[8], d[8], e[8], f[8], g[8], h[8];
-            load8(x + (size_t)r * N + col, a);
-            load8(x + (size_t)(r + 4) * N + col, b);
-            load8(x + (size_t)(r + 8) * N + col, c);
-            load8(x + (size_t)(r + 12) * N + col, d);
-            load8(x + (size_t)(r + 16) * N + col, e);
-            load8(x + (size_t)(r + 20) * N + col, f);
-            load8(x + (size_t)(r + 24) * N + col, g);
-            load8(x + (size_t)(r + 28) * N + col, h);
+            load8(x + (size_t)r * ld + col, a);
+            load8(x + (size_t)(r + 4) * ld + col, b);
+            load8(x + (size_t)(r + 8) * ld + col, c);
+            load8(x + (size_t)(r + 12) * ld + col, d);
+            load8(x + (size_t)(r + 16) * ld + col, e);
+            load8(x + (size_t)(r + 20) * ld + col, f);
+            load8(x + (size_t)(r + 24) * ld + col, g);
+            load8(x + (size_t)(r + 28) * ld + col, h);
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] += ((a[i] + b[i]) + (c[i] + d[i])) + ((e[i] + f[i]) + (g[i] + h[i]));
         }
         for (; r + 12 < r1; r += 16) {  // 4 rows of this wave in flight
             float a[8], b[8], c[8], d[8];
-            load8(x + (size_t)r * N + col, a);
-            load8(x + (size_t)(r + 4) * N + col, b);
-            load8(x + (size_t)(r + 8) * N + col, c);
-            load8(x + (size_t)(r + 12) * N + col, d);
+            load8(x + (size_t)r * ld + col, a);
+            load8(x + (size_t)(r + 4) * ld + col, b);
+            load8(x + (size_t)(r + 8) * ld + col, c);
+            load8(x + (size_t)(r + 12) * ld + col, d);
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] += (a[i] + b[i]) + (c[i] + d[i]);
         }
         for (; r < r1; r += 4) {
             float a[8];
-            load8(x + (size_t)r * N + col, a);
+            load8(x + (size_t)r * ld + col, a);
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] += a[i];
         }
@@ -69,8 +99,8 @@ void colsum_kernel(const T* __restrict__ x, int M, int N, int rows_per_slab, flo
     for (int i = 0; i < 8; ++i) red[wave][lane * 8 + i] = acc[i];
     __syncthreads();
     for (int j = threadIdx.x; j < 512; j += 256) {
-        const int c = blockIdx.x * 512 + j;
-        if (c < N) partial[(size_t)blockIdx.y * N + c] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+        const int c = bx * 512 + j;
+        if (c < N) partial[(size_t)by * N + c] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
     }
 }
 
@@ -259,5 +289,26 @@ extern "C" int grit_colsum(const void* x, int M, int N, int x_is_bf16, int slabs
     else
         hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, M, N, rows_per_slab,
                            partial);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+extern "C" int grit_colsum_grouped(const grit_colsum_job* jobs, int n_jobs, void* stream) {
+    if (!jobs || n_jobs <= 0 || n_jobs > GRIT_COLSUM_GROUP_MAX) return GRIT_ERR_BAD_ARG;
+    ColsumGroupArgs a;
+    a.n_jobs = n_jobs;
+    unsigned long long total = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const grit_colsum_job& jb = jobs[j];
+        if (!jb.x || !jb.partial || jb.M <= 0 || jb.N <= 0 || jb.slabs <= 0 || jb.slabs > GRIT_COLSUM_MAX_SLABS || jb.ld < jb.N)
+            return GRIT_ERR_BAD_ARG;
+        if (jb.N % 8 || jb.ld % 8 || ((uintptr_t)jb.x % 16)) return GRIT_ERR_UNSUPPORTED;
+        a.job[j] = jb;
+        a.strips[j] = (unsigned)((jb.N + 511) / 512);
+        a.first_block[j] = (unsigned)total;
+        total += (unsigned long long)a.strips[j] * (unsigned)jb.slabs;
+        if (total > 0x7fffffffULL) return GRIT_ERR_UNSUPPORTED;
+    }
+    a.first_block[n_jobs] = (unsigned)total;
+    hipLaunchKernelGGL(colsum_grouped_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }

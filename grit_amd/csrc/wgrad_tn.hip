@@ -59,15 +59,9 @@ __device__ __forceinline__ v4i tr_pair(unsigned addr) {
     return v4i{lo[0], lo[1], hi[0], hi[1]};
 }
 
-__global__ __launch_bounds__(kThreads, 2)
-void wgrad_tn_256(const TnArgs g) {
-    extern __shared__ __attribute__((aligned(1024))) char lds[];
-    // XCD-aware order: the workgroups of one XCD (equal blockIdx % 8) take a contiguous band of (slice, tile) pairs, so a slice's
-    // rows of dY and X are fetched into one L2 and shared by the tiles that run next to each other
-    const int tiles = g.tiles_n * g.tiles_k, nwg = tiles * g.S;
-    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
-    const int qd = nwg >> 3, rm = nwg & 7;
-    const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+// logical = index of the (slice, tile) pair this workgroup takes, in [0, tiles x S)
+__device__ __forceinline__ void tn_body(const TnArgs& g, int logical, char* lds) {
+    const int tiles = g.tiles_n * g.tiles_k;
     const int split = logical / tiles, tile = logical - split * tiles;
     const int tn = tile / g.tiles_k, tk = tile - tn * g.tiles_k;
     const int n0 = tn * kT, k0 = tk * kT;
@@ -186,6 +180,49 @@ void wgrad_tn_256(const TnArgs g) {
             for (int j = 0; j < 4; ++j) out[(size_t)(16 * i + r) * g.K + 16 * j] = acc[i][j][r];
 }
 
+__global__ __launch_bounds__(kThreads, 2)
+void wgrad_tn_256(const TnArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    // XCD-aware order: the workgroups of one XCD (equal blockIdx % 8) take a contiguous band of (slice, tile) pairs, so a slice's
+    // rows of dY and X are fetched into one L2 and shared by the tiles that run next to each other
+    const int nwg = g.tiles_n * g.tiles_k * g.S;
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int qd = nwg >> 3, rm = nwg & 7;
+    tn_body(g, (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx, lds);
+}
+
+// Several problems in ONE launch (job table by value): the deferred weight gradients of the decoders' short-map Linears.  One of
+// them alone (M = 4 800: four 256 x 256 tiles, 150 steps) cannot fill the chip without cutting its rows into slices of a few steps;
+// thirty of them together are 128+ tiles whose workgroups each run a long loop -- the regime this kernel is good at.
+struct TnGroupArgs {
+    TnArgs job[GRIT_WGRAD_GROUP_MAX];
+    unsigned first_block[GRIT_WGRAD_GROUP_MAX + 1];
+    int n_jobs;
+};
+
+__global__ __launch_bounds__(kThreads, 2)
+void wgrad_tn_256_grouped(const TnGroupArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    int j = 0;
+    while (j + 1 < a.n_jobs && blockIdx.x >= a.first_block[j + 1]) ++j;
+    tn_body(a.job[j], (int)(blockIdx.x - a.first_block[j]), lds);
+}
+
+bool tn_shape_ok(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && N % kT == 0 && K % kT == 0 && M % kBK == 0; }
+
+bool tn_fill(TnArgs& a, const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial) {
+    if (!dY || !X || !partial || splits <= 0 || !tn_shape_ok(M, N, K)) return false;
+    if (ldy % 8 || ldx % 8 || ldy < N || ldx < K || ((uintptr_t)dY % 16) || ((uintptr_t)X % 16) || ((uintptr_t)partial % 16)) return false;
+    const int steps = M / kBK;
+    if (splits > steps) return false;
+    a.dY = (const __bf16*)dY; a.ldy = ldy; a.X = (const __bf16*)X; a.ldx = ldx; a.partial = partial;
+    a.M = M; a.N = N; a.K = K; a.S = splits;
+    a.rows_per_split = ((steps + splits - 1) / splits) * kBK;
+    if ((M + a.rows_per_split - 1) / a.rows_per_split != splits) return false;  // every slice must own at least one step
+    a.tiles_n = N / kT; a.tiles_k = K / kT;
+    return true;
+}
+
 }  // namespace
 
 extern "C" int grit_wgrad_tn_splits(int M, int N, int K) {
@@ -221,5 +258,31 @@ extern "C" int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, 
     }
     hipLaunchKernelGGL(wgrad_tn_256, dim3((unsigned)(a.tiles_n * a.tiles_k * splits)), dim3(kThreads), kStages * kStageBytes,
                        (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+extern "C" int grit_wgrad_tn_group_ok(int M, int N, int K) { return tn_shape_ok(M, N, K) ? 1 : 0; }
+
+extern "C" int grit_wgrad_tn_grouped(const grit_wgrad_job* jobs, int n_jobs, void* stream) {
+    if (!jobs || n_jobs <= 0 || n_jobs > GRIT_WGRAD_GROUP_MAX) return GRIT_ERR_BAD_ARG;
+    TnGroupArgs a;
+    a.n_jobs = n_jobs;
+    unsigned long long total = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const grit_wgrad_job& jb = jobs[j];
+        if (jb.db_partial) return GRIT_ERR_BAD_ARG;  // this kernel has no bias-gradient by-product: grit_colsum_grouped
+        if (!tn_fill(a.job[j], jb.dY, jb.ldy, jb.X, jb.ldx, jb.M, jb.N, jb.K, jb.splits, jb.dW_partial)) return GRIT_ERR_UNSUPPORTED;
+        a.first_block[j] = (unsigned)total;
+        total += (unsigned long long)a.job[j].tiles_n * a.job[j].tiles_k * jb.splits;
+        if (total > 0x7fffffffULL) return GRIT_ERR_UNSUPPORTED;
+    }
+    a.first_block[n_jobs] = (unsigned)total;
+    static bool attr_set = false;  // idempotent attribute
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)wgrad_tn_256_grouped, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes) != hipSuccess)
+            return GRIT_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_tn_256_grouped, dim3((unsigned)total), dim3(kThreads), kStages * kStageBytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -30,6 +30,9 @@ SIGNATURES = {
     "grit_msda_fwd_bf16_strided": [_ptr, _c.c_long] + [_ptr] * 4 + [_int] * 7 + [_ptr, _ptr],
     "grit_msda_bwd_bf16acc_strided": [_ptr, _c.c_long] + [_ptr] * 5 + [_int] * 7 + [_ptr] * 4,
     "grit_msda_bwd_bf16_staged": [_ptr, _c.c_long] + [_ptr] * 5 + [_int] * 7 + [_ptr] * 6,
+    "grit_wgrad_tn_group_ok": [_int] * 3,
+    "grit_wgrad_tn_grouped": [_ptr, _int, _ptr],
+    "grit_colsum_grouped": [_ptr, _int, _ptr],
     "grit_wgrad_tn_splits": [_int] * 3,
     "grit_wgrad_tn": [_ptr, _c.c_long, _ptr, _c.c_long] + [_int] * 4 + [_ptr, _ptr],
     "grit_msda_bwd_sorted_supported": [_int] * 6,
@@ -94,6 +97,12 @@ class WgradJob(_c.Structure):
                 ("K", _c.c_int), ("splits", _c.c_int), ("dW_partial", _c.c_void_p), ("db_partial", _c.c_void_p)]
 
 
+class ColsumJob(_c.Structure):
+    """grit_colsum_job of include/grit_hip.h."""
+    _fields_ = [("x", _c.c_void_p), ("ld", _c.c_long), ("M", _c.c_int), ("N", _c.c_int), ("slabs", _c.c_int), ("partial", _c.c_void_p)]
+
+
+COLSUM_GROUP_MAX = 32
 _lib = None
 
 

@@ -187,32 +187,62 @@ def flush_deferred(final=False):
     _deferral["jobs"] = []
     lib = _lib.load()
     dev = jobs[0][0].device
+    for dy2, x2, w, b, pw, pb, M, N, K in jobs:
+        _verify(w, pw, "weight gradient [%d, %d]" % (N, K), final)
+        if b is not None:
+            _verify(b, pb, "bias gradient [%d]" % N, final)
+    # problems the long-map kernel takes (256 x 256 tiles) go through it TOGETHER: one of them alone is four tiles, thirty of them
+    # are a launch of 256 workgroups with 75-step loops (1 PFLOP/s instead of the L2-bound 0.26 of the 64 x 64-tile kernel)
+    big = [j for j in jobs if WGRAD_TN_GROUPED and lib.grit_wgrad_tn_group_ok(j[6], j[7], j[8])]
+    small = [j for j in jobs if not (WGRAD_TN_GROUPED and lib.grit_wgrad_tn_group_ok(j[6], j[7], j[8]))]
+    chunks = [("tn", big[i:i + _lib.WGRAD_GROUP_MAX]) for i in range(0, len(big), _lib.WGRAD_GROUP_MAX)]
+    chunks += [("small", small[i:i + _lib.WGRAD_GROUP_MAX]) for i in range(0, len(small), _lib.WGRAD_GROUP_MAX)]
     with _lib.device_guard(dev):
-        for i in range(0, len(jobs), _lib.WGRAD_GROUP_MAX):
-            chunk = jobs[i:i + _lib.WGRAD_GROUP_MAX]
+        for ci, (kind, chunk) in enumerate(chunks):
+            if kind == "tn":
+                tiles = sum((j[7] // 256) * (j[8] // 256) for j in chunk)
+                best, best_fill = 1, 0.0
+                for cand in range(1, 9):  # row slices per problem: the fullest last round of workgroups, loops of >= 16 steps
+                    wgs = sum((j[7] // 256) * (j[8] // 256) * max(1, min(cand, (j[6] // 32) // 16)) for j in chunk)
+                    fill = wgs / (-(-wgs // 256) * 256.0)
+                    if fill > best_fill + 0.02:
+                        best, best_fill = cand, fill
+                splits = [max(1, min(best, (j[6] // 32) // 16)) for j in chunk]
+                slabs = [max(1, min(256, j[6] // 64)) for j in chunk]
+            else:
+                splits = [lib.grit_wgrad_group_splits(j[6]) for j in chunk]
+                slabs = splits
             sizes, total = [], 0
-            for dy2, x2, w, b, pw, pb, M, N, K in chunk:
-                _verify(w, pw, "weight gradient [%d, %d]" % (N, K), final)
-                if b is not None:
-                    _verify(b, pb, "bias gradient [%d]" % N, final)
-                S = lib.grit_wgrad_group_splits(M)
-                sizes.append((S, total, total + S * N * K))
-                total += S * N * K + (S * N if b is not None else 0)
+            for job, S, sl in zip(chunk, splits, slabs):
+                dy2, x2, w, b, pw, pb, M, N, K = job
+                sizes.append((S, sl, total, total + S * N * K))
+                total += S * N * K + (sl * N if b is not None else 0)
             work = torch.empty(total, dtype=torch.float32, device=dev)
             base = work.data_ptr()
             table = (_lib.WgradJob * len(chunk))()
+            ctable = (_lib.ColsumJob * len(chunk))()
+            nc = 0
             group = SlabGroup()
-            for t, (job, (S, woff, boff)) in enumerate(zip(chunk, sizes)):
+            for t, (job, (S, sl, woff, boff)) in enumerate(zip(chunk, sizes)):
                 dy2, x2, w, b, pw, pb, M, N, K = job
+                bias_here = (base + 4 * boff) if b is not None else None
                 table[t] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, base + 4 * woff,
-                                         (base + 4 * boff) if b is not None else None)
+                                         None if kind == "tn" else bias_here)
+                if kind == "tn" and b is not None:
+                    ctable[nc] = _lib.ColsumJob(dy2.data_ptr(), dy2.stride(0), M, N, sl, bias_here)
+                    nc += 1
                 group.add_raw(work[woff:], 1, 0, S, N * K, pw, True)
                 if b is not None:
-                    group.add_raw(work[boff:], 1, 0, S, N, pb, True)
+                    group.add_raw(work[boff:], 1, 0, sl, N, pb, True)
             with timed("gemm_own", flops=2.0 * sum(j[6] * j[7] * j[8] for j in chunk)):
-                st = lib.grit_wgrad_small_grouped(table, len(chunk), _lib.current_stream_ptr())
-            _lib.check(st, "grit_wgrad_small_grouped")
-            if i + _lib.WGRAD_GROUP_MAX >= len(jobs):
+                if kind == "tn":
+                    st = lib.grit_wgrad_tn_grouped(table, len(chunk), _lib.current_stream_ptr())
+                else:
+                    st = lib.grit_wgrad_small_grouped(table, len(chunk), _lib.current_stream_ptr())
+            _lib.check(st, "grit_wgrad_tn_grouped" if kind == "tn" else "grit_wgrad_small_grouped")
+            if nc:
+                _lib.check(lib.grit_colsum_grouped(ctable, nc, _lib.current_stream_ptr()), "grit_colsum_grouped")
+            if ci == len(chunks) - 1:
                 _flush_deferred_slabs(into=group, final=final)  # the nodes' own deferred reductions ride in the last chunk's launch
             group.run()  # keeps `work` (and through `chunk` the operands) alive until the launches are enqueued
 
@@ -461,6 +491,9 @@ def small_weight_bias_grad(dy2, x2, need_db, out_dtype, group=None):
 # against 0.76-0.99 on the Swin shapes (profiles/r03/wgrad_tn.txt).  The slices' fp32 partials are summed by the grouped slab sum as
 # before.
 WGRAD_TN = os.environ.get("GRIT_WGRAD_TN", "1") != "0"
+# GRIT_WGRAD_TN_GROUPED (default 1): the deferred short-map weight gradients whose shapes fit (N, K multiples of 256, M of 32) run
+# through the same kernel in one grouped launch (grit_wgrad_tn_grouped), their bias gradients through grit_colsum_grouped
+WGRAD_TN_GROUPED = os.environ.get("GRIT_WGRAD_TN_GROUPED", "1") != "0"
 
 
 def long_weight_grad_partials(dy2, x2):

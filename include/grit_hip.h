@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 29
+#define GRIT_ABI_VERSION 30
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -362,6 +362,22 @@ typedef struct grit_wgrad_job {
 } grit_wgrad_job;
 int grit_wgrad_group_splits(int M);
 int grit_wgrad_small_grouped(const grit_wgrad_job* jobs, int n_jobs, void* stream);
+/* The same job table through the long-map kernel (grit_wgrad_tn's 256 x 256 tiles, one launch for all jobs): for jobs with
+ * N % 256 == 0, K % 256 == 0, M % 32 == 0 (grit_wgrad_tn_group_ok), db_partial == NULL (no bias by-product: grit_colsum_grouped),
+ * splits = any number of row slices such that every slice owns at least one 32-row step -- the caller picks it so that the tiles of
+ * all jobs together fill the chip with LONG loops (thirty M = 4 800 problems are 128 tiles x 2 slices of 75 steps).  dW_partial
+ * [splits, N, K] fp32 as above. */
+int grit_wgrad_tn_group_ok(int M, int N, int K);
+int grit_wgrad_tn_grouped(const grit_wgrad_job* jobs, int n_jobs, void* stream);
+/* Column sums of up to GRIT_COLSUM_GROUP_MAX bf16 matrices x [M, N] (leading dimension ld) in one launch:
+ * partial[slabs, N] fp32 per job, slab s = rows [s * ceil(M / slabs), ...); N % 8 == 0, ld % 8 == 0, 16-byte aligned bases. */
+#define GRIT_COLSUM_GROUP_MAX 32
+typedef struct grit_colsum_job {
+    const void* x; long ld;
+    int M, N, slabs;
+    float* partial;
+} grit_colsum_job;
+int grit_colsum_grouped(const grit_colsum_job* jobs, int n_jobs, void* stream);
 
 /* Weight gradient of a Linear on a LONG token map (the Swin blocks): partial[s, N, K] (fp32) = dY[rows of slice s]^T . X[rows of
  * slice s] for S = grit_wgrad_tn_splits(M, N, K) row slices (chosen so that tiles x S fills the chip with one 256 x 256-tile

@@ -269,3 +269,39 @@ def test_weight_grad_routes_long_maps_to_the_own_kernel(monkeypatch):
     lib_path = L.weight_grad(dy, x)
     assert own.dtype == torch.bfloat16 and own.shape == (512, 512)
     torch.testing.assert_close(own.float(), lib_path.float(), rtol=1e-2, atol=1e-2 * float(lib_path.float().abs().max()))
+
+
+@pytest.mark.gpu
+def test_grouped_long_kernel_and_grouped_column_sums():
+    """grit_wgrad_tn_grouped: several short-map problems (different shapes, row counts, slice counts, one with padded leading
+    dimensions) in one launch of the 256 x 256-tile kernel; grit_colsum_grouped: their column sums in one launch.  Against fp64."""
+    import ctypes
+    from grit_amd import lib as _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    problems = [(4800, 512, 512, 2, 0), (4800, 1024, 512, 3, 0), (640, 512, 2048, 1, 0), (4800, 256, 512, 2, 8), (3200, 512, 256, 5, 0)]
+    assert all(lib.grit_wgrad_tn_group_ok(M, N, K) for M, N, K, _, _ in problems) and not lib.grit_wgrad_tn_group_ok(4800, 128, 512)
+    table = (_lib.WgradJob * len(problems))()
+    ctable = (_lib.ColsumJob * len(problems))()
+    keep = []
+    for t, (M, N, K, S, pad) in enumerate(problems):
+        dy = torch.randn(M, N + pad, device=DEV, generator=g).bfloat16()[:, :N]
+        x = torch.randn(M, K + pad, device=DEV, generator=g).bfloat16()[:, :K]
+        part = torch.full((S, N, K), float("nan"), dtype=torch.float32, device=DEV)
+        slabs = max(1, M // 64)
+        bpart = torch.full((slabs, N), float("nan"), dtype=torch.float32, device=DEV)
+        table[t] = _lib.WgradJob(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K, S, part.data_ptr(), None)
+        ctable[t] = _lib.ColsumJob(dy.data_ptr(), dy.stride(0), M, N, slabs, bpart.data_ptr())
+        keep.append((dy, x, part, bpart))
+    assert lib.grit_wgrad_tn_grouped(table, len(problems), _lib.current_stream_ptr()) == 0
+    assert lib.grit_colsum_grouped(ctable, len(problems), _lib.current_stream_ptr()) == 0
+    torch.cuda.synchronize()
+    for dy, x, part, bpart in keep:
+        ref = dy.double().t() @ x.double()
+        assert float((part.double().sum(0) - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-4
+        refb = dy.double().sum(0)
+        assert float((bpart.double().sum(0) - refb).abs().max()) <= 1e-5 * float(refb.abs().max()) + 1e-4
+    # a slice count that would leave a slice without a step is refused, and so is a bias by-product
+    table[2] = _lib.WgradJob(keep[2][0].data_ptr(), keep[2][0].stride(0), keep[2][1].data_ptr(), keep[2][1].stride(0), 640, 512, 2048, 21,
+                             keep[2][2].data_ptr(), None)
+    assert lib.grit_wgrad_tn_grouped(table, len(problems), _lib.current_stream_ptr()) != 0

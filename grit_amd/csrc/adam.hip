@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/grit_hip.h"
 
 namespace {
@@ -24,35 +25,66 @@ template <> __device__ __forceinline__ void load4<__hip_bfloat16>(const __hip_bf
     g[2] = __uint_as_float(u.y << 16); g[3] = __uint_as_float(u.y & 0xffff0000u);
 }
 
-template <typename GT>
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ f4 ldq(const f4* q) {
+    if constexpr (NT) return __builtin_nontemporal_load(q);
+    else return *q;
+}
+
+template <typename GT, bool NT>
 __global__ __launch_bounds__(256)
 void adam_flat(float* __restrict__ p, const GT* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
                __hip_bfloat16* __restrict__ compute, long n4, float step_size, float beta1, float beta2, float eps,
                float inv_bc2_sqrt, float grad_scale) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        float g[4];
-        load4<GT>(grad + 4 * i, g);
-        float4 pp = *reinterpret_cast<const float4*>(p + 4 * i);
-        float4 mm = *reinterpret_cast<const float4*>(m + 4 * i);
-        float4 vv = *reinterpret_cast<const float4*>(v + 4 * i);
-        float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+    // masters and moments are touched once per step: nontemporal loads / stores (they need not displace the weights the next
+    // forward is about to read); two quads per thread and trip: eight 16-byte loads in flight
+    const long stride = (long)gridDim.x * 256;
+    auto update = [&](long i, const float (&g)[4], f4 pp, f4 mm, f4 vv) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float gk = g[k] * grad_scale;
-            ma[k] = ma[k] + (gk - ma[k]) * (1.0f - beta1);
-            va[k] = beta2 * va[k] + (1.0f - beta2) * gk * gk;
-            const float denom = sqrtf(va[k]) * inv_bc2_sqrt + eps;
-            pa[k] -= step_size * (ma[k] / denom);
+            mm[k] = mm[k] + (gk - mm[k]) * (1.0f - beta1);
+            vv[k] = beta2 * vv[k] + (1.0f - beta2) * gk * gk;
+            const float denom = sqrtf(vv[k]) * inv_bc2_sqrt + eps;
+            pp[k] -= step_size * (mm[k] / denom);
         }
-        *reinterpret_cast<float4*>(p + 4 * i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
-        *reinterpret_cast<float4*>(m + 4 * i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
-        *reinterpret_cast<float4*>(v + 4 * i) = make_float4(va[0], va[1], va[2], va[3]);
+        if constexpr (NT) {
+            __builtin_nontemporal_store(pp, reinterpret_cast<f4*>(p + 4 * i));
+            __builtin_nontemporal_store(mm, reinterpret_cast<f4*>(m + 4 * i));
+            __builtin_nontemporal_store(vv, reinterpret_cast<f4*>(v + 4 * i));
+        } else {
+            *reinterpret_cast<f4*>(p + 4 * i) = pp;
+            *reinterpret_cast<f4*>(m + 4 * i) = mm;
+            *reinterpret_cast<f4*>(v + 4 * i) = vv;
+        }
         if (compute) {
             union { __hip_bfloat16 h[4]; uint2 u; } pk;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pk.h[k] = __float2bfloat16(pa[k]);
+            for (int k = 0; k < 4; ++k) pk.h[k] = __float2bfloat16(pp[k]);
             *reinterpret_cast<uint2*>(compute + 4 * i) = pk.u;
         }
+    };
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        const long j = i + stride;
+        float g0[4], g1[4];
+        load4<GT>(grad + 4 * i, g0);
+        load4<GT>(grad + 4 * j, g1);
+        const f4 p0 = ldq<NT>(reinterpret_cast<const f4*>(p + 4 * i));
+        const f4 m0 = ldq<NT>(reinterpret_cast<const f4*>(m + 4 * i));
+        const f4 v0 = ldq<NT>(reinterpret_cast<const f4*>(v + 4 * i));
+        const f4 p1 = ldq<NT>(reinterpret_cast<const f4*>(p + 4 * j));
+        const f4 m1 = ldq<NT>(reinterpret_cast<const f4*>(m + 4 * j));
+        const f4 v1 = ldq<NT>(reinterpret_cast<const f4*>(v + 4 * j));
+        update(i, g0, p0, m0, v0);
+        update(j, g1, p1, m1, v1);
+    }
+    if (i < n4) {
+        float g0[4];
+        load4<GT>(grad + 4 * i, g0);
+        update(i, g0, ldq<NT>(reinterpret_cast<const f4*>(p + 4 * i)),
+               ldq<NT>(reinterpret_cast<const f4*>(m + 4 * i)),
+               ldq<NT>(reinterpret_cast<const f4*>(v + 4 * i)));
     }
 }
 
@@ -71,13 +103,18 @@ extern "C" int grit_adam_flat(float* param, const void* grad, int grad_is_bf16, 
     long blocks = (n4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;  // grid-stride: 32 workgroups per CU
     const float step_size = lr / bias_correction1, inv_bc2_sqrt = 1.0f / bias_correction2_sqrt;
-    if (grad_is_bf16)
-        hipLaunchKernelGGL(adam_flat<__hip_bfloat16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param,
-                           (const __hip_bfloat16*)grad, exp_avg, exp_avg_sq, (__hip_bfloat16*)compute_bf16, n4, step_size, beta1,
-                           beta2, eps, inv_bc2_sqrt, grad_scale);
-    else
-        hipLaunchKernelGGL(adam_flat<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param,
-                           (const float*)grad, exp_avg, exp_avg_sq, (__hip_bfloat16*)compute_bf16, n4, step_size, beta1, beta2, eps,
-                           inv_bc2_sqrt, grad_scale);
+    // GRIT_ADAM_NT=0 (A/B): plain loads / stores of the masters and moments
+    static const bool nt = !(getenv("GRIT_ADAM_NT") && atoi(getenv("GRIT_ADAM_NT")) == 0);
+#define GRIT_ADAM_LAUNCH(GT_, NT_, GPTR_)                                                                                          \
+    hipLaunchKernelGGL((adam_flat<GT_, NT_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, GPTR_, exp_avg,    \
+                       exp_avg_sq, (__hip_bfloat16*)compute_bf16, n4, step_size, beta1, beta2, eps, inv_bc2_sqrt, grad_scale)
+    if (grad_is_bf16) {
+        if (nt) GRIT_ADAM_LAUNCH(__hip_bfloat16, true, (const __hip_bfloat16*)grad);
+        else GRIT_ADAM_LAUNCH(__hip_bfloat16, false, (const __hip_bfloat16*)grad);
+    } else {
+        if (nt) GRIT_ADAM_LAUNCH(float, true, (const float*)grad);
+        else GRIT_ADAM_LAUNCH(float, false, (const float*)grad);
+    }
+#undef GRIT_ADAM_LAUNCH
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }

@@ -36,12 +36,15 @@ constexpr int kT = 256, kBK = 32, kThreads = 512, kStages = 4;
 constexpr int kOpBytes = kBK * kT * 2;       // 16 KB: one operand of one step
 constexpr int kStageBytes = 2 * kOpBytes;    // 32 KB
 constexpr int kLoads = 4;                    // DMA instructions per thread and stage (2 per operand)
+constexpr int kColBytes = 4 * kT * 4;        // bias by-product: four copies (one per k-slot group lg) of 256 fp32 column sums
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
 
 struct TnArgs {
     const __bf16* dY; long ldy;
     const __bf16* X; long ldx;
     float* partial;           // [S][N][K] fp32
     int M, N, K, S, rows_per_split, tiles_n, tiles_k;
+    float* db_partial;        // [S][N] fp32 column sums of dY per slice (the bias gradient), or nullptr
 };
 
 typedef int v2i __attribute__((ext_vector_type(2)));
@@ -95,12 +98,24 @@ __device__ __forceinline__ void tn_body(const TnArgs& g, int logical, char* lds)
 
     // ---- fragment read offsets: row (half 16 + 4 lg + trq), 32-byte group (block ^ (row & 7)), 8 bytes at trp
     const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)lds;
+    // Bias gradient as a by-product (db_partial != nullptr, workgroups of k-tile 0, waves wn == 0): the A fragments ARE dY^T -- lane
+    // (n = l15 of block i, k-slot group lg) holds 8 of a step's 32 rows of column n.  v_dot2_f32_bf16 with ones folds them (4 per
+    // fragment), one ds_add_f32 per fragment adds the lane's share to copy lg of the column sums in LDS: ~40 instructions per step in
+    // the shadow of the MFMAs, instead of a separate HBM pass over dY (24 column-sum launches of 30 us per training step).
+    const bool colsum = g.db_partial != nullptr && tk == 0;  // workgroup-uniform
+    const int cw = __builtin_amdgcn_readfirstlane(wn);    // the four waves of a row half hold the SAME A fragments: wave wn sums
+                                                          // fragments wn and wn + 4 (the work spreads over all four SIMDs)
+    float* colacc = reinterpret_cast<float*>(lds + kStages * kStageBytes);
+    float cs[2] = {0.f, 0.f};  // this lane's share of columns 128 wm + 16 (wn + 4 h) + l15, h = 0, 1 (k-slot group lg)
     const int r_lo = 4 * lg + trq, sr = r_lo & 7;
-    unsigned aoff[8], boff[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) aoff[i] = lds_base + r_lo * 512 + (((wm * 8 + i) ^ sr) * 32) + trp * 8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) boff[j] = lds_base + kOpBytes + r_lo * 512 + (((wn * 4 + j) ^ sr) * 32) + trp * 8;
+    // (block ^ sr) is not kept per block (12 address registers): with i < 8, j < 4 and sr < 8,
+    //   (8 wm + i) ^ sr = 8 wm | (i ^ sr)        (4 wn + j) ^ sr = (4 wn ^ (sr & 4)) | (j ^ (sr & 3))
+    // so a fragment address is a per-lane base plus ((i ^ sr) << 5): two VALU per read instead of one, ten registers back
+    const unsigned a_base = lds_base + r_lo * 512 + wm * 8 * 32 + trp * 8;
+    const unsigned b_base = lds_base + kOpBytes + r_lo * 512 + ((wn * 4) ^ (sr & 4)) * 32 + trp * 8;
+    unsigned srv = (unsigned)sr;  // made opaque once per step (below): otherwise the 12 addresses are hoisted out of the loop again
+    auto aoff_of = [&](int i) { return a_base + (((unsigned)i ^ srv) << 5); };
+    auto boff_of = [&](int j) { return b_base + (((unsigned)j ^ (srv & 3u)) << 5); };
 
     v4f acc[8][4];
 #pragma unroll
@@ -123,9 +138,9 @@ __device__ __forceinline__ void tn_body(const TnArgs& g, int logical, char* lds)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage 0 landed
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fb[j] = tr_pair(boff[j]);
+    for (int j = 0; j < 4; ++j) fb[j] = tr_pair(boff_of(j));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) fa[i] = tr_pair(aoff[i]);
+    for (int i = 0; i < 8; ++i) fa[i] = tr_pair(aoff_of(i));
     // One step: MFMAs on the fragments (ca, cb) that are complete, reads of the next step's fragments into (na, nb).  The loop is
     // unrolled by two with the two register sets swapping roles: a register COPY of (na, nb) right after the reads were issued
     // would copy whatever the registers held before the data arrived (the compiler cannot know: the reads are asm).
@@ -138,14 +153,23 @@ __device__ __forceinline__ void tn_body(const TnArgs& g, int logical, char* lds)
                        "+v"(cb[0]), "+v"(cb[1]), "+v"(cb[2]), "+v"(cb[3])
                      :: "memory");
         const unsigned sn = (unsigned)(((t + 1) % kStages) * kStageBytes);
+        asm volatile("" : "+v"(srv));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, ca[i]), __builtin_bit_cast(v8bf, cb[j]),
                                                                     acc[i][j], 0, 0, 0);
-            na[i] = tr_pair(aoff[i] + sn);
-            if (i < 4) nb[i] = tr_pair(boff[i] + sn);
+            if (colsum && (i & 3) == cw) {
+                const v2bf one = {(__bf16)1.0f, (__bf16)1.0f};
+                const int c0 = ca[i].x, c1 = ca[i].y, c2 = ca[i].z, c3 = ca[i].w;
+                float sacc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, c0), one, cs[i >> 2], false);
+                sacc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, c1), one, sacc, false);
+                sacc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, c2), one, sacc, false);
+                cs[i >> 2] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, c3), one, sacc, false);
+            }
+            na[i] = tr_pair(aoff_of(i) + sn);
+            if (i < 4) nb[i] = tr_pair(boff_of(i) + sn);
             if (i >= 4) issue_stage_piece(t + kStages - 1, i - 4);  // slot (t + 3) % 4 = (t - 1) % 4: read during step t - 2
         }
     };
@@ -178,6 +202,14 @@ __device__ __forceinline__ void tn_body(const TnArgs& g, int logical, char* lds)
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int j = 0; j < 4; ++j) out[(size_t)(16 * i + r) * g.K + 16 * j] = acc[i][j][r];
+    if (g.db_partial != nullptr && tk == 0) {  // workgroup-uniform
+        __syncthreads();  // the ring is free: nothing of the main loop reads LDS any more
+#pragma unroll
+        for (int h = 0; h < 2; ++h) colacc[lg * kT + wm * 128 + 16 * (cw + 4 * h) + l15] = cs[h];
+        __syncthreads();
+        if (tid < kT)
+            g.db_partial[(size_t)split * g.N + n0 + tid] = (colacc[tid] + colacc[kT + tid]) + (colacc[2 * kT + tid] + colacc[3 * kT + tid]);
+    }
 }
 
 __global__ __launch_bounds__(kThreads, 2)
@@ -210,7 +242,9 @@ void wgrad_tn_256_grouped(const TnGroupArgs a) {
 
 bool tn_shape_ok(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && N % kT == 0 && K % kT == 0 && M % kBK == 0; }
 
-bool tn_fill(TnArgs& a, const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial) {
+bool tn_fill(TnArgs& a, const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial,
+             float* db_partial = nullptr) {
+    a.db_partial = db_partial;
     if (!dY || !X || !partial || splits <= 0 || !tn_shape_ok(M, N, K)) return false;
     if (ldy % 8 || ldx % 8 || ldy < N || ldx < K || ((uintptr_t)dY % 16) || ((uintptr_t)X % 16) || ((uintptr_t)partial % 16)) return false;
     const int steps = M / kBK;
@@ -238,7 +272,7 @@ extern "C" int grit_wgrad_tn_splits(int M, int N, int K) {
 }
 
 extern "C" int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial,
-                             void* stream) {
+                             float* db_partial, void* stream) {
     if (!dY || !X || !partial || M <= 0 || N <= 0 || K <= 0 || splits <= 0) return GRIT_ERR_BAD_ARG;
     if (N % kT || K % kT || M % kBK || ldy % 8 || ldx % 8 || ldy < N || ldx < K || ((uintptr_t)dY % 16) || ((uintptr_t)X % 16) ||
         ((uintptr_t)partial % 16))
@@ -247,16 +281,17 @@ extern "C" int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, 
     TnArgs a;
     a.dY = (const __bf16*)dY; a.ldy = ldy; a.X = (const __bf16*)X; a.ldx = ldx; a.partial = partial;
     a.M = M; a.N = N; a.K = K; a.S = splits;
+    a.db_partial = db_partial;
     const int steps = M / kBK;
     a.rows_per_split = ((steps + splits - 1) / splits) * kBK;
     a.tiles_n = N / kT; a.tiles_k = K / kT;
     static bool attr_set = false;  // idempotent attribute
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)wgrad_tn_256, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)wgrad_tn_256, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes + kColBytes) != hipSuccess)
             return GRIT_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad_tn_256, dim3((unsigned)(a.tiles_n * a.tiles_k * splits)), dim3(kThreads), kStages * kStageBytes,
+    hipLaunchKernelGGL(wgrad_tn_256, dim3((unsigned)(a.tiles_n * a.tiles_k * splits)), dim3(kThreads), kStages * kStageBytes + kColBytes,
                        (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
@@ -270,8 +305,8 @@ extern "C" int grit_wgrad_tn_grouped(const grit_wgrad_job* jobs, int n_jobs, voi
     unsigned long long total = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const grit_wgrad_job& jb = jobs[j];
-        if (jb.db_partial) return GRIT_ERR_BAD_ARG;  // this kernel has no bias-gradient by-product: grit_colsum_grouped
-        if (!tn_fill(a.job[j], jb.dY, jb.ldy, jb.X, jb.ldx, jb.M, jb.N, jb.K, jb.splits, jb.dW_partial)) return GRIT_ERR_UNSUPPORTED;
+        if (!tn_fill(a.job[j], jb.dY, jb.ldy, jb.X, jb.ldx, jb.M, jb.N, jb.K, jb.splits, jb.dW_partial, jb.db_partial))
+            return GRIT_ERR_UNSUPPORTED;
         a.first_block[j] = (unsigned)total;
         total += (unsigned long long)a.job[j].tiles_n * a.job[j].tiles_k * jb.splits;
         if (total > 0x7fffffffULL) return GRIT_ERR_UNSUPPORTED;
@@ -279,10 +314,10 @@ extern "C" int grit_wgrad_tn_grouped(const grit_wgrad_job* jobs, int n_jobs, voi
     a.first_block[n_jobs] = (unsigned)total;
     static bool attr_set = false;  // idempotent attribute
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)wgrad_tn_256_grouped, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)wgrad_tn_256_grouped, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes + kColBytes) != hipSuccess)
             return GRIT_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad_tn_256_grouped, dim3((unsigned)total), dim3(kThreads), kStages * kStageBytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(wgrad_tn_256_grouped, dim3((unsigned)total), dim3(kThreads), kStages * kStageBytes + kColBytes, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }

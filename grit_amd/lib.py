@@ -34,7 +34,7 @@ SIGNATURES = {
     "grit_wgrad_tn_grouped": [_ptr, _int, _ptr],
     "grit_colsum_grouped": [_ptr, _int, _ptr],
     "grit_wgrad_tn_splits": [_int] * 3,
-    "grit_wgrad_tn": [_ptr, _c.c_long, _ptr, _c.c_long] + [_int] * 4 + [_ptr, _ptr],
+    "grit_wgrad_tn": [_ptr, _c.c_long, _ptr, _c.c_long] + [_int] * 4 + [_ptr, _ptr, _ptr],
     "grit_msda_bwd_sorted_supported": [_int] * 6,
     "grit_msda_bwd_bf16_sorted": [_ptr, _c.c_long] + [_ptr] * 5 + [_int] * 7 + [_ptr] * 4,
     "grit_winattn_fwd_bf16": [_ptr] * 4 + [_int] * 8 + [_f32, _ptr, _ptr, _ptr],

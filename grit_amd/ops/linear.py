@@ -208,7 +208,7 @@ def flush_deferred(final=False):
                     if fill > best_fill + 0.02:
                         best, best_fill = cand, fill
                 splits = [max(1, min(best, (j[6] // 32) // 16)) for j in chunk]
-                slabs = [max(1, min(256, j[6] // 64)) for j in chunk]
+                slabs = splits if WGRAD_TN_BIAS else [max(1, min(256, j[6] // 64)) for j in chunk]  # bias: by-product per slice
             else:
                 splits = [lib.grit_wgrad_group_splits(j[6]) for j in chunk]
                 slabs = splits
@@ -227,8 +227,8 @@ def flush_deferred(final=False):
                 dy2, x2, w, b, pw, pb, M, N, K = job
                 bias_here = (base + 4 * boff) if b is not None else None
                 table[t] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, base + 4 * woff,
-                                         None if kind == "tn" else bias_here)
-                if kind == "tn" and b is not None:
+                                         None if (kind == "tn" and not WGRAD_TN_BIAS) else bias_here)
+                if kind == "tn" and b is not None and not WGRAD_TN_BIAS:
                     ctable[nc] = _lib.ColsumJob(dy2.data_ptr(), dy2.stride(0), M, N, sl, bias_here)
                     nc += 1
                 group.add_raw(work[woff:], 1, 0, S, N * K, pw, True)
@@ -494,10 +494,13 @@ WGRAD_TN = os.environ.get("GRIT_WGRAD_TN", "1") != "0"
 # GRIT_WGRAD_TN_GROUPED (default 1): the deferred short-map weight gradients whose shapes fit (N, K multiples of 256, M of 32) run
 # through the same kernel in one grouped launch (grit_wgrad_tn_grouped), their bias gradients through grit_colsum_grouped
 WGRAD_TN_GROUPED = os.environ.get("GRIT_WGRAD_TN_GROUPED", "1") != "0"
+# GRIT_WGRAD_TN_BIAS (default 1): the bias gradient of a long-map Linear (qkv) as a by-product of its weight-gradient launch
+WGRAD_TN_BIAS = os.environ.get("GRIT_WGRAD_TN_BIAS", "1") != "0"
 
 
-def long_weight_grad_partials(dy2, x2):
-    """fp32 partials [S, N, K] of dW = dy2^T x2 from the own kernel, or None where it does not apply (the library path runs)."""
+def long_weight_grad_partials(dy2, x2, need_db=False):
+    """fp32 partials [S, N, K] of dW = dy2^T x2 from the own kernel, or None where it does not apply (the library path runs).
+    need_db: returns (partials, [S, N] fp32 column sums of dy2 per slice) -- the bias gradient as a by-product of the same launch."""
     if not (WGRAD_TN and dy2.is_cuda and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16):
         return None
     M, N = dy2.shape
@@ -509,11 +512,13 @@ def long_weight_grad_partials(dy2, x2):
     if S <= 0 or dy2.stride(0) % 8 or x2.stride(0) % 8 or dy2.data_ptr() % 16 or x2.data_ptr() % 16:
         return None
     part = torch.empty((S, N, K), dtype=torch.float32, device=dy2.device)
+    bpart = torch.empty((S, N), dtype=torch.float32, device=dy2.device) if need_db else None
     with _lib.device_guard(dy2.device), timed("gemm_own", flops=2.0 * M * N * K):
         st = lib.grit_wgrad_tn(ctypes.c_void_p(dy2.data_ptr()), dy2.stride(0), ctypes.c_void_p(x2.data_ptr()), x2.stride(0), M, N, K, S,
-                               ctypes.c_void_p(part.data_ptr()), _lib.current_stream_ptr())
+                               ctypes.c_void_p(part.data_ptr()), ctypes.c_void_p(bpart.data_ptr()) if need_db else None,
+                               _lib.current_stream_ptr())
     _lib.check(st, "grit_wgrad_tn")
-    return part
+    return (part, bpart) if need_db else part
 
 
 def weight_grad(dy2, x2, group=None, param=None):
@@ -580,10 +585,18 @@ class _LinearFn(Function):
             if both is not None:  # short map: dW and db partials from one launch
                 dw, db = both
             else:
-                if ctx.needs_input_grad[1]:
-                    dw = weight_grad(dy2, x2, group, param=weight)
-                if need_b:
-                    db = column_sum(dy2, weight.dtype, group)
+                pair = long_weight_grad_partials(dy2, x2, True) if (WGRAD_TN_BIAS and need_b and ctx.needs_input_grad[1]
+                                                                      and group is not None) else None
+                if pair is not None:  # long map: dW slices and the bias gradient's column sums from ONE launch
+                    slot = grad_slot(weight, dy2.dtype, dy2.device)
+                    dw = group.add(pair[0].unsqueeze(0), dy2.dtype,
+                                   out=None if slot is None else slot.view(1, dy2.shape[1], x2.shape[1]))[0]
+                    db = group.add(pair[1].unsqueeze(0), weight.dtype)[0]
+                else:
+                    if ctx.needs_input_grad[1]:
+                        dw = weight_grad(dy2, x2, group, param=weight)
+                    if need_b:
+                        db = column_sum(dy2, weight.dtype, group)
             if side is None:
                 finish_group(group, ctx.single_use, [(ctx.weight_param, dw), (ctx.bias_param, db)])
             elif group is not None:

@@ -363,7 +363,7 @@ typedef struct grit_wgrad_job {
 int grit_wgrad_group_splits(int M);
 int grit_wgrad_small_grouped(const grit_wgrad_job* jobs, int n_jobs, void* stream);
 /* The same job table through the long-map kernel (grit_wgrad_tn's 256 x 256 tiles, one launch for all jobs): for jobs with
- * N % 256 == 0, K % 256 == 0, M % 32 == 0 (grit_wgrad_tn_group_ok), db_partial == NULL (no bias by-product: grit_colsum_grouped),
+ * N % 256 == 0, K % 256 == 0, M % 32 == 0 (grit_wgrad_tn_group_ok), db_partial [splits, N] (column sums per slice) or NULL,
  * splits = any number of row slices such that every slice owns at least one 32-row step -- the caller picks it so that the tiles of
  * all jobs together fill the chip with LONG loops (thirty M = 4 800 problems are 128 tiles x 2 slices of 75 steps).  dW_partial
  * [splits, N, K] fp32 as above. */
@@ -385,9 +385,11 @@ int grit_colsum_grouped(const grit_colsum_job* jobs, int n_jobs, void* stream);
  * operands; the transpose happens in the LDS reads (ds_read_b64_tr_b16 on both MFMA operands, grit_amd/csrc/wgrad_tn.hip).
  * Replaces the batched library GEMM over row slices of autograd's Linear backward (models/common/swin_model.py:26-35, 147-149).
  * N, K multiples of 256, M a multiple of 32 (grit_wgrad_tn_splits returns 0 otherwise: use the library), 16-byte aligned bases,
- * leading dimensions multiples of 8. */
+ * leading dimensions multiples of 8.  db_partial != NULL: [S, N] fp32 column sums of dY per slice (the bias gradient) as a
+ * by-product of the workgroups of k-tile 0 (v_dot2 on the dY^T fragments they hold anyway + LDS adds, in the MFMAs' shadow). */
 int grit_wgrad_tn_splits(int M, int N, int K);
-int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial, void* stream);
+int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial,
+                  float* db_partial, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Adam step on one flat range of the fp32-master / bf16-compute training state (torch.optim.Adam as configured by the

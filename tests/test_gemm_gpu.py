@@ -243,14 +243,17 @@ def test_long_map_weight_gradient_tn(M, N, K, pad):
     assert S >= 1 and (N // 256) * (K // 256) * S <= 256
     part = torch.full((S, N, K), float("nan"), dtype=torch.float32, device=DEV)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    st = lib.grit_wgrad_tn(p(dy), dy.stride(0), p(x), x.stride(0), M, N, K, S, p(part), _lib.current_stream_ptr())
+    bpart = torch.full((S, N), float("nan"), dtype=torch.float32, device=DEV)
+    st = lib.grit_wgrad_tn(p(dy), dy.stride(0), p(x), x.stride(0), M, N, K, S, p(part), p(bpart), _lib.current_stream_ptr())
     assert st == 0
+    refb = dy.double().sum(0)  # the bias gradient as a by-product of the same launch
+    assert float((bpart.double().sum(0) - refb).abs().max()) <= 1e-5 * float(refb.abs().max()) + 1e-3
     got = part.double().sum(0)
     ref = dy.double().t() @ x.double()
     scale = float(ref.abs().max())
     assert float((got - ref).abs().max()) <= 2e-5 * scale * max(1.0, M / 51200) + 1e-4
     assert lib.grit_wgrad_tn_splits(51200, 384, 128) == 0 and lib.grit_wgrad_tn_splits(51201, 512, 512) == 0
-    assert lib.grit_wgrad_tn(p(dy), dy.stride(0), p(x), x.stride(0), M, N, K, S + 1, p(part), _lib.current_stream_ptr()) != 0
+    assert lib.grit_wgrad_tn(p(dy), dy.stride(0), p(x), x.stride(0), M, N, K, S + 1, p(part), None, _lib.current_stream_ptr()) != 0
 
 
 @pytest.mark.gpu
@@ -283,25 +286,31 @@ def test_grouped_long_kernel_and_grouped_column_sums():
     assert all(lib.grit_wgrad_tn_group_ok(M, N, K) for M, N, K, _, _ in problems) and not lib.grit_wgrad_tn_group_ok(4800, 128, 512)
     table = (_lib.WgradJob * len(problems))()
     ctable = (_lib.ColsumJob * len(problems))()
-    keep = []
+    keep, keep_b = [], []
     for t, (M, N, K, S, pad) in enumerate(problems):
         dy = torch.randn(M, N + pad, device=DEV, generator=g).bfloat16()[:, :N]
         x = torch.randn(M, K + pad, device=DEV, generator=g).bfloat16()[:, :K]
         part = torch.full((S, N, K), float("nan"), dtype=torch.float32, device=DEV)
         slabs = max(1, M // 64)
         bpart = torch.full((slabs, N), float("nan"), dtype=torch.float32, device=DEV)
-        table[t] = _lib.WgradJob(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K, S, part.data_ptr(), None)
+        bslice = torch.full((S, N), float("nan"), dtype=torch.float32, device=DEV)
+        table[t] = _lib.WgradJob(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K, S, part.data_ptr(),
+                                 bslice.data_ptr() if t % 2 == 0 else None)
+        keep_b.append(bslice if t % 2 == 0 else None)
         ctable[t] = _lib.ColsumJob(dy.data_ptr(), dy.stride(0), M, N, slabs, bpart.data_ptr())
         keep.append((dy, x, part, bpart))
     assert lib.grit_wgrad_tn_grouped(table, len(problems), _lib.current_stream_ptr()) == 0
     assert lib.grit_colsum_grouped(ctable, len(problems), _lib.current_stream_ptr()) == 0
     torch.cuda.synchronize()
-    for dy, x, part, bpart in keep:
+    for (dy, x, part, bpart), bslice in zip(keep, keep_b):
+        if bslice is not None:  # the by-product of the GEMM launch itself
+            refb = dy.double().sum(0)
+            assert float((bslice.double().sum(0) - refb).abs().max()) <= 1e-5 * float(refb.abs().max()) + 1e-3
         ref = dy.double().t() @ x.double()
         assert float((part.double().sum(0) - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-4
         refb = dy.double().sum(0)
         assert float((bpart.double().sum(0) - refb).abs().max()) <= 1e-5 * float(refb.abs().max()) + 1e-4
-    # a slice count that would leave a slice without a step is refused, and so is a bias by-product
+    # a slice count that would leave a slice without a step is refused
     table[2] = _lib.WgradJob(keep[2][0].data_ptr(), keep[2][0].stride(0), keep[2][1].data_ptr(), keep[2][1].stride(0), 640, 512, 2048, 21,
                              keep[2][2].data_ptr(), None)
     assert lib.grit_wgrad_tn_grouped(table, len(problems), _lib.current_stream_ptr()) != 0

@@ -46,14 +46,17 @@ def main():
             print(f"M{M} N{N} K{K}: library S{S0} {t_lib:.0f} + sum {t_lib_sum:.0f} us | own: shape not supported", flush=True)
             continue
         part = torch.empty(S, N, K, dtype=torch.float32, device="cuda")
-        own = lambda: lib.grit_wgrad_tn(p(dy), N, p(x), K, M, N, K, S, p(part), _lib.current_stream_ptr())
+        bpart = torch.empty(S, N, dtype=torch.float32, device="cuda")
+        own = lambda: lib.grit_wgrad_tn(p(dy), N, p(x), K, M, N, K, S, p(part), None, _lib.current_stream_ptr())
+        own_b = lambda: lib.grit_wgrad_tn(p(dy), N, p(x), K, M, N, K, S, p(part), p(bpart), _lib.current_stream_ptr())
         assert own() == 0
         got = slab_sum(part.unsqueeze(0), torch.float32)[0]
         err = float((got - ref).abs().max() / ref.abs().max())
         t_own, t_own_sum = timed(own), timed(lambda: slab_sum(part.unsqueeze(0), torch.bfloat16))
+        t_own_b = timed(own_b)
         fl = 2.0 * M * N * K
         print(f"M{M} N{N} K{K}: library S{S0} {t_lib:.0f} us ({fl / t_lib / 1e9:.2f} PF/s) + sum {t_lib_sum:.0f} | own S{S} {t_own:.0f} us "
-              f"({fl / t_own / 1e9:.2f} PF/s) + sum {t_own_sum:.0f} | rel err {err:.1e}", flush=True)
+              f"({fl / t_own / 1e9:.2f} PF/s) + sum {t_own_sum:.0f} | with bias by-product {t_own_b:.0f} us | rel err {err:.1e}", flush=True)
 
 
 if __name__ == "__main__":

@@ -546,6 +546,20 @@ def weight_grad(dy2, x2, group=None, param=None):
     return slab_sum(part.unsqueeze(0), dy2.dtype)[0]
 
 
+def weight_bias_grad(dy2, x2, group, need_w, need_b, weight):
+    """(dW, db) of a Linear from dy2 [M, N], x2 [M, K]; either may be None when not wanted.  Long maps with both wanted: ONE launch of
+    the own kernel yields the weight-gradient slices and, as a by-product, the bias gradient's column sums (no pass over dy2 of its
+    own); otherwise weight_grad / column_sum.  group: the node's SlabGroup (the sums are left to its launch)."""
+    pair = long_weight_grad_partials(dy2, x2, True) if (WGRAD_TN_BIAS and need_w and need_b and group is not None) else None
+    if pair is not None:
+        slot = grad_slot(weight, dy2.dtype, dy2.device)
+        dw = group.add(pair[0].unsqueeze(0), dy2.dtype, out=None if slot is None else slot.view(1, dy2.shape[1], x2.shape[1]))[0]
+        return dw, group.add(pair[1].unsqueeze(0), weight.dtype)[0]
+    dw = weight_grad(dy2, x2, group, param=weight) if need_w else None
+    db = column_sum(dy2 if dy2.is_contiguous() else dy2.contiguous(), weight.dtype, group) if need_b else None
+    return dw, db
+
+
 class _LinearFn(Function):
 
     @staticmethod
@@ -585,18 +599,7 @@ class _LinearFn(Function):
             if both is not None:  # short map: dW and db partials from one launch
                 dw, db = both
             else:
-                pair = long_weight_grad_partials(dy2, x2, True) if (WGRAD_TN_BIAS and need_b and ctx.needs_input_grad[1]
-                                                                      and group is not None) else None
-                if pair is not None:  # long map: dW slices and the bias gradient's column sums from ONE launch
-                    slot = grad_slot(weight, dy2.dtype, dy2.device)
-                    dw = group.add(pair[0].unsqueeze(0), dy2.dtype,
-                                   out=None if slot is None else slot.view(1, dy2.shape[1], x2.shape[1]))[0]
-                    db = group.add(pair[1].unsqueeze(0), weight.dtype)[0]
-                else:
-                    if ctx.needs_input_grad[1]:
-                        dw = weight_grad(dy2, x2, group, param=weight)
-                    if need_b:
-                        db = column_sum(dy2, weight.dtype, group)
+                dw, db = weight_bias_grad(dy2, x2, group, ctx.needs_input_grad[1], need_b, weight)
             if side is None:
                 finish_group(group, ctx.single_use, [(ctx.weight_param, dw), (ctx.bias_param, db)])
             elif group is not None:
@@ -642,10 +645,7 @@ class _SharedInputLinearsFn(Function):
                         dx2 = torch.mm(dy2, weights[l])
                     else:
                         dx2.addmm_(dy2, weights[l])
-            if ctx.needs_input_grad[2 + l]:
-                dws[l] = weight_grad(dy2, x2, group)
-            if ctx.needs_input_grad[2 + n + l]:
-                dbs[l] = column_sum(dy2, weights[l].dtype, group)
+            dws[l], dbs[l] = weight_bias_grad(dy2, x2, group, ctx.needs_input_grad[2 + l], ctx.needs_input_grad[2 + n + l], weights[l])
         if group is not None:
             group.run()
         dx = None if dx2 is None else dx2.view(x.shape)

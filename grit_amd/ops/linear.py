@@ -83,6 +83,10 @@ def single_use_now(flag):
 # contiguous gradient), otherwise the parameter received a second gradient and the run stops with an error instead of training
 # on garbage.
 WGRAD_DEFER = os.environ.get("GRIT_WGRAD_DEFER", "1") != "0"
+# GRIT_WGRAD_DEFER_LONG=1 (default 0): the long maps' weight gradients too (where single-use).  Measured +0.45 ms
+# (profiles/r03/negative_results.txt #14): fewer and fatter slices, but operands that were in the Infinity Cache when their node ran
+# come back from HBM a bucket later.
+WGRAD_DEFER_LONG = os.environ.get("GRIT_WGRAD_DEFER_LONG", "0") == "1"
 _deferral["jobs"] = []
 _deferral["slabs"] = []
 
@@ -96,10 +100,17 @@ def defer_weight_bias_grad(dy2, x2, weight, bias, need_dw, need_db, single_use):
         return None
     M, N = dy2.shape
     K = x2.shape[1]
-    if not (M < WGRAD_SMALL_MAX_ROWS and N % 64 == 0 and K % 64 == 0 and dy2.stride(1) == 1 and x2.stride(1) == 1
+    # short maps always; long maps (the Swin blocks) when the long-map kernel takes the shape: the ten or so weight gradients a
+    # gradient bucket collects then run as ONE launch of ~256 workgroups with 800-step loops and TWO row slices each instead of ten
+    # launches with 16-64 slices -- the fp32 slices (3.9 GB per step written and read back) shrink by an order of magnitude
+    long_ok = (WGRAD_DEFER_LONG and WGRAD_TN_GROUPED and M >= WGRAD_SMALL_MAX_ROWS
+               and _lib.load().grit_wgrad_tn_group_ok(M, N, K) == 1)
+    if not ((M < WGRAD_SMALL_MAX_ROWS or long_ok) and N % 64 == 0 and K % 64 == 0 and dy2.stride(1) == 1 and x2.stride(1) == 1
             and dy2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0):
         return None
-    dw = torch.empty((N, K), dtype=torch.bfloat16, device=dy2.device)
+    dw = grad_slot(weight, torch.bfloat16, dy2.device) if long_ok else None  # straight into the gradient bucket
+    if dw is None:
+        dw = torch.empty((N, K), dtype=torch.bfloat16, device=dy2.device)
     db = torch.empty((N,), dtype=torch.bfloat16, device=dy2.device) if need_db else None
     # no reference to dw / db is kept (autograd only adopts a gradient tensor nobody else holds): addresses only
     _deferral["jobs"].append((dy2, x2, weight, bias if need_db else None, dw.data_ptr(), db.data_ptr() if need_db else 0, M, N, K))
@@ -195,7 +206,10 @@ def flush_deferred(final=False):
     # are a launch of 256 workgroups with 75-step loops (1 PFLOP/s instead of the L2-bound 0.26 of the 64 x 64-tile kernel)
     big = [j for j in jobs if WGRAD_TN_GROUPED and lib.grit_wgrad_tn_group_ok(j[6], j[7], j[8])]
     small = [j for j in jobs if not (WGRAD_TN_GROUPED and lib.grit_wgrad_tn_group_ok(j[6], j[7], j[8]))]
-    chunks = [("tn", big[i:i + _lib.WGRAD_GROUP_MAX]) for i in range(0, len(big), _lib.WGRAD_GROUP_MAX)]
+    longs = [j for j in big if j[6] >= WGRAD_SMALL_MAX_ROWS]  # their own launches: a workgroup of theirs runs ~10x longer
+    big = [j for j in big if j[6] < WGRAD_SMALL_MAX_ROWS]
+    chunks = [("tn", longs[i:i + _lib.WGRAD_GROUP_MAX]) for i in range(0, len(longs), _lib.WGRAD_GROUP_MAX)]
+    chunks += [("tn", big[i:i + _lib.WGRAD_GROUP_MAX]) for i in range(0, len(big), _lib.WGRAD_GROUP_MAX)]
     chunks += [("small", small[i:i + _lib.WGRAD_GROUP_MAX]) for i in range(0, len(small), _lib.WGRAD_GROUP_MAX)]
     with _lib.device_guard(dev):
         for ci, (kind, chunk) in enumerate(chunks):

@@ -20,8 +20,8 @@ from grit_amd import lib as _lib
 from grit_amd.ops import backend
 from grit_amd.ops import gemm as G
 from grit_amd.ops import layer_norm as LN
-from grit_amd.ops.linear import (WGRAD_STREAM, SlabGroup, column_sum, finish_group, fork, join, on_stream, single_use_now, slab_sum,
-                                 weight_grad)
+from grit_amd.ops.linear import (WGRAD_STREAM, SlabGroup, column_sum, defer_weight_bias_grad, finish_group, fork, join, on_stream,
+                                 single_use_now, slab_sum, weight_grad)
 from grit_amd.ops.profiling import timed
 
 MIN_ROWS = 2048
@@ -36,7 +36,7 @@ def _rows(t):
     return t2 if t2.is_contiguous() else t2.contiguous()
 
 
-def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=None):
+def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=None, params=None):
     """Gradients of branch = fc2(gelu(fc1(n2))) w.r.t. (n2, w1, b1, w2[, b2]) given d_branch [M, C].  The chain of input
     gradients runs on the current stream, the weight / bias gradients beside it on the side stream (linear.fork).  `group`:
     the caller's SlabGroup -- every partial sum of the node (dW2, db1, dW1[, db2]) is then reduced by the caller's one launch
@@ -47,8 +47,13 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=No
     side = fork(d_branch, act) if (chain and (need_w2 or need_b2)) else None
     if side is not None:
         group = None
+    # params = (fc1.weight, fc2.weight) as Parameters when the module is declared single-use: inside a gradient-bucket scope the two
+    # weight gradients then join the scope's grouped launch (ops.linear.defer_weight_bias_grad) instead of running here
+    dfr2 = defer_weight_bias_grad(d_branch, act, params[1], None, need_w2, False, True) if (params is not None and side is None) else None
     with on_stream(side):
-        if need_w2:
+        if dfr2 is not None:
+            d_w2 = dfr2[0]
+        elif need_w2:
             d_w2 = weight_grad(d_branch, act, group, param=w2)
         if need_b2:
             d_b2 = column_sum(d_branch, w2.dtype, group)
@@ -61,7 +66,10 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=No
         with on_stream(side):
             if need_b1:
                 d_b1 = (group.add(partial.unsqueeze(0), w1.dtype) if group is not None else slab_sum(partial.unsqueeze(0), w1.dtype))[0]
-            if need_w1:
+            dfr1 = defer_weight_bias_grad(d_pre, n2, params[0], None, need_w1, False, True) if (params is not None and side is None) else None
+            if dfr1 is not None:
+                d_w1 = dfr1[0]
+            elif need_w1:
                 d_w1 = weight_grad(d_pre, n2, group, param=w1)
         if need_x:
             with timed("gemm_lib", flops=2.0 * d_pre.numel() * w1.shape[1]):
@@ -91,8 +99,9 @@ class _MlpFn(Function):
         d_branch = _rows(dy)
         ni = ctx.needs_input_grad
         group = SlabGroup()
-        d_x, d_w1, d_b1, d_w2, d_b2 = _mlp_backward(d_branch, x2, w1, pre, act, w2, (ni[0], ni[1], ni[2], ni[3]), ni[4], group)
         ps = ctx.params
+        d_x, d_w1, d_b1, d_w2, d_b2 = _mlp_backward(d_branch, x2, w1, pre, act, w2, (ni[0], ni[1], ni[2], ni[3]), ni[4], group,
+                                                    params=None if ps is None else (ps[0], ps[2]))
         finish_group(group, ps is not None and not WGRAD_STREAM, [] if ps is None else
                      [(ps[0], d_w1), (ps[1], d_b1), (ps[2], d_w2), (ps[3], d_b2)])
         return (None if d_x is None else d_x.view(ctx.shape)), d_w1, d_b1, d_w2, d_b2, None
@@ -133,8 +142,9 @@ class _MlpAddLayerNormFn(Function):
         group = SlabGroup()  # LayerNorm sums, dW2, db1, dW1: one reduction launch for the whole node
         dx, d_branch, sums = LN._add_layer_norm_backward(x, weight, mean, rstd, scale, gx, gy, ctx.shape[0], True, 0.0, None, group)
         ni = ctx.needs_input_grad
-        d_x, d_w1, d_b1, d_w2, _ = _mlp_backward(d_branch, x2, w1, pre, act, w2, (ni[0], ni[1], ni[2], ni[3]), group=group)
         ps = ctx.params
+        d_x, d_w1, d_b1, d_w2, _ = _mlp_backward(d_branch, x2, w1, pre, act, w2, (ni[0], ni[1], ni[2], ni[3]), group=group,
+                                                 params=None if ps is None else (ps[0], ps[2]))
         # (sums in another dtype than the parameters would be converted -- read -- below, before a deferred launch has run)
         finish_group(group, ps is not None and not WGRAD_STREAM and sums.dtype == w2.dtype and ni[4] and ni[7] and ni[8],
                      [] if ps is None else [(ps[0], d_w1), (ps[1], d_b1), (ps[2], d_w2), (ps[3], sums[2]), (ps[4], sums[0]),

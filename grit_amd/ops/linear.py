@@ -535,6 +535,43 @@ def long_weight_grad_partials(dy2, x2, need_db=False):
     return (part, bpart) if need_db else part
 
 
+WGRAD_TN_PAIR = os.environ.get("GRIT_WGRAD_TN_PAIR", "1") != "0"  # the two weight gradients of a Swin Mlp as one grouped launch
+
+
+def long_weight_grads_together(pairs):
+    """[fp32 partials [S_j, N_j, K_j]] of dW_j = dy_j^T x_j for several long-map problems of ONE backward node from one grouped launch
+    of the long-map kernel -- together their tiles fill the chip with fewer row slices each (fc1 + fc2 of a Swin Mlp: 16 + 16 tiles,
+    8 slices of 200 steps instead of 16 of 100: half the fp32 slices to write and to sum).  None when it does not apply."""
+    if not (WGRAD_TN and WGRAD_TN_PAIR and len(pairs) > 1):
+        return None
+    lib = _lib.load()
+    tiles = 0
+    for dy2, x2 in pairs:
+        M, N = dy2.shape
+        K = x2.shape[1]
+        if not (dy2.is_cuda and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and M >= 8192 and dy2.stride(1) == 1
+                and x2.stride(1) == 1 and dy2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0
+                and x2.data_ptr() % 16 == 0 and lib.grit_wgrad_tn_group_ok(M, N, K) == 1):
+            return None
+        tiles += (N // 256) * (K // 256)
+    if tiles > 256:
+        return None
+    S = max(1, 256 // tiles)
+    S = min([S] + [(dy2.shape[0] // 32) // 16 or 1 for dy2, _ in pairs])
+    table = (_lib.WgradJob * len(pairs))()
+    parts = []
+    for t, (dy2, x2) in enumerate(pairs):
+        M, N = dy2.shape
+        K = x2.shape[1]
+        part = torch.empty((S, N, K), dtype=torch.float32, device=dy2.device)
+        parts.append(part)
+        table[t] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, part.data_ptr(), None)
+    with _lib.device_guard(pairs[0][0].device), timed("gemm_own", flops=2.0 * sum(d.shape[0] * d.shape[1] * x.shape[1] for d, x in pairs)):
+        st = lib.grit_wgrad_tn_grouped(table, len(pairs), _lib.current_stream_ptr())
+    _lib.check(st, "grit_wgrad_tn_grouped")
+    return parts
+
+
 def weight_grad(dy2, x2, group=None, param=None):
     """dW [N, K] = dy2^T [N, M] @ x2 [M, K], split over M into one batched GEMM with fp32 partial sums.  With `group` (a
     SlabGroup) the sum over the partials is left to the group's launch.  param: the weight this is the gradient of -- inside a

@@ -20,8 +20,8 @@ from grit_amd import lib as _lib
 from grit_amd.ops import backend
 from grit_amd.ops import gemm as G
 from grit_amd.ops import layer_norm as LN
-from grit_amd.ops.linear import (WGRAD_STREAM, SlabGroup, column_sum, defer_weight_bias_grad, finish_group, fork, join, on_stream,
-                                 single_use_now, slab_sum, weight_grad)
+from grit_amd.ops.linear import (WGRAD_STREAM, SlabGroup, column_sum, defer_weight_bias_grad, finish_group, fork, grad_slot, join,
+                                 long_weight_grads_together, on_stream, single_use_now, slab_sum, weight_grad)
 from grit_amd.ops.profiling import timed
 
 MIN_ROWS = 2048
@@ -50,10 +50,12 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=No
     # params = (fc1.weight, fc2.weight) as Parameters when the module is declared single-use: inside a gradient-bucket scope the two
     # weight gradients then join the scope's grouped launch (ops.linear.defer_weight_bias_grad) instead of running here
     dfr2 = defer_weight_bias_grad(d_branch, act, params[1], None, need_w2, False, True) if (params is not None and side is None) else None
+    # both weight gradients of the node in one grouped launch (after d_pre exists): see linear.long_weight_grads_together
+    together = dfr2 is None and side is None and group is not None and need_w2 and need_w1 and chain
     with on_stream(side):
         if dfr2 is not None:
             d_w2 = dfr2[0]
-        elif need_w2:
+        elif need_w2 and not together:
             d_w2 = weight_grad(d_branch, act, group, param=w2)
         if need_b2:
             d_b2 = column_sum(d_branch, w2.dtype, group)
@@ -67,10 +69,21 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=No
             if need_b1:
                 d_b1 = (group.add(partial.unsqueeze(0), w1.dtype) if group is not None else slab_sum(partial.unsqueeze(0), w1.dtype))[0]
             dfr1 = defer_weight_bias_grad(d_pre, n2, params[0], None, need_w1, False, True) if (params is not None and side is None) else None
-            if dfr1 is not None:
-                d_w1 = dfr1[0]
-            elif need_w1:
-                d_w1 = weight_grad(d_pre, n2, group, param=w1)
+            parts = long_weight_grads_together([(d_branch, act), (d_pre, n2)]) if (together and dfr1 is None) else None
+            if parts is not None:
+                outs = []
+                for part, (wt, dyt, xt) in zip(parts, ((w2, d_branch, act), (w1, d_pre, n2))):
+                    slot = grad_slot(wt, dyt.dtype, dyt.device)
+                    outs.append(group.add(part.unsqueeze(0), dyt.dtype,
+                                          out=None if slot is None else slot.view(1, dyt.shape[1], xt.shape[1]))[0])
+                d_w2, d_w1 = outs
+            else:
+                if together:
+                    d_w2 = weight_grad(d_branch, act, group, param=w2)
+                if dfr1 is not None:
+                    d_w1 = dfr1[0]
+                elif need_w1:
+                    d_w1 = weight_grad(d_pre, n2, group, param=w1)
         if need_x:
             with timed("gemm_lib", flops=2.0 * d_pre.numel() * w1.shape[1]):
                 d_n2 = torch.mm(d_pre, w1)

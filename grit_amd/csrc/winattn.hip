@@ -567,15 +567,16 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     }
 }
 
-// DMA-staged variant (the default; GRIT_WINATTN_BWD_DMA=0 selects the register-staged kernel above): LDS plan, 161 808 of the 163 840 bytes of the CU:
+// DMA-staged variant (the default; GRIT_WINATTN_BWD_DMA=0 selects the register-staged kernel above): LDS plan, 162 384 of the 163 840 bytes of the CU:
 //   bias slab, TRANSPOSED [key][query], as bf16 with a 152-element pitch (conflict-free 8-byte reads per half-wave): 43 776 B.  The
 //     slab is the output of grit_relbias_fwd on a bf16 table in the training step, so the conversion is exact there; with an
 //     fp32 table it rounds the bias to bf16 inside this kernel only (2^-9 relative on an O(0.1) logit term, below the bf16
 //     resolution of P / dS that the products run in);
 //   dS^T [key][query] bf16, pitch 148: 42 624 B;  Q / dO / K tiles [144][32] bf16, DOUBLE buffered: 55 296 B;  V and O tiles,
-//     single (consumed at the top of their window): 18 432 B;  statistics 1 680 B.
+//     single (consumed at the top of their window): 18 432 B;  statistics 2 256 B (the row log-sum-exps double buffered: they arrive
+//     by DMA with the tiles).
 constexpr int kBP2 = 152;
-constexpr size_t kBwdDmaLds = (size_t)kN * kBP2 * 2 + (size_t)kN * kSP * 2 + 8 * (size_t)kN * kTP * 2 + 2 * kN * 4 + 3 * kHd * 4 + kN;
+constexpr size_t kBwdDmaLds = (size_t)kN * kBP2 * 2 + (size_t)kN * kSP * 2 + 8 * (size_t)kN * kTP * 2 + 3 * kN * 4 + 3 * kHd * 4 + kN;
 static_assert(kBwdDmaLds <= 160 * 1024, "one workgroup per CU");
 
 template <bool kExplicitMask>
@@ -590,8 +591,8 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     __bf16* tiles = dSt + kN * kSP;                                         // Q, dO, K of buffer 0, then of buffer 1: [144][kTP] each
     __bf16* Vs1 = tiles + 6 * kN * kTP;                                     // V and O of the window being STARTED (read at its
     __bf16* Os1 = Vs1 + kN * kTP;                                           //   top only: single buffers)
-    float* lse_s = reinterpret_cast<float*>(Os1 + kN * kTP);                // [144]
-    float* delta_s = lse_s + kN;                                            // [144]
+    float* lse_s = reinterpret_cast<float*>(Os1 + kN * kTP);                // [2][144], buffer = the tile buffer of the window
+    float* delta_s = lse_s + 2 * kN;                                        // [144]
     float* pad_s = delta_s + kN;                                            // [96]
     uint8_t* rid = reinterpret_cast<uint8_t*>(pad_s + 3 * kHd);             // [144]
 
@@ -624,7 +625,7 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     // compute hides them, and no register holds them meanwhile (the register-staged version could only issue them after phase
     // 1, its register peak: ~20 % of the kernel was exposed load latency, profiles/r01/winattn_bwd_notes.txt).  Window-padding
     // tokens: q / k / v come from pad_qkv, dO / O rows are zero-filled by the owning thread.
-    struct Next { float lse_v; int reg, tkk, kreg, wy, wx; size_t img; };
+    struct Next { int reg, tkk, kreg, wy, wx; size_t img; };
     // Issued as inline asm: through __builtin_amdgcn_global_load_lds hipcc cannot tell which later LDS reads the transfer may
     // alias (one dynamic LDS block) and puts `s_waitcnt vmcnt(0)` right behind the issue -- the prefetch then overlaps nothing
     // (found in round 3 on the weight-gradient GEMM; it is why this variant measured no better than register staging).  The
@@ -633,6 +634,16 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
         const unsigned dst = __builtin_amdgcn_readfirstlane(
             (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(tile) + w * 1024));
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory", "m0");
+    };
+    // The row log-sum-exps (4 bytes per lane, threads 0 .. 143) travel the same way.  As a plain load into a register that is
+    // carried to the next window they cost a fifth of the kernel: hipcc, which does not see the asm transfers, puts
+    // `s_waitcnt vmcnt(0)` in front of the load (the register still has the previous window's load pending in its model) --
+    // right behind the five tile transfers just issued, so every window waited for its prefetch to land
+    // (s_memtime stamps: 3.5-5.4k of 17.4k cycles per window, profiles/r03/winattn_bwd_stamps.txt).
+    auto dma4 = [&](const float* src, float* dst_base) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(
+            (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(dst_base) + w * 256));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(dst), "v"(src) : "memory", "m0");
     };
     auto prefetch = [&](int win, int buf) {
         Next f;
@@ -653,8 +664,7 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
             *reinterpret_cast<uint4*>(&Os1[sn * kTP + sc * 8]) = make_uint4(0, 0, 0, 0);
         }
         f.tkk = token_of(16 * w + l15, f.wy, f.wx, g, f.kreg);  // this lane's key in phase 1 / query in phase 2
-        f.lse_v = 0.f;
-        if (tid < kN) f.lse_v = lse2[((size_t)win * g.nH + h) * kN + tid];
+        if (tid < kN) dma4(lse2 + ((size_t)win * g.nH + h) * kN + tid, lse_s + buf * kN);
         return f;
     };
     Next nxt;
@@ -663,7 +673,6 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     for (int win = grp; win < NW; win += ngrp, cur ^= 1) {
         const int wy = nxt.wy, wx = nxt.wx, reg = nxt.reg, tkk = nxt.tkk, kreg = nxt.kreg;
         const size_t img = nxt.img;
-        const float lse_v = nxt.lse_v;
         __bf16* Qs = tiles + cur * 3 * kN * kTP;
         __bf16* dOs = Qs + kN * kTP;
         __bf16* Ks = dOs + kN * kTP;
@@ -679,7 +688,6 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
             dpart += __shfl_xor(dpart, 2, 64);
         }
         if (sc == 0) { rid[sn] = (uint8_t)reg; delta_s[sn] = dpart; }
-        if (tid < kN) lse_s[tid] = lse_v;
         // this lane's K / V fragments (B operands of phase 1): key 16 w + l15, channels 8 lg ..
         const v8bf kf = as_v8bf(*reinterpret_cast<const uint4*>(&Ks[(16 * w + l15) * kTP + lg * 8]));
         const v8bf vf = as_v8bf(*reinterpret_cast<const uint4*>(&Vs1[(16 * w + l15) * kTP + lg * 8]));
@@ -691,9 +699,10 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
         int oRow = l15 * kTP + lg * 8;                   // row reads of Qs / dOs      (+ 16 qt kTP)
         int oTr = (4 * lg + trq) * kTP + 4 * trp;        // transposing reads, phase 1 (+ 32 s kTP)
         int oB = (16 * w + l15) * kBP2 + 4 * lg;         // bias slab (bf16)           (+ 16 qt)
-        int oSt = 4 * lg;                                // lse / delta                (+ 16 qt)
+        int oSt = 4 * lg;                                // delta, region ids          (+ 16 qt)
+        int oLse = cur * kN + 4 * lg;                    // lse of this window's buffer (+ 16 qt)
         int oW = (16 * w + l15) * kSP + 4 * lg;          // dS^T writes                (+ 16 qt)
-        asm volatile("" : "+v"(oRow), "+v"(oTr), "+v"(oB), "+v"(oSt), "+v"(oW));
+        asm volatile("" : "+v"(oRow), "+v"(oTr), "+v"(oB), "+v"(oSt), "+v"(oLse), "+v"(oW));
 
         // ================= phase 1: wave w = key tile w =================
         // S[q][k] = Q K^T, dP[q][k] = dO V^T on tiles (qt, w); after each PAIR of query tiles (one 32-deep k-step of
@@ -726,7 +735,7 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
             const v2f b_lo = v2f{__uint_as_float(braw.x << 16), __uint_as_float(braw.x & 0xffff0000u)} * v2f{kLog2e, kLog2e};
             const v2f b_hi = v2f{__uint_as_float(braw.y << 16), __uint_as_float(braw.y & 0xffff0000u)} * v2f{kLog2e, kLog2e};
             const v4f bq = {b_lo[0], b_lo[1], b_hi[0], b_hi[1]};
-            const v4f lq = *reinterpret_cast<const v4f*>(&lse_s[oSt + 16 * qt]);
+            const v4f lq = *reinterpret_cast<const v4f*>(&lse_s[oLse + 16 * qt]);
             const v4f dl = *reinterpret_cast<const v4f*>(&delta_s[oSt + 16 * qt]);
             const v2f c2v = {c2, c2};
             // first consumers of the two MFMA results: compiler-visible

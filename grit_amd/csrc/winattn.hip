@@ -567,16 +567,16 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     }
 }
 
-// DMA-staged variant (the default; GRIT_WINATTN_BWD_DMA=0 selects the register-staged kernel above): LDS plan, 162 528 of the 163 840 bytes of the CU:
+// DMA-staged variant (the default; GRIT_WINATTN_BWD_DMA=0 selects the register-staged kernel above): LDS plan, 163 680 of the 163 840 bytes of the CU:
 //   bias slab, TRANSPOSED [key][query], as bf16 with a 152-element pitch (conflict-free 8-byte reads per half-wave): 43 776 B.  The
 //     slab is the output of grit_relbias_fwd on a bf16 table in the training step, so the conversion is exact there; with an
 //     fp32 table it rounds the bias to bf16 inside this kernel only (2^-9 relative on an O(0.1) logit term, below the bf16
 //     resolution of P / dS that the products run in);
 //   dS^T [key][query] bf16, pitch 148: 42 624 B;  Q / dO / K tiles [144][32] bf16, DOUBLE buffered: 55 296 B;  V and O tiles,
-//     single (consumed at the top of their window): 18 432 B;  statistics 2 400 B (the row log-sum-exps and the region ids double buffered:
-//     they arrive with the tiles).
+//     single (consumed at the top of their window): 18 432 B;  statistics 3 552 B (the row log-sum-exps, the region ids and the token indices of the
+//     144 window positions double buffered: they arrive with the tiles).
 constexpr int kBP2 = 152;
-constexpr size_t kBwdDmaLds = (size_t)kN * kBP2 * 2 + (size_t)kN * kSP * 2 + 8 * (size_t)kN * kTP * 2 + 3 * kN * 4 + 3 * kHd * 4 + 2 * kN;
+constexpr size_t kBwdDmaLds = (size_t)kN * kBP2 * 2 + (size_t)kN * kSP * 2 + 8 * (size_t)kN * kTP * 2 + 3 * kN * 4 + 3 * kHd * 4 + 2 * kN + 2 * kN * 4;
 static_assert(kBwdDmaLds <= 160 * 1024, "one workgroup per CU");
 
 template <bool kExplicitMask>
@@ -595,6 +595,7 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     float* delta_s = lse_s + 2 * kN;                                        // [144]
     float* pad_s = delta_s + kN;                                            // [96]
     uint8_t* rid = reinterpret_cast<uint8_t*>(pad_s + 3 * kHd);             // [2][144]
+    int* tok_s = reinterpret_cast<int*>(rid + 2 * kN);                      // [2][144] token index of a window position, -1: padding
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -625,14 +626,17 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     // compute hides them, and no register holds them meanwhile (the register-staged version could only issue them after phase
     // 1, its register peak: ~20 % of the kernel was exposed load latency, profiles/r01/winattn_bwd_notes.txt).  Window-padding
     // tokens: q / k / v come from pad_qkv, dO / O rows are zero-filled by the owning thread.
-    struct Next { int tkk, kreg, wy, wx; size_t img; };
+    struct Next { int wy, wx; size_t img; };
     // Issued as inline asm: through __builtin_amdgcn_global_load_lds hipcc cannot tell which later LDS reads the transfer may
     // alias (one dynamic LDS block) and puts `s_waitcnt vmcnt(0)` right behind the issue -- the prefetch then overlaps nothing
     // (found in round 3 on the weight-gradient GEMM; it is why this variant measured no better than register staging).  The
     // waits are this kernel's own: `vmcnt(0)` + barrier at the top of the window that consumes the tiles.
-    auto dma16 = [&](const __bf16* src, __bf16* tile, int group) {  // rows 16 group .. 16 group + 15 of a [144][32] tile
-        const unsigned dst = __builtin_amdgcn_readfirstlane(
-            (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(tile) + group * 1024));
+    // (LDS destinations as 32-bit offsets from the block's base: generic pointers cost a register pair and a null check each)
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem_raw;
+    constexpr unsigned kOffTiles = (kN * kBP2 + kN * kSP) * 2, kTileBytes = kN * kTP * 2;
+    constexpr unsigned kOffV = kOffTiles + 6 * kTileBytes, kOffO = kOffV + kTileBytes, kOffLse = kOffO + kTileBytes;
+    auto dma16 = [&](const __bf16* src, unsigned tile_off, int group) {  // rows 16 group .. 16 group + 15 of a [144][32] tile
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + tile_off + group * 1024);
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory", "m0");
     };
     // The row log-sum-exps (4 bytes per lane, threads 0 .. 143) travel the same way.  As a plain load into a register that is
@@ -640,9 +644,8 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     // `s_waitcnt vmcnt(0)` in front of the load (the register still has the previous window's load pending in its model) --
     // right behind the five tile transfers just issued, so every window waited for its prefetch to land
     // (s_memtime stamps: 3.5-5.4k of 17.4k cycles per window, profiles/r03/winattn_bwd_stamps.txt).
-    auto dma4 = [&](const float* src, float* dst_base, int piece) {
-        const unsigned dst = __builtin_amdgcn_readfirstlane(
-            (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(dst_base) + piece * 256));
+    auto dma4 = [&](const float* src, unsigned row_off, int piece) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + row_off + piece * 256);
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(dst), "v"(src) : "memory", "m0");
     };
     // Who issues them: the nine waves sit on four SIMDs, 3-2-2-2, and the kernel is instruction-issue bound on the SIMD that carries
@@ -651,23 +654,25 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     // SIMDs: loader li moves token rows 16 li .. 16 li + 15 of all five tiles, and rows 96 .. 143 are shared by loader pairs (the
     // even one takes Q / K / V and the log-sum-exps, the odd one dO / O).
     const int li = (w & 3) == 0 ? -1 : (w < 4 ? w - 1 : w - 2);
-    auto fetch_rows = [&](int group, int wy, int wx, size_t img, __bf16* tb, uint8_t* rid_n, bool qkv_part, bool do_part) {
+    auto fetch_rows = [&](int group, int wy, int wx, size_t img, int buf, uint8_t* rid_n, int* tok_n, bool qkv_part, bool do_part) {
+        const unsigned tb_off = kOffTiles + buf * 3 * kTileBytes;
         int reg;
         int row = 16 * group + (lane >> 2), col = hoff + sc * 8;
         asm volatile("" : "+v"(row), "+v"(col));  // per-window values: hoisted out of the window loop they cost registers the loop does not have
         const int tk = token_of(row, wy, wx, g, reg);
         if (qkv_part) {
             const __bf16* src = tk >= 0 ? qkv + (img + tk) * C3 + col : pad_qkv + col;
-            dma16(src, tb, group);                              // Q
-            dma16(src + g.C, tb + 2 * kN * kTP, group);         // K
-            dma16(src + 2 * g.C, Vs1, group);                   // V
-            if (sc == 0) rid_n[row] = (uint8_t)reg;
+            dma16(src, tb_off, group);                          // Q
+            dma16(src + g.C, tb_off + 2 * kTileBytes, group);   // K
+            dma16(src + 2 * g.C, kOffV, group);                 // V
+            if (sc == 0) { rid_n[row] = (uint8_t)reg; tok_n[row] = tk; }
         }
         if (do_part) {
             if (tk >= 0) {
-                dma16(dout + (img + tk) * g.C + col, tb + kN * kTP, group);   // dO
-                dma16(out + (img + tk) * g.C + col, Os1, group);              // O
+                dma16(dout + (img + tk) * g.C + col, tb_off + kTileBytes, group);   // dO
+                dma16(out + (img + tk) * g.C + col, kOffO, group);                  // O
             } else {
+                __bf16* tb = tiles + buf * 3 * kN * kTP;
                 *reinterpret_cast<uint4*>(&tb[kN * kTP + row * kTP + sc * 8]) = make_uint4(0, 0, 0, 0);
                 *reinterpret_cast<uint4*>(&Os1[row * kTP + sc * 8]) = make_uint4(0, 0, 0, 0);
             }
@@ -679,25 +684,24 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
         window_of(win, g, b, f.wy, f.wx);
         f.img = (size_t)b * g.T;
         if (li >= 0) {  // wave-uniform
-            __bf16* tb = tiles + buf * 3 * kN * kTP;
             uint8_t* rid_n = rid + buf * kN;
-            fetch_rows(li, f.wy, f.wx, f.img, tb, rid_n, true, true);
-            fetch_rows(6 + (li >> 1), f.wy, f.wx, f.img, tb, rid_n, !(li & 1), (li & 1) != 0);
+            int* tok_n = tok_s + buf * kN;
+            fetch_rows(li, f.wy, f.wx, f.img, buf, rid_n, tok_n, true, true);
+            fetch_rows(6 + (li >> 1), f.wy, f.wx, f.img, buf, rid_n, tok_n, !(li & 1), (li & 1) != 0);
             if (!(li & 1)) {
                 const int piece = li >> 1;
                 int t = 64 * piece + lane;
                 asm volatile("" : "+v"(t));
-                if (t < kN) dma4(lse2 + ((size_t)win * g.nH + h) * kN + t, lse_s + buf * kN, piece);
+                if (t < kN) dma4(lse2 + ((size_t)win * g.nH + h) * kN + t, kOffLse + buf * kN * 4, piece);
             }
         }
-        f.tkk = token_of(16 * w + l15, f.wy, f.wx, g, f.kreg);  // this lane's key in phase 1 / query in phase 2
         return f;
     };
     Next nxt;
     int cur = 0;
     if (grp < NW) nxt = prefetch(grp, 0);
     for (int win = grp; win < NW; win += ngrp, cur ^= 1) {
-        const int wy = nxt.wy, wx = nxt.wx, tkk = nxt.tkk, kreg = nxt.kreg;
+        const int wy = nxt.wy, wx = nxt.wx;
         const size_t img = nxt.img;
         __bf16* Qs = tiles + cur * 3 * kN * kTP;
         __bf16* dOs = Qs + kN * kTP;
@@ -714,6 +718,8 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
             dpart += __shfl_xor(dpart, 2, 64);
         }
         if (sc == 0) delta_s[sn] = dpart;
+        // this lane's key in phase 1: its token (-1: window padding) and shift-mask region, as the loaders left them
+        const int tkk = tok_s[cur * kN + 16 * w + l15], kreg = rid[cur * kN + 16 * w + l15];
         // this lane's K / V fragments (B operands of phase 1): key 16 w + l15, channels 8 lg ..
         const v8bf kf = as_v8bf(*reinterpret_cast<const uint4*>(&Ks[(16 * w + l15) * kTP + lg * 8]));
         const v8bf vf = as_v8bf(*reinterpret_cast<const uint4*>(&Vs1[(16 * w + l15) * kTP + lg * 8]));
@@ -846,6 +852,8 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
 
         // ================= phase 2: wave w = query tile w : dQ^T[d][q] = scale * sum_k K^T[d][k] dS^T[k][q]
         // k-slot (lg, j) = key 32s + 8lg + j; the last step covers keys 128..143 only (lanes lg >= 2 contribute zeros)
+        // (Handing the nine query tiles to the six waves off SIMD 0 as 18 half-units, three each, was tried: nothing at stages
+        // 0 / 1, +4 % at stage 2 -- this phase is bound by its dependent MFMA / LDS chain, not by issue slots.)
         v4f dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
         int oS2 = (8 * lg + trq) * kSP + 16 * w + 4 * trp, oK2 = (8 * lg + trq) * kTP + 4 * trp;
         int oS2d = trq * kSP + 16 * w + 4 * trp - 128 * kSP, oK2d = trq * kTP + 4 * trp - 128 * kTP;  // dead lanes, s5 = 4

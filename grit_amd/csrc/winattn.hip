@@ -294,8 +294,13 @@ constexpr int kSP = 148;   // pitch (bf16) of the transposed dS tile
 constexpr int kBP = 148;   // pitch (float) of the transposed bias slab
 
 // sum over the 16 lanes that share (lane >> 4): the 16 keys / queries of a tile for fixed (channel group, r)
+// (DPP row rotations: a row IS those 16 lanes.  As __shfl_xor each step is a ds_bpermute round trip through the LDS pipe plus a
+// full lgkmcnt wait -- 24 sums per wave and window wherever a tile holds window-padding tokens, i.e. in 7 of the 16 windows of a
+// 40 x 40 map: 11-13 % of the backward kernel there.)
 __device__ __forceinline__ float sum16(float v) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+#define GRIT_ROW_ROR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + (n), 0xf, 0xf, false))
+    v += GRIT_ROW_ROR(v, 8); v += GRIT_ROW_ROR(v, 4); v += GRIT_ROW_ROR(v, 2); v += GRIT_ROW_ROR(v, 1);
+#undef GRIT_ROW_ROR
     return v;
 }
 

@@ -132,6 +132,13 @@ __device__ __forceinline__ v8bf pack8(const v4f& a, const v4f& b) {
 }
 
 __device__ __forceinline__ float xor_max(float v, int o) { return fmaxf(v, __shfl_xor(v, o, 64)); }
+// (v_permlane16_swap / v_permlane32_swap instead of the two ds_bpermute steps of the forward's row max / row sum: -1 % at best; not kept)
+// sum over the 4 lanes of a quad, as DPP quad permutes
+__device__ __forceinline__ float sum_quad(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+    return v;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // forward
@@ -391,8 +398,7 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
             const v8bf a = as_v8bf(do_c), c = as_v8bf(o_c);
 #pragma unroll
             for (int e = 0; e < 8; ++e) dpart = fmaf((float)a[e], (float)c[e], dpart);
-            dpart += __shfl_xor(dpart, 1, 64);
-            dpart += __shfl_xor(dpart, 2, 64);
+            dpart = sum_quad(dpart);
         }
         __syncthreads();  // previous window fully consumed (and, first time, the bias slab is complete)
         *reinterpret_cast<uint4*>(&Qs[sn * kTP + sc * 8]) = q_c;
@@ -719,8 +725,7 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
             const v8bf c = as_v8bf(*reinterpret_cast<const uint4*>(&Os1[sn * kTP + sc * 8]));
 #pragma unroll
             for (int e = 0; e < 8; ++e) dpart = fmaf((float)a[e], (float)c[e], dpart);
-            dpart += __shfl_xor(dpart, 1, 64);
-            dpart += __shfl_xor(dpart, 2, 64);
+            dpart = sum_quad(dpart);
         }
         if (sc == 0) delta_s[sn] = dpart;
         // this lane's key in phase 1: its token (-1: window padding) and shift-mask region, as the loaders left them

@@ -118,6 +118,16 @@ __device__ __forceinline__ v2f dgelu2(v2f x) {
     return s * __builtin_elementwise_fma(x * q, v2f{1.0f, 1.0f} - s, v2f{1.0f, 1.0f});
 }
 
+// Sum over the 16 lanes of a DPP row (the 16 token lanes of an accumulator quarter) by row rotations: plain VALU.  As four
+// __shfl_xor steps it is four ds_bpermute round trips with a full lgkmcnt wait each -- 64 of them per wave in the column-sum
+// epilogue of the GELU' GEMM.
+__device__ __forceinline__ float row_sum16(float v) {
+#define GRIT_ROW_ROR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + (n), 0xf, 0xf, false))
+    v += GRIT_ROW_ROR(v, 8); v += GRIT_ROW_ROR(v, 4); v += GRIT_ROW_ROR(v, 2); v += GRIT_ROW_ROR(v, 1);
+#undef GRIT_ROW_ROR
+    return v;
+}
+
 template <int BK> __device__ __forceinline__ int chunk_swizzle(int r16) {
     // permutation of the 16-byte chunks of row r16 (row index within its 16-row block) that makes the ds_read_b128 fragment
     // reads conflict-free (BK = 32: 64-byte rows, 4 chunks; BK = 64: 128-byte rows, 8 chunks)
@@ -422,12 +432,7 @@ void gemm_nt_bf16(const GemmArgs g) {
         for (int j = 0; j < NTL; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = cs[j][r];
-                v += __shfl_xor(v, 1, 64);
-                v += __shfl_xor(v, 2, 64);
-                v += __shfl_xor(v, 4, 64);
-                v += __shfl_xor(v, 8, 64);
-                cs[j][r] = v;
+                cs[j][r] = row_sum16(cs[j][r]);
             }
         // (a wave whose rows all lie past M has no slab in colsum [ceil(M / 128), N]: found in round 3 as 4 KB of zeros written
         // behind the partials of a 37-row problem)
@@ -630,12 +635,7 @@ void gemm_pp_bf16(const GemmArgs g) {
             for (int j = 0; j < NTL; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = cs[j][r];
-                    v += __shfl_xor(v, 1, 64);
-                    v += __shfl_xor(v, 2, 64);
-                    v += __shfl_xor(v, 4, 64);
-                    v += __shfl_xor(v, 8, 64);
-                    cs[j][r] = v;
+                    cs[j][r] = row_sum16(cs[j][r]);
                 }
             if (l15 == 0 && mw < g.M) {
                 float* dst = g.colsum + (size_t)(mw / 128) * g.N + nw + 4 * lq;

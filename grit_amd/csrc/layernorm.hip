@@ -80,11 +80,27 @@ __device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned lo
     return u >= p ? inv_keep : 0.0f;
 }
 
+// Sum over the LPR lanes of a row.  Not as __shfl_xor steps: each of those is a ds_bpermute round trip through the LDS pipe with
+// a full lgkmcnt wait, twelve of them on the dependent chain load -> mean -> variance -> store of a row, and a wave of these
+// kernels is nothing but that chain.  Within a DPP row (16 lanes) four row rotations (plain VALU); across the rows of a wave the
+// four row sums are read into scalars.
 template <int LPR>
 __device__ __forceinline__ float row_sum(float v) {
+    if constexpr (LPR >= 16) {
+#define GRIT_ROW_ROR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + (n), 0xf, 0xf, false))
+        v += GRIT_ROW_ROR(v, 8); v += GRIT_ROW_ROR(v, 4); v += GRIT_ROW_ROR(v, 2); v += GRIT_ROW_ROR(v, 1);
+#undef GRIT_ROW_ROR
+        if constexpr (LPR == 16) return v;
+        const int iv = __builtin_bit_cast(int, v);
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+        if constexpr (LPR == 64) return (r0 + r1) + (r2 + r3);
+        return (threadIdx.x & 32) ? r2 + r3 : r0 + r1;
+    } else {
 #pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+        for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
 }
 
 // LPR lanes per row, CH chunks of 8 channels per lane: C = LPR * 8 * CH

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from grit_amd.ops.layer_norm import LayerNorm, add_layer_norm, linear_add_layer_norm
-from grit_amd.ops.linear import Linear, linear, mark_single_use
+from grit_amd.ops.linear import Linear, linear, mark_single_use, park_weight_grad_for_partner
 from grit_amd.ops.mlp import hidden as fused_hidden, mlp as fused_mlp, mlp_add_layer_norm
 from grit_amd.ops.rel_bias import relative_position_bias
 from grit_amd.ops.window_attention import window_attention
@@ -189,6 +189,8 @@ class SwinTransformerBlock(nn.Module):
         # NOT attn.qkv: its bias receives a second gradient in every pass (the q / k / v rows of the window-padding tokens ARE the
         # bias: WindowAttention's pad_qkv) -- found by the deferral's own check on the first try
         mark_single_use(self.attn.proj, self.mlp.fc1, self.mlp.fc2)
+        # backward reaches proj two kernels before qkv: their weight gradients share one launch (grit_amd/ops/linear.py GRIT_WGRAD_PARK)
+        park_weight_grad_for_partner(self.attn.proj, self.attn.qkv)
         self.H = None
         self.W = None
 

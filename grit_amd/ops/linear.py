@@ -89,6 +89,20 @@ WGRAD_DEFER = os.environ.get("GRIT_WGRAD_DEFER", "1") != "0"
 WGRAD_DEFER_LONG = os.environ.get("GRIT_WGRAD_DEFER_LONG", "0") == "1"
 _deferral["jobs"] = []
 _deferral["slabs"] = []
+# GRIT_WGRAD_PARK (default 1): a long-map weight gradient whose Linear is marked with park_weight_grad_for_partner (the attention
+# output projection of a Swin block) is not launched by its own node: it waits -- two kernels -- for the weight gradient of the
+# partner that backward reaches next (the qkv Linear of the same block) and runs in THAT node's launch of the long-map kernel.
+# Alone the projection is 4 output tiles cut into 64 row slices (64 MB of fp32 partials for a 0.5 MB gradient) and qkv 12 tiles in
+# 21 slices; together they are 16 tiles in 16 slices of 100 steps: half the partial bytes to write and to sum, one launch less.
+WGRAD_PARK = os.environ.get("GRIT_WGRAD_PARK", "1") != "0"
+_deferral["parked"] = []
+
+
+def park_weight_grad_for_partner(first, partner):
+    """first, partner: Linear modules; backward reaches `first` (its weight gradient is parked) shortly before `partner` (whose node
+    launches both).  Both must run once per forward pass; `first` must be single-use (mark_single_use)."""
+    first.weight._grit_wgrad_park = True
+    partner.weight._grit_wgrad_pickup = True
 
 
 def defer_weight_bias_grad(dy2, x2, weight, bias, need_dw, need_db, single_use):
@@ -105,6 +119,9 @@ def defer_weight_bias_grad(dy2, x2, weight, bias, need_dw, need_db, single_use):
     # launches with 16-64 slices -- the fp32 slices (3.9 GB per step written and read back) shrink by an order of magnitude
     long_ok = (WGRAD_DEFER_LONG and WGRAD_TN_GROUPED and M >= WGRAD_SMALL_MAX_ROWS
                and _lib.load().grit_wgrad_tn_group_ok(M, N, K) == 1)
+    park = (WGRAD_PARK and WGRAD_TN and WGRAD_TN_GROUPED and not long_ok and not need_db and M >= WGRAD_SMALL_MAX_ROWS
+            and getattr(weight, "_grit_wgrad_park", False) and _lib.load().grit_wgrad_tn_group_ok(M, N, K) == 1)
+    long_ok = long_ok or park
     if not ((M < WGRAD_SMALL_MAX_ROWS or long_ok) and N % 64 == 0 and K % 64 == 0 and dy2.stride(1) == 1 and x2.stride(1) == 1
             and dy2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0):
         return None
@@ -113,7 +130,8 @@ def defer_weight_bias_grad(dy2, x2, weight, bias, need_dw, need_db, single_use):
         dw = torch.empty((N, K), dtype=torch.bfloat16, device=dy2.device)
     db = torch.empty((N,), dtype=torch.bfloat16, device=dy2.device) if need_db else None
     # no reference to dw / db is kept (autograd only adopts a gradient tensor nobody else holds): addresses only
-    _deferral["jobs"].append((dy2, x2, weight, bias if need_db else None, dw.data_ptr(), db.data_ptr() if need_db else 0, M, N, K))
+    _deferral["parked" if park else "jobs"].append((dy2, x2, weight, bias if need_db else None, dw.data_ptr(),
+                                                    db.data_ptr() if need_db else 0, M, N, K))
     return dw, db
 
 
@@ -191,11 +209,11 @@ def flush_deferred(final=False):
     """Compute every deferred weight / bias gradient (one grouped GEMM launch + one grouped reduction per <= 32 problems) and
     every deferred reduction.  final: backward is over (finish_gradient_sync), every gradient must have been delivered."""
     _verify_earlier(final)
-    jobs = _deferral["jobs"]
+    jobs = _deferral["jobs"] + _deferral["parked"]  # parked jobs whose partner never came (a bucket boundary, a frozen partner)
     if not jobs:
         _flush_deferred_slabs(final=final)
         return
-    _deferral["jobs"] = []
+    _deferral["jobs"], _deferral["parked"] = [], []
     lib = _lib.load()
     dev = jobs[0][0].device
     for dy2, x2, w, b, pw, pb, M, N, K in jobs:
@@ -269,7 +287,7 @@ def begin_deferral():
 
 def abandon_deferred():
     """Forget every pending job (after an exception: the gradients of that pass are void anyway)."""
-    _deferral["jobs"], _deferral["slabs"], _deferral["unverified"] = [], [], []
+    _deferral["jobs"], _deferral["slabs"], _deferral["unverified"], _deferral["parked"] = [], [], [], []
 
 
 def wait_deferred(final=False):
@@ -538,6 +556,43 @@ def long_weight_grad_partials(dy2, x2, need_db=False):
 WGRAD_TN_PAIR = os.environ.get("GRIT_WGRAD_TN_PAIR", "1") != "0"  # the two weight gradients of a Swin Mlp as one grouped launch
 
 
+def long_weight_grad_with_parked(dy2, x2, group, weight):
+    """(partials [S, N, K], bias column sums [S, N]) of this node's long-map Linear like long_weight_grad_partials(.., True), from a
+    grouped launch that also computes the parked weight gradients (park_weight_grad_for_partner); their slice sums join `group`.
+    None when nothing is parked or it does not apply (the parked jobs then stay for the scope's flush)."""
+    parked = _deferral["parked"]
+    if not (parked and WGRAD_PARK and WGRAD_TN_BIAS and getattr(weight, "_grit_wgrad_pickup", False) and group is not None
+            and dy2.is_cuda and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and SlabGroup.ENABLED):
+        return None
+    M, N = dy2.shape
+    K = x2.shape[1]
+    lib = _lib.load()
+    if (M < 8192 or dy2.stride(1) != 1 or x2.stride(1) != 1 or dy2.stride(0) % 8 or x2.stride(0) % 8 or dy2.data_ptr() % 16
+            or x2.data_ptr() % 16 or lib.grit_wgrad_tn_group_ok(M, N, K) != 1 or len(parked) + 1 > _lib.WGRAD_GROUP_MAX
+            or any(j[0].device != dy2.device for j in parked)):
+        return None
+    tiles = (N // 256) * (K // 256) + sum((j[7] // 256) * (j[8] // 256) for j in parked)
+    if tiles > 256:
+        return None
+    S = min([max(1, 256 // tiles), (M // 32) // 16 or 1] + [(j[6] // 32) // 16 or 1 for j in parked])
+    _deferral["parked"] = []
+    part = torch.empty((S, N, K), dtype=torch.float32, device=dy2.device)
+    bpart = torch.empty((S, N), dtype=torch.float32, device=dy2.device)
+    table = (_lib.WgradJob * (len(parked) + 1))()
+    table[0] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, part.data_ptr(), bpart.data_ptr())
+    flops = 2.0 * M * N * K
+    for t, (pdy, px, pw_param, _, pw, _, pM, pN, pK) in enumerate(parked):
+        work = torch.empty(S * pN * pK, dtype=torch.float32, device=dy2.device)
+        table[t + 1] = _lib.WgradJob(pdy.data_ptr(), pdy.stride(0), px.data_ptr(), px.stride(0), pM, pN, pK, S, work.data_ptr(), None)
+        group.add_raw(work, 1, 0, S, pN * pK, pw, True)
+        _deferral["unverified"].append((pw_param, pw, "parked weight gradient [%d, %d]" % (pN, pK)))
+        flops += 2.0 * pM * pN * pK
+    with _lib.device_guard(dy2.device), timed("gemm_own", flops=flops):
+        st = lib.grit_wgrad_tn_grouped(table, len(parked) + 1, _lib.current_stream_ptr())
+    _lib.check(st, "grit_wgrad_tn_grouped")
+    return part, bpart
+
+
 def long_weight_grads_together(pairs):
     """[fp32 partials [S_j, N_j, K_j]] of dW_j = dy_j^T x_j for several long-map problems of ONE backward node from one grouped launch
     of the long-map kernel -- together their tiles fill the chip with fewer row slices each (fc1 + fc2 of a Swin Mlp: 16 + 16 tiles,
@@ -601,7 +656,9 @@ def weight_bias_grad(dy2, x2, group, need_w, need_b, weight):
     """(dW, db) of a Linear from dy2 [M, N], x2 [M, K]; either may be None when not wanted.  Long maps with both wanted: ONE launch of
     the own kernel yields the weight-gradient slices and, as a by-product, the bias gradient's column sums (no pass over dy2 of its
     own); otherwise weight_grad / column_sum.  group: the node's SlabGroup (the sums are left to its launch)."""
-    pair = long_weight_grad_partials(dy2, x2, True) if (WGRAD_TN_BIAS and need_w and need_b and group is not None) else None
+    pair = long_weight_grad_with_parked(dy2, x2, group, weight) if (need_w and need_b) else None
+    if pair is None:
+        pair = long_weight_grad_partials(dy2, x2, True) if (WGRAD_TN_BIAS and need_w and need_b and group is not None) else None
     if pair is not None:
         slot = grad_slot(weight, dy2.dtype, dy2.device)
         dw = group.add(pair[0].unsqueeze(0), dy2.dtype, out=None if slot is None else slot.view(1, dy2.shape[1], x2.shape[1]))[0]

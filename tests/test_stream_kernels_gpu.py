@@ -512,3 +512,67 @@ def test_long_map_weight_gradients_are_written_into_their_bucket_slots(monkeypat
     for n, g in results[0].items():
         assert torch.equal(g, results[1][n]), n
     assert copied[1] <= copied[0] - net.a.weight.numel() - net.b.weight.numel()
+
+
+@pytest.mark.gpu
+def test_parked_weight_gradient_runs_in_its_partners_launch(monkeypatch):
+    """park_weight_grad_for_partner: inside a gradient-bucket scope the long-map weight gradient of the first Linear (single-use) is
+    not launched by its own node; the partner's node, reached next by backward, computes both in one grouped launch of the long-map
+    kernel.  Same gradients as with the knob off (fp32 slice sums: a different number of row slices, so bf16-rounding close, not
+    bit-equal); nothing stays parked; a parked job whose partner never runs is computed by the scope's flush."""
+    from grit_amd.ddp import BucketedDataParallel
+    from grit_amd.ops import linear as L
+    from grit_amd.ops.layer_norm import linear_add_layer_norm
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.qkv = L.Linear(512, 1536)
+            self.proj = L.Linear(512, 512)
+            self.norm = torch.nn.LayerNorm(512)
+            L.mark_single_use(self.proj)
+            L.park_weight_grad_for_partner(self.proj, self.qkv)
+            self.skip_partner = False
+
+        def forward(self, x):
+            h = x if self.skip_partner else torch.tanh(self.qkv(x)[..., :512])
+            s, n = linear_add_layer_norm(h, self.proj, x, None, self.norm.weight, self.norm.bias, self.norm.eps)
+            return s + n
+
+    torch.manual_seed(0)
+    net = Net().to(DEV).bfloat16()
+    x = torch.randn(16, 1024, 512, device=DEV).bfloat16()          # 16 384 rows: a long map
+    cot = torch.randn(16, 1024, 512, device=DEV).bfloat16()
+    ddp = BucketedDataParallel(net, bucket_mb=64, tail_mb=0)  # one bucket: no pack (= flush) between the two nodes
+    launches, results = [], []
+    lib = L._lib.load()
+    real = lib.grit_wgrad_tn_grouped
+
+    class Spy(object):
+        def __call__(self, table, n, stream):
+            launches[-1].append(n)
+            return real(table, n, stream)
+
+    for knob, skip in ((False, False), (True, False), (False, True), (True, True)):
+        monkeypatch.setattr(L, "WGRAD_PARK", knob)
+        net.skip_partner = skip
+        launches.append([])
+        monkeypatch.setattr(lib, "grit_wgrad_tn_grouped", Spy(), raising=False)
+        y = ddp(x)
+        (y.float() * cot.float()).sum().backward()
+        assert not L._deferral["parked"] or skip
+        ddp.finish_gradient_sync()
+        monkeypatch.setattr(lib, "grit_wgrad_tn_grouped", real, raising=False)
+        assert not L._deferral["parked"]
+        torch.cuda.synchronize()
+        results.append({n: (None if p.grad is None else p.grad.float().clone()) for n, p in net.named_parameters()})
+        for p in net.parameters():
+            p.grad = None
+    assert launches == [[], [2], [], [1]]   # partner + parked together; a leftover alone at the scope's flush
+    for a, b in ((0, 1), (2, 3)):
+        for n, g in results[a].items():
+            if g is None:
+                assert results[b][n] is None and n.startswith("qkv"), n
+                continue
+            scale = g.abs().max().clamp_min(1e-6)
+            assert (g - results[b][n]).abs().max() <= 0.02 * scale, n

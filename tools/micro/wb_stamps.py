@@ -1,4 +1,5 @@
-"""Scratch: phase stamps of winattn_bwd_dma (diagnostic build only)."""
+"""Phase stamps of winattn_bwd_dma: cycles per workgroup, wave and phase.  Needs the diagnostic build of
+tools/micro/wb_stamps_patch.py (apply -> run this on the GPU box -> restore)."""
 import ctypes, sys, torch
 sys.path.insert(0, ".")
 from grit_amd import lib

@@ -289,6 +289,183 @@ void winattn_fwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
     }
 }
 
+// DMA-staged forward (the default; GRIT_WINATTN_FWD_DMA=0 or an explicit mask select the register-staged kernel above).  Same
+// arithmetic; what changes is who moves the operands and when (s_memtime stamps, profiles/r03/winattn_bwd_stamps.txt: in the
+// register-staged kernel the third wave of SIMD 0 needs 2x the first waves' time for its fetch and everybody waits a third of the
+// kernel for it):
+//   * the Q / K / V tiles of the NEXT window travel global -> LDS by global_load_lds (double-buffered tiles, no staging registers,
+//     no LDS writes, ONE barrier per window instead of two), issued as asm by the six waves that do not sit on SIMD 0 -- loader li
+//     moves token rows 16 li .. + 15 of the three tiles, rows 96 .. 143 are shared by loader pairs; they also leave the token index
+//     and the shift-mask region of every window position in LDS, so no other wave runs token_of;
+//   * the 64-byte rows of a DMA image cannot be padded: the 16-byte chunks are permuted on the SOURCE address instead
+//     (Q / K, read with ds_read_b128 by 16 rows x one chunk: chunk ^ 3 in rows 8 .. 15 of a 16-row block; V, read with
+//     ds_read_b64_tr_b16 by 8 rows x 32 bytes: chunk ^ 2 in rows 4 .. 7 of an 8-row block -- conflict-free by the lane groups of
+//     MI355X_MICROARCH.md "LDS").
+constexpr unsigned kFTile = kN * 64, kFVTile = kRows * 64;
+constexpr unsigned kFOffQ = 0, kFOffK = 2 * kFTile, kFOffV = 4 * kFTile, kFOffTok = kFOffV + 2 * kFVTile, kFOffRid = kFOffTok + 2 * kN * 4;
+constexpr size_t kFwdDmaLds = kFOffRid + 2 * kN;
+
+__global__ __launch_bounds__(kThreads)
+void winattn_fwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ rel_bias, const __bf16* __restrict__ pad_qkv, Geom g,
+                     __bf16* __restrict__ out, float* __restrict__ lse2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int* tok_s = reinterpret_cast<int*>(smem_raw + kFOffTok);       // [2][144]
+    uint8_t* rid = smem_raw + kFOffRid;                              // [2][144]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    int h, grp;
+    head_and_group(g, h, grp);
+    const int ngrp = gridDim.x / g.nH;
+    const int NW = g.B * g.nWh * g.nWw;
+    const int C3 = 3 * g.C;
+    const int hoff = h * kHd;
+    const float c2 = g.scale * kLog2e;
+
+    // rows 144 .. 159 of both V buffers: the k-padding of the last PV step, never written by the transfers
+    for (int i = tid; i < 2 * (kRows - kN) * 16; i += kThreads) {
+        const int b = i / ((kRows - kN) * 16), r = i - b * (kRows - kN) * 16;
+        reinterpret_cast<uint32_t*>(smem_raw + kFOffV + b * kFVTile + kN * 64)[r] = 0u;
+    }
+
+    v4f b2[kTiles];  // b2[kt][r] = bias[h][query 16w + l15][key 16kt + 4lg + r] * log2(e)
+    {
+        const float* brow = rel_bias + ((size_t)h * kN + 16 * w + l15) * kN + 4 * lg;
+#pragma unroll
+        for (int kt = 0; kt < kTiles; ++kt) {
+            const float4 t = *reinterpret_cast<const float4*>(brow + 16 * kt);
+            b2[kt] = v4f{t.x * kLog2e, t.y * kLog2e, t.z * kLog2e, t.w * kLog2e};
+        }
+    }
+    // the bias loads are the only compiler-visible loads of the kernel: consumed here, so that hipcc's wait for them sits in front
+    // of the window loop and not -- as `vmcnt(0)`, i.e. a wait for the transfers -- in front of their first use inside it
+#pragma unroll
+    for (int kt = 0; kt < kTiles; ++kt) asm volatile("" : "+v"(b2[kt]));
+
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem_raw;
+    auto dma16 = [&](const __bf16* src, unsigned tile_off, int group) {  // rows 16 group .. + 15 of a tile with 64-byte rows
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + tile_off + group * 1024);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory", "m0");
+    };
+    const int li = (w & 3) == 0 ? -1 : (w < 4 ? w - 1 : w - 2);
+    auto fetch_rows = [&](int group, int wy, int wx, size_t img, int buf, bool qk_part, bool v_part) {
+        int reg;
+        int row = 16 * group + (lane >> 2), p = lane & 3;
+        asm volatile("" : "+v"(row), "+v"(p));  // per-window values (hoisted they cost registers)
+        const int tk = token_of(row, wy, wx, g, reg);
+        const __bf16* src = tk >= 0 ? qkv + (img + tk) * C3 + hoff : pad_qkv + hoff;
+        if (qk_part) {
+            const int c = p ^ ((row & 8) ? 3 : 0);
+            dma16(src + c * 8, kFOffQ + buf * kFTile, group);
+            dma16(src + g.C + c * 8, kFOffK + buf * kFTile, group);
+            if (p == 0) { rid[buf * kN + row] = (uint8_t)reg; tok_s[buf * kN + row] = tk; }
+        }
+        if (v_part) {
+            const int c = p ^ ((row & 4) ? 2 : 0);
+            dma16(src + 2 * g.C + c * 8, kFOffV + buf * kFVTile, group);
+        }
+    };
+    struct Next { int wy, wx; size_t img; };
+    auto prefetch = [&](int win, int buf) {
+        Next f;
+        int b;
+        window_of(win, g, b, f.wy, f.wx);
+        f.img = (size_t)b * g.T;
+        if (li >= 0) {  // wave-uniform
+            fetch_rows(li, f.wy, f.wx, f.img, buf, true, true);
+            fetch_rows(6 + (li >> 1), f.wy, f.wx, f.img, buf, !(li & 1), (li & 1) != 0);
+        }
+        return f;
+    };
+
+    const int sk = (l15 & 8) ? 3 : 0;
+    const int trq = l15 >> 2, trp = l15 & 3;
+    Next nxt;
+    int cur = 0;
+    if (grp < NW) nxt = prefetch(grp, 0);
+    for (int win = grp; win < NW; win += ngrp, cur ^= 1) {
+        const int wy = nxt.wy, wx = nxt.wx;
+        const size_t img = nxt.img;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's transfers (and its stores of the previous window)
+        __syncthreads();  // everybody's: the tiles of this window are complete, and nobody reads the other buffers any more
+        const __bf16* Qs = reinterpret_cast<const __bf16*>(smem_raw + kFOffQ + cur * kFTile);
+        const __bf16* Ks = reinterpret_cast<const __bf16*>(smem_raw + kFOffK + cur * kFTile);
+        const __bf16* Vs = reinterpret_cast<const __bf16*>(smem_raw + kFOffV + cur * kFVTile);
+        int oFrag = l15 * 32 + ((lg ^ sk) << 3);                         // row read of a 16-row block (+ 16 block * 32)
+        int oTrV = (4 * lg + trq) * 32 + ((((trp >> 1) ^ ((lg & 1) << 1))) << 3) + ((trp & 1) << 2);  // transposing reads (+ 32 s * 32)
+        int oId = cur * kN;
+        asm volatile("" : "+v"(oFrag), "+v"(oTrV), "+v"(oId));
+        const int tq = tok_s[oId + 16 * w + l15], qreg = rid[oId + 16 * w + l15];
+        const v8bf qf = as_v8bf(*reinterpret_cast<const uint4*>(&Qs[oFrag + 16 * w * 32]));
+        if (win + ngrp < NW) nxt = prefetch(win + ngrp, cur ^ 1);  // lands under this window's compute
+
+        // ---- S^T = K Q^T : acc[kt][r] = <q(16w + l15), k(16kt + 4lg + r)>
+        v4f acc[kTiles];
+#pragma unroll
+        for (int kt = 0; kt < kTiles; ++kt) {
+            const v8bf kf = as_v8bf(*reinterpret_cast<const uint4*>(&Ks[oFrag + 16 * kt * 32]));
+            acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+        const bool analytic = g.shift > 0 && (wy == g.nWh - 1 || wx == g.nWw - 1);
+#pragma unroll
+        for (int kt = 0; kt < kTiles; ++kt) {
+            const v2f lo = __builtin_elementwise_fma(v2f{acc[kt][0], acc[kt][1]}, v2f{c2, c2}, v2f{b2[kt][0], b2[kt][1]});
+            const v2f hi = __builtin_elementwise_fma(v2f{acc[kt][2], acc[kt][3]}, v2f{c2, c2}, v2f{b2[kt][2], b2[kt][3]});
+            acc[kt] = v4f{lo[0], lo[1], hi[0], hi[1]};
+        }
+        if (analytic) {
+#pragma unroll
+            for (int kt = 0; kt < kTiles; ++kt) {
+                const uint32_t ids = *reinterpret_cast<const uint32_t*>(&rid[oId + 16 * kt + 4 * lg]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((int)((ids >> (8 * r)) & 0xff) != qreg) acc[kt][r] += -100.0f * kLog2e;
+            }
+        }
+        float m = acc[0][0];
+#pragma unroll
+        for (int kt = 0; kt < kTiles; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[kt][r]);
+        m = xor_max(xor_max(m, 16), 32);
+        v2f sum2 = {0.f, 0.f};
+        const v2f m2 = {m, m};
+#pragma unroll
+        for (int kt = 0; kt < kTiles; ++kt) {
+            const v2f d_lo = v2f{acc[kt][0], acc[kt][1]} - m2, d_hi = v2f{acc[kt][2], acc[kt][3]} - m2;
+            const v2f e_lo = {__builtin_amdgcn_exp2f(d_lo[0]), __builtin_amdgcn_exp2f(d_lo[1])};
+            const v2f e_hi = {__builtin_amdgcn_exp2f(d_hi[0]), __builtin_amdgcn_exp2f(d_hi[1])};
+            acc[kt] = v4f{e_lo[0], e_lo[1], e_hi[0], e_hi[1]};
+            sum2 += e_lo + e_hi;
+        }
+        float sum = sum2[0] + sum2[1];
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+
+        // ---- O^T = V^T P^T; k-slot (lg, j<4) = key 32s + 4lg + j, (lg, j>=4) = key 32s + 16 + 4lg + (j-4)
+        v4f o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const v8bf pf = s < 4 ? pack8(acc[2 * s], acc[2 * s + 1]) : pack8(acc[8], v4f{0.f, 0.f, 0.f, 0.f});
+            const __bf16* lo = &Vs[oTrV + 32 * s * 32];
+            const __bf16* hi = lo + 16 * 32;
+            // channels 16 .. 31 are logical chunks 2, 3: position chunk ^ 2 relative to chunks 0, 1
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(lo, hi), pf, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(lo + 16 - ((lg & 1) << 5), hi + 16 - ((lg & 1) << 5)), pf, o1, 0, 0, 0);
+        }
+        if (tq >= 0) {
+            __bf16* orow = out + (img + tq) * g.C + hoff + 4 * lg;
+            v4bf a, c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = (__bf16)(o0[r] * inv); c[r] = (__bf16)(o1[r] * inv); }
+            GRIT_ST4(orow, a);
+            GRIT_ST4(orow + 16, c);
+        }
+        if (lg == 0) lse2[((size_t)win * g.nH + h) * kN + 16 * w + l15] = m + __builtin_amdgcn_logf(sum);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------
@@ -1135,6 +1312,18 @@ int grit_winattn_fwd_bf16(const void* qkv, const float* rel_bias, const void* pa
     if (mask && n_mask_windows <= 0) return GRIT_ERR_BAD_ARG;
     const Geom g0 = make_geom(B, H, W, C, num_heads, shift, scale, n_mask_windows);
     const Geom g = with_xcd_mapping(g0, grid_blocks(g0, 256));
+    static const bool use_dma = [] { const char* e = getenv("GRIT_WINATTN_FWD_DMA"); return !(e && atoi(e) == 0); }();
+    if (use_dma && !mask) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute((const void*)winattn_fwd_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdDmaLds) != hipSuccess)
+                return GRIT_ERR_LAUNCH;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(winattn_fwd_dma, dim3(grid_blocks(g, 256)), dim3(kThreads), kFwdDmaLds, (hipStream_t)stream,
+                           (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, g, (__bf16*)out, lse);
+        return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL(winattn_fwd, dim3(grid_blocks(g, 256)), dim3(kThreads), 0, (hipStream_t)stream,
                        (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (__bf16*)out, lse);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;

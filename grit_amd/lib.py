@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -33,6 +33,7 @@ SIGNATURES = {
     "grit_wgrad_tn_group_ok": [_int] * 3,
     "grit_wgrad_tn_grouped": [_ptr, _int, _ptr],
     "grit_colsum_grouped": [_ptr, _int, _ptr],
+    "grit_transpose_bf16_grouped": [_ptr, _int, _ptr],
     "grit_wgrad_tn_splits": [_int] * 3,
     "grit_wgrad_tn": [_ptr, _c.c_long, _ptr, _c.c_long] + [_int] * 4 + [_ptr, _ptr, _ptr],
     "grit_msda_bwd_sorted_supported": [_int] * 6,
@@ -102,7 +103,13 @@ class ColsumJob(_c.Structure):
     _fields_ = [("x", _c.c_void_p), ("ld", _c.c_long), ("M", _c.c_int), ("N", _c.c_int), ("slabs", _c.c_int), ("partial", _c.c_void_p)]
 
 
+class TransposeJob(_c.Structure):
+    """grit_transpose_job of include/grit_hip.h."""
+    _fields_ = [("src", _c.c_void_p), ("dst", _c.c_void_p), ("rows", _c.c_int), ("cols", _c.c_int)]
+
+
 COLSUM_GROUP_MAX = 32
+TRANSPOSE_GROUP_MAX = 32
 _lib = None
 
 

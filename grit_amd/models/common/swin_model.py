@@ -27,6 +27,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from grit_amd.ops.layer_norm import LayerNorm, add_layer_norm, linear_add_layer_norm
+from grit_amd.ops import transposed as _transposed
 from grit_amd.ops.linear import Linear, linear, mark_single_use, park_weight_grad_for_partner
 from grit_amd.ops.mlp import hidden as fused_hidden, mlp as fused_mlp, mlp_add_layer_norm
 from grit_amd.ops.rel_bias import relative_position_bias
@@ -437,6 +438,10 @@ class SwinTransformer(nn.Module):
         B = x.shape[0]
         if _POOLED_DROP_PATH and self.training and x.is_cuda and torch.is_grad_enabled():
             self._draw_drop_path(B, x.device)
+        if x.is_cuda and torch.is_grad_enabled():
+            # fc2.weight^T of every block (the K-contiguous operand of the fused GELU' input-gradient GEMM): one launch here instead
+            # of a transpose inside each block's backward (grit_amd/ops/transposed.py)
+            _transposed.refresh([blk.mlp.fc2.weight for stage in self.layers for blk in stage.blocks if blk.mlp.fc2.weight.requires_grad])
         x, Wh, Ww = self.patch_embed.tokens(x.to(self.patch_embed.proj.weight.dtype))
         if self.ape:
             pos = F.interpolate(self.absolute_pos_embed, size=(Wh, Ww), mode='bicubic')

@@ -20,6 +20,7 @@ from grit_amd import lib as _lib
 from grit_amd.ops import backend
 from grit_amd.ops import gemm as G
 from grit_amd.ops import layer_norm as LN
+from grit_amd.ops import transposed as _transposed
 from grit_amd.ops.linear import (WGRAD_STREAM, SlabGroup, column_sum, defer_weight_bias_grad, finish_group, fork, grad_slot, join,
                                  long_weight_grads_together, on_stream, single_use_now, slab_sum, weight_grad)
 from grit_amd.ops.profiling import timed
@@ -60,7 +61,8 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=No
         if need_b2:
             d_b2 = column_sum(d_branch, w2.dtype, group)
     if chain:
-        d_pre, partial = G.input_grad_dgelu(d_branch, w2.t().contiguous(), pre)
+        w2t = _transposed.lookup(params[1] if params is not None else w2)  # made for all blocks at once by the backbone's forward
+        d_pre, partial = G.input_grad_dgelu(d_branch, w2t if w2t is not None else w2.t().contiguous(), pre)
         join(side, d_w2, d_b2)
         side = fork(d_pre, partial, n2) if (need_x and (need_w1 or need_b1)) else None
         if side is not None:

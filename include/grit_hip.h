@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 30
+#define GRIT_ABI_VERSION 31
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -378,6 +378,17 @@ typedef struct grit_colsum_job {
     float* partial;
 } grit_colsum_job;
 int grit_colsum_grouped(const grit_colsum_job* jobs, int n_jobs, void* stream);
+
+/* Transposed copies dst [cols, rows] of up to GRIT_TRANSPOSE_GROUP_MAX bf16 matrices src [rows, cols] (contiguous) in one launch:
+ * the K-contiguous B operands grit_gemm_bf16_nt needs for an input gradient (fc2.weight^T of every Swin Mlp,
+ * models/common/swin_model.py:31-37: autograd's Linear backward leaves that transpose to its GEMM) made once per optimizer step
+ * instead of once per block inside backward.  rows, cols multiples of 64, 16-byte aligned bases. */
+#define GRIT_TRANSPOSE_GROUP_MAX 32
+typedef struct grit_transpose_job {
+    const void* src; void* dst;
+    int rows, cols;
+} grit_transpose_job;
+int grit_transpose_bf16_grouped(const grit_transpose_job* jobs, int n_jobs, void* stream);
 
 /* Weight gradient of a Linear on a LONG token map (the Swin blocks): partial[s, N, K] (fp32) = dY[rows of slice s]^T . X[rows of
  * slice s] for S = grit_wgrad_tn_splits(M, N, K) row slices (chosen so that tiles x S fills the chip with one 256 x 256-tile

@@ -576,3 +576,28 @@ def test_parked_weight_gradient_runs_in_its_partners_launch(monkeypatch):
                 continue
             scale = g.abs().max().clamp_min(1e-6)
             assert (g - results[b][n]).abs().max() <= 0.02 * scale, n
+
+
+@pytest.mark.gpu
+def test_grouped_weight_transposes_and_their_cache():
+    """grit_transpose_bf16_grouped against torch (bit-exact: a copy), and ops.transposed: a copy is served only for the weight value
+    it was made from (tensor version, data pointer, weights_epoch) -- anything else falls back to the node's own transpose."""
+    from grit_amd.ops import transposed as T
+    from grit_amd.ops import weights_epoch
+    torch.manual_seed(0)
+    ws = [torch.randn(r, c, device=DEV).bfloat16() for r, c in ((512, 2048), (128, 512), (1024, 4096), (64, 64), (256, 1024))]
+    ws.append(torch.randn(100, 64, device=DEV).bfloat16())           # rows not a multiple of 64: never cached
+    assert all(T.lookup(w) is None for w in ws)
+    T.refresh(ws)
+    for w in ws[:-1]:
+        assert torch.equal(T.lookup(w), w.t().contiguous())
+    assert T.lookup(ws[-1]) is None
+    kept = T.lookup(ws[0])
+    ws[0].add_(1.0)                                                   # visible in-place write: the copy is stale
+    assert T.lookup(ws[0]) is None
+    T.refresh(ws)
+    assert T.lookup(ws[0]).data_ptr() == kept.data_ptr() and torch.equal(T.lookup(ws[0]), ws[0].t().contiguous())  # buffer re-used
+    weights_epoch.bump()                                              # a raw-kernel write (flat optimizer step): everything is stale
+    assert all(T.lookup(w) is None for w in ws)
+    T.refresh(ws)
+    assert torch.equal(T.lookup(ws[2]), ws[2].t().contiguous())

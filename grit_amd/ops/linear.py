@@ -266,7 +266,7 @@ def flush_deferred(final=False):
                 group.add_raw(work[woff:], 1, 0, S, N * K, pw, True)
                 if b is not None:
                     group.add_raw(work[boff:], 1, 0, sl, N, pb, True)
-            with timed("gemm_own", flops=2.0 * sum(j[6] * j[7] * j[8] for j in chunk)):
+            with timed("gemm_own", flops=2.0 * sum(j[6] * j[7] * j[8] for j in chunk), kernel="wgrad_tn" if kind == "tn" else "wgrad_small"):
                 if kind == "tn":
                     st = lib.grit_wgrad_tn_grouped(table, len(chunk), _lib.current_stream_ptr())
                 else:
@@ -501,7 +501,7 @@ def small_weight_bias_grad(dy2, x2, need_db, out_dtype, group=None):
     else:
         wpart = torch.empty((1, S, N, K), dtype=torch.float32, device=dy2.device)
         bpart = torch.empty((1, S, N), dtype=torch.float32, device=dy2.device) if need_db else None
-    with _lib.device_guard(dy2.device), timed("gemm_own", flops=2.0 * M * N * K):
+    with _lib.device_guard(dy2.device), timed("gemm_own", flops=2.0 * M * N * K, kernel="wgrad_small"):
         st = lib.grit_wgrad_small(ctypes.c_void_p(dy2.data_ptr()), dy2.stride(0), ctypes.c_void_p(x2.data_ptr()), x2.stride(0), M, N, K,
                                   S, ctypes.c_void_p(wpart.data_ptr()), ctypes.c_void_p(bpart.data_ptr()) if need_db else None,
                                   _lib.current_stream_ptr())
@@ -545,7 +545,7 @@ def long_weight_grad_partials(dy2, x2, need_db=False):
         return None
     part = torch.empty((S, N, K), dtype=torch.float32, device=dy2.device)
     bpart = torch.empty((S, N), dtype=torch.float32, device=dy2.device) if need_db else None
-    with _lib.device_guard(dy2.device), timed("gemm_own", flops=2.0 * M * N * K):
+    with _lib.device_guard(dy2.device), timed("gemm_own", flops=2.0 * M * N * K, kernel="wgrad_tn"):
         st = lib.grit_wgrad_tn(ctypes.c_void_p(dy2.data_ptr()), dy2.stride(0), ctypes.c_void_p(x2.data_ptr()), x2.stride(0), M, N, K, S,
                                ctypes.c_void_p(part.data_ptr()), ctypes.c_void_p(bpart.data_ptr()) if need_db else None,
                                _lib.current_stream_ptr())
@@ -587,7 +587,7 @@ def long_weight_grad_with_parked(dy2, x2, group, weight):
         group.add_raw(work, 1, 0, S, pN * pK, pw, True)
         _deferral["unverified"].append((pw_param, pw, "parked weight gradient [%d, %d]" % (pN, pK)))
         flops += 2.0 * pM * pN * pK
-    with _lib.device_guard(dy2.device), timed("gemm_own", flops=flops):
+    with _lib.device_guard(dy2.device), timed("gemm_own", flops=flops, kernel="wgrad_tn"):
         st = lib.grit_wgrad_tn_grouped(table, len(parked) + 1, _lib.current_stream_ptr())
     _lib.check(st, "grit_wgrad_tn_grouped")
     return part, bpart
@@ -621,7 +621,7 @@ def long_weight_grads_together(pairs):
         part = torch.empty((S, N, K), dtype=torch.float32, device=dy2.device)
         parts.append(part)
         table[t] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, part.data_ptr(), None)
-    with _lib.device_guard(pairs[0][0].device), timed("gemm_own", flops=2.0 * sum(d.shape[0] * d.shape[1] * x.shape[1] for d, x in pairs)):
+    with _lib.device_guard(pairs[0][0].device), timed("gemm_own", flops=2.0 * sum(d.shape[0] * d.shape[1] * x.shape[1] for d, x in pairs), kernel="wgrad_tn"):
         st = lib.grit_wgrad_tn_grouped(table, len(pairs), _lib.current_stream_ptr())
     _lib.check(st, "grit_wgrad_tn_grouped")
     return parts

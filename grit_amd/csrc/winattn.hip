@@ -845,7 +845,11 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     auto fetch_rows = [&](int group, int wy, int wx, size_t img, int buf, uint8_t* rid_n, int* tok_n, bool qkv_part, bool do_part) {
         const unsigned tb_off = kOffTiles + buf * 3 * kTileBytes;
         int reg;
-        int row = 16 * group + (lane >> 2), col = hoff + sc * 8;
+        // 64-byte DMA rows cannot be padded: the 16-byte chunks of a row are permuted on the SOURCE address instead -- position p of
+        // row r holds logical chunk p ^ swz(r & 15), swz = (r & 8 ? 3 : 0) ^ (r & 4 ? 2 : 0): conflict-free for the row reads
+        // (ds_read_b128, 16 rows x one chunk) and for both transposing read patterns (8 rows x 32 bytes, rows 4 or 8 apart)
+        // by the lane groups of MI355X_MICROARCH.md "LDS" (SQ_LDS_BANK_CONFLICT, profiles/r03/winattn_sq_counters*.txt)
+        int row = 16 * group + (lane >> 2), col = hoff + ((sc ^ (((lane >> 2) & 8) ? 3 : 0) ^ (((lane >> 2) & 4) ? 2 : 0)) << 3);
         asm volatile("" : "+v"(row), "+v"(col));  // per-window values: hoisted out of the window loop they cost registers the loop does not have
         const int tk = token_of(row, wy, wx, g, reg);
         if (qkv_part) {
@@ -908,20 +912,24 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
         // this lane's key in phase 1: its token (-1: window padding) and shift-mask region, as the loaders left them
         const int tkk = tok_s[cur * kN + 16 * w + l15], kreg = rid[cur * kN + 16 * w + l15];
         // this lane's K / V fragments (B operands of phase 1): key 16 w + l15, channels 8 lg ..
-        const v8bf kf = as_v8bf(*reinterpret_cast<const uint4*>(&Ks[(16 * w + l15) * kTP + lg * 8]));
-        const v8bf vf = as_v8bf(*reinterpret_cast<const uint4*>(&Vs1[(16 * w + l15) * kTP + lg * 8]));
+        const int swr = ((l15 & 8) ? 3 : 0) ^ ((l15 & 4) ? 2 : 0);   // chunk permutation of row l15 of a 16-row block (see fetch_rows)
+        const v8bf kf = as_v8bf(*reinterpret_cast<const uint4*>(&Ks[(16 * w + l15) * kTP + ((lg ^ swr) << 3)]));
+        const v8bf vf = as_v8bf(*reinterpret_cast<const uint4*>(&Vs1[(16 * w + l15) * kTP + ((lg ^ swr) << 3)]));
         __syncthreads();  // statistics visible; the V / O tiles and the other tile buffer are free for the next window's DMA
         if (win + ngrp < NW) nxt = prefetch(win + ngrp, cur ^ 1);  // lands under phases 1 and 2 of this window
 
         // Per-lane LDS offsets, made opaque once per window: without this hipcc hoists ~90 loop-invariant LDS
         // addresses out of the window loop, runs out of registers and reloads them from scratch before every read.
-        int oRow = l15 * kTP + lg * 8;                   // row reads of Qs / dOs      (+ 16 qt kTP)
-        int oTr = (4 * lg + trq) * kTP + 4 * trp;        // transposing reads, phase 1 (+ 32 s kTP)
+        int oRow = l15 * kTP + ((lg ^ swr) << 3);        // row reads of Qs / dOs      (+ 16 qt kTP)
+        // transposing reads, phase 1 (+ 32 s kTP): row 4 lg + trq, channels 4 trp .. (logical chunk trp >> 1) and + 16 (chunk + 2)
+        const int pa = (trp >> 1) ^ ((lg & 2) ? 3 : 0) ^ ((lg & 1) ? 2 : 0);
+        int oTr = (4 * lg + trq) * kTP + (pa << 3) + ((trp & 1) << 2);
+        int oTr16 = (4 * lg + trq) * kTP + ((pa ^ 2) << 3) + ((trp & 1) << 2);
         int oB = (16 * w + l15) * kBP2 + 4 * lg;         // bias slab (bf16)           (+ 16 qt)
         int oSt = 4 * lg;                                // delta, region ids          (+ 16 qt)
         int oLse = cur * kN + 4 * lg;                    // lse of this window's buffer (+ 16 qt)
         int oW = (16 * w + l15) * kSP + 4 * lg;          // dS^T writes                (+ 16 qt)
-        asm volatile("" : "+v"(oRow), "+v"(oTr), "+v"(oB), "+v"(oSt), "+v"(oLse), "+v"(oW));
+        asm volatile("" : "+v"(oRow), "+v"(oTr), "+v"(oTr16), "+v"(oB), "+v"(oSt), "+v"(oLse), "+v"(oW));
 
         // ================= phase 1: wave w = key tile w =================
         // S[q][k] = Q K^T, dP[q][k] = dO V^T on tiles (qt, w); after each PAIR of query tiles (one 32-deep k-step of
@@ -998,12 +1006,14 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
                 const int r0 = 16 * (single ? qt : qt - 1);  // queries 32s + 4lg + (0..3) | +16
                 const __bf16* dlo = &dOs[oTr + r0 * kTP];
                 const __bf16* qlo = &Qs[oTr + r0 * kTP];
-                const v4s d_hi0 = single ? z4s : tr_read(dlo + 16 * kTP), d_hi1 = single ? z4s : tr_read(dlo + 16 * kTP + 16);
-                const v4s q_hi0 = single ? z4s : tr_read(qlo + 16 * kTP), q_hi1 = single ? z4s : tr_read(qlo + 16 * kTP + 16);
+                const __bf16* dlo16 = &dOs[oTr16 + r0 * kTP];  // channels + 16 of the same rows
+                const __bf16* qlo16 = &Qs[oTr16 + r0 * kTP];
+                const v4s d_hi0 = single ? z4s : tr_read(dlo + 16 * kTP), d_hi1 = single ? z4s : tr_read(dlo16 + 16 * kTP);
+                const v4s q_hi0 = single ? z4s : tr_read(qlo + 16 * kTP), q_hi1 = single ? z4s : tr_read(qlo16 + 16 * kTP);
                 dv0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(dlo), d_hi0), pf, dv0, 0, 0, 0);
-                dv1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(dlo + 16), d_hi1), pf, dv1, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(dlo16), d_hi1), pf, dv1, 0, 0, 0);
                 dk0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(qlo), q_hi0), sf, dk0, 0, 0, 0);
-                dk1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(qlo + 16), q_hi1), sf, dk1, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(qlo16), q_hi1), sf, dk1, 0, 0, 0);
             }
             pprev = pp;
             sprev = sp;
@@ -1042,18 +1052,23 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
         // (Handing the nine query tiles to the six waves off SIMD 0 as 18 half-units, three each, was tried: nothing at stages
         // 0 / 1, +4 % at stage 2 -- this phase is bound by its dependent MFMA / LDS chain, not by issue slots.)
         v4f dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
-        int oS2 = (8 * lg + trq) * kSP + 16 * w + 4 * trp, oK2 = (8 * lg + trq) * kTP + 4 * trp;
+        // K rows 8 lg + trq (and + 4) of a 32-key step: position of logical chunk trp >> 1 in row r is pk, in row r + 4 it is pk ^ 2,
+        // and channels + 16 (chunk + 2) sit at the other of the two
+        const int pk = (trp >> 1) ^ ((lg & 1) ? 3 : 0);
+        int oS2 = (8 * lg + trq) * kSP + 16 * w + 4 * trp, oK2 = (8 * lg + trq) * kTP + (pk << 3) + ((trp & 1) << 2);
+        int oK2x = (8 * lg + trq) * kTP + ((pk ^ 2) << 3) + ((trp & 1) << 2);
         int oS2d = trq * kSP + 16 * w + 4 * trp - 128 * kSP, oK2d = trq * kTP + 4 * trp - 128 * kTP;  // dead lanes, s5 = 4
-        asm volatile("" : "+v"(oS2), "+v"(oK2), "+v"(oS2d), "+v"(oK2d));
+        asm volatile("" : "+v"(oS2), "+v"(oK2), "+v"(oK2x), "+v"(oS2d), "+v"(oK2d));
 #pragma unroll
         for (int s5 = 0; s5 < 5; ++s5) {
             const bool live = (s5 < 4) || (lg < 2);  // dead lanes read a valid address (EXEC stays full), then zero
             const __bf16* slo = &dSt[(live ? oS2 : oS2d) + 32 * s5 * kSP];
             const __bf16* klo = &Ks[(live ? oK2 : oK2d) + 32 * s5 * kTP];
+            const __bf16* klx = &Ks[(live ? oK2x : oK2d) + 32 * s5 * kTP];
             v8bf sf = join(tr_read(slo), tr_read(slo + 4 * kSP));
             if (!live) sf = v8bf{0, 0, 0, 0, 0, 0, 0, 0};
-            dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(klo), tr_read(klo + 4 * kTP)), sf, dq0, 0, 0, 0);
-            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(klo + 16), tr_read(klo + 4 * kTP + 16)), sf, dq1, 0, 0, 0);
+            dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(klo), tr_read(klx + 4 * kTP)), sf, dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(tr_read(klx), tr_read(klo + 4 * kTP)), sf, dq1, 0, 0, 0);
         }
         if (tkk >= 0) {
             __bf16* base = dqkv + (img + tkk) * C3 + hoff + 4 * lg;

@@ -181,10 +181,27 @@ def test_register_staged_backward_variant_passes_the_same_tests():
     import os
     import subprocess
     import sys
-    if os.environ.get("GRIT_WINATTN_BWD_DMA") == "0":
-        pytest.skip("already the child run")
+    if os.environ.get("GRIT_WINATTN_BWD_DMA") == "0" or os.environ.get("GRIT_WINATTN_FWD_DMA") == "0":
+        pytest.skip("already a child run")
     env = dict(os.environ, GRIT_WINATTN_BWD_DMA="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
                         "backward or explicit_mask or properties"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_register_staged_forward_variant_passes_the_same_tests():
+    """The default forward is winattn_fwd_dma (Q / K / V tiles of the next window DMA'd into double-buffered LDS tiles, chunks permuted on
+    the source address); GRIT_WINATTN_FWD_DMA=0 selects the register-staged winattn_fwd (also the kernel of explicit-mask calls).  The
+    library reads the knob once per process, so the forward tests of this file are re-run in a child process with the knob set."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("GRIT_WINATTN_FWD_DMA") == "0" or os.environ.get("GRIT_WINATTN_BWD_DMA") == "0":
+        pytest.skip("already a child run")
+    env = dict(os.environ, GRIT_WINATTN_FWD_DMA="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "forward or explicit_mask or properties"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert " passed" in r.stdout

@@ -213,6 +213,9 @@ int grit_attn_bwd_bf16(const void* q, int64_t ldq, int64_t bsq, const void* k, i
  *   scale     q scaling (head_dim^-0.5);  C = num_heads*32;  0 <= shift < 12;  window must be 12.
  * Backward: dqkv bf16 like qkv (fully overwritten); drel_bias f32 like rel_bias and dpad f32 [3*C] are
  * ACCUMULATED with float atomics -- the caller zeroes them.
+ * Two kernels behind each entry point, same results: the DMA-staged ones (default; operands of the next window by global_load_lds into
+ * double-buffered LDS tiles, 160 KB of dynamic LDS for the backward) and the register-staged ones (environment
+ * GRIT_WINATTN_FWD_DMA=0 / GRIT_WINATTN_BWD_DMA=0, read once per process; a non-NULL mask always takes the register-staged forward).
  * ------------------------------------------------------------------------------------------------------ */
 int grit_winattn_fwd_bf16(const void* qkv, const float* rel_bias, const void* pad_qkv, const float* mask, int n_mask_windows,
                           int B, int H, int W, int C, int num_heads, int window, int shift, float scale,

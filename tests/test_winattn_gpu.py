@@ -205,3 +205,29 @@ def test_register_staged_forward_variant_passes_the_same_tests():
                         "forward or explicit_mask or properties"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert " passed" in r.stdout
+
+
+def test_dma_and_register_staged_kernels_agree_bit_for_bit_on_random_geometries():
+    """36 random geometries (B 1-3, maps 5-50 on a side, 1-16 heads, shift 0 / 6; bf16-representable bias, as the training step's is):
+    the DMA-staged forward / backward kernels (chunk permutations, token tables from the loader waves, one barrier per window) and the
+    register-staged ones give the same output and the same dqkv BIT FOR BIT, and the same sum |d(bias)|.  Two child processes: the
+    library reads the knobs once."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("GRIT_WINATTN_FWD_DMA") == "0" or os.environ.get("GRIT_WINATTN_BWD_DMA") == "0":
+        pytest.skip("a child run")
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "micro", "fuzz_winattn_variants.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = []
+    for knobs in ({}, {"GRIT_WINATTN_FWD_DMA": "0", "GRIT_WINATTN_BWD_DMA": "0"}):
+        r = subprocess.run([sys.executable, script], env=dict(os.environ, **knobs), cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append([l for l in r.stdout.split("\n") if " fwd " in l])
+    assert len(runs[0]) == len(runs[1]) == 36
+    for a, b in zip(runs[0], runs[1]):
+        fa, fb = a.split(" fwd ")[1].split()[0], b.split(" fwd ")[1].split()[0]
+        qa, qb = a.split(" dqkv ")[1].split()[0], b.split(" dqkv ")[1].split()[0]
+        assert fa == fb and qa == qb, (a, b)
+        da, db = float(a.split(" dbias ")[1].split()[0]), float(b.split(" dbias ")[1].split()[0])
+        assert abs(da - db) <= 1e-5 * abs(db) + 1e-9, (a, b)

@@ -32,6 +32,8 @@ _SHARED_VALUE_PROJ = os.environ.get('GRIT_SHARED_VALUE_PROJ', '1') != '0'  # A/B
 _STACKED_VALUE_MAPS = os.environ.get('GRIT_STACKED_VALUE_MAPS', '1') != '0'
 from grit_amd.utils.misc import inverse_sigmoid
 
+_QK_LINEAR = os.environ.get("GRIT_DET_QK_LINEAR", "1") != "0"  # A/B knob: 0 = F.linear for the self-attention in-projections
+
 
 class MLP(nn.Module):
     """Linear-ReLU stack; the last layer is linear."""
@@ -100,8 +102,11 @@ class DeformableTransformerDecoderLayer(nn.Module):
         # split (not slices): the backward of a split is one concatenation, a slice's is a zero fill + copy + add each
         w_qk, w_v = mha.in_proj_weight.split([2 * E, E])
         b_qk, b_v = mha.in_proj_bias.split([2 * E, E])
-        qk = F.linear(qk_in, w_qk, b_qk)  # one GEMM for q and k
-        v = F.linear(tgt, w_v, b_v)
+        # (ops.linear.linear, not F.linear: its backward sums the bias gradient with the column-sum kernel -- autograd's reduce kernel
+        # needs 23 us for a [4 800, 1 024] column sum, eleven of them per step)
+        lin = linear if _QK_LINEAR else F.linear
+        qk = lin(qk_in, w_qk, b_qk)  # one GEMM for q and k
+        v = lin(tgt, w_v, b_v)
         q, k = (t.view(B, Lq, h, E // h) for t in qk.split(E, -1))
         out = fused_attention(q, k, v.view(B, Lq, h, E // h), None, scale=1.0 / math.sqrt(E // h),
                               dropout_p=mha.dropout, training=self.training)

@@ -26,8 +26,8 @@ want = ("aten::copy_", "aten::add", "aten::add_", "aten::mul", "aten::sum", "ate
 rows = {}
 for e in prof.events():
     if e.name in want and e.device_time > 0:
-        stack = [s for s in (e.stack or []) if "grit_amd" in s or "bench" in s][:2]
-        key = (e.name, str(e.input_shapes)[:80], " <- ".join(s.split("/")[-1][:60] for s in stack))
+        stack = [s for s in (e.stack or []) if "grit_amd" in s or "bench" in s][:3]
+        key = (e.name, str(e.input_shapes)[:80], " <- ".join(s.split("/")[-1][:70] for s in stack))
         r = rows.setdefault(key, [0, 0.0])
         r[0] += 1; r[1] += e.device_time
 tot = sum(r[1] for r in rows.values())

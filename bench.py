@@ -449,10 +449,35 @@ def main():
     if args.points == "spread":
         msda_op.LOC_OVERRIDE = _SpreadOverride()
 
-    def step(i):
+    def eager_step(i):
         return train_xe_step(wrapped, batches[i % len(batches)], optimizers, loss_fn)
 
-    for i in range(args.warmup):
+    # The step as ONE HIP graph (grit_amd/engine/graph_step.py; default on one rank, GRIT_STEP_GRAPH=0 = eager launches): the first
+    # two warm-up steps run eagerly and a third pass is captured, every later step -- the rest of the warm-up and the whole timed
+    # region -- is a device-to-device copy of the batch into the graph's input buffers, the optimizers' per-step scalars and one
+    # hipGraphLaunch.  What is timed is the same work (forward, backward, gradient buckets, both Adam steps), enqueued differently.
+    from grit_amd.engine import graph_step
+    graphed, graph_error = None, None
+    want_graph = graph_step.ENABLED and not args.fp32 and args.warmup >= 1 and graph_step.supported(wrapped, optimizers)
+    eager_warmup = min(2, args.warmup) if want_graph else args.warmup
+    for i in range(eager_warmup):
+        loss = eager_step(i)
+    if want_graph:
+        try:
+            graphed = graph_step.GraphedXEStep(wrapped, optimizers, loss_fn, batches[eager_warmup % len(batches)], eager_steps=0)
+        except Exception as e:  # stay on the eager HIP path and say so in the line (config.step_graph_error)
+            graph_error = "%s: %s" % (type(e).__name__, str(e)[:300])
+            sys.stderr.write("bench.py: step graph not captured (%s); running eager launches\n" % graph_error)
+            torch.cuda.synchronize()
+            for o in (optimizers['model'], optimizers['backbone']):
+                o.device_hyper = False
+
+    def step(i):
+        if graphed is not None:
+            return graphed(batches[i % len(batches)])
+        return eager_step(i)
+
+    for i in range(eager_warmup, args.warmup):
         loss = step(i)
     torch.cuda.synchronize()
     if world > 1:
@@ -478,10 +503,24 @@ def main():
 
     # ---- after the timed region: analysis steps (every rank takes them: the gradient all-reduce is collective) -----------
     geom_events, gemm_events = [], []
+    event_steps = args.steps  # steps the per-launch events of the MSDA / window-attention kernels cover
+    if graphed is not None:
+        # a replayed graph runs no Python, so no per-launch HIP events were recorded inside the timed region: the same launches are
+        # timed in eager steps right behind it (the graph is dropped first; the optimizers go back to launch-argument scalars)
+        graphed.release()
+        torch.cuda.synchronize()
+        if not args.no_analysis:
+            msda_op.PROFILE_EVENTS, wa_op.PROFILE_EVENTS = [], []
+            event_steps = 3
+            for i in range(event_steps):
+                eager_step(args.warmup + args.steps + i)
+            torch.cuda.synchronize()
+            events, msda_op.PROFILE_EVENTS = msda_op.PROFILE_EVENTS, None
+            wa_events, wa_op.PROFILE_EVENTS = wa_op.PROFILE_EVENTS, None
     if not args.no_analysis:
         msda_op.PROFILE_EVENTS, msda_op.PROFILE_RECORD_GEOMETRY, profiling.EVENTS = geom_events, True, gemm_events
         for i in range(2):
-            step(args.warmup + args.steps + i)
+            eager_step(args.warmup + args.steps + 3 + i)
         torch.cuda.synchronize()
         msda_op.PROFILE_EVENTS, msda_op.PROFILE_RECORD_GEOMETRY, profiling.EVENTS = None, False, None
 
@@ -573,13 +612,13 @@ def main():
                 nbytes = units * tensors * 144 * 32 * 2
                 wa_traffic, wa_src = pmc_traffic(name) if (not args.fp32 and args.batch == 32 and args.size == 640
                                                            and not args.ragged) else (None, None)
-                window_attention[name] = {"bound": "hbm", "kernel": name, "launches_per_step": len(ev) / args.steps,
+                window_attention[name] = {"bound": "hbm", "kernel": name, "launches_per_step": len(ev) / event_steps,
                                           "traffic": wa_traffic, "traffic_source": wa_src,
                                           "traffic_note": "PMC bytes per launch, mean over the launches of a step (stages differ)",
                                           "algorithmic_bytes_per_launch": int(nbytes / len(ev)),
                                           "traffic_frac": (wa_traffic / (tt / len(ev)) / 1e9 / HBM_PEAK_GBPS) if wa_traffic else None,
-                                          "ms_per_step": tt / args.steps * 1e3, "avg_launch_us": tt / len(ev) * 1e6,
-                                          "algorithmic_bytes_per_step": int(nbytes / args.steps),
+                                          "ms_per_step": tt / event_steps * 1e3, "avg_launch_us": tt / len(ev) * 1e6,
+                                          "algorithmic_bytes_per_step": int(nbytes / event_steps),
                                           "algorithmic_bytes_basis": "%d bf16 [144, 32] slices per (window, head)" % tensors,
                                           "achieved": nbytes / tt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                           "frac": nbytes / tt / 1e9 / HBM_PEAK_GBPS,
@@ -636,6 +675,10 @@ def main():
                                           backend + " SELF-collectives of a one-rank group (" + grad_sync + "): the sync path "
                                           "without a wire, not a multi-GPU number"),
                        "grad_sync": grad_sync if (world > 1 or self_coll) else None, "self_collectives": bool(self_coll),
+                       "step_graph": graphed is not None, "step_graph_error": graph_error,
+                       "step_enqueue": ("one captured HIP graph replayed per step (grit_amd/engine/graph_step.py); per-launch kernel "
+                                        "events come from %d eager steps behind the timed region" % event_steps) if graphed is not None
+                       else "eager launches",
                        "rccl_env": rccl_env,
                        "points": args.points, "ragged": bool(args.ragged),
                        "msda_backward_accumulation": ("f32" if args.fp32 else ("f32 (" + msda_op.F32_METHOD + ")") if msda_op.F32_ACCUMULATE

@@ -62,6 +62,12 @@ class FlatAdam(torch.optim.Optimizer):
         slice when the optimizer is sharded."""
         self._runs = self._owner._runs(self._mine, key=self._steps.get)
         self._layout_version = self._owner.ddp.layout_version
+        self._hyper_host = None  # the device table of per-step scalars has one row per run
+        # parameters of this optimizer outside every run (outside the live set) that share their age -- and therefore their
+        # state['step'] tensor -- with a parameter that WILL be stepped: the next step must give the two groups tensors of their own
+        stepped = {id(p) for _, params, _ in self._runs for p in params}
+        ages = {self._steps[p] for _, params, _ in self._runs for p in params}
+        self._split_ages = any(id(p) not in stepped and self._steps[p] in ages for p in self._mine)
         self._link_state()
 
     def _link_state(self):
@@ -89,10 +95,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._step_tensors = {}
         self._derive_runs()
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        from grit_amd import lib as _lib
-        from grit_amd.ops import backend
+    def _hyper(self):
         hyper = {(g['lr'], tuple(g['betas']), g['eps'], g['weight_decay'], g['amsgrad'], g['maximize']) for g in self.param_groups}
         if len(hyper) != 1:
             raise NotImplementedError("FlatAdam: the parameter groups of one optimizer must share lr / betas / eps "
@@ -100,16 +103,47 @@ class FlatAdam(torch.optim.Optimizer):
         lr, (b1, b2), eps, wd, amsgrad, maximize = next(iter(hyper))
         if wd != 0 or amsgrad or maximize:
             raise NotImplementedError("FlatAdam implements Adam with weight_decay = 0, amsgrad = False, maximize = False")
+        return float(lr), float(b1), float(b2), float(eps)
+
+    # ---- per-step scalars in device memory (device_hyper = True): what a step captured in a HIP graph reads ---------------
+    device_hyper = False
+
+    def prepare_replay(self):
+        """Write {lr / bias_correction1, 1 / sqrt(bias_correction2)} of the step every run is ABOUT to take into the device table
+        the launches read (pinned host copy -> one asynchronous H2D copy on the current stream).  grit_amd.engine.graph_step calls
+        this before every replay of a captured step; step() calls it itself when it is not being captured."""
+        lr, b1, b2, _ = self._hyper()
+        n = max(1, len(self._runs))
+        if getattr(self, '_hyper_host', None) is None or self._hyper_host.shape[0] < n:
+            dev = self._runs[0][0][2].device if self._runs else torch.device('cpu')
+            self._hyper_host = torch.zeros((n, 2), dtype=torch.float32).pin_memory() if dev.type == 'cuda' else torch.zeros((n, 2))
+            self._hyper_dev = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+        for i, (_, _, age) in enumerate(self._runs):
+            t = age + 1
+            self._hyper_host[i, 0] = lr / (1.0 - b1 ** t)
+            self._hyper_host[i, 1] = 1.0 / math.sqrt(1.0 - b2 ** t)
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from grit_amd import lib as _lib
+        from grit_amd.ops import backend
+        lr, b1, b2, eps = self._hyper()
         if self._layout_version != self._owner.ddp.layout_version:  # the live parameter set changed: parameters without a
             self._derive_runs()                                       # gradient are not stepped (torch.optim.Adam skips them)
         grad_scale = 1.0 / self._owner.ddp.world  # the buckets hold the SUM over ranks: the average is folded in here
         ov = backend.override()
         kernel = getattr(ov, 'adam_flat', None) if ov is not None else None  # tests on CPU inject the torch restatement
         lib = _lib.load() if kernel is None else None
-        ages = set()
-        for (bucket, compute, master, mom, var, start, end), params, age in self._runs:
+        from_device = self.device_hyper and kernel is None
+        capturing = from_device and torch.cuda.is_current_stream_capturing()
+        if from_device and (not capturing or getattr(self, '_hyper_host', None) is None):
+            if capturing:
+                raise RuntimeError("FlatAdam: call prepare_replay() once before capturing a step (the device table of the per-step "
+                                   "scalars must exist before the capture begins)")
+            self.prepare_replay()
+        for i, ((bucket, compute, master, mom, var, start, end), params, age) in enumerate(self._runs):
             t = age + 1
-            ages.add(age)
             bc1, bc2s = 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)
             n = end - start
             if n <= 0:
@@ -119,30 +153,49 @@ class FlatAdam(torch.optim.Optimizer):
                        float(b1), float(b2), float(eps), bc1, bc2s, grad_scale)
                 continue
             with _lib.device_guard(master.device):
-                st = lib.grit_adam_flat(
-                    ctypes.c_void_p(master[start:].data_ptr()), ctypes.c_void_p(bucket.flat[start:].data_ptr()),
-                    int(bucket.flat.dtype == torch.bfloat16), ctypes.c_void_p(mom[start:].data_ptr()),
-                    ctypes.c_void_p(var[start:].data_ptr()), ctypes.c_void_p(compute[start:].data_ptr()), n, float(lr),
-                    float(b1), float(b2), float(eps), bc1, bc2s, grad_scale, _lib.current_stream_ptr())
+                if from_device:
+                    st = lib.grit_adam_flat_dev(
+                        ctypes.c_void_p(master[start:].data_ptr()), ctypes.c_void_p(bucket.flat[start:].data_ptr()),
+                        int(bucket.flat.dtype == torch.bfloat16), ctypes.c_void_p(mom[start:].data_ptr()),
+                        ctypes.c_void_p(var[start:].data_ptr()), ctypes.c_void_p(compute[start:].data_ptr()), n,
+                        float(b1), float(b2), float(eps), grad_scale, ctypes.c_void_p(self._hyper_dev[i].data_ptr()),
+                        _lib.current_stream_ptr())
+                else:
+                    st = lib.grit_adam_flat(
+                        ctypes.c_void_p(master[start:].data_ptr()), ctypes.c_void_p(bucket.flat[start:].data_ptr()),
+                        int(bucket.flat.dtype == torch.bfloat16), ctypes.c_void_p(mom[start:].data_ptr()),
+                        ctypes.c_void_p(var[start:].data_ptr()), ctypes.c_void_p(compute[start:].data_ptr()), n, float(lr),
+                        float(b1), float(b2), float(eps), bc1, bc2s, grad_scale, _lib.current_stream_ptr())
             _lib.check(st, "grit_adam_flat")
-        # every stepped parameter is one step older; the runs stay valid because the ages of a run move together
+        if not capturing:  # a capture records the launches only; the replaying caller advances the books once per replay
+            self.advance()
+        return None
+
+    def advance(self):
+        """Host-side books of one optimizer step: every stepped parameter is one step older (the runs stay valid because the ages
+        of a run move together), state['step'] follows, derived-weight caches are invalidated."""
+        ages = {age for _, _, age in self._runs}
         for i, (run, params, age) in enumerate(self._runs):
             for p in params:
                 self._steps[p] = age + 1
             self._runs[i] = (run, params, age + 1)
-        tensors = {}
-        for age in ages:  # state['step'] tensors move with their parameters
-            tnsr = self._step_tensors.pop(age, None)
-            if tnsr is not None:
-                tnsr.fill_(float(age + 1))
-                tensors[age + 1] = tnsr
-        merged = any(a in self._step_tensors for a in tensors)
-        self._step_tensors.update(tensors)
-        if merged:
+        if self._split_ages:  # unstepped parameters keep their age: fresh step tensors per age for everybody, once
+            self._split_ages = False
+            self._step_tensors = {}
             self._link_state()
+        else:
+            tensors = {}
+            for age in ages:  # state['step'] tensors move with their parameters
+                tnsr = self._step_tensors.pop(age, None)
+                if tnsr is not None:
+                    tnsr.fill_(float(age + 1))
+                    tensors[age + 1] = tnsr
+            merged = any(a in self._step_tensors for a in tensors)
+            self._step_tensors.update(tensors)
+            if merged:
+                self._link_state()
         self._owner._masters_current = False
         weights_epoch.bump()  # the compute weights were rewritten by a raw kernel: no version counter saw it
-        return None
 
 
 class Bf16Compute(nn.Module):

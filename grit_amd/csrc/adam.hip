@@ -35,7 +35,13 @@ template <typename GT, bool NT>
 __global__ __launch_bounds__(256)
 void adam_flat(float* __restrict__ p, const GT* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
                __hip_bfloat16* __restrict__ compute, long n4, float step_size, float beta1, float beta2, float eps,
-               float inv_bc2_sqrt, float grad_scale) {
+               float inv_bc2_sqrt, float grad_scale, const float* __restrict__ hyper) {
+    // hyper != NULL: the two per-step scalars come from device memory {lr / bias_correction1, 1 / sqrt(bias_correction2)} -- a
+    // launch captured in a HIP graph is replayed with the learning rate and the step count of the step it is replayed for
+    if (hyper) {
+        step_size = hyper[0];
+        inv_bc2_sqrt = hyper[1];
+    }
     // masters and moments are touched once per step: nontemporal loads / stores (they need not displace the weights the next
     // forward is about to read); two quads per thread and trip: eight 16-byte loads in flight
     const long stride = (long)gridDim.x * 256;
@@ -90,10 +96,33 @@ void adam_flat(float* __restrict__ p, const GT* __restrict__ grad, float* __rest
 
 }  // namespace
 
+namespace {
+int adam_launch(float* param, const void* grad, int grad_is_bf16, float* exp_avg, float* exp_avg_sq, void* compute_bf16, long n,
+                float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt, float grad_scale,
+                const float* hyper, void* stream);
+}
+
 extern "C" int grit_adam_flat(float* param, const void* grad, int grad_is_bf16, float* exp_avg, float* exp_avg_sq,
                               void* compute_bf16, long n, float lr, float beta1, float beta2, float eps, float bias_correction1,
                               float bias_correction2_sqrt, float grad_scale, void* stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || bias_correction1 <= 0.f || bias_correction2_sqrt <= 0.f)
+    if (bias_correction1 <= 0.f || bias_correction2_sqrt <= 0.f) return GRIT_ERR_BAD_ARG;
+    return adam_launch(param, grad, grad_is_bf16, exp_avg, exp_avg_sq, compute_bf16, n, lr, beta1, beta2, eps, bias_correction1,
+                       bias_correction2_sqrt, grad_scale, nullptr, stream);
+}
+
+extern "C" int grit_adam_flat_dev(float* param, const void* grad, int grad_is_bf16, float* exp_avg, float* exp_avg_sq,
+                                  void* compute_bf16, long n, float beta1, float beta2, float eps, float grad_scale,
+                                  const float* hyper, void* stream) {
+    if (!hyper || ((uintptr_t)hyper % 8)) return GRIT_ERR_BAD_ARG;
+    return adam_launch(param, grad, grad_is_bf16, exp_avg, exp_avg_sq, compute_bf16, n, 0.f, beta1, beta2, eps, 1.f, 1.f, grad_scale,
+                       hyper, stream);
+}
+
+namespace {
+int adam_launch(float* param, const void* grad, int grad_is_bf16, float* exp_avg, float* exp_avg_sq, void* compute_bf16, long n,
+                float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt, float grad_scale,
+                const float* hyper, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0)
         return GRIT_ERR_BAD_ARG;
     const uintptr_t align = (uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq;
     if (n % 4 != 0 || (align % 16) != 0 || ((uintptr_t)grad % (grad_is_bf16 ? 8 : 16)) != 0 ||
@@ -107,7 +136,7 @@ extern "C" int grit_adam_flat(float* param, const void* grad, int grad_is_bf16, 
     static const bool nt = !(getenv("GRIT_ADAM_NT") && atoi(getenv("GRIT_ADAM_NT")) == 0);
 #define GRIT_ADAM_LAUNCH(GT_, NT_, GPTR_)                                                                                          \
     hipLaunchKernelGGL((adam_flat<GT_, NT_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, GPTR_, exp_avg,    \
-                       exp_avg_sq, (__hip_bfloat16*)compute_bf16, n4, step_size, beta1, beta2, eps, inv_bc2_sqrt, grad_scale)
+                       exp_avg_sq, (__hip_bfloat16*)compute_bf16, n4, step_size, beta1, beta2, eps, inv_bc2_sqrt, grad_scale, hyper)
     if (grad_is_bf16) {
         if (nt) GRIT_ADAM_LAUNCH(__hip_bfloat16, true, (const __hip_bfloat16*)grad);
         else GRIT_ADAM_LAUNCH(__hip_bfloat16, false, (const __hip_bfloat16*)grad);
@@ -118,3 +147,4 @@ extern "C" int grit_adam_flat(float* param, const void* grad, int grad_is_bf16, 
 #undef GRIT_ADAM_LAUNCH
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
+}  // namespace

@@ -163,6 +163,15 @@ class BucketedDataParallel(nn.Module):
     def _refresh_expected(self):
         for b in self.buckets:
             b.expected = b.pending = sum(1 for p in b.params if p not in self._dead)
+        self._open_slots()
+
+    def _open_slots(self):
+        """Which parameters may have their gradient written straight into the bucket slot in the coming backward pass
+        (ops/linear.py grad_slot): those of the live set.  _pack closes the slots of its bucket, grad_slot closes a slot it hands
+        out -- a gradient that arrives outside the bucket reductions must live in a tensor of its own (the late path)."""
+        dead = self._dead
+        for p in self._params:
+            p._grit_slot_open = p not in dead
 
     # ------------------------------------------------------------------ backward-time hooks
     def _on_grad(self, param):
@@ -196,6 +205,7 @@ class BucketedDataParallel(nn.Module):
         if stale:
             torch._foreach_zero_(stale)
         for p, view in zip(b.params, b.views):
+            p._grit_slot_open = False
             if p.grad is not None:
                 p.grad = view
         b.packed = True
@@ -308,7 +318,12 @@ class BucketedDataParallel(nn.Module):
         self.release_gradients()
         # from here to finish_gradient_sync() this wrapper is the only consumer of parameter gradients: nodes may leave the
         # weight gradients of small maps running on a side stream until _pack / finish_gradient_sync wait for it
-        _linear_ops.begin_deferral()
+        # (only a forward pass that records a graph opens the scope: after a no-grad / evaluation forward through the wrapper
+        # nobody would call finish_gradient_sync, and a later backward elsewhere would queue jobs that are never flushed)
+        if torch.is_grad_enabled():
+            _linear_ops.begin_deferral(owner=self)
+        else:
+            _linear_ops.close_deferral(owner=self)
         return self.module(*args, **kwargs)
 
     def release_gradients(self):
@@ -321,6 +336,7 @@ class BucketedDataParallel(nn.Module):
         for b in self.buckets:
             b.packed = False
             b.pending = b.expected
+        self._open_slots()
 
     def gradient_bytes(self):
         return sum(b.flat.numel() * b.flat.element_size() for b in self.buckets)

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -51,6 +51,7 @@ SIGNATURES = {
     "grit_groupnorm_tokens_fwd": [_ptr, _c.c_long, _ptr, _ptr, _int, _int, _int, _int, _f32, _int, _int, _ptr, _c.c_long] + [_ptr] * 4,
     "grit_groupnorm_tokens_bwd": [_ptr, _c.c_long, _ptr, _c.c_long, _ptr, _ptr, _ptr, _int, _int, _int, _int, _int, _int] + [_ptr] * 5,
     "grit_adam_flat": [_ptr, _ptr, _int, _ptr, _ptr, _ptr, _c.c_long] + [_f32] * 7 + [_ptr],
+    "grit_adam_flat_dev": [_ptr, _ptr, _int, _ptr, _ptr, _ptr, _c.c_long] + [_f32] * 4 + [_ptr, _ptr],
     "grit_resample_taps_bicubic": [_int, _int, _ptr, _ptr, _c.c_long],
     "grit_image_batch_fwd": [_ptr] * 5 + [_int] * 6 + [_ptr] * 3,
     "grit_colsum": [_ptr, _int, _int, _int, _int, _ptr, _ptr],

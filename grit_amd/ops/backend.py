@@ -39,6 +39,8 @@ class _SeedPool(object):
     def take(self, device):
         import torch
         if self.buf is None or self.used >= self.block or self.buf.device != device:
+            if train_capture() and torch.cuda.is_current_stream_capturing() and self.buf is not None:
+                raise RuntimeError("dropout seed pool: a captured training step drew more than %d seeds" % self.block)
             with torch.inference_mode(False):
                 self.buf = torch.empty(self.block, dtype=torch.int64, device=device).random_()
             self.used = 0
@@ -46,8 +48,43 @@ class _SeedPool(object):
         self.used += 1
         return seed
 
+    def begin_captured_step(self, device):
+        """First thing inside the capture of a training step: a block of seeds that the graph itself refills (torch's generator
+        is graph-safe: every replay advances its Philox offset), so each replay of the step drops different elements."""
+        import torch
+        self.buf = torch.empty(self.block, dtype=torch.int64, device=device).random_()
+        self.used = 0
+
+    def end_captured_step(self):
+        self.buf = None  # the next eager draw starts a block of its own: the captured one belongs to the graph
+
 
 _seeds = _SeedPool()
+_train_capture = False
+
+
+def train_capture():
+    """True while grit_amd.engine.graph_step captures a whole training step.  The ops that step aside under a capture they do not
+    know (a beam-search graph replays with frozen weights; deferred weight gradients keep raw addresses) take part in this one: the
+    graph owns every tensor of the step, and the weight-derived copies are rebuilt inside it on every replay."""
+    return _train_capture
+
+
+def foreign_capture():
+    """The current stream is being captured by somebody other than the training-step graph."""
+    import torch
+    return torch.cuda.is_current_stream_capturing() and not _train_capture
+
+
+@contextmanager
+def capturing_train_step(device):
+    global _train_capture
+    prev, _train_capture = _train_capture, True
+    try:
+        yield _seeds
+    finally:
+        _train_capture = prev
+        _seeds.end_captured_step()
 
 
 def dropout_seed(device):

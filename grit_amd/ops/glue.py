@@ -29,7 +29,7 @@ def _ptr(t):
 
 def _on_device(*ts):
     return (ENABLED and backend.override() is None and all(t.is_cuda for t in ts) and not torch.is_autocast_enabled()
-            and not torch.cuda.is_current_stream_capturing())
+            and not backend.foreign_capture())
 
 
 # ----------------------------------------------------------------------------------------------------------------------

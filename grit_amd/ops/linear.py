@@ -110,7 +110,7 @@ def defer_weight_bias_grad(dy2, x2, weight, bias, need_dw, need_db, single_use):
     if not (WGRAD_DEFER and single_use and need_dw and _deferral["active"] and dy2.is_cuda and dy2.dtype == torch.bfloat16
             and x2.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.grad is None
             and (not need_db or (bias is not None and bias.grad is None and bias.dtype == torch.bfloat16))
-            and not torch.cuda.is_current_stream_capturing()):
+            and not backend.foreign_capture()):
         return None
     M, N = dy2.shape
     K = x2.shape[1]
@@ -139,7 +139,7 @@ def defer_slab_group(group, checks):
     """Leave the pending reductions of `group` (a SlabGroup whose outputs are parameter gradients of a single-use node: LayerNorm
     dgamma / dbeta, a projection's bias gradient) to flush_deferred() instead of launching them now.  checks: [(parameter, device
     address its gradient must have at flush time)].  False (nothing deferred) when the deferral does not apply."""
-    if not (WGRAD_DEFER and _deferral["active"] and group.jobs and not torch.cuda.is_current_stream_capturing()
+    if not (WGRAD_DEFER and _deferral["active"] and group.jobs and not backend.foreign_capture()
             and all(p is not None and p.grad is None for p, _ in checks)):
         return False
     _deferral["slabs"].append((group.jobs, group.keep, checks))
@@ -239,7 +239,7 @@ def flush_deferred(final=False):
                     fill = wgs / (-(-wgs // 256) * 256.0)
                     if fill > best_fill + 0.02:
                         best, best_fill = cand, fill
-                splits = [max(1, min(best, (j[6] // 32) // 16)) for j in chunk]
+                splits = [tn_slices(j[6], max(1, min(best, (j[6] // 32) // 16))) for j in chunk]
                 slabs = splits if WGRAD_TN_BIAS else [max(1, min(256, j[6] // 64)) for j in chunk]  # bias: by-product per slice
             else:
                 splits = [lib.grit_wgrad_group_splits(j[6]) for j in chunk]
@@ -279,10 +279,20 @@ def flush_deferred(final=False):
             group.run()  # keeps `work` (and through `chunk` the operands) alive until the launches are enqueued
 
 
-def begin_deferral():
-    if not _deferral["active"]:  # leftovers of a pass that ended with an exception
+def begin_deferral(owner=None):
+    """owner: the gradient-bucket wrapper that will call end_deferral() (finish_gradient_sync).  A scope left open by ANOTHER
+    wrapper -- its pass ended with an exception, or its backward never ran -- is abandoned, not inherited."""
+    if not _deferral["active"] or _deferral.get("owner") is not owner:
         abandon_deferred()
     _deferral["active"] = True
+    _deferral["owner"] = owner
+
+
+def close_deferral(owner=None):
+    """A forward pass of `owner` that records no graph: whatever scope it had open is over (nothing will flush it)."""
+    if _deferral["active"] and _deferral.get("owner") is owner:
+        abandon_deferred()
+        _deferral["active"] = False
 
 
 def abandon_deferred():
@@ -313,7 +323,7 @@ def fork(*inputs, rows=None, single_use=False):
     if not (inputs and inputs[0].is_cuda):
         return None
     small = (WGRAD_STREAM_SMALL and single_use and rows is not None and rows < SMALL_ROWS and _deferral["active"]
-             and not torch.cuda.is_current_stream_capturing())
+             and not backend.foreign_capture())
     if not (WGRAD_STREAM or small):
         return None
     dev = inputs[0].device
@@ -365,11 +375,16 @@ def grad_slot(param, dtype, device):
     node to write the gradient into -- autograd adopts the view as .grad, the bucket pack finds it in place and skips its copy
     (~400 MB of read + write per step for the Swin weight gradients).  None when it does not apply."""
     slot = getattr(param, "_grit_grad_slot", None) if (GRAD_IN_PLACE and param is not None and _deferral["active"]) else None
-    if slot is None or param.grad is not None:
+    # _grit_slot_open is the bucket wrapper's word (grit_amd/ddp.py): the parameter is in the live set, its bucket has not been
+    # packed yet in this backward pass, and nobody has been handed the slot before -- a second node of a weight used twice gets
+    # None (a fresh tensor: autograd sums the two), a parameter outside the live set or behind a sent bucket goes the late path
+    # with a tensor of its own (the late path all-reduces what .grad holds; a view of the slot there reads as "already reduced")
+    if slot is None or param.grad is not None or not getattr(param, "_grit_slot_open", False):
         return None
     flat, off, n, shape = slot
     if flat.dtype != dtype or flat.device != device or (flat.data_ptr() + off * flat.element_size()) % 16:
         return None
+    param._grit_slot_open = False
     return flat[off:off + n].view(shape)
 
 
@@ -556,6 +571,16 @@ def long_weight_grad_partials(dy2, x2, need_db=False):
 WGRAD_TN_PAIR = os.environ.get("GRIT_WGRAD_TN_PAIR", "1") != "0"  # the two weight gradients of a Swin Mlp as one grouped launch
 
 
+def tn_slices(M, want):
+    """Row slices the long-map kernel accepts for an M-row problem when `want` are asked for: every slice a whole number of
+    32-row steps and none of them empty (wgrad_tn.hip tn_fill rejects anything else: 58 368 rows = 1 824 steps cut 64 ways are
+    29-step slices, i.e. 63 of them).  Same normalisation as grit_wgrad_tn_splits."""
+    steps = max(1, M // 32)
+    want = max(1, min(int(want), steps))
+    per = -(-steps // want)
+    return -(-steps // per)
+
+
 def long_weight_grad_with_parked(dy2, x2, group, weight):
     """(partials [S, N, K], bias column sums [S, N]) of this node's long-map Linear like long_weight_grad_partials(.., True), from a
     grouped launch that also computes the parked weight gradients (park_weight_grad_for_partner); their slice sums join `group`.
@@ -574,17 +599,19 @@ def long_weight_grad_with_parked(dy2, x2, group, weight):
     tiles = (N // 256) * (K // 256) + sum((j[7] // 256) * (j[8] // 256) for j in parked)
     if tiles > 256:
         return None
-    S = min([max(1, 256 // tiles), (M // 32) // 16 or 1] + [(j[6] // 32) // 16 or 1 for j in parked])
-    _deferral["parked"] = []
+    want = min([max(1, 256 // tiles), (M // 32) // 16 or 1] + [(j[6] // 32) // 16 or 1 for j in parked])
+    S = tn_slices(M, want)  # per problem: the slice count the kernel's contract admits for ITS row count
+    _deferral["parked"] = []  # (from here on nothing may fail softly: the parked jobs are this launch's)
     part = torch.empty((S, N, K), dtype=torch.float32, device=dy2.device)
     bpart = torch.empty((S, N), dtype=torch.float32, device=dy2.device)
     table = (_lib.WgradJob * (len(parked) + 1))()
     table[0] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, part.data_ptr(), bpart.data_ptr())
     flops = 2.0 * M * N * K
     for t, (pdy, px, pw_param, _, pw, _, pM, pN, pK) in enumerate(parked):
-        work = torch.empty(S * pN * pK, dtype=torch.float32, device=dy2.device)
-        table[t + 1] = _lib.WgradJob(pdy.data_ptr(), pdy.stride(0), px.data_ptr(), px.stride(0), pM, pN, pK, S, work.data_ptr(), None)
-        group.add_raw(work, 1, 0, S, pN * pK, pw, True)
+        pS = tn_slices(pM, want)
+        work = torch.empty(pS * pN * pK, dtype=torch.float32, device=dy2.device)
+        table[t + 1] = _lib.WgradJob(pdy.data_ptr(), pdy.stride(0), px.data_ptr(), px.stride(0), pM, pN, pK, pS, work.data_ptr(), None)
+        group.add_raw(work, 1, 0, pS, pN * pK, pw, True)
         _deferral["unverified"].append((pw_param, pw, "parked weight gradient [%d, %d]" % (pN, pK)))
         flops += 2.0 * pM * pN * pK
     with _lib.device_guard(dy2.device), timed("gemm_own", flops=flops, kernel="wgrad_tn"):
@@ -611,13 +638,14 @@ def long_weight_grads_together(pairs):
         tiles += (N // 256) * (K // 256)
     if tiles > 256:
         return None
-    S = max(1, 256 // tiles)
-    S = min([S] + [(dy2.shape[0] // 32) // 16 or 1 for dy2, _ in pairs])
+    want = max(1, 256 // tiles)
+    want = min([want] + [(dy2.shape[0] // 32) // 16 or 1 for dy2, _ in pairs])
     table = (_lib.WgradJob * len(pairs))()
     parts = []
     for t, (dy2, x2) in enumerate(pairs):
         M, N = dy2.shape
         K = x2.shape[1]
+        S = tn_slices(M, want)
         part = torch.empty((S, N, K), dtype=torch.float32, device=dy2.device)
         parts.append(part)
         table[t] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, part.data_ptr(), None)

@@ -14,7 +14,7 @@ import os
 import torch
 
 from grit_amd import lib as _lib
-from grit_amd.ops import weights_epoch
+from grit_amd.ops import backend, weights_epoch
 
 ENABLED = os.environ.get("GRIT_TRANSPOSED_WEIGHTS", "1") != "0"  # A/B knob: 0 = every backward node transposes its own weight
 
@@ -33,9 +33,11 @@ def refresh(weights):
                 and w.shape[1] % 64 == 0 and w.data_ptr() % 16 == 0):
             continue
         hit = getattr(w, "_grit_transposed", None)
-        if hit is None or hit[0] != _tag(w):
+        # inside the capture of a whole training step the copies are part of the graph: every replay transposes the weights as the
+        # optimizer step of the previous replay left them, whatever the host-side tags say
+        if hit is None or hit[0] != _tag(w) or backend.train_capture():
             stale.append(w)
-    if not stale or torch.cuda.is_current_stream_capturing():
+    if not stale or backend.foreign_capture():
         return
     lib = _lib.load()
     with torch.no_grad():

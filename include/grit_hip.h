@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 31
+#define GRIT_ABI_VERSION 32
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -416,6 +416,11 @@ int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, int M, int 
 int grit_adam_flat(float* param, const void* grad, int grad_is_bf16, float* exp_avg, float* exp_avg_sq, void* compute_bf16,
                    long n, float lr, float beta1, float beta2, float eps, float bias_correction1,
                    float bias_correction2_sqrt, float grad_scale, void* stream);
+/* The same step with its two per-step scalars read from DEVICE memory at run time: hyper[0] = lr / bias_correction1,
+ * hyper[1] = 1 / bias_correction2_sqrt (8-byte aligned).  For a training step captured in a HIP graph (grit_amd/engine/graph_step.py):
+ * the host rewrites hyper before every replay, so the learning-rate schedule and the step count advance without a re-capture. */
+int grit_adam_flat_dev(float* param, const void* grad, int grad_is_bf16, float* exp_avg, float* exp_avg_sq, void* compute_bf16,
+                       long n, float beta1, float beta2, float eps, float grad_scale, const float* hyper, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Decoded RGB images -> the model's input batch: bicubic resize with Pillow's 8-bit arithmetic

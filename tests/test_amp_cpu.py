@@ -90,3 +90,38 @@ def test_parameters_leave_and_rejoin_the_live_set():
     assert wrapped.unused_parameters == []
     assert not torch.equal(masters["det.weight"], det_after_first_cached)  # stepped again, in the very step it came back
     assert not torch.equal(masters["head.weight"], head_before)
+
+
+def test_flat_adam_step_counts_survive_freeze_save_load_unfreeze():
+    """parameters of one optimizer share a state['step'] tensor per age.  `det` sits out two steps (cached features):
+    its state['step'] must stay 1 in the state dict while `head` advances, and after load_state_dict + rejoining it continues with
+    the bias corrections of ITS age (torch.optim.Adam's per-parameter step counts)."""
+    from grit_amd.amp import Bf16Compute
+    from tests.helpers import oracle_ops
+    torch.manual_seed(0)
+    model = Net()
+    wrapped = Bf16Compute(model, bucket_mb=0.0002, flat_optimizer=True)
+    masters = dict(wrapped.named_master_parameters())
+    opt = wrapped.flat_adam(list(masters.values()), lr=1e-2)
+    x, y = torch.randn(4, 8).bfloat16(), torch.randn(4, 4)
+    with oracle_ops():
+        _step(wrapped, opt, x, y)            # everybody: age 1
+        model.cached = True
+        _step(wrapped, opt, x, y)            # det outside the live set from the end of this step on
+        _step(wrapped, opt, x, y)
+        _step(wrapped, opt, x, y)
+        ages = {n: int(float(opt.state[m]['step'])) for n, m in masters.items()}
+        assert ages["head.weight"] == 4 and ages["head.bias"] == 4, ages
+        assert ages["det.weight"] == ages["det.bias"] and ages["det.weight"] < 4, ages
+        det_age = ages["det.weight"]
+        sd = opt.state_dict()
+        steps_saved = sorted({int(float(s['step'])) for s in sd['state'].values()})
+        assert steps_saved == sorted({det_age, 4}), steps_saved
+        opt2 = wrapped.flat_adam(list(masters.values()), lr=1e-2)
+        opt2.load_state_dict(sd)
+        assert {n: opt2._steps[m] for n, m in masters.items()} == ages
+        model.cached = False
+        _step(wrapped, opt2, x, y)
+        _step(wrapped, opt2, x, y)  # (the step in which det's gradient arrives late does not step it: it rejoins the runs after it)
+        after = {n: int(float(opt2.state[m]['step'])) for n, m in masters.items()}
+        assert after["head.weight"] == 6 and det_age < after["det.weight"] <= det_age + 2, after

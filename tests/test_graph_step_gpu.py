@@ -1,0 +1,131 @@
+"""The training step replayed from ONE captured HIP graph (grit_amd/engine/graph_step.py) against the same steps launched eagerly
+(engine/caption_engine.py train_xe_step, reference :312-350): same losses and masters, learning rate and Adam step count read at
+replay time, fresh dropout masks on every replay."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import build_model, disable_drop_path, load, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _setup(dropout=0.0):
+    from grit_amd.amp import Bf16Compute
+    from grit_amd.engine.caption_engine import build_optimizers
+    model, cfg = build_model(3, **{'model.dropout': dropout, 'model.detector.dropout': dropout})
+    model.train().to(DEV)
+    if dropout == 0.0:
+        disable_drop_path(model)
+    wrapped = Bf16Compute(model)
+    return wrapped, build_optimizers(wrapped, cfg, mode='xe'), torch.nn.NLLLoss(ignore_index=1)
+
+
+def _batches():
+    from grit_amd.utils.misc import NestedTensor
+    g = load("step_g8.npz")
+    images, mask, caps = t(g["images"], device=DEV), t(g["mask"], device=DEV), t(g["caps"], device=DEV)
+    a = {'samples': NestedTensor(images, mask), 'captions': caps}
+    b = {'samples': NestedTensor(images.flip(0).contiguous(), mask.flip(0).contiguous()), 'captions': caps.flip(0).contiguous()}
+    return a, b
+
+
+def _masters(wrapped, picks):
+    named = dict(wrapped.named_master_parameters())
+    return {n: named[n].detach().float().clone() for n in picks}
+
+
+PICKS = ('cap_generator.fc.weight', 'grid_net.fc.weight', 'detector.backbone.layers.2.blocks.5.mlp.fc1.weight',
+         'detector.backbone.layers.3.blocks.1.attn.qkv.weight', 'detector.det_module.decoder_layers.2.linear1.weight',
+         'detector.input_proj.1.0.weight')
+
+
+def test_replayed_steps_equal_eager_steps():
+    """5 steps on alternating batches: eager, and 1 eager + 4 replays of the captured step.  Dropout / drop-path off, so the two
+    runs differ only by the summation order inside the kernels that use LDS counters or atomics (MSDeformAttn backward)."""
+    from grit_amd.engine.caption_engine import train_xe_step
+    from grit_amd.engine.graph_step import GraphedXEStep
+    a, b = _batches()
+    order = [a, b, a, b, a]
+    wrapped, opts, loss_fn = _setup()
+    m_init = _masters(wrapped, PICKS)
+    eager = [float(train_xe_step(wrapped, x, opts, loss_fn)) for x in order]
+    m_eager = _masters(wrapped, PICKS)
+    del wrapped, opts
+    torch.cuda.empty_cache()
+    wrapped, opts, loss_fn = _setup()
+    first = float(train_xe_step(wrapped, order[0], opts, loss_fn))
+    step = GraphedXEStep(wrapped, opts, loss_fn, order[1], eager_steps=0)
+    replayed = [first] + [float(step(x)) for x in order[1:]]
+    m_graph = _masters(wrapped, PICKS)
+    assert all(np.isfinite(replayed)) and replayed[-1] < replayed[0] - 0.02, replayed
+    for e, r in zip(eager, replayed):
+        assert abs(e - r) < 3e-3 * abs(e), (eager, replayed)
+    for n in PICKS:
+        moved = float(torch.linalg.norm(m_eager[n] - m_init[n]))
+        diff = float(torch.linalg.norm(m_eager[n] - m_graph[n]))
+        assert moved > 0 and diff < 0.05 * moved, (n, diff, moved)
+    # every stepped parameter is 5 steps old in both books
+    assert {int(float(opts[k].state[p]['step'])) for k in ('model', 'backbone') for p in opts[k]._mine
+            if opts[k]._steps[p]} == {5}
+
+
+def test_replay_reads_learning_rate_and_step_count_at_replay_time():
+    from grit_amd.engine.caption_engine import train_xe_step
+    from grit_amd.engine.graph_step import GraphedXEStep
+    a, _ = _batches()
+    wrapped, opts, loss_fn = _setup()
+    train_xe_step(wrapped, a, opts, loss_fn)
+    step = GraphedXEStep(wrapped, opts, loss_fn, a, eager_steps=0)
+    step(a)
+    before = _masters(wrapped, PICKS)
+    lrs = {k: opts[k].param_groups[0]['lr'] for k in ('model', 'backbone')}
+    for k in lrs:
+        for g in opts[k].param_groups:
+            g['lr'] = 0.0
+    step(a)
+    frozen = _masters(wrapped, PICKS)
+    for n in PICKS:
+        assert torch.equal(before[n], frozen[n]), n  # lr = 0 reached the captured Adam launches
+    for k in lrs:
+        for g in opts[k].param_groups:
+            g['lr'] = lrs[k]
+    step(a)
+    after = _masters(wrapped, PICKS)
+    assert all(not torch.equal(after[n], frozen[n]) for n in PICKS)
+    # bias corrections follow the step count: the table holds lr / (1 - beta1^t) for the step just taken (t = 4)
+    o = opts['model']
+    b1 = o.param_groups[0]['betas'][0]
+    assert abs(float(o._hyper_host[0, 0]) - lrs['model'] / (1 - b1 ** 4)) < 1e-6 * lrs['model'] / (1 - b1 ** 4)
+
+
+def test_replays_draw_fresh_dropout_masks():
+    from grit_amd.engine.caption_engine import train_xe_step
+    from grit_amd.engine.graph_step import GraphedXEStep
+    a, _ = _batches()
+    wrapped, opts, loss_fn = _setup(dropout=0.2)
+    for k in ('model', 'backbone'):
+        for g in opts[k].param_groups:
+            g['lr'] = 0.0  # same weights every step: only the masks can change the loss
+    train_xe_step(wrapped, a, opts, loss_fn)
+    step = GraphedXEStep(wrapped, opts, loss_fn, a, eager_steps=0)
+    losses = [float(step(a)) for _ in range(4)]
+    assert len({round(x, 5) for x in losses}) == 4, losses
+    assert max(losses) - min(losses) < 0.5, losses
+
+
+def test_batch_that_does_not_fit_is_refused():
+    from grit_amd.data import synthetic_batch
+    from grit_amd.engine.caption_engine import train_xe_step
+    from grit_amd.engine.graph_step import GraphedXEStep
+    a, _ = _batches()
+    wrapped, opts, loss_fn = _setup()
+    train_xe_step(wrapped, a, opts, loss_fn)
+    step = GraphedXEStep(wrapped, opts, loss_fn, a, eager_steps=0)
+    other = synthetic_batch(a['captions'].shape[0], 256, 224, a['captions'].shape[1], device=DEV, seed=3)
+    assert not step.matches(other)
+    with pytest.raises(ValueError):
+        step(other)
+    step.release()
+    assert float(train_xe_step(wrapped, a, opts, loss_fn)) > 0  # eager steps work again after the graph is dropped

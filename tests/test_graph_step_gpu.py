@@ -65,7 +65,10 @@ def test_replayed_steps_equal_eager_steps():
     for n in PICKS:
         moved = float(torch.linalg.norm(m_eager[n] - m_init[n]))
         diff = float(torch.linalg.norm(m_eager[n] - m_graph[n]))
-        assert moved > 0 and diff < 0.05 * moved, (n, diff, moved)
+        # Adam turns gradient noise of any size into weight differences of the size of the step while the moments are young
+        # (update ~ lr * g / |g|): two EAGER runs differ as much (7 % measured on grid_net.fc.weight); a replay that read stale
+        # inputs, weights or scalars is off by the whole movement
+        assert moved > 0 and diff < 0.25 * moved, (n, diff, moved)
     # every stepped parameter is 5 steps old in both books
     assert {int(float(opts[k].state[p]['step'])) for k in ('model', 'backbone') for p in opts[k]._mine
             if opts[k]._steps[p]} == {5}
@@ -110,9 +113,13 @@ def test_replays_draw_fresh_dropout_masks():
             g['lr'] = 0.0  # same weights every step: only the masks can change the loss
     train_xe_step(wrapped, a, opts, loss_fn)
     step = GraphedXEStep(wrapped, opts, loss_fn, a, eager_steps=0)
+    before = _masters(wrapped, PICKS)
     losses = [float(step(a)) for _ in range(4)]
     assert len({round(x, 5) for x in losses}) == 4, losses
-    assert max(losses) - min(losses) < 0.5, losses
+    # dropout 0.2 + drop-path 0.3 on a randomly initialised model, two images: the loss moves by tenths from mask to mask
+    assert max(losses) - min(losses) < 1.5 and all(8.0 < x < 11.0 for x in losses), losses
+    after = _masters(wrapped, PICKS)
+    assert all(torch.equal(before[n], after[n]) for n in PICKS)
 
 
 def test_batch_that_does_not_fit_is_refused():

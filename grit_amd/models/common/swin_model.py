@@ -441,7 +441,11 @@ class SwinTransformer(nn.Module):
         if x.is_cuda and torch.is_grad_enabled():
             # fc2.weight^T of every block (the K-contiguous operand of the fused GELU' input-gradient GEMM): one launch here instead
             # of a transpose inside each block's backward (grit_amd/ops/transposed.py)
-            _transposed.refresh([blk.mlp.fc2.weight for stage in self.layers for blk in stage.blocks if blk.mlp.fc2.weight.requires_grad])
+            # ... and the other three weights of a block: every input gradient dx = dy W of the long maps runs as an NT product on
+            # W^T (own kernel or the library's NT kernel, both ahead of the NN form: grit_amd/ops/gemm.py long_input_grad)
+            _transposed.refresh([w for stage in self.layers for blk in stage.blocks
+                                 for w in (blk.mlp.fc2.weight, blk.attn.proj.weight, blk.attn.qkv.weight, blk.mlp.fc1.weight)
+                                 if w.requires_grad])
         x, Wh, Ww = self.patch_embed.tokens(x.to(self.patch_embed.proj.weight.dtype))
         if self.ape:
             pos = F.interpolate(self.absolute_pos_embed, size=(Wh, Ww), mode='bicubic')

@@ -60,3 +60,52 @@ def input_grad_dgelu(dy2, weight_t, pre):
     partial = torch.empty((-(-M // COLSUM_ROWS), N), dtype=torch.float32, device=dy2.device)
     d_pre = gemm_nt(dy2, weight_t, DGELU, aux=pre, colsum=partial)
     return d_pre, partial
+
+
+# ---- the long token maps' plain Linears on the own four-wave kernel (grit_gemm_bf16_nt variant 7, grit_amd/csrc/gemm_w4.hip) ----------
+# GRIT_GEMM_OWN (default 1): forward GEMMs y = x W^T + b and input gradients dx = dy W (as NT on W^T, grit_amd/ops/transposed.py) of the
+# Swin blocks / value projection go to the persistent 128 x 128-wave-tile kernel where it is at least as fast as the tuned library
+# kernel (profiles/r04/w4_vs_lib.txt); the rest -- the K >= 1536 problems with 512 output columns, whose 400 tiles fill 256 CUs 1.56
+# times: the library's stream-K kernel has no such quantisation -- stays with the library.
+OWN = os.environ.get("GRIT_GEMM_OWN", "1") != "0"
+OWN_MIN_ROWS = 8192
+_CUS = 256
+
+
+def prefers_own(M, N, K):
+    """Shape policy, measured on MI355X against the tuned library kernels (profiles/r04/w4_vs_lib.txt): the own kernel wins or ties
+    where a tile has few K steps (K <= 512: the library pays a ring fill per tile; e.g. stage-1 proj 58 -> 42 us, stage-2 qkv 84 ->
+    77 us) and at K = 1 024 with wide outputs; the library's stream-K kernel is ahead at K >= 1 024 with <= 512 output columns (400
+    tiles on 256 CUs) and on the 12 000-tile value projection."""
+    if N % 256 or K % 64 or M < OWN_MIN_ROWS or M * K * 2 >= 2 ** 31 or N * K * 2 >= 2 ** 31:
+        return False
+    tiles = -(-M // 256) * (N // 256)
+    return tiles <= 8192 and (K <= 512 or (K <= 1024 and N >= 1024))
+
+
+def long_linear(x2, weight, bias):
+    """x2 [M, K] @ weight [N, K]^T (+ bias) on the own kernel, or None where the library path is to run."""
+    if not (OWN and supported(x2, weight) and (bias is None or (bias.dtype == torch.bfloat16 and bias.data_ptr() % 16 == 0))):
+        return None
+    M, K = x2.shape
+    N = weight.shape[0]
+    if not prefers_own(M, N, K):
+        return None
+    return gemm_nt(x2, weight, BIAS if bias is not None else NONE, bias=bias, variant=7)
+
+
+def long_input_grad(dy2, weight):
+    """dx [M, K_in] = dy2 [M, N_out] @ weight [N_out, K_in] as an NT product on the transposed copy of the weight kept by
+    grit_amd.ops.transposed: on the own kernel where the policy prefers it, else the library's NT kernel -- which is 5-25 % faster
+    than the NN form torch.mm(dy, W) runs (stage 2: fc1 input gradient 102 -> 89 us, qkv 78 -> 69 us).  None: no copy for the
+    weight's current value (the caller runs torch.mm)."""
+    if not (OWN and dy2.is_cuda and dy2.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
+        return None
+    from grit_amd.ops import transposed
+    wt = transposed.lookup(weight)
+    if wt is None:
+        return None
+    if supported(dy2, wt) and prefers_own(dy2.shape[0], wt.shape[0], wt.shape[1]):
+        return gemm_nt(dy2, wt, NONE, variant=7)
+    with timed("gemm_lib", flops=2.0 * dy2.numel() * wt.shape[0]):
+        return torch.nn.functional.linear(dy2, wt)

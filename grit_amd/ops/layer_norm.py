@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 
 from grit_amd import lib as _lib
 from grit_amd.ops import backend
-from grit_amd.ops.linear import (SlabGroup, defer_slab_group, defer_weight_bias_grad, finish_group, fork, join, on_stream, single_use_now,
+from grit_amd.ops.linear import (SlabGroup, _own_input_grad, _own_linear, defer_slab_group, defer_weight_bias_grad, finish_group, fork, join, on_stream, single_use_now,
                                  slab_sum)
 from grit_amd.ops.profiling import timed
 
@@ -166,8 +166,11 @@ class _LinearAddLayerNormFn(Function):
         ctx.single_use = single_use
         ctx.sum_params = (weight, bias, lin_b) if single_use else None  # the parameters whose gradients the node's sums are
         ctx.lin_w_param = lin_w if single_use else None
-        with timed("gemm_lib", flops=2.0 * inp.numel() * lin_w.shape[0]):
-            branch = F.linear(inp, lin_w, lin_b)
+        ctx.lin_w_obj = lin_w  # the tensor object of the call: transposed copies are attached to it (grit_amd/ops/transposed.py)
+        branch = _own_linear(inp, lin_w, lin_b)  # long maps: the own four-wave kernel where it is the faster one
+        if branch is None:
+            with timed("gemm_lib", flops=2.0 * inp.numel() * lin_w.shape[0]):
+                branch = F.linear(inp, lin_w, lin_b)
         C = shortcut.shape[-1]
         s2 = shortcut.reshape(-1, C)
         s2 = s2 if s2.is_contiguous() else s2.contiguous()
@@ -211,8 +214,10 @@ class _LinearAddLayerNormFn(Function):
                                                  (ctx.sum_params[2], sums.data_ptr() + 2 * esz)])):
                 group.run()  # ... and so do the node's LayerNorm / bias sums when all three gradients are wanted
             if ctx.needs_input_grad[0]:
-                with timed("gemm_lib", flops=2.0 * d_branch.numel() * lin_w.shape[1]):
-                    d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
+                d_inp = _own_input_grad(d_branch, ctx.lin_w_obj, inp.shape)
+                if d_inp is None:
+                    with timed("gemm_lib", flops=2.0 * d_branch.numel() * lin_w.shape[1]):
+                        d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
             return (d_inp, deferred[0], sums[2].to(lin_w.dtype), dx.view(ctx.shape), None, sums[0], sums[1], None, None, None,
                     None)
         # small maps inside a deferral scope: the projection's weight gradient beside the chain (grit_amd/ops/linear.py fork)
@@ -223,8 +228,10 @@ class _LinearAddLayerNormFn(Function):
             with on_stream(side):
                 d_lin_w = weight_grad(d_branch, inp2)
         if ctx.needs_input_grad[0]:
-            with timed("gemm_lib", flops=2.0 * d_branch.numel() * lin_w.shape[1]):
-                d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
+            d_inp = _own_input_grad(d_branch, ctx.lin_w_obj, inp.shape)
+            if d_inp is None:
+                with timed("gemm_lib", flops=2.0 * d_branch.numel() * lin_w.shape[1]):
+                    d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
         if d_lin_w is None:
             d_lin_w = weight_grad(d_branch, inp2, group, param=lin_w) if ctx.needs_input_grad[1] else None
             sp = ctx.sum_params

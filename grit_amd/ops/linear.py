@@ -696,6 +696,24 @@ def weight_bias_grad(dy2, x2, group, need_w, need_b, weight):
     return dw, db
 
 
+def _own_linear(x, weight, bias):
+    """F.linear on the own long-map kernel (grit_amd/ops/gemm.py long_linear) or None."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.numel() // x.shape[-1] >= 8192):
+        return None
+    from grit_amd.ops import gemm as _gemm
+    x2 = x.reshape(-1, x.shape[-1])
+    y = _gemm.long_linear(x2 if x2.is_contiguous() else x2.contiguous(), weight, bias)
+    return None if y is None else y.view(x.shape[:-1] + (weight.shape[0],))
+
+
+def _own_input_grad(dy2, weight, shape):
+    if not (dy2.is_cuda and dy2.dtype == torch.bfloat16 and dy2.shape[0] >= 8192):
+        return None
+    from grit_amd.ops import gemm as _gemm
+    dx = _gemm.long_input_grad(dy2, weight)
+    return None if dx is None else dx.view(shape)
+
+
 class _LinearFn(Function):
 
     @staticmethod
@@ -705,6 +723,10 @@ class _LinearFn(Function):
         ctx.single_use = single_use
         ctx.bias_param = bias if single_use else None  # the parameter itself: the deferred path checks its .grad
         ctx.weight_param = weight if single_use else None
+        ctx.weight_obj = weight  # the tensor object the forward was called with: transposed copies are attached to IT
+        own = _own_linear(x, weight, bias)
+        if own is not None:
+            return own
         with timed("gemm_lib", flops=2.0 * x.numel() * weight.shape[0]):
             return F.linear(x, weight, bias)
 
@@ -741,8 +763,10 @@ class _LinearFn(Function):
             elif group is not None:
                 group.run()
         if ctx.needs_input_grad[0]:
-            with timed("gemm_lib", flops=2.0 * dy2.numel() * weight.shape[1]):
-                dx = torch.mm(dy2, weight).view(x.shape)
+            dx = _own_input_grad(dy2, ctx.weight_obj, x.shape)
+            if dx is None:
+                with timed("gemm_lib", flops=2.0 * dy2.numel() * weight.shape[1]):
+                    dx = torch.mm(dy2, weight).view(x.shape)
         join(side, dw, db)
         return dx, dw, db, None
 

@@ -87,8 +87,10 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=No
                 elif need_w1:
                     d_w1 = weight_grad(d_pre, n2, group, param=w1)
         if need_x:
-            with timed("gemm_lib", flops=2.0 * d_pre.numel() * w1.shape[1]):
-                d_n2 = torch.mm(d_pre, w1)
+            d_n2 = G.long_input_grad(d_pre, params[0] if params is not None else w1)  # NT on fc1.weight^T (own kernel / library NT)
+            if d_n2 is None:
+                with timed("gemm_lib", flops=2.0 * d_pre.numel() * w1.shape[1]):
+                    d_n2 = torch.mm(d_pre, w1)
         join(side, d_b1, d_w1)
     return d_n2, d_w1, d_b1, d_w2, d_b2
 

@@ -62,6 +62,71 @@ def test_gemm_epilogues(M, N, K, variant):
     assert (db - ref_db).abs().max().item() <= 2e-3 * ref_db.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 256, 128), (4096 + 17, 512, 512), (70000, 768, 192), (51200, 1536, 512),
+                                   (12800, 1024, 1024)])
+def test_gemm_four_wave_persistent_kernel(M, N, K):
+    """Variant 7 (grit_amd/csrc/gemm_w4.hip: four waves, 128 x 128 wave tiles, persistent stream of K steps over a workgroup's
+    tiles): every epilogue against the float32 contraction of the same bf16 inputs; bias epilogue bit for bit equal to the
+    per-tile kernel (same products, same k order per accumulator); the last row tile is shifted back to end at row M (odd M), its
+    shared rows must not be counted twice in the GELU' column sums; nothing written outside the [2 ceil(M / 256), N] partials."""
+    from grit_amd.ops import gemm as G
+    x, w, b = _inputs(M, N, K, seed=M % 97)
+    ref = x.float() @ w.float().t()
+    _close(G.gemm_nt(x, w, G.NONE, variant=7), ref)
+    own = G.gemm_nt(x, w, G.BIAS, bias=b, variant=7)
+    _close(own, ref + b.float())
+    if K % 64 == 0:
+        assert torch.equal(own, G.gemm_nt(x, w, G.BIAS, bias=b, variant=4))
+    pre = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
+    act = G.gemm_nt(x, w, G.BIAS_GELU, bias=b, aux=pre, variant=7)
+    _close(pre, ref + b.float())
+    _close(act, F.gelu(ref + b.float()))
+    assert torch.equal(act, G.gemm_nt(x, w, G.BIAS_GELU, bias=b, variant=7))  # no pre-activation kept: same activation
+    aux = torch.randn(M, N, device='cuda').bfloat16()
+    slabs = 2 * (-(-M // 256))
+    fenced = torch.full((slabs + 2, N), float('nan'), device='cuda')
+    part = fenced[1:1 + slabs]
+    part.zero_()
+    d = G.gemm_nt(x, w, G.DGELU, aux=aux, colsum=part, variant=7)
+    assert torch.isnan(fenced[0]).all() and torch.isnan(fenced[-1]).all()
+    a32 = aux.float().requires_grad_(True)
+    F.gelu(a32).backward(ref)
+    _close(d, a32.grad)
+    db = part.sum(0)
+    ref_db = a32.grad.sum(0)
+    assert (db - ref_db).abs().max().item() <= 4e-3 * ref_db.abs().max().item() + 1e-2, (db - ref_db).abs().max().item()
+
+
+def test_own_long_map_policy_and_linear_nodes():
+    """grit_amd.ops.gemm.prefers_own / long_linear / long_input_grad and the Linear node on top: the own kernel takes the long-map
+    shapes the policy names (values and gradients equal to the library path within bf16 rounding), everything else runs the library."""
+    from grit_amd.ops import gemm as G
+    from grit_amd.ops import transposed
+    from grit_amd.ops.linear import linear
+    assert G.prefers_own(51200, 1536, 512) and G.prefers_own(51200, 512, 512) and G.prefers_own(12800, 3072, 1024)
+    assert not G.prefers_own(51200, 512, 2048) and not G.prefers_own(4800, 512, 512) and not G.prefers_own(51200, 384, 512)
+    assert not G.prefers_own(272000, 3072, 512)  # 12 756 tiles: the library's kernel is ahead there (profiles/r04/w4_vs_lib.txt)
+    torch.manual_seed(0)
+    M, N, K = 16384, 512, 256
+    x = torch.randn(M, K, device='cuda').bfloat16().requires_grad_(True)
+    w = (torch.randn(N, K, device='cuda') * K ** -0.5).bfloat16().requires_grad_(True)
+    b = torch.randn(N, device='cuda').bfloat16().requires_grad_(True)
+    cot = torch.randn(M, N, device='cuda').bfloat16()
+    assert G.long_linear(x.detach(), w.detach(), b.detach()) is not None
+    transposed.refresh([w])
+    assert G.long_input_grad(cot, w) is not None
+    y = linear(x, w, b)
+    (y * cot).sum().backward()
+    got = [y.detach().float(), x.grad.float().clone(), w.grad.float().clone(), b.grad.float().clone()]
+    for t in (x, w, b):
+        t.grad = None
+    yr = F.linear(x, w, b)
+    (yr * cot).sum().backward()
+    ref = [yr.detach().float(), x.grad.float(), w.grad.float(), b.grad.float()]
+    for g_, r_ in zip(got, ref):
+        _close(g_, r_)
+
+
 def test_gemm_full_size_property():
     """BASELINE shape of Swin stage 2 (M = 32 * 40 * 40, 512 -> 2048): linearity in the bias and exact row independence --
     a row's result does not depend on which tile / workgroup computed it."""

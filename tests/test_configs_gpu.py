@@ -1,0 +1,232 @@
+"""BASELINE configs 4 and 5 at their per-rank workloads, with assertions (they ran only inside bench.py), and the
+gradient synchronisation of A14 against an oracle ON the HIP path.
+
+config 4 (reference train_caption.py:61,205-215 + engine/caption_engine.py:312-350): one rank's share of the 8-GPU job -- 32 synthetic
+  640 x 640 images, T = 20, bf16 compute / fp32 masters -- forward + backward + gradient sync through a ONE-RANK RCCL process group
+  with every collective issued: equal to the run without a process group (bit for bit where the kernels are deterministic; the
+  MSDeformAttn backward sums a cell's contributions in LDS-counter order), and to the fp32-kernel step within bf16 tolerances.
+A14: two gloo ranks sharing cuda:0 run the real model on half a batch each; the reduced gradients and the losses equal ONE process on
+  the concatenated batch.
+config 5 (reference models/caption/transformer.py:75-132): beam 5, 20 steps, batch 64 from synthetic 640 x 640-sized features, fp32
+  weights: the batched decode equals 64 single-image decodes and the loop that composes the reference's operations one by one.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.helpers import build_model, disable_drop_path
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+PICKS = ('cap_generator.fc.weight', 'grid_net.fc.weight', 'cap_generator.layers.1.self_att.attention.fc_q.weight',
+         'detector.det_module.decoder_layers.5.cross_attn.value_proj.weight',
+         'detector.det_module.decoder_layers.0.cross_attn.sampling_offsets.weight',
+         'detector.backbone.layers.2.blocks.17.attn.qkv.weight', 'detector.backbone.layers.2.blocks.0.mlp.fc1.weight',
+         'detector.input_proj.0.0.weight')
+DETERMINISTIC = PICKS[:3]  # downstream of the loss only through the caption decoder / grid net: no atomics, no LDS-counter order
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _config4_worker(rank, port, mode, ret):
+    """mode: 'plain' (no process group), 'rccl' (one-rank nccl group, self-collectives), 'fp32' (fp32 weights and kernels)."""
+    from grit_amd.amp import Bf16Compute
+    from grit_amd.data import synthetic_batch
+    torch.cuda.set_device(0)
+    if mode == 'rccl':
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GRIT_DDP_SELF_COLLECTIVES="1")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    torch.manual_seed(0)
+    model, cfg = build_model(3, fill=False, **{'model.dropout': 0.0, 'model.detector.dropout': 0.0})
+    model.train().to(DEV)
+    disable_drop_path(model)
+    loss_fn = torch.nn.NLLLoss(ignore_index=1)
+    batch = synthetic_batch(32, 640, 640, 20, device=DEV, seed=4)
+    issued = []
+    if mode == 'fp32':
+        out = model(batch['samples'], batch['captions'])
+        loss = loss_fn(out[:, :-1].reshape(-1, out.shape[-1]), batch['captions'][:, 1:].reshape(-1))
+        loss.backward()
+        named = dict(model.named_parameters())
+    else:
+        wrapped = Bf16Compute(model, bucket_mb=64)
+        assert wrapped.flat_optimizer and wrapped.ddp.collective == (mode == 'rccl')
+        if mode == 'rccl':
+            def spy(*a, _f=dist.all_reduce, **k):
+                issued.append(int(a[0].numel()))
+                return _f(*a, **k)
+            dist.all_reduce = spy
+        out = wrapped(batch['samples'], batch['captions'])
+        loss = loss_fn(out[:, :-1].reshape(-1, out.shape[-1]).float(), batch['captions'][:, 1:].reshape(-1))
+        loss.backward()
+        wrapped.finish_gradient_sync()
+        named = dict(model.named_parameters())
+    torch.cuda.synchronize()
+    ret["loss"] = float(loss)
+    ret["grads"] = {n: named[n].grad.detach().float().cpu() for n in PICKS}
+    ret["finite"] = all(bool(torch.isfinite(p.grad).all()) for p in named.values() if p.grad is not None)
+    ret["issued"] = issued
+    if mode == 'rccl':
+        dist.destroy_process_group()
+
+
+def _run(worker, *args):
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(worker, args=args + (ret,), nprocs=1, join=True)
+        return dict(ret)
+
+
+def test_config4_rank_workload_through_rccl_equals_no_group_and_fp32_step():
+    plain = _run(_config4_worker, _free_port(), 'plain')
+    rccl = _run(_config4_worker, _free_port(), 'rccl')
+    fp32 = _run(_config4_worker, _free_port(), 'fp32')
+    assert plain["finite"] and rccl["finite"] and fp32["finite"]
+    assert 8.0 < plain["loss"] < 10.5  # ~ log(10201) for a randomly initialised decoder
+    # every bucket went through an RCCL all-reduce (64 MiB buckets of bf16 + the small tail): >= 147 M gradients in all
+    assert len(rccl["issued"]) >= 5 and sum(rccl["issued"]) >= 140e6, rccl["issued"]
+    # forward is deterministic: the loss is the same number; gradients that do not pass through the MSDeformAttn backward too
+    assert rccl["loss"] == plain["loss"]
+    for n in DETERMINISTIC:
+        assert torch.equal(rccl["grads"][n], plain["grads"][n]), n
+    for n in PICKS:
+        a, b = rccl["grads"][n], plain["grads"][n]
+        assert float(torch.linalg.norm(a - b)) <= 2e-2 * float(torch.linalg.norm(b)) + 1e-12, n
+    # against the fp32 kernels end to end (the G8 parity path at this workload): bf16 storage of ~60 layers of activations
+    assert abs(plain["loss"] - fp32["loss"]) < 2e-2 * fp32["loss"], (plain["loss"], fp32["loss"])
+    rels = {n: float(torch.linalg.norm(plain["grads"][n] - fp32["grads"][n]) / torch.linalg.norm(fp32["grads"][n])) for n in PICKS}
+    for n, rel in rels.items():
+        assert rel < (0.6 if 'cross_attn' in n else 0.3), rels
+    assert sorted(rels.values())[len(rels) // 2] < 0.12, rels
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _small_batch(n, seed):
+    from grit_amd.data import synthetic_batch
+    return synthetic_batch(n, 224, 224, 12, device=DEV, seed=seed)
+
+
+def _a14_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grit_amd.amp import Bf16Compute
+    from grit_amd.engine.caption_engine import build_optimizers, train_xe_step
+    from grit_amd.utils.misc import NestedTensor
+    model, cfg = build_model(3, **{'model.dropout': 0.0, 'model.detector.dropout': 0.0})  # deterministic fill: same on every rank
+    model.train().to(DEV)
+    disable_drop_path(model)
+    wrapped = Bf16Compute(model, bucket_mb=64)
+    opts = build_optimizers(wrapped, cfg, mode='xe')
+    loss_fn = torch.nn.NLLLoss(ignore_index=1)
+    full = _small_batch(4, seed=21)
+    per = 4 // world
+    lo = rank * per
+    mine = {'samples': NestedTensor(full['samples'].tensors[lo:lo + per].contiguous(), full['samples'].mask[lo:lo + per].contiguous(),
+                                    any_padding=False),
+            'captions': full['captions'][lo:lo + per].contiguous()}
+    # step 1 by hand, to look at the reduced gradients before the optimizer consumes them
+    out = wrapped(mine['samples'], mine['captions'])
+    loss = loss_fn(out[:, :-1].reshape(-1, out.shape[-1]).float(), mine['captions'][:, 1:].reshape(-1))
+    loss.backward()
+    wrapped.finish_gradient_sync()
+    named = dict(model.named_parameters())
+    grads = {n: (named[n].grad.detach().float() / wrapped.ddp.world).cpu() for n in PICKS}  # buckets hold the SUM over ranks
+    opts['model'].step()
+    opts['backbone'].step()
+    wrapped.after_optimizer_step()
+    losses = [float(loss)]
+    for _ in range(2):
+        losses.append(float(train_xe_step(wrapped, mine, opts, loss_fn)))  # (rank-averaged by gather_result)
+    torch.cuda.synchronize()
+    if rank == 0:
+        ret["grads"], ret["losses"] = grads, losses
+        ret["unused"] = len(wrapped.unused_parameters)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_a14_two_ranks_on_the_hip_path_equal_one_process_on_the_whole_batch():
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_a14_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+        two = dict(ret)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_a14_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+        one = dict(ret)
+    assert two["unused"] == one["unused"] == 80  # the reference's static unused set
+    # step-1 loss of rank 0 is its half batch's; steps 2-3 are rank averages = the whole-batch loss of the single process
+    for a, b in zip(two["losses"][1:], one["losses"][1:]):
+        assert abs(a - b) < 5e-3 * abs(b), (two["losses"], one["losses"])
+    assert one["losses"][-1] < one["losses"][0]
+    for n in PICKS:
+        a, b = two["grads"][n], one["grads"][n]
+        rel = float(torch.linalg.norm(a - b) / torch.linalg.norm(b))
+        # mean over two ranks of half-batch gradients, summed in bf16 on the wire, against the whole-batch gradient: bf16 rounding
+        # of the partial results (2^-9 relative per tensor element) and the batch-size dependent reduction orders
+        # (gradients through the deformable attention of a freshly filled decoder -- sampling_offsets starts from zero weights -- are
+        # sums of cancelling terms: the same noise floor as tests/test_model_gpu.py::test_config3_*)
+        # measured: 1-7 % per tensor (the same run-to-run floor test_config3_* documents: 2-6 %); a rank whose gradient were dropped
+        # or doubled would show ~50-100 %
+        assert rel < (0.3 if 'cross_attn' in n else 0.15), (n, rel)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_config5_batch64_beam5_equals_single_image_decodes_and_reference_order_loop(monkeypatch):
+    import grit_amd.models.caption.cap_generator as CG
+    import grit_amd.models.caption.transformer as T
+    import grit_amd.models.common.attention as A
+    from grit_amd.ops import gate as gate_ops
+    model, _ = build_model(3)
+    model.eval().to(DEV)
+    B = 64
+    gen = torch.Generator().manual_seed(64)
+    feats = {"gri_feat": torch.randn(B, 100, 1024, generator=gen).to(DEV), "reg_feat": torch.randn(B, 150, 512, generator=gen).to(DEV),
+             "gri_mask": torch.zeros(B, 1, 1, 100, dtype=torch.bool, device=DEV),
+             "reg_mask": torch.zeros(B, 1, 1, 150, dtype=torch.bool, device=DEV)}
+
+    def decode(batch):
+        model.cached_features = True
+        try:
+            with torch.no_grad():
+                return model(batch, seq=None, use_beam_search=True, max_len=20, eos_idx=3, beam_size=5, out_size=1)
+        finally:
+            model.cached_features = False
+
+    tokens, lps = decode(feats)
+    assert tokens.shape == (B, 20)
+    singles = [decode({k: v[i:i + 1].contiguous() for k, v in feats.items()}) for i in range(B)]
+    single_tokens = torch.cat([s[0] for s in singles], 0)
+    single_lps = torch.cat([s[1] for s in singles], 0)
+    # batched == per image.  fp32 GEMMs of 320 rows and of 5 rows run different library kernels (summation order): where a pair of
+    # candidates is closer than that round-off the beam may legitimately take the other one -- allowed only as an exact tie in score
+    same = (tokens == single_tokens).all(1)
+    score_b, score_s = lps.sum(-1), single_lps.sum(-1)
+    assert int(same.sum()) >= B - 2, int(same.sum())
+    assert torch.allclose(score_b[same], score_s[same], rtol=1e-4, atol=1e-4)
+    assert torch.allclose(score_b[~same], score_s[~same], rtol=0, atol=2e-4)  # a flipped near-tie changes the score by < 2e-4
+    # ... == the loop composed of the reference's operations (every inference restructuring off, eager)
+    monkeypatch.setattr(T, "_GRAPH_DECODE", False)
+    monkeypatch.setattr(T, "_FUSED_BEAM_STEP", False)
+    monkeypatch.setattr(A, "_KV_CACHE", False)
+    monkeypatch.setattr(A, "_KV_FUSED_APPEND", False)
+    monkeypatch.setattr(CG, "_FUSED_STEP_INPUTS", False)
+    monkeypatch.setattr(gate_ops, "supported", lambda *a, **k: False)
+    ref_tokens, ref_lps = decode(feats)
+    same_ref = (tokens == ref_tokens).all(1)
+    assert int(same_ref.sum()) >= B - 2, int(same_ref.sum())
+    assert torch.allclose(lps.sum(-1), ref_lps.sum(-1), rtol=1e-4, atol=2e-4)

@@ -17,21 +17,31 @@ captions of 20 tokens, train mode (dropout / DropPath on), bf16 compute copies o
 forward + backward + gradient all-reduce (RCCL, bucketed, overlapped with backward) + two fused Adam steps, exactly
 the order of reference engine/caption_engine.py:312-350.  Weak scaling: the per-GPU batch is fixed.
 
+The step runs as ONE captured HIP graph on one rank (grit_amd/engine/graph_step.py; GRIT_STEP_GRAPH=0 = eager launches; N > 1 runs
+eager launches with the bucketed RCCL all-reduce): two eager warm-up steps, capture, every later step is a copy of the batch into the
+graph's input buffers + one graph launch.  `config.step_graph` says which one ran.
+
 One JSON line on rank 0.  Besides the contract keys:
-  roofline      the dominant hand-written kernel of the step by ms/step -- the window-attention backward -- against its compulsory
-                HBM bytes (7 bf16 [144, 32] slices per window-head), launch times from HIP events on the launch stream inside the
-                timed region, `traffic` = PMC bytes per launch of the same kernel read from profiles/r03/pmc_in_step.txt.
+  roofline      the hand-written kernel FAMILY with the most ms/step among {gemm_nt_bf16 (fused Mlp GEMMs), wgrad_tn (weight gradients),
+                gemm_w4 (persistent long-map GEMM), window-attention backward / forward}, chosen from the measured per-launch times of
+                this run, against the larger of its two bounds (algorithmic flops / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s); both
+                fractions are in it (`frac_mfma`, `frac_hbm`).  Launch times: HIP events on the launch stream in eager steps right
+                behind the timed region (a replayed graph runs no Python to record events).  `traffic` = PMC bytes per launch of the
+                same kernel from profiles/r04/pmc_in_step.txt where present.
+  roofline_gemm_nt_bf16 / _gemm_w4 / _wgrad_tn   the three own GEMM families, same fields, always reported.
+  gemm          EVERY GEMM family of the step incl. `gemm_lib` (hipBLASLt / rocBLAS launches): launches/step, ms/step, average launch,
+                TFLOP/s + frac_mfma, GB/s + frac_hbm, bound, frac.
+  config3_bs16  (N = 1 only) SURVEY 8(d) config 3: the same step at 16 images, img/s and ms/step over 10 steps.
   roofline_msda MSDeformAttn forward kernel (HBM-bound gather) as it runs INSIDE the step: algorithmic bytes per launch /
                 average launch time measured with HIP events on the launch stream inside the timed region, against 8 TB/s.
                 Algorithmic bytes = the distinct 128-byte lines of the value map that the launch's sampling points touch (counted
                 from the recorded sampling locations after the timed region) + locations + weights + output, each once -- so the
-                fraction cannot exceed 1 by construction (charging the whole map, as round 1 did, gave 1.29).
+                fraction cannot exceed 1 by construction (charging the whole map, as round 1 did, gave 1.29).  Both denominators
+                are reported: `frac_touched` (= frac) and `frac_compulsory_8d` (SURVEY 8d's whole-value-map figure).
   roofline_msda_spread   the same kernel(s) stand-alone on SURVEY 8d config 2's point distribution (learned-offset-like spread
                 points), value maps rotated through > 512 MB so the 256 MB Infinity Cache cannot serve them: bf16 B = 32 and the
                 fp32 kernel at B = 8 (config 2 itself).
   roofline_winattn_bwd / _fwd   window attention against its compulsory HBM bytes (7 resp. 4 bf16 [144, 32] slices per window-head).
-  gemm          aggregate rate of the GEMMs of the long token maps (library and own), timed per launch in extra steps after the
-                timed region (an event pair per GEMM inside it would cost ~2 ms per step).
   cpu_baseline  (N = 1 only) the same training step on the host CPU: this repo's modules with the oracle ops
                 (oracle/torch_ref.py) injected -- a port, not the reference -- on a bounded sample: batch 1
                 over a thread sweep (8 / 16 / 32 / 64), headline = the best point, plus batch 4 there; budgeted at 60 s.
@@ -59,7 +69,7 @@ MSDA_FWD_KERNEL = {"fwd": "msda_fwd_vec4<16,4> (MSDeformAttn forward, fp32 value
                    "fwd_bf16": "msda_fwd_bf16_rows4<2> (MSDeformAttn forward, bf16 value map, fp32 sampling geometry)"}
 # HBM-side bytes per launch come from the committed PMC summary of THIS command (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), read at run time: no figure is typed in here
-PMC_SUMMARIES = ("profiles/r03/pmc_in_step.txt", "profiles/r02/pmc_in_step.txt")
+PMC_SUMMARIES = ("profiles/r04/pmc_in_step.txt", "profiles/r03/pmc_in_step.txt", "profiles/r02/pmc_in_step.txt")
 
 
 def pmc_traffic(kernel_substring):
@@ -524,6 +534,34 @@ def main():
         torch.cuda.synchronize()
         msda_op.PROFILE_EVENTS, msda_op.PROFILE_RECORD_GEOMETRY, profiling.EVENTS = None, False, None
 
+    # SURVEY 8(d) config 3 (full GRIT fwd+bwd, ONE GPU, 16 images, bf16) on the same model and optimizer state, driver-visible:
+    # 2 eager steps, the step captured as a HIP graph like the headline's, 3 + 10 replays
+    config3 = None
+    if world == 1 and not args.no_analysis and not args.fp32 and args.batch == 32 and not args.ragged:
+        try:
+            b16 = [synthetic_batch(16, args.size, args.size, args.caption_len, device=device, seed=77 + i) for i in range(2)]
+            for i in range(2):
+                train_xe_step(wrapped, b16[i], optimizers, loss_fn)
+            g16 = graph_step.GraphedXEStep(wrapped, optimizers, loss_fn, b16[0], eager_steps=0) if graphed is not None else None
+            run16 = (lambda i: g16(b16[i % 2])) if g16 is not None else (lambda i: train_xe_step(wrapped, b16[i % 2], optimizers, loss_fn))
+            for i in range(3):
+                run16(i)
+            torch.cuda.synchronize()
+            t16 = time.perf_counter()
+            for i in range(10):
+                l16 = run16(i)
+            torch.cuda.synchronize()
+            t16 = time.perf_counter() - t16
+            if g16 is not None:
+                g16.release()
+            config3 = {"workload": "config 3: the same XE training step at 16 images of %dx%d on one GPU, bf16" % (args.size, args.size),
+                       "images_per_sec": 160.0 / t16, "ms_per_step": t16 * 100.0, "steps": 10, "warmup": 5,
+                       "step_graph": g16 is not None, "final_loss": float(l16)}
+            del b16, g16
+        except Exception as e:
+            config3 = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        torch.cuda.synchronize()
+
     # what an event pair reads with NOTHING between its two markers: the part of every per-launch figure below that is
     # marker / dispatch latency, not kernel time (reported, not subtracted: the roofline figures stay conservative)
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
@@ -623,37 +661,76 @@ def main():
                                           "achieved": nbytes / tt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                           "frac": nbytes / tt / 1e9 / HBM_PEAK_GBPS,
                                           "achieved_TFLOPs": ff / tt / 1e12, "mfma_frac_bf16": ff / tt / MFMA_PEAK_BF16}
-        gemm = None
+        # ---- GEMM families of the step, each against BOTH of its bounds (per-launch HIP events in 2 eager steps behind the timed region)
+        FAMILIES = {
+            "gemm_nt_bf16": "gemm_nt_bf16<256,256,64,...> (grit_amd/csrc/gemm.hip): the Swin Mlp's fused GEMMs -- fc1 + bias + GELU "
+                            "writing pre-activation and activation, fc2 input gradient x GELU' + bias-gradient column sums",
+            "gemm_w4": "gemm_w4_bf16 (grit_amd/csrc/gemm_w4.hip): persistent four-wave kernel, 128 x 128 wave tiles -- qkv / proj / value "
+                       "forward GEMMs and NT input gradients of the long maps where it beats the library",
+            "wgrad_tn": "wgrad_tn_256 + wgrad_tn_256_grouped (grit_amd/csrc/wgrad_tn.hip): weight gradients dW = dY^T X of the long token "
+                        "maps and, grouped, of the decoders' short ones; fp32 row-slice partials",
+            "wgrad_small": "wgrad_small (grit_amd/csrc/wgrad.hip): 64 x 64-tile grouped weight gradients of shapes outside 256-multiples",
+            "gemm_lib": "hipBLASLt / rocBLAS through torch (tuned table grit_amd/tunableop_gfx950.csv): K >= 1024 long-map GEMMs with 512 "
+                        "output columns (stream-K), the value projection, every GEMM of the two decoders",
+        }
+        n_an = 2  # analysis steps the events cover
+        gemm, families = None, {}
         if gemm_events:
-            gemm = {"note": "GEMMs of the long token maps (Swin blocks, value / input projections), per-launch HIP events in "
-                            "2 extra steps after the timed region"}
-            for kind in ("gemm_lib", "gemm_own"):
-                ev = [(a.elapsed_time(b) * 1e-3, pl["flops"]) for k, a, b, pl in gemm_events if k == kind]
-                if ev:
-                    tt, ff = sum(t for t, _ in ev), sum(f for _, f in ev)
-                    gemm[kind] = {"launches_per_step": len(ev) / 2, "ms_per_step": tt / 2 * 1e3, "PFLOPs": ff / tt / 1e15,
-                                  "mfma_frac_bf16": ff / tt / MFMA_PEAK_BF16}
-            ev = [(a.elapsed_time(b) * 1e-3, pl["flops"]) for k, a, b, pl in gemm_events]
-            tt, ff = sum(t for t, _ in ev), sum(f for _, f in ev)
-            gemm["all"] = {"ms_per_step": tt / 2 * 1e3, "PFLOPs": ff / tt / 1e15, "mfma_frac_bf16": ff / tt / MFMA_PEAK_BF16}
-        # the long-map weight-gradient kernel (wgrad_tn_256 / wgrad_tn_256_grouped, grit_amd/csrc/wgrad_tn.hip) against the dense bf16
-        # MFMA peak: since the window-attention backward dropped to 4.7 ms it is the hand-written kernel with the most time per step
-        roof_wgrad = None
-        ev = [(a.elapsed_time(b) * 1e-3, pl["flops"]) for k, a, b, pl in (gemm_events or []) if pl.get("kernel") == "wgrad_tn"]
-        if ev:
-            tt, ff = sum(t for t, _ in ev), sum(f for _, f in ev)
-            roof_wgrad = {"bound": "mfma", "kernel": "wgrad_tn_256 + wgrad_tn_256_grouped (weight gradients dW = dY^T X of the Swin blocks' "
-                                                     "long token maps and, grouped, of the decoders' short ones; 256 x 256 tiles, one "
-                                                     "workgroup per CU, transposing LDS reads on both MFMA operands)",
-                          "launches_per_step": len(ev) / 2, "ms_per_step": tt / 2 * 1e3, "avg_launch_us": tt / len(ev) * 1e6,
-                          "algorithmic_flops_per_launch": ff / len(ev),
-                          "algorithmic_flops_basis": "2 M N K per problem (fp32 accumulation of bf16 products), summed over the problems of a launch",
-                          "achieved": ff / tt / 1e12, "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ff / tt / MFMA_PEAK_BF16,
-                          "traffic": None,
-                          "timing": "per-launch HIP events in 2 extra steps after the timed region (an event pair adds ~5 us of marker "
-                                    "latency to a ~150 us launch)"}
-        wa_bwd = window_attention.get("winattn_bwd")
-        dominant = roof_wgrad if (roof_wgrad and (not wa_bwd or roof_wgrad["ms_per_step"] >= wa_bwd["ms_per_step"])) else (wa_bwd or roof)
+            def fam_of(kind, pl):
+                return "gemm_lib" if kind == "gemm_lib" else pl.get("kernel", "gemm_nt_bf16")
+            for kind, a, b, pl in gemm_events:
+                f = families.setdefault(fam_of(kind, pl), {"t": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+                f["t"] += a.elapsed_time(b) * 1e-3
+                f["flops"] += pl.get("flops", 0.0)
+                f["bytes"] += pl.get("bytes", 0.0)
+                f["n"] += 1
+            gemm = {"note": "every GEMM family of the step against BOTH bounds: `frac_mfma` = algorithmic flops / time / 2.5 PFLOP/s (dense bf16), "
+                            "`frac_hbm` = algorithmic bytes (operands once + outputs once + fp32 split partials) / time / 8 TB/s; `bound` names "
+                            "the larger one, `frac` is its value.  Per-launch HIP events on the launch stream in %d eager steps right behind "
+                            "the timed region (an event pair adds ~5 us to a launch); `traffic` = PMC bytes per launch where "
+                            "profiles/r04/pmc_in_step.txt has the kernel" % n_an}
+            for name, f in families.items():
+                tt = f["t"]
+                fm, fh = f["flops"] / tt / MFMA_PEAK_BF16, f["bytes"] / tt / 1e9 / HBM_PEAK_GBPS
+                traffic, tsrc = pmc_traffic({"gemm_nt_bf16": "gemm_nt_bf16", "gemm_w4": "gemm_w4_bf16", "wgrad_tn": "wgrad_tn_256_grouped"}.get(name, "\0"))
+                gemm[name] = {"kernel": FAMILIES.get(name, name), "launches_per_step": f["n"] / n_an, "ms_per_step": tt / n_an * 1e3,
+                              "avg_launch_us": tt / f["n"] * 1e6, "algorithmic_flops_per_launch": f["flops"] / f["n"],
+                              "algorithmic_bytes_per_launch": f["bytes"] / f["n"], "TFLOPs": f["flops"] / tt / 1e12,
+                              "GBps": f["bytes"] / tt / 1e9, "frac_mfma": fm, "frac_hbm": fh, "bound": "mfma" if fm >= fh else "hbm",
+                              "frac": max(fm, fh), "traffic": traffic, "traffic_source": tsrc}
+            own = [v for k, v in gemm.items() if isinstance(v, dict) and k != "gemm_lib"]
+            for label, sel in (("gemm_own", own), ("all", [v for v in gemm.values() if isinstance(v, dict)])):
+                if sel:
+                    tt = sum(v["ms_per_step"] for v in sel) * 1e-3
+                    ff = sum(v["algorithmic_flops_per_launch"] * v["launches_per_step"] for v in sel)
+                    gemm[label] = {"ms_per_step": tt * 1e3, "PFLOPs": ff / tt / 1e15, "mfma_frac_bf16": ff / tt / MFMA_PEAK_BF16}
+
+        def family_roofline(name):
+            v = gemm.get(name) if gemm else None
+            if not v:
+                return None
+            mf = v["bound"] == "mfma"
+            return {"bound": v["bound"], "kernel": v["kernel"], "launches_per_step": v["launches_per_step"], "ms_per_step": v["ms_per_step"],
+                    "avg_launch_us": v["avg_launch_us"],
+                    "achieved": v["TFLOPs"] if mf else v["GBps"], "peak": MFMA_PEAK_BF16 / 1e12 if mf else HBM_PEAK_GBPS,
+                    "unit": "TFLOP/s" if mf else "GB/s", "frac": v["frac"], "frac_mfma": v["frac_mfma"], "frac_hbm": v["frac_hbm"],
+                    "algorithmic_flops_per_launch": v["algorithmic_flops_per_launch"],
+                    "algorithmic_bytes_per_launch": v["algorithmic_bytes_per_launch"],
+                    "algorithmic_basis": "2 M N K flop per problem; bytes: both operands once, every output map once (two for fc1 + GELU; the "
+                                         "GELU' GEMM also reads the pre-activation map), fp32 row-slice partials of the weight gradients",
+                    "traffic": v["traffic"], "traffic_source": v["traffic_source"],
+                    "timing": "per-launch HIP events on the launch stream in %d eager steps right behind the timed region" % n_an}
+        roof_wgrad = family_roofline("wgrad_tn")
+        # the hand-written kernel family with the most time per step (of the GEMM families and the two window-attention kernels)
+        candidates = [r for r in (family_roofline("gemm_nt_bf16"), roof_wgrad, family_roofline("gemm_w4"),
+                                  window_attention.get("winattn_bwd"), window_attention.get("winattn_fwd")) if r]
+        dominant = max(candidates, key=lambda r: r["ms_per_step"]) if candidates else roof
+        if roof:  # MSDeformAttn forward: both denominators side by side
+            roof["frac_touched"] = roof["frac"]
+            roof["frac_compulsory_8d"] = roof["whole_map_bytes_per_launch"] / (roof["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
+            roof["denominators"] = ("frac / frac_touched: distinct value cells the recorded sampling locations reach + locations + weights + "
+                                    "output; frac_compulsory_8d: every tensor once incl. the WHOLE value map (SURVEY 8d's figure -- counts "
+                                    "cells the kernel never needs)")
         out = {
             "metric": _baseline_metric(),
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -688,12 +765,15 @@ def main():
             # the hand-written kernel with the most time per step (profiles/r03/*steady_state.txt): the long-map weight-gradient GEMM
             # (MFMA-bound) once the analysis steps ran, else the window-attention backward (HBM-bound); both are always reported below
             "roofline": dominant,
+            "roofline_gemm_nt_bf16": family_roofline("gemm_nt_bf16"),
+            "roofline_gemm_w4": family_roofline("gemm_w4"),
             "roofline_wgrad_tn": roof_wgrad,
             "roofline_msda": roof,
             "msda_backward": msda_bwd,
             "roofline_winattn_bwd": window_attention.get("winattn_bwd"),
             "roofline_winattn_fwd": window_attention.get("winattn_fwd"),
             "gemm": gemm,
+            "config3_bs16": config3,
         }
         if not args.no_analysis:
             del wrapped, optimizers, model

@@ -10,7 +10,7 @@ import os
 import torch
 
 from grit_amd import lib as _lib
-from grit_amd.ops.profiling import timed
+from grit_amd.ops.profiling import gemm_work, timed
 
 NONE, BIAS, BIAS_GELU, DGELU = 0, 1, 2, 3
 COLSUM_ROWS = 128
@@ -36,7 +36,9 @@ def gemm_nt(a, b, epilogue=NONE, bias=None, aux=None, colsum=None, out=None, var
     N = b.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
-    with _lib.device_guard(a.device), timed("gemm_own", flops=2.0 * M * N * K, epilogue=epilogue):
+    v = VARIANT if variant is None else variant
+    work = gemm_work(M, N, K, outputs=2 if (epilogue == BIAS_GELU and aux is not None) else 1, extra_in=1 if epilogue == DGELU else 0)
+    with _lib.device_guard(a.device), timed("gemm_own", epilogue=epilogue, kernel="gemm_w4" if v == 7 else "gemm_nt_bf16", **work):
         st = _lib.load().grit_gemm_bf16_nt(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0), M, N, K,
                                            epilogue, _ptr(bias), _ptr(aux), aux.stride(0) if aux is not None else 0,
                                            _ptr(colsum), VARIANT if variant is None else variant, _lib.current_stream_ptr())
@@ -107,5 +109,5 @@ def long_input_grad(dy2, weight):
         return None
     if supported(dy2, wt) and prefers_own(dy2.shape[0], wt.shape[0], wt.shape[1]):
         return gemm_nt(dy2, wt, NONE, variant=7)
-    with timed("gemm_lib", flops=2.0 * dy2.numel() * wt.shape[0]):
+    with timed("gemm_lib", **gemm_work(dy2.shape[0], wt.shape[0], wt.shape[1])):
         return torch.nn.functional.linear(dy2, wt)

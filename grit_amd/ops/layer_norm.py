@@ -15,7 +15,7 @@ from grit_amd import lib as _lib
 from grit_amd.ops import backend
 from grit_amd.ops.linear import (SlabGroup, _own_input_grad, _own_linear, defer_slab_group, defer_weight_bias_grad, finish_group, fork, join, on_stream, single_use_now,
                                  slab_sum)
-from grit_amd.ops.profiling import timed
+from grit_amd.ops.profiling import gemm_work, timed
 
 SUPPORTED_C = (128, 256, 512, 1024, 2048, 4096)
 LN_BWD_PARTIALS = 1024  # GRIT_LN_BWD_PARTIALS in include/grit_hip.h
@@ -169,7 +169,7 @@ class _LinearAddLayerNormFn(Function):
         ctx.lin_w_obj = lin_w  # the tensor object of the call: transposed copies are attached to it (grit_amd/ops/transposed.py)
         branch = _own_linear(inp, lin_w, lin_b)  # long maps: the own four-wave kernel where it is the faster one
         if branch is None:
-            with timed("gemm_lib", flops=2.0 * inp.numel() * lin_w.shape[0]):
+            with timed("gemm_lib", **gemm_work(inp.numel() // inp.shape[-1], lin_w.shape[0], lin_w.shape[1])):
                 branch = F.linear(inp, lin_w, lin_b)
         C = shortcut.shape[-1]
         s2 = shortcut.reshape(-1, C)
@@ -216,7 +216,7 @@ class _LinearAddLayerNormFn(Function):
             if ctx.needs_input_grad[0]:
                 d_inp = _own_input_grad(d_branch, ctx.lin_w_obj, inp.shape)
                 if d_inp is None:
-                    with timed("gemm_lib", flops=2.0 * d_branch.numel() * lin_w.shape[1]):
+                    with timed("gemm_lib", **gemm_work(d_branch.shape[0], lin_w.shape[1], lin_w.shape[0])):
                         d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
             return (d_inp, deferred[0], sums[2].to(lin_w.dtype), dx.view(ctx.shape), None, sums[0], sums[1], None, None, None,
                     None)
@@ -230,7 +230,7 @@ class _LinearAddLayerNormFn(Function):
         if ctx.needs_input_grad[0]:
             d_inp = _own_input_grad(d_branch, ctx.lin_w_obj, inp.shape)
             if d_inp is None:
-                with timed("gemm_lib", flops=2.0 * d_branch.numel() * lin_w.shape[1]):
+                with timed("gemm_lib", **gemm_work(d_branch.shape[0], lin_w.shape[1], lin_w.shape[0])):
                     d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
         if d_lin_w is None:
             d_lin_w = weight_grad(d_branch, inp2, group, param=lin_w) if ctx.needs_input_grad[1] else None

@@ -18,7 +18,7 @@ from torch.autograd.function import once_differentiable
 
 from grit_amd import lib as _lib
 from grit_amd.ops import backend
-from grit_amd.ops.profiling import timed
+from grit_amd.ops.profiling import gemm_work, timed
 
 MIN_ROWS = int(os.environ.get("GRIT_LINEAR_MIN_ROWS", "512"))  # below this the launch overhead dominates: leave it to torch
 
@@ -266,7 +266,8 @@ def flush_deferred(final=False):
                 group.add_raw(work[woff:], 1, 0, S, N * K, pw, True)
                 if b is not None:
                     group.add_raw(work[boff:], 1, 0, sl, N, pb, True)
-            with timed("gemm_own", flops=2.0 * sum(j[6] * j[7] * j[8] for j in chunk), kernel="wgrad_tn" if kind == "tn" else "wgrad_small"):
+            with timed("gemm_own", flops=2.0 * sum(j[6] * j[7] * j[8] for j in chunk), kernel="wgrad_tn" if kind == "tn" else "wgrad_small",
+                       bytes=sum(2.0 * j[6] * (j[7] + j[8]) + 4.0 * S * j[7] * j[8] for j, S in zip(chunk, splits))):
                 if kind == "tn":
                     st = lib.grit_wgrad_tn_grouped(table, len(chunk), _lib.current_stream_ptr())
                 else:
@@ -516,7 +517,7 @@ def small_weight_bias_grad(dy2, x2, need_db, out_dtype, group=None):
     else:
         wpart = torch.empty((1, S, N, K), dtype=torch.float32, device=dy2.device)
         bpart = torch.empty((1, S, N), dtype=torch.float32, device=dy2.device) if need_db else None
-    with _lib.device_guard(dy2.device), timed("gemm_own", flops=2.0 * M * N * K, kernel="wgrad_small"):
+    with _lib.device_guard(dy2.device), timed("gemm_own", flops=2.0 * M * N * K, kernel="wgrad_small", bytes=2.0 * M * (N + K) + 4.0 * S * N * K):
         st = lib.grit_wgrad_small(ctypes.c_void_p(dy2.data_ptr()), dy2.stride(0), ctypes.c_void_p(x2.data_ptr()), x2.stride(0), M, N, K,
                                   S, ctypes.c_void_p(wpart.data_ptr()), ctypes.c_void_p(bpart.data_ptr()) if need_db else None,
                                   _lib.current_stream_ptr())
@@ -560,7 +561,7 @@ def long_weight_grad_partials(dy2, x2, need_db=False):
         return None
     part = torch.empty((S, N, K), dtype=torch.float32, device=dy2.device)
     bpart = torch.empty((S, N), dtype=torch.float32, device=dy2.device) if need_db else None
-    with _lib.device_guard(dy2.device), timed("gemm_own", flops=2.0 * M * N * K, kernel="wgrad_tn"):
+    with _lib.device_guard(dy2.device), timed("gemm_own", flops=2.0 * M * N * K, kernel="wgrad_tn", bytes=2.0 * M * (N + K) + 4.0 * S * N * K):
         st = lib.grit_wgrad_tn(ctypes.c_void_p(dy2.data_ptr()), dy2.stride(0), ctypes.c_void_p(x2.data_ptr()), x2.stride(0), M, N, K, S,
                                ctypes.c_void_p(part.data_ptr()), ctypes.c_void_p(bpart.data_ptr()) if need_db else None,
                                _lib.current_stream_ptr())
@@ -607,6 +608,7 @@ def long_weight_grad_with_parked(dy2, x2, group, weight):
     table = (_lib.WgradJob * (len(parked) + 1))()
     table[0] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, part.data_ptr(), bpart.data_ptr())
     flops = 2.0 * M * N * K
+    nbytes = 2.0 * M * (N + K) + 4.0 * S * N * K
     for t, (pdy, px, pw_param, _, pw, _, pM, pN, pK) in enumerate(parked):
         pS = tn_slices(pM, want)
         work = torch.empty(pS * pN * pK, dtype=torch.float32, device=dy2.device)
@@ -614,7 +616,8 @@ def long_weight_grad_with_parked(dy2, x2, group, weight):
         group.add_raw(work, 1, 0, pS, pN * pK, pw, True)
         _deferral["unverified"].append((pw_param, pw, "parked weight gradient [%d, %d]" % (pN, pK)))
         flops += 2.0 * pM * pN * pK
-    with _lib.device_guard(dy2.device), timed("gemm_own", flops=flops, kernel="wgrad_tn"):
+        nbytes += 2.0 * pM * (pN + pK) + 4.0 * pS * pN * pK
+    with _lib.device_guard(dy2.device), timed("gemm_own", flops=flops, kernel="wgrad_tn", bytes=nbytes):
         st = lib.grit_wgrad_tn_grouped(table, len(parked) + 1, _lib.current_stream_ptr())
     _lib.check(st, "grit_wgrad_tn_grouped")
     return part, bpart
@@ -649,7 +652,8 @@ def long_weight_grads_together(pairs):
         part = torch.empty((S, N, K), dtype=torch.float32, device=dy2.device)
         parts.append(part)
         table[t] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, part.data_ptr(), None)
-    with _lib.device_guard(pairs[0][0].device), timed("gemm_own", flops=2.0 * sum(d.shape[0] * d.shape[1] * x.shape[1] for d, x in pairs), kernel="wgrad_tn"):
+    with _lib.device_guard(pairs[0][0].device), timed("gemm_own", flops=2.0 * sum(d.shape[0] * d.shape[1] * x.shape[1] for d, x in pairs), kernel="wgrad_tn",
+                                                      bytes=sum(2.0 * d.shape[0] * (d.shape[1] + x.shape[1]) + 4.0 * p.numel() for (d, x), p in zip(pairs, parts))):
         st = lib.grit_wgrad_tn_grouped(table, len(pairs), _lib.current_stream_ptr())
     _lib.check(st, "grit_wgrad_tn_grouped")
     return parts
@@ -671,7 +675,7 @@ def weight_grad(dy2, x2, group=None, param=None):
             return group.add(own.unsqueeze(0), dy2.dtype, out=out)[0]
         return slab_sum(own.unsqueeze(0), dy2.dtype, out=out)[0]
     S = split_k(M) if (dy2.is_cuda and dy2.dtype == torch.bfloat16) else 1
-    with timed("gemm_lib", flops=2.0 * M * N * x2.shape[1]):
+    with timed("gemm_lib", **gemm_work(M, N, x2.shape[1], partial_f32=0.0)):
         if S == 1:
             return torch.mm(dy2.t(), x2)
         part = torch.bmm(dy2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, x2.shape[1]), out_dtype=torch.float32)
@@ -727,7 +731,7 @@ class _LinearFn(Function):
         own = _own_linear(x, weight, bias)
         if own is not None:
             return own
-        with timed("gemm_lib", flops=2.0 * x.numel() * weight.shape[0]):
+        with timed("gemm_lib", **gemm_work(x.numel() // x.shape[-1], weight.shape[0], weight.shape[1])):
             return F.linear(x, weight, bias)
 
     @staticmethod
@@ -746,7 +750,7 @@ class _LinearFn(Function):
         if deferred is not None:  # short map inside a gradient-bucket scope: dW / db come from the scope's grouped launch
             dw, db = deferred
             if ctx.needs_input_grad[0]:
-                with timed("gemm_lib", flops=2.0 * dy2.numel() * weight.shape[1]):
+                with timed("gemm_lib", **gemm_work(dy2.shape[0], weight.shape[1], weight.shape[0])):
                     dx = torch.mm(dy2, weight).view(x.shape)
             return dx, dw, db, None
         side = fork(dy2, x2, rows=dy2.shape[0], single_use=ctx.single_use) \
@@ -765,7 +769,7 @@ class _LinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = _own_input_grad(dy2, ctx.weight_obj, x.shape)
             if dx is None:
-                with timed("gemm_lib", flops=2.0 * dy2.numel() * weight.shape[1]):
+                with timed("gemm_lib", **gemm_work(dy2.shape[0], weight.shape[1], weight.shape[0])):
                     dx = torch.mm(dy2, weight).view(x.shape)
         join(side, dw, db)
         return dx, dw, db, None
@@ -782,7 +786,7 @@ class _SharedInputLinearsFn(Function):
         ctx.save_for_backward(x, *weights)
         ctx.n = n
         ctx.set_materialize_grads(False)  # an unused output arrives as None, not as a zero map to multiply
-        with timed("gemm_lib", flops=2.0 * x.numel() * weights[0].shape[0] * n):
+        with timed("gemm_lib", **gemm_work(x.numel() // x.shape[-1], weights[0].shape[0] * n, weights[0].shape[1])):
             return tuple(F.linear(x, w, b) for w, b in zip(weights, biases))
 
     @staticmethod
@@ -800,7 +804,7 @@ class _SharedInputLinearsFn(Function):
             dy2 = dys[l].reshape(-1, dys[l].shape[-1])
             dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
             if ctx.needs_input_grad[0]:
-                with timed("gemm_lib", flops=2.0 * dy2.numel() * weights[l].shape[1]):
+                with timed("gemm_lib", **gemm_work(dy2.shape[0], weights[l].shape[1], weights[l].shape[0])):
                     if dx2 is None:
                         dx2 = torch.mm(dy2, weights[l])
                     else:

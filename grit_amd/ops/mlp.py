@@ -23,7 +23,7 @@ from grit_amd.ops import layer_norm as LN
 from grit_amd.ops import transposed as _transposed
 from grit_amd.ops.linear import (WGRAD_STREAM, SlabGroup, column_sum, defer_weight_bias_grad, finish_group, fork, grad_slot, join,
                                  long_weight_grads_together, on_stream, single_use_now, slab_sum, weight_grad)
-from grit_amd.ops.profiling import timed
+from grit_amd.ops.profiling import gemm_work, timed
 
 MIN_ROWS = 2048
 
@@ -89,7 +89,7 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=No
         if need_x:
             d_n2 = G.long_input_grad(d_pre, params[0] if params is not None else w1)  # NT on fc1.weight^T (own kernel / library NT)
             if d_n2 is None:
-                with timed("gemm_lib", flops=2.0 * d_pre.numel() * w1.shape[1]):
+                with timed("gemm_lib", **gemm_work(d_pre.shape[0], w1.shape[1], w1.shape[0])):
                     d_n2 = torch.mm(d_pre, w1)
         join(side, d_b1, d_w1)
     return d_n2, d_w1, d_b1, d_w2, d_b2
@@ -103,7 +103,7 @@ class _MlpFn(Function):
         ctx.params = (w1, b1, w2, b2) if single_use else None
         x2 = _rows(x)
         pre, act = G.linear_bias_gelu(x2, w1, b1)
-        with timed("gemm_lib", flops=2.0 * act.numel() * w2.shape[0]):
+        with timed("gemm_lib", **gemm_work(act.numel() // act.shape[-1], w2.shape[0], w2.shape[1])):
             out = F.linear(act, w2, b2)
         ctx.save_for_backward(x2, w1, pre, act, w2)
         ctx.shape = x.shape
@@ -132,7 +132,7 @@ class _MlpAddLayerNormFn(Function):
         ctx.params = (w1, b1, w2, b2, weight, bias) if single_use else None
         x2 = _rows(x_in)
         pre, act = G.linear_bias_gelu(x2, w1, b1)
-        with timed("gemm_lib", flops=2.0 * act.numel() * w2.shape[0]):
+        with timed("gemm_lib", **gemm_work(act.numel() // act.shape[-1], w2.shape[0], w2.shape[1])):
             branch = F.linear(act, w2, b2)
         C = shortcut.shape[-1]
         s2 = _rows(shortcut)

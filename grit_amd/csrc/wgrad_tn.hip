@@ -20,7 +20,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 #include "../../include/grit_hip.h"
+#include "gemm_math.h"
 
 namespace {
 
@@ -240,18 +243,256 @@ void wgrad_tn_256_grouped(const TnGroupArgs a) {
     tn_body(a.job[j], (int)(blockIdx.x - a.first_block[j]), lds);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Four-wave variant (the default wherever a problem's rows are a multiple of 64): ONE wave per SIMD with a 128 (n) x 128 (k) wave
+// tile -- 256 accumulators in the AGPR half of the register file -- and gemm_w4.hip's loop shape: a 64-row K step is 128 MFMAs,
+// each followed by at most one LDS read / transfer / address update (plus one VALU of the bias by-product), so everything else
+// issues in the shadow of the matrix pipe; two barriers per step.  Per MFMA the wave reads half the LDS bytes of the eight-wave
+// kernel above (16 fragments feed 64 MFMAs instead of 12 feeding 32), which is what that kernel's loop was bound by (75 % LDS
+// occupancy at two waves per SIMD).
+//   * LDS: two buffers of 64 KB (dY 64 rows x 512 B, X 64 rows x 512 B), rows swizzled exactly as above, + 4 KB column sums;
+//   * transfers: buffer_load_dwordx4 ... lds, a per-lane offset register per operand, scalar offsets per piece and step, the
+//     16 transfers of step s + 2 one at a time between MFMAs once every wave has read the buffer's last fragments;
+//   * fragments of k half 1 (rows 32..63) are read during the first 32 MFMAs of the step, those of half 0 of the NEXT step during
+//     the last 40; the 16 fragment addresses are kept for the buffer in use and flipped (+- 64 KB) in between.
+template <class F, int... Is>
+__device__ __forceinline__ void tn4_each(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+
+template <int OFF> __device__ __forceinline__ v2i tn4_tr(unsigned addr) {
+    v2i v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
+constexpr int k4Rows = 64, k4Op = k4Rows * 512, k4Buf = 2 * k4Op, k4Threads = 256;
+constexpr int k4Lds = 2 * k4Buf + kColBytes;
+
+// CS: 0 no bias by-product; 1 / 2: this wave folds the even / odd dY fragments into column sums (waves wn = 0 / 1 of k-tile 0)
+template <int CS>
+__device__ __forceinline__ void tn4_run(const TnArgs& g, int split, int n0, int k0, int m_begin, int nsteps, char* lds) {
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;  // wave tile: rows n [128 wm, +128), columns k [128 wn, +128)
+    const int l15 = lane & 15, lg = lane >> 4, trq = l15 >> 2, trp = l15 & 3;
+
+    // ---- transfers: piece P = wave + 4 p (p = 0..7) of an operand = rows 2 P, 2 P + 1 of the step, one 1 KB instruction;
+    // LDS position p16 of a row holds logical 16-byte chunk (((p16 >> 1) ^ (row & 7)) << 1) | (p16 & 1); row & 7 = (2 wave + lane / 32) & 7
+    const int prow = 2 * wave + (lane >> 5), p16 = lane & 31;
+    const int pchunk = (((p16 >> 1) ^ (prow & 7)) << 1) | (p16 & 1);
+    const unsigned voffY = (unsigned)(((long)prow * g.ldy + pchunk * 8) * 2);
+    const unsigned voffX = (unsigned)(((long)prow * g.ldx + pchunk * 8) * 2);
+    const int pieceY = (int)(8 * g.ldy * 2), pieceX = (int)(8 * g.ldx * 2);      // bytes between the pieces of a wave
+    const int stepY = (int)(k4Rows * g.ldy * 2), stepX = (int)(k4Rows * g.ldx * 2);
+    const __amdgpu_buffer_rsrc_t rsY =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(g.dY + (size_t)m_begin * g.ldy + n0), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(g.X + (size_t)m_begin * g.ldx + k0), 0, 0x7fffffff, 0x00020000);
+    // the transfer side runs two steps ahead; past the last step it re-fetches the last rows (nobody reads them): no branch in the loop
+    int lks = 0, soffY = 0, soffX = 0;
+    auto dmaY = [&](int buf, int p) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lptr_t)(lds + buf * k4Buf + (wave + 4 * p) * 1024), 16, voffY, p * pieceY + soffY, 0, 0);
+    };
+    auto dmaX = [&](int buf, int p) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lptr_t)(lds + buf * k4Buf + k4Op + (wave + 4 * p) * 1024), 16, voffX, p * pieceX + soffX, 0, 0);
+    };
+    auto advance_load = [&]() {
+        if (lks + 1 < nsteps) { ++lks; soffY += stepY; soffX += stepX; }
+    };
+
+    // ---- fragment addresses (buffer 0): row 4 lg + trq of a 16-row group, 32-byte group (block ^ (row & 7)), 8 bytes at trp;
+    // k half h at +16 384 h, the second 16 rows of a half at +8 192 (immediates)
+    const int r_lo = 4 * lg + trq, sr = r_lo & 7;
+    unsigned ya[8], xa[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        ya[i] = lds0 + r_lo * 512 + wm * 256 + ((i ^ sr) << 5) + trp * 8;
+        xa[i] = lds0 + k4Op + r_lo * 512 + wn * 256 + ((i ^ sr) << 5) + trp * 8;
+    }
+
+    v4f acc[8][8];
+    v4i Y0[8], X0[8], Y1[8], X1[8];                                      // fragments of k half 0 / 1 as the MFMAs take them
+    v2i y0l[8], y0h[8], x0l[8], x0h[8], y1l[8], y1h[8], x1l[8], x1h[8];  // ... as the reads deliver them: rows 0..15 / 16..31 of the half
+#define GRIT_TN4_JOIN(D, L, H)                                                                  \
+    _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) D[e_] = v4i{L[e_][0], L[e_][1], H[e_][0], H[e_][1]}; \
+    GRIT_TN4_TIE(D)
+#define GRIT_TN4_TIE(f) asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]))
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};  // CS: this lane's share of columns 128 wm + 16 (2 f + CS - 1) + l15 (k-slot group lg)
+
+    // ---- prologue: steps 0 and 1 in flight, step 0 landed, its first half in registers
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) dmaY(q, p);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) dmaX(q, p);
+        advance_load();
+    }
+    wait_vm<16>();
+    __builtin_amdgcn_s_barrier();
+    tn4_each([&](auto kc) { constexpr int k = decltype(kc)::value; const unsigned a = xa[k]; x0l[k] = tn4_tr<0>(a); x0h[k] = tn4_tr<8192>(a); },
+             std::make_integer_sequence<int, 8>{});
+    tn4_each([&](auto kc) { constexpr int k = decltype(kc)::value; const unsigned a = ya[k]; y0l[k] = tn4_tr<0>(a); y0h[k] = tn4_tr<8192>(a); },
+             std::make_integer_sequence<int, 8>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    GRIT_TN4_TIE(x0l); GRIT_TN4_TIE(x0h); GRIT_TN4_TIE(y0l); GRIT_TN4_TIE(y0h);
+    GRIT_TN4_JOIN(X0, x0l, x0h); GRIT_TN4_JOIN(Y0, y0l, y0h);
+
+    // One 64-row K step = 128 MFMAs (index m: k half m >> 6, dY block i = (m >> 3) & 7, X block j = m & 7):
+    //   m   0..31   the 32 transposing reads of k half 1 of this buffer (dY blocks, then X blocks)
+    //   m  34       they are in registers + barrier: every wave is done with this buffer
+    //   m  36..81   every 3rd: the 16 transfers of step s + 2 into this buffer
+    //   m  37..82   every 3rd: the 16 fragment addresses move to the other buffer
+    //   m  88       step s + 1 has landed (only the 16 transfers just issued stay counted) + barrier
+    //   m  89..120  the 32 reads of k half 0 of the other buffer (X blocks first: the next step's first MFMAs need all of them)
+    //   CS: m 0..15 and m 38..83 every 3rd: the 16 + 16 dot products of the bias by-product
+    auto kstep = [&](auto firstc, int s) {
+        constexpr bool first = decltype(firstc)::value;
+        const int b = s & 1;
+        const unsigned flip = b ? (unsigned)(-k4Buf) : (unsigned)k4Buf;
+        auto slot = [&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            constexpr int h = m >> 6, i = (m >> 3) & 7, j = m & 7;
+            if constexpr (h == 0 && first) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[i][j]) : "v"(Y0[i]), "v"(X0[j]));
+            else if constexpr (h == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(Y0[i]), "v"(X0[j]));
+            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(Y1[i]), "v"(X1[j]));
+            if constexpr (m < 16) {
+                const unsigned a = ya[m >> 1];
+                if constexpr ((m & 1) == 0) y1l[m >> 1] = tn4_tr<16384>(a);
+                else y1h[m >> 1] = tn4_tr<16384 + 8192>(a);
+            } else if constexpr (m < 32) {
+                const unsigned a = xa[(m - 16) >> 1];
+                if constexpr ((m & 1) == 0) x1l[(m - 16) >> 1] = tn4_tr<16384>(a);
+                else x1h[(m - 16) >> 1] = tn4_tr<16384 + 8192>(a);
+            } else if constexpr (m == 34) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                GRIT_TN4_TIE(y1l); GRIT_TN4_TIE(y1h); GRIT_TN4_TIE(x1l); GRIT_TN4_TIE(x1h);
+                GRIT_TN4_JOIN(Y1, y1l, y1h); GRIT_TN4_JOIN(X1, x1l, x1h);
+                __builtin_amdgcn_s_barrier();
+            } else if constexpr (m >= 36 && m <= 81 && (m - 36) % 3 == 0) {
+                constexpr int d = (m - 36) / 3;
+                if constexpr (d < 8) dmaY(b, d);
+                else dmaX(b, d - 8);
+                if constexpr (d == 15) advance_load();
+            } else if constexpr (m >= 37 && m <= 82 && (m - 37) % 3 == 0) {
+                constexpr int t = (m - 37) / 3;
+                if constexpr (t < 8) { unsigned v = ya[t]; asm volatile("v_add_u32 %0, %1, %0" : "+v"(v) : "s"(flip)); ya[t] = v; }
+                else { unsigned v = xa[t - 8]; asm volatile("v_add_u32 %0, %1, %0" : "+v"(v) : "s"(flip)); xa[t - 8] = v; }
+            } else if constexpr (m == 88) {
+                wait_vm<16>();
+                __builtin_amdgcn_s_barrier();
+            } else if constexpr (m >= 89 && m <= 104) {
+                const unsigned a = xa[(m - 89) >> 1];
+                if constexpr (((m - 89) & 1) == 0) x0l[(m - 89) >> 1] = tn4_tr<0>(a);
+                else x0h[(m - 89) >> 1] = tn4_tr<8192>(a);
+            } else if constexpr (m >= 105 && m <= 120) {
+                const unsigned a = ya[(m - 105) >> 1];
+                if constexpr (((m - 105) & 1) == 0) y0l[(m - 105) >> 1] = tn4_tr<0>(a);
+                else y0h[(m - 105) >> 1] = tn4_tr<8192>(a);
+            }
+            if constexpr (CS != 0) {
+                // dY fragment 2 f + CS - 1, register q of its four: v_dot2 with ones adds the two rows it holds to the column's sum
+                if constexpr (m < 16) {
+                    constexpr int f = m >> 2, q = m & 3, fi = 2 * f + CS - 1;
+                    const int r = Y0[fi][q];
+                    asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(cs[f]) : "v"(r), "s"(0x3f803f80));
+                } else if constexpr (m >= 38 && m <= 83 && (m - 38) % 3 == 0) {
+                    constexpr int e = (m - 38) / 3, f = e >> 2, q = e & 3, fi = 2 * f + CS - 1;
+                    const int r = Y1[fi][q];
+                    asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(cs[f]) : "v"(r), "s"(0x3f803f80));
+                }
+            }
+        };
+        tn4_each(slot, std::make_integer_sequence<int, 128>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        GRIT_TN4_TIE(x0l); GRIT_TN4_TIE(x0h); GRIT_TN4_TIE(y0l); GRIT_TN4_TIE(y0h);
+        GRIT_TN4_JOIN(X0, x0l, x0h); GRIT_TN4_JOIN(Y0, y0l, y0h);
+    };
+    kstep(std::true_type{}, 0);
+    for (int s = 1; s < nsteps; ++s) kstep(std::false_type{}, s);
+    wait_vm<0>();  // the transfers issued past the end must not land in another workgroup's LDS
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last asm MFMAs retire before their accumulators are read
+
+    // ---- epilogue: acc[i][j][r] = dW[n0 + 128 wm + 16 i + 4 lg + r][k0 + 128 wn + 16 j + l15] of this slice
+    float* out = g.partial + ((size_t)split * g.N + n0 + 128 * wm + 4 * lg) * g.K + k0 + 128 * wn + l15;
+    tn4_each([&](auto qc) {
+        constexpr int q = decltype(qc)::value, i = q >> 3, j = q & 7;
+        asm volatile("" : "+a"(acc[i][j]));  // (keeps the quad in its AGPRs up to here: no wholesale copy + spill at the top)
+        const v4f v = acc[i][j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(16 * i + r) * g.K + 16 * j] = v[r];
+    }, std::make_integer_sequence<int, 64>{});
+    if constexpr (CS != 0) {
+        float* colacc = reinterpret_cast<float*>(lds + 2 * k4Buf);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) colacc[lg * kT + wm * 128 + 16 * (2 * f + CS - 1) + l15] = cs[f];
+    }
+}
+
+__device__ __forceinline__ void tn4_body(const TnArgs& g, int logical, char* lds) {
+    const int tiles = g.tiles_n * g.tiles_k;
+    const int split = logical / tiles, tile = logical - split * tiles;
+    const int tn = tile / g.tiles_k, tk = tile - tn * g.tiles_k;
+    const int m_begin = split * g.rows_per_split, m_end = min(g.M, m_begin + g.rows_per_split);
+    const int nsteps = (m_end - m_begin) / k4Rows;
+    const bool colsum = g.db_partial != nullptr && tk == 0;  // workgroup-uniform
+    const int mode = colsum ? 1 + (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) : 0;  // wave-uniform; same barriers on all paths
+    if (mode == 0) tn4_run<0>(g, split, tn * kT, tk * kT, m_begin, nsteps, lds);
+    else if (mode == 1) tn4_run<1>(g, split, tn * kT, tk * kT, m_begin, nsteps, lds);
+    else tn4_run<2>(g, split, tn * kT, tk * kT, m_begin, nsteps, lds);
+    if (colsum) {
+        __syncthreads();
+        const float* colacc = reinterpret_cast<const float*>(lds + 2 * k4Buf);
+        const int tid = threadIdx.x;
+        g.db_partial[(size_t)split * g.N + tn * kT + tid] = (colacc[tid] + colacc[kT + tid]) + (colacc[2 * kT + tid] + colacc[3 * kT + tid]);
+    }
+}
+
+__global__ __launch_bounds__(k4Threads, 1)
+void wgrad_tn4_256(const TnArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int nwg = g.tiles_n * g.tiles_k * g.S;
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int qd = nwg >> 3, rm = nwg & 7;
+    tn4_body(g, (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx, lds);
+}
+
+__global__ __launch_bounds__(k4Threads, 1)
+void wgrad_tn4_256_grouped(const TnGroupArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    int j = 0;
+    while (j + 1 < a.n_jobs && blockIdx.x >= a.first_block[j + 1]) ++j;
+    tn4_body(a.job[j], (int)(blockIdx.x - a.first_block[j]), lds);
+}
+
+// GRIT_WGRAD_TN_W4=0: the eight-wave kernel everywhere (A/B switch)
+bool tn4_enabled() {
+    static const bool on = [] { const char* e = getenv("GRIT_WGRAD_TN_W4"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// the four-wave kernel's conditions on one filled job: 64-row steps, 32-bit byte offsets within a slice
+bool tn4_fits(const TnArgs& a) {
+    return a.M % k4Rows == 0 && a.rows_per_split % k4Rows == 0 && (long)(a.rows_per_split + 8) * a.ldy * 2 < 0x7fffffffL &&
+           (long)(a.rows_per_split + 8) * a.ldx * 2 < 0x7fffffffL;
+}
+
 bool tn_shape_ok(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && N % kT == 0 && K % kT == 0 && M % kBK == 0; }
+
+// rows a slice is a multiple of: 64 (the four-wave kernel's K step) wherever the row count allows it, else the 32 of the eight-wave one
+inline int tn_granule(int M) { return M % 64 == 0 ? 64 : kBK; }
 
 bool tn_fill(TnArgs& a, const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial,
              float* db_partial = nullptr) {
     a.db_partial = db_partial;
     if (!dY || !X || !partial || splits <= 0 || !tn_shape_ok(M, N, K)) return false;
     if (ldy % 8 || ldx % 8 || ldy < N || ldx < K || ((uintptr_t)dY % 16) || ((uintptr_t)X % 16) || ((uintptr_t)partial % 16)) return false;
-    const int steps = M / kBK;
+    const int gr = tn_granule(M), steps = M / gr;
     if (splits > steps) return false;
     a.dY = (const __bf16*)dY; a.ldy = ldy; a.X = (const __bf16*)X; a.ldx = ldx; a.partial = partial;
     a.M = M; a.N = N; a.K = K; a.S = splits;
-    a.rows_per_split = ((steps + splits - 1) / splits) * kBK;
+    a.rows_per_split = ((steps + splits - 1) / splits) * gr;
     if ((M + a.rows_per_split - 1) / a.rows_per_split != splits) return false;  // every slice must own at least one step
     a.tiles_n = N / kT; a.tiles_k = K / kT;
     return true;
@@ -265,9 +506,9 @@ extern "C" int grit_wgrad_tn_splits(int M, int N, int K) {
     const int tiles = (N / kT) * (K / kT);
     int S = 256 / tiles;  // never a second round of workgroups
     if (S < 1) S = 1;
-    const int steps = M / kBK;
+    const int gr = tn_granule(M), steps = M / gr;
     if (S > steps) S = steps;
-    const int rows = ((steps + S - 1) / S) * kBK;
+    const int rows = ((steps + S - 1) / S) * gr;
     return (M + rows - 1) / rows;
 }
 
@@ -282,9 +523,19 @@ extern "C" int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, 
     a.dY = (const __bf16*)dY; a.ldy = ldy; a.X = (const __bf16*)X; a.ldx = ldx; a.partial = partial;
     a.M = M; a.N = N; a.K = K; a.S = splits;
     a.db_partial = db_partial;
-    const int steps = M / kBK;
-    a.rows_per_split = ((steps + splits - 1) / splits) * kBK;
+    const int gr = tn_granule(M), steps = M / gr;
+    a.rows_per_split = ((steps + splits - 1) / splits) * gr;
     a.tiles_n = N / kT; a.tiles_k = K / kT;
+    if (tn4_enabled() && tn4_fits(a)) {
+        static bool attr4_set = false;
+        if (!attr4_set) {
+            if (hipFuncSetAttribute((const void*)wgrad_tn4_256, hipFuncAttributeMaxDynamicSharedMemorySize, k4Lds) != hipSuccess)
+                return GRIT_ERR_LAUNCH;
+            attr4_set = true;
+        }
+        hipLaunchKernelGGL(wgrad_tn4_256, dim3((unsigned)(a.tiles_n * a.tiles_k * splits)), dim3(k4Threads), k4Lds, (hipStream_t)stream, a);
+        return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+    }
     static bool attr_set = false;  // idempotent attribute
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)wgrad_tn_256, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes + kColBytes) != hipSuccess)
@@ -312,6 +563,18 @@ extern "C" int grit_wgrad_tn_grouped(const grit_wgrad_job* jobs, int n_jobs, voi
         if (total > 0x7fffffffULL) return GRIT_ERR_UNSUPPORTED;
     }
     a.first_block[n_jobs] = (unsigned)total;
+    bool four = tn4_enabled();
+    for (int j = 0; j < n_jobs && four; ++j) four = tn4_fits(a.job[j]);
+    if (four) {
+        static bool attr4_set = false;
+        if (!attr4_set) {
+            if (hipFuncSetAttribute((const void*)wgrad_tn4_256_grouped, hipFuncAttributeMaxDynamicSharedMemorySize, k4Lds) != hipSuccess)
+                return GRIT_ERR_LAUNCH;
+            attr4_set = true;
+        }
+        hipLaunchKernelGGL(wgrad_tn4_256_grouped, dim3((unsigned)total), dim3(k4Threads), k4Lds, (hipStream_t)stream, a);
+        return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+    }
     static bool attr_set = false;  // idempotent attribute
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)wgrad_tn_256_grouped, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes + kColBytes) != hipSuccess)

@@ -48,6 +48,10 @@ class GraphedXEStep(object):
         from grit_amd.engine.caption_engine import train_xe_step
         if not supported(model, optimizers):
             raise ValueError("GraphedXEStep needs a Bf16Compute wrapper with FlatAdam optimizers and no collectives in the step")
+        if getattr(model, '_grit_step_graph_taken', False):
+            # a second capture on a wrapper whose first graph was released dies in hipStreamEndCapture (ROCm 7.2, seen in bench.py):
+            # refuse here, callers stay on eager launches
+            raise RuntimeError("this wrapper's training step was captured once already: one step graph per wrapper and process")
         self.model, self.optimizers, self.loss_fn, self.scheduler = model, optimizers, loss_fn, scheduler
         samples = batch['samples']
         self.any_padding = samples.any_padding
@@ -69,6 +73,7 @@ class GraphedXEStep(object):
             with torch.cuda.graph(self.graph):
                 seeds.begin_captured_step(self.device)
                 self.loss = train_xe_step(model, self.static, optimizers, loss_fn)
+        model._grit_step_graph_taken = True
         self.replays = 0
 
     def matches(self, batch):

@@ -574,9 +574,9 @@ WGRAD_TN_PAIR = os.environ.get("GRIT_WGRAD_TN_PAIR", "1") != "0"  # the two weig
 
 def tn_slices(M, want):
     """Row slices the long-map kernel accepts for an M-row problem when `want` are asked for: every slice a whole number of
-    32-row steps and none of them empty (wgrad_tn.hip tn_fill rejects anything else: 58 368 rows = 1 824 steps cut 64 ways are
+    64-row (M % 64 == 0) or 32-row steps and none of them empty (wgrad_tn.hip tn_fill rejects anything else: 58 368 rows = 1 824 steps cut 64 ways are
     29-step slices, i.e. 63 of them).  Same normalisation as grit_wgrad_tn_splits."""
-    steps = max(1, M // 32)
+    steps = max(1, M // (64 if M % 64 == 0 else 32))  # 64-row steps (the four-wave kernel's) wherever the row count allows
     want = max(1, min(int(want), steps))
     per = -(-steps // want)
     return -(-steps // per)

@@ -292,11 +292,13 @@ DEV = "cuda"
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K,pad", [(51200, 2048, 512, 0), (51200, 512, 512, 0), (51200, 1536, 512, 0), (12800, 1024, 4096, 0),
-                                       (2464 * 3 + 32, 256, 256, 8), (64, 256, 512, 0), (204800, 768, 256, 0)])
+                                       (2464 * 3 + 32, 256, 256, 8), (64, 256, 512, 0), (204800, 768, 256, 0),
+                                       (51232, 512, 512, 0), (96, 256, 256, 0), (128, 512, 256, 8), (204800, 256, 1024, 0)])
 def test_long_map_weight_gradient_tn(M, N, K, pad):
-    """grit_wgrad_tn: dW = dY^T X over row slices (fp32 partials) on the Swin shapes -- even and odd numbers of 32-row steps per
-    slice, a last slice shorter than the others, fewer workgroups than CUs, operands with a leading dimension larger than their
-    width -- against an fp64 reference of the same bf16 inputs; shapes outside the contract answer 0 slices."""
+    """grit_wgrad_tn: dW = dY^T X over row slices (fp32 partials) on the Swin shapes -- the four-wave kernel (rows a multiple of
+    64: 64-row steps) and the eight-wave one (M % 64 == 32: 32-row steps), even and odd numbers of steps per slice, one and two
+    steps in all, a last slice shorter than the others, fewer workgroups than CUs, operands with a leading dimension larger than
+    their width -- against an fp64 reference of the same bf16 inputs; shapes outside the contract answer 0 slices."""
     import ctypes
     from grit_amd import lib as _lib
     lib = _lib.load()

@@ -1,6 +1,6 @@
 """Host logic around in-place gradient slots and row slices of the long-map weight-gradient kernel:
   * grit_amd.ops.linear.tn_slices: the slice count handed to grit_wgrad_tn_grouped satisfies the kernel's contract for ANY row count
-    (wgrad_tn.hip tn_fill: every slice a whole number of 32-row steps and none empty);
+    (wgrad_tn.hip tn_fill: every slice a whole number of 64- / 32-row steps and none empty);
   * grad_slot hands a bucket slot out once, only for live parameters whose bucket has not been packed;
   * two gloo ranks, live set flipped between steps, a backward node that writes its weight gradient into the slot: the late path
     must all-reduce the gradient (the round-3 code all-reduced zeros for it and the replicas diverged)."""
@@ -14,17 +14,19 @@ from torch import nn
 
 
 def _contract_ok(M, S):
-    steps = M // 32
+    gr = 64 if M % 64 == 0 else 32  # wgrad_tn.hip tn_granule
+    steps = M // gr
     if S > steps or S <= 0:
         return False
-    rows = -(-steps // S) * 32
+    rows = -(-steps // S) * gr
     return -(-M // rows) == S
 
 
 def test_tn_slices_meets_the_kernel_contract_for_every_row_count():
     from grit_amd.ops.linear import tn_slices
     # ADVICE's example first: Swin stage 1 at 384 x 608, batch 16 -> 58 368 rows, 1 824 steps, 64 slices asked for
-    assert not _contract_ok(58368, 64)
+    assert not _contract_ok(58368, 64) and not _contract_ok(51200, 64)
+    assert tn_slices(51200, 64) == 62 and tn_slices(204800, 64) == 64
     assert _contract_ok(58368, tn_slices(58368, 64))
     bad = []
     for M in list(range(32, 4096, 32)) + [16 * (384 // 8) * (w // 8) for w in range(320, 648, 8)] + [16640, 58368, 51200, 204800]:

@@ -987,7 +987,7 @@ __host__ __device__ inline size_t value_lds_bytes(int S, int L, int Lq, int P) {
 __global__ __launch_bounds__(kValueThreads)
 void msda_bwd_value(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, const float* __restrict__ loc,
                     const float* __restrict__ aw, const __hip_bfloat16* __restrict__ grad_out,
-                    __hip_bfloat16* __restrict__ grad_value, int S, int M, int L, int Lq, int P, int pix_el) {
+                    __hip_bfloat16* __restrict__ grad_value, int S, int M, int L, int Lq, int P, int pix_el, int parts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int LP = L * P, npts = Lq * LP, cap = npts * 4;
     int* cnt = reinterpret_cast<int*>(smem);                                     // [S + 1] counters, then exclusive offsets
@@ -995,7 +995,9 @@ void msda_bwd_value(const int64_t* __restrict__ shapes, const int64_t* __restric
     unsigned char* gol = reinterpret_cast<unsigned char*>(recs + cap);           // [Lq][128 B] rows of grad_out
     int* wsum = reinterpret_cast<int*>(gol + ((size_t)Lq + 1) * 128);            // [16] wave totals of the scan
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int seg = blockIdx.x, b = seg / M, m = seg - b * M;
+    // parts > 1 (B * M below the CU count, e.g. 16 images x 8 heads on 256 CUs): `parts` workgroups per (image, head); each bins all
+    // of the segment's contributions (steps 1 - 3, the cheap part) and takes an equal-cost share of the cell tiles in step 4
+    const int seg = blockIdx.x / parts, part = blockIdx.x - seg * parts, b = seg / M, m = seg - b * M;
 
     // ---- 1. counters to zero, grad_out rows of this (image, head) into LDS, contributions binned
     for (int i = tid; i <= S; i += kValueThreads) cnt[i] = 0;
@@ -1097,8 +1099,9 @@ void msda_bwd_value(const int64_t* __restrict__ shapes, const int64_t* __restric
         }
         return lo;
     };
-    const int tlo = wave == 0 ? 0 : first_tile_at((int)((long)total * wave / nwave));
-    const int thi = wave == nwave - 1 ? T : first_tile_at((int)((long)total * (wave + 1) / nwave));
+    const int gw = part * nwave + wave, ngw = parts * nwave;  // this wave among the segment's waves
+    const int tlo = gw == 0 ? 0 : first_tile_at((int)((long)total * gw / ngw));
+    const int thi = gw == ngw - 1 ? T : first_tile_at((int)((long)total * (gw + 1) / ngw));
     __hip_bfloat16* gbase = grad_value + (size_t)b * S * pix_el + (size_t)m * 64 + 4 * lg;
     const unsigned char* grow = gol + 8 * trp;  // + q * 128 + 32 * cb
     for (int t = tlo; t < thi; ++t) {
@@ -1404,9 +1407,13 @@ int grit_msda_bwd_bf16_sorted(const void* value, long pixel_stride, const int64_
             return GRIT_ERR_LAUNCH;
         lds_attr_set = true;
     }
-    hipLaunchKernelGGL(msda_bwd_value, dim3(B * M), dim3(kValueThreads), value_lds_bytes(S, L, Lq, P), st, spatial_shapes,
+    // fewer (image, head) segments than CUs: several workgroups per segment (GRIT_MSDA_VALUE_PARTS overrides: A/B)
+    static const int parts_env = getenv("GRIT_MSDA_VALUE_PARTS") ? atoi(getenv("GRIT_MSDA_VALUE_PARTS")) : 0;
+    int parts = parts_env > 0 ? parts_env : 256 / (B * M);
+    parts = parts < 1 ? 1 : (parts > 8 ? 8 : parts);
+    hipLaunchKernelGGL(msda_bwd_value, dim3(B * M * parts), dim3(kValueThreads), value_lds_bytes(S, L, Lq, P), st, spatial_shapes,
                        level_start, loc, attn_w, (const __hip_bfloat16*)grad_out, (__hip_bfloat16*)grad_value, S, M, L, Lq, P,
-                       (int)pixel_stride);
+                       (int)pixel_stride, parts);
     if (hipGetLastError() != hipSuccess) return GRIT_ERR_LAUNCH;
     const int nrows = B * Lq * M;
     static const bool rows1 = getenv("GRIT_MSDA_BWD_ROWS1") && atoi(getenv("GRIT_MSDA_BWD_ROWS1")) != 0;  // A/B: one row per wave

@@ -85,15 +85,24 @@ def prefers_own(M, N, K):
     return tiles <= 8192 and (K <= 512 or (K <= 1024 and N >= 1024))
 
 
+def prefers_own_narrow(M, N, K):
+    """The stage-0 maps (819 200 tokens, C = 128): 128 / 384 output columns and K <= 512 are pure HBM streams, where the eight-wave
+    kernel of gemm.hip (variant 0: tile chosen by shape) runs at 0.48-0.63 of the 8 TB/s bound against the library's 0.35-0.58
+    (profiles/r04/s0_gemms.txt: qkv 298 -> 219 us, proj 115 -> 84, qkv input gradient 225 -> 169, fc1 input gradient 274 -> 210)."""
+    return N in (128, 384) and K % 32 == 0 and K <= 512 and M >= 262144 and M * max(N, K) * 2 < 2 ** 31
+
+
 def long_linear(x2, weight, bias):
     """x2 [M, K] @ weight [N, K]^T (+ bias) on the own kernel, or None where the library path is to run."""
     if not (OWN and supported(x2, weight) and (bias is None or (bias.dtype == torch.bfloat16 and bias.data_ptr() % 16 == 0))):
         return None
     M, K = x2.shape
     N = weight.shape[0]
-    if not prefers_own(M, N, K):
-        return None
-    return gemm_nt(x2, weight, BIAS if bias is not None else NONE, bias=bias, variant=7)
+    if prefers_own(M, N, K):
+        return gemm_nt(x2, weight, BIAS if bias is not None else NONE, bias=bias, variant=7)
+    if prefers_own_narrow(M, N, K):
+        return gemm_nt(x2, weight, BIAS if bias is not None else NONE, bias=bias, variant=0)
+    return None
 
 
 def long_input_grad(dy2, weight):
@@ -109,5 +118,7 @@ def long_input_grad(dy2, weight):
         return None
     if supported(dy2, wt) and prefers_own(dy2.shape[0], wt.shape[0], wt.shape[1]):
         return gemm_nt(dy2, wt, NONE, variant=7)
+    if supported(dy2, wt) and prefers_own_narrow(dy2.shape[0], wt.shape[0], wt.shape[1]):
+        return gemm_nt(dy2, wt, NONE, variant=0)
     with timed("gemm_lib", **gemm_work(dy2.shape[0], wt.shape[0], wt.shape[1])):
         return torch.nn.functional.linear(dy2, wt)

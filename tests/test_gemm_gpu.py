@@ -127,6 +127,32 @@ def test_own_long_map_policy_and_linear_nodes():
         _close(g_, r_)
 
 
+@pytest.mark.gpu
+def test_narrow_output_policy_for_the_stage0_maps():
+    """grit_amd.ops.gemm.prefers_own_narrow: the 128- / 384-column products of the 819 200-token stage-0 map run the eight-wave own
+    kernel (variant 0) in the forward and -- on the transposed weight -- in the input gradient; values against fp32 torch."""
+    from grit_amd.ops import gemm as G
+    from grit_amd.ops import transposed
+    assert G.prefers_own_narrow(819200, 384, 128) and G.prefers_own_narrow(819200, 128, 512) and G.prefers_own_narrow(819200, 128, 384)
+    assert not G.prefers_own_narrow(204800, 128, 128) and not G.prefers_own_narrow(819200, 256, 128) and not G.prefers_own_narrow(819200, 128, 1024)
+    torch.manual_seed(3)
+    M = 262144 + 64
+    for N, K in ((384, 128), (128, 512)):
+        x = torch.randn(M, K, device='cuda').bfloat16()
+        w = (torch.randn(N, K, device='cuda') * K ** -0.5).bfloat16()
+        b = torch.randn(N, device='cuda').bfloat16()
+        y = G.long_linear(x, w, b)
+        assert y is not None
+        rows = torch.tensor([0, 255, 256, 99999, M - 1], device='cuda')
+        _close(y[rows], x[rows].float() @ w.float().t() + b.float())
+        cot = torch.randn(M, N, device='cuda').bfloat16()
+        transposed.refresh([w])
+        dx = G.long_input_grad(cot, w)
+        assert dx is not None and dx.shape == (M, K)
+        _close(dx[rows], cot[rows].float() @ w.float())
+
+
+@pytest.mark.gpu
 def test_gemm_full_size_property():
     """BASELINE shape of Swin stage 2 (M = 32 * 40 * 40, 512 -> 2048): linearity in the bias and exact row independence --
     a row's result does not depend on which tile / workgroup computed it."""

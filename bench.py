@@ -658,13 +658,14 @@ def main():
         # ---- GEMM families of the step, each against BOTH of its bounds (per-launch HIP events in 2 eager steps behind the timed region)
         FAMILIES = {
             "gemm_nt_bf16": "gemm_nt_bf16<256,256,64,...> (grit_amd/csrc/gemm.hip): the Swin Mlp's fused GEMMs -- fc1 + bias + GELU "
-                            "writing pre-activation and activation, fc2 input gradient x GELU' + bias-gradient column sums",
+                            "writing pre-activation and activation, fc2 input gradient x GELU' + bias-gradient column sums -- and the stage-0 map's "
+                            "narrow products (128 / 384 output columns, K <= 512: HBM streams)",
             "gemm_w4": "gemm_w4_bf16 (grit_amd/csrc/gemm_w4.hip): persistent four-wave kernel, 128 x 128 wave tiles -- qkv / proj / value "
                        "forward GEMMs and NT input gradients of the long maps where it beats the library",
             "wgrad_tn": "wgrad_tn_256 + wgrad_tn_256_grouped (grit_amd/csrc/wgrad_tn.hip): weight gradients dW = dY^T X of the long token "
                         "maps and, grouped, of the decoders' short ones; fp32 row-slice partials",
             "wgrad_small": "wgrad_small (grit_amd/csrc/wgrad.hip): 64 x 64-tile grouped weight gradients of shapes outside 256-multiples",
-            "gemm_lib": "hipBLASLt / rocBLAS through torch (tuned table grit_amd/tunableop_gfx950.csv): K >= 1024 long-map GEMMs with 512 "
+            "gemm_lib": "hipBLASLt / rocBLAS through torch (tuned table grit_amd/tunableop_gfx950.csv): K >= 1024 long-map GEMMs with <= 512 "
                         "output columns (stream-K), the value projection, every GEMM of the two decoders",
         }
         n_an = 2  # analysis steps the events cover
@@ -686,7 +687,7 @@ def main():
             for name, f in families.items():
                 tt = f["t"]
                 fm, fh = f["flops"] / tt / MFMA_PEAK_BF16, f["bytes"] / tt / 1e9 / HBM_PEAK_GBPS
-                traffic, tsrc = pmc_traffic({"gemm_nt_bf16": "gemm_nt_bf16", "gemm_w4": "gemm_w4_bf16", "wgrad_tn": "wgrad_tn_256_grouped"}.get(name, "\0"))
+                traffic, tsrc = pmc_traffic("family:" + name)
                 gemm[name] = {"kernel": FAMILIES.get(name, name), "launches_per_step": f["n"] / n_an, "ms_per_step": tt / n_an * 1e3,
                               "avg_launch_us": tt / f["n"] * 1e6, "algorithmic_flops_per_launch": f["flops"] / f["n"],
                               "algorithmic_bytes_per_launch": f["bytes"] / f["n"], "TFLOPs": f["flops"] / tt / 1e12,

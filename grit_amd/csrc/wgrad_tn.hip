@@ -48,6 +48,7 @@ struct TnArgs {
     float* partial;           // [S][N][K] fp32
     int M, N, K, S, rows_per_split, tiles_n, tiles_k;
     float* db_partial;        // [S][N] fp32 column sums of dY per slice (the bias gradient), or nullptr
+    int dbg;                  // diagnostics of the four-wave kernel (GRIT_WGRAD_TN_DBG): 1 = every workgroup of a slice LOADS tile (0, 0)
 };
 
 typedef int v2i __attribute__((ext_vector_type(2)));
@@ -287,9 +288,9 @@ __device__ __forceinline__ void tn4_run(const TnArgs& g, int split, int n0, int 
     const int pieceY = (int)(8 * g.ldy * 2), pieceX = (int)(8 * g.ldx * 2);      // bytes between the pieces of a wave
     const int stepY = (int)(k4Rows * g.ldy * 2), stepX = (int)(k4Rows * g.ldx * 2);
     const __amdgpu_buffer_rsrc_t rsY =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(g.dY + (size_t)m_begin * g.ldy + n0), 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(g.dY + (size_t)m_begin * g.ldy + ((g.dbg & 1) ? 0 : n0)), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(g.X + (size_t)m_begin * g.ldx + k0), 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(g.X + (size_t)m_begin * g.ldx + ((g.dbg & 1) ? 0 : k0)), 0, 0x7fffffff, 0x00020000);
     // the transfer side runs two steps ahead; past the last step it re-fetches the last rows (nobody reads them): no branch in the loop
     int lks = 0, soffY = 0, soffX = 0;
     auto dmaY = [&](int buf, int p) {
@@ -319,7 +320,10 @@ __device__ __forceinline__ void tn4_run(const TnArgs& g, int split, int n0, int 
     _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) D[e_] = v4i{L[e_][0], L[e_][1], H[e_][0], H[e_][1]}; \
     GRIT_TN4_TIE(D)
 #define GRIT_TN4_TIE(f) asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]))
-    float cs[4] = {0.f, 0.f, 0.f, 0.f};  // CS: this lane's share of columns 128 wm + 16 (2 f + CS - 1) + l15 (k-slot group lg)
+    // CS: cs[f][r] = column sum of dY at n = 128 wm + 16 (2 f + CS - 1) + 4 lg + r (the same value in all 16 lanes of a group)
+    v4f cs[4] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+    v4i ones = {0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};
+    asm volatile("" : "+v"(ones));
 
     // ---- prologue: steps 0 and 1 in flight, step 0 landed, its first half in registers
 #pragma unroll
@@ -347,7 +351,7 @@ __device__ __forceinline__ void tn4_run(const TnArgs& g, int split, int n0, int 
     //   m  37..82   every 3rd: the 16 fragment addresses move to the other buffer
     //   m  88       step s + 1 has landed (only the 16 transfers just issued stay counted) + barrier
     //   m  89..120  the 32 reads of k half 0 of the other buffer (X blocks first: the next step's first MFMAs need all of them)
-    //   CS: m 0..15 and m 38..83 every 3rd: the 16 + 16 dot products of the bias by-product
+    //   CS: m 16..19 and m 84..87: one more MFMA each (the bias by-product, dY fragment x ones)
     auto kstep = [&](auto firstc, int s) {
         constexpr bool first = decltype(firstc)::value;
         const int b = s & 1;
@@ -393,15 +397,16 @@ __device__ __forceinline__ void tn4_run(const TnArgs& g, int split, int n0, int 
                 else y0h[(m - 105) >> 1] = tn4_tr<8192>(a);
             }
             if constexpr (CS != 0) {
-                // dY fragment 2 f + CS - 1, register q of its four: v_dot2 with ones adds the two rows it holds to the column's sum
-                if constexpr (m < 16) {
-                    constexpr int f = m >> 2, q = m & 3, fi = 2 * f + CS - 1;
-                    const int r = Y0[fi][q];
-                    asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(cs[f]) : "v"(r), "s"(0x3f803f80));
-                } else if constexpr (m >= 38 && m <= 83 && (m - 38) % 3 == 0) {
-                    constexpr int e = (m - 38) / 3, f = e >> 2, q = e & 3, fi = 2 * f + CS - 1;
-                    const int r = Y1[fi][q];
-                    asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(cs[f]) : "v"(r), "s"(0x3f803f80));
+                // bias by-product: dY fragment 2 f + CS - 1 times a block of ones on the matrix pipe -- D[n][*] += sum over the half
+                // step's 32 rows of dY[row][n]: 8 extra MFMAs per K step (+6 %).  (As v_dot2_f32_bf16 chains on the VALU the same
+                // sums cost the workgroup 22 % -- 97 -> 120 us at M 51 200, N 2 048, K 512 -- and the workgroups that carry them fell
+                // behind their L2 neighbours.)
+                if constexpr (m >= 16 && m < 20) {
+                    constexpr int f = m - 16, fi = 2 * f + CS - 1;
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(cs[f]) : "v"(Y0[fi]), "v"(ones));
+                } else if constexpr (m >= 84 && m < 88) {
+                    constexpr int f = m - 84, fi = 2 * f + CS - 1;
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(cs[f]) : "v"(Y1[fi]), "v"(ones));
                 }
             }
         };
@@ -425,9 +430,15 @@ __device__ __forceinline__ void tn4_run(const TnArgs& g, int split, int n0, int 
         for (int r = 0; r < 4; ++r) out[(size_t)(16 * i + r) * g.K + 16 * j] = v[r];
     }, std::make_integer_sequence<int, 64>{});
     if constexpr (CS != 0) {
+        // lanes l15 = 0 write the sums into copy 0 of the column-sum block, lanes 1..3 zero copies 1..3 (tn4_body adds the four)
+        asm volatile("s_nop 15" ::: "memory");
         float* colacc = reinterpret_cast<float*>(lds + 2 * k4Buf);
+        if (l15 < 4) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) colacc[lg * kT + wm * 128 + 16 * (2 * f + CS - 1) + l15] = cs[f];
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) colacc[l15 * kT + wm * 128 + 16 * (2 * f + CS - 1) + 4 * lg + r] = l15 == 0 ? cs[f][r] : 0.f;
+        }
     }
 }
 
@@ -438,7 +449,10 @@ __device__ __forceinline__ void tn4_body(const TnArgs& g, int logical, char* lds
     const int m_begin = split * g.rows_per_split, m_end = min(g.M, m_begin + g.rows_per_split);
     const int nsteps = (m_end - m_begin) / k4Rows;
     const bool colsum = g.db_partial != nullptr && tk == 0;  // workgroup-uniform
-    const int mode = colsum ? 1 + (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) : 0;  // wave-uniform; same barriers on all paths
+    // (GRIT_WGRAD_TN_DBG & 2: EVERY workgroup of a problem with a by-product runs its MFMAs, so that all run at one pace; measured
+    // equal to k-tile 0 alone, stand-alone and in the step -- profiles/r04/wgrad_tn_notes.txt)
+    const bool cs_code = (g.dbg & 2) ? g.db_partial != nullptr : colsum;
+    const int mode = cs_code ? 1 + (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) : 0;  // wave-uniform; same barriers on all paths
     if (mode == 0) tn4_run<0>(g, split, tn * kT, tk * kT, m_begin, nsteps, lds);
     else if (mode == 1) tn4_run<1>(g, split, tn * kT, tk * kT, m_begin, nsteps, lds);
     else tn4_run<2>(g, split, tn * kT, tk * kT, m_begin, nsteps, lds);
@@ -473,6 +487,10 @@ bool tn4_enabled() {
     return on;
 }
 // the four-wave kernel's conditions on one filled job: 64-row steps, 32-bit byte offsets within a slice
+int tn4_dbg() {
+    static const int v = [] { const char* e = getenv("GRIT_WGRAD_TN_DBG"); return e ? atoi(e) : 0; }();
+    return v;
+}
 bool tn4_fits(const TnArgs& a) {
     return a.M % k4Rows == 0 && a.rows_per_split % k4Rows == 0 && (long)(a.rows_per_split + 8) * a.ldy * 2 < 0x7fffffffL &&
            (long)(a.rows_per_split + 8) * a.ldx * 2 < 0x7fffffffL;
@@ -486,6 +504,7 @@ inline int tn_granule(int M) { return M % 64 == 0 ? 64 : kBK; }
 bool tn_fill(TnArgs& a, const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial,
              float* db_partial = nullptr) {
     a.db_partial = db_partial;
+    a.dbg = tn4_dbg();
     if (!dY || !X || !partial || splits <= 0 || !tn_shape_ok(M, N, K)) return false;
     if (ldy % 8 || ldx % 8 || ldy < N || ldx < K || ((uintptr_t)dY % 16) || ((uintptr_t)X % 16) || ((uintptr_t)partial % 16)) return false;
     const int gr = tn_granule(M), steps = M / gr;
@@ -523,6 +542,7 @@ extern "C" int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, 
     a.dY = (const __bf16*)dY; a.ldy = ldy; a.X = (const __bf16*)X; a.ldx = ldx; a.partial = partial;
     a.M = M; a.N = N; a.K = K; a.S = splits;
     a.db_partial = db_partial;
+    a.dbg = tn4_dbg();
     const int gr = tn_granule(M), steps = M / gr;
     a.rows_per_split = ((steps + splits - 1) / splits) * gr;
     a.tiles_n = N / kT; a.tiles_k = K / kT;

@@ -27,7 +27,7 @@ def main():
     torch.manual_seed(0)
     rows = {0: 819200, 1: 204800, 2: 51200, 3: 12800}
     shapes = []
-    for st, C in ((1, 256), (2, 512), (3, 1024)):
+    for st, C in ((0, 128), (1, 256), (2, 512), (3, 1024)):
         M = rows[st]
         shapes += [("qkv fwd s%d" % st, M, 3 * C, C), ("proj fwd/dgrad s%d" % st, M, C, C), ("fc2 fwd / fc1 dgrad s%d" % st, M, C, 4 * C),
                    ("qkv dgrad s%d" % st, M, C, 3 * C), ("fc1 fwd (bias only) s%d" % st, M, 4 * C, C)]
@@ -45,10 +45,15 @@ def main():
             G.gemm_nt(x, w, G.BIAS, bias=b, out=out, variant=7)
             err = ((out.float() - ref.float()).abs().max() / ref.float().abs().max()).item()
             t_own = t(lambda: G.gemm_nt(x, w, G.BIAS, bias=b, out=out, variant=7))
-            print("%-26s M%-7d N%-5d K%-5d  lib NT %6.1f  lib NN %6.1f  own %6.1f us  (%.2f x NT)  err %.1e" %
-                  (name, M, N, K, t_lib, t_mm, t_own, t_lib / t_own, err), flush=True)
+            t_v0 = t(lambda: G.gemm_nt(x, w, G.BIAS, bias=b, out=out, variant=0))
+            print("%-26s M%-7d N%-5d K%-5d  lib NT %6.1f  lib NN %6.1f  own %6.1f us  (%.2f x NT)  err %.1e  | eight-wave v0 %6.1f" %
+                  (name, M, N, K, t_lib, t_mm, t_own, t_lib / t_own, err, t_v0), flush=True)
         except Exception as e:
-            print("%-26s M%-7d N%-5d K%-5d  lib NT %6.1f  lib NN %6.1f  own: %s" % (name, M, N, K, t_lib, t_mm, str(e)[:60]), flush=True)
+            try:
+                t_v0 = t(lambda: G.gemm_nt(x, w, G.BIAS, bias=b, out=out, variant=0))
+            except Exception:
+                t_v0 = float("nan")
+            print("%-26s M%-7d N%-5d K%-5d  lib NT %6.1f  lib NN %6.1f  own: %s  | eight-wave v0 %6.1f" % (name, M, N, K, t_lib, t_mm, str(e)[:40], t_v0), flush=True)
 
 
 if __name__ == "__main__":

@@ -236,12 +236,29 @@ struct TnGroupArgs {
     int n_jobs;
 };
 
+
+// XCD-aware order inside a grouped launch: hardware sends workgroup b to XCD b % 8.  The workgroups of job j occupy the block range
+// [first, first + nwg); those of one XCD take a CONTIGUOUS band of the job's (slice, tile) pairs in block order, so that the tiles of a
+// slice -- which share its rows of dY and X -- run in one XCD and meet in its L2 (the single-job kernels do the same from block 0).
+// Without it the 16 tiles of a slice sit in 8 different L2s: PMC in the step, 1 081 MB fetched per grouped launch against 524 MB of
+// unique operands (profiles/r04/pmc_in_step.txt).
+__device__ __forceinline__ int tn_group_logical(unsigned bid, unsigned first, unsigned nwg) {
+    const unsigned x = bid & 7u;
+    unsigned start = 0;
+    for (unsigned xx = 0; xx < x; ++xx) {
+        const unsigned f0 = first + ((xx + 8u - (first & 7u)) & 7u);  // first block of the job on XCD xx
+        start += f0 < first + nwg ? (first + nwg - 1u - f0) / 8u + 1u : 0u;
+    }
+    const unsigned fx = first + ((x + 8u - (first & 7u)) & 7u);
+    return (int)(start + ((bid - fx) >> 3));
+}
+
 __global__ __launch_bounds__(kThreads, 2)
 void wgrad_tn_256_grouped(const TnGroupArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     int j = 0;
     while (j + 1 < a.n_jobs && blockIdx.x >= a.first_block[j + 1]) ++j;
-    tn_body(a.job[j], (int)(blockIdx.x - a.first_block[j]), lds);
+    tn_body(a.job[j], tn_group_logical(blockIdx.x, a.first_block[j], a.first_block[j + 1] - a.first_block[j]), lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -478,7 +495,9 @@ void wgrad_tn4_256_grouped(const TnGroupArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     int j = 0;
     while (j + 1 < a.n_jobs && blockIdx.x >= a.first_block[j + 1]) ++j;
-    tn4_body(a.job[j], (int)(blockIdx.x - a.first_block[j]), lds);
+    const int logical = (a.job[j].dbg & 4) ? (int)(blockIdx.x - a.first_block[j])  // (A/B: block order, tiles of a slice over all XCDs)
+                                           : tn_group_logical(blockIdx.x, a.first_block[j], a.first_block[j + 1] - a.first_block[j]);
+    tn4_body(a.job[j], logical, lds);
 }
 
 // GRIT_WGRAD_TN_W4=0: the eight-wave kernel everywhere (A/B switch)

@@ -439,12 +439,16 @@ __device__ __forceinline__ void tn4_run(const TnArgs& g, int split, int n0, int 
 
     // ---- epilogue: acc[i][j][r] = dW[n0 + 128 wm + 16 i + 4 lg + r][k0 + 128 wn + 16 j + l15] of this slice
     float* out = g.partial + ((size_t)split * g.N + n0 + 128 * wm + 4 * lg) * g.K + k0 + 128 * wn + l15;
+    const bool nt_out = (g.dbg & 8) != 0;  // A/B: the slice partials streamed past L2
     tn4_each([&](auto qc) {
         constexpr int q = decltype(qc)::value, i = q >> 3, j = q & 7;
         asm volatile("" : "+a"(acc[i][j]));  // (keeps the quad in its AGPRs up to here: no wholesale copy + spill at the top)
         const v4f v = acc[i][j];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(size_t)(16 * i + r) * g.K + 16 * j] = v[r];
+        for (int r = 0; r < 4; ++r) {
+            if (nt_out) __builtin_nontemporal_store(v[r], &out[(size_t)(16 * i + r) * g.K + 16 * j]);
+            else out[(size_t)(16 * i + r) * g.K + 16 * j] = v[r];
+        }
     }, std::make_integer_sequence<int, 64>{});
     if constexpr (CS != 0) {
         // lanes l15 = 0 write the sums into copy 0 of the column-sum block, lanes 1..3 zero copies 1..3 (tn4_body adds the four)

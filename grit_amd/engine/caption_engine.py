@@ -156,6 +156,45 @@ def train_xe_step(model, batch, optimizers, loss_fn, scheduler=None, autocast_dt
     return loss
 
 
+class _XEStepper(object):
+    """train_xe's step: eager launches, or -- GRIT_TRAIN_STEP_GRAPH=1, one rank, Bf16Compute + FlatAdam, no autocast -- the step
+    captured ONCE as a HIP graph (grit_amd/engine/graph_step.py) after two eager steps on the first batch shape and replayed for
+    every batch of that shape (collators that pad to a fixed size make that every batch but an epoch's last); other batches, and
+    everything once the wrapper's live parameter set changed, run eagerly.  The captured graph is kept on the wrapper across epochs
+    (one capture per wrapper and process)."""
+
+    def __init__(self, model, optimizers, loss_fn, scheduler, autocast_dtype):
+        import os
+        self.args = (model, optimizers, loss_fn, scheduler, autocast_dtype)
+        self.want = os.environ.get("GRIT_TRAIN_STEP_GRAPH", "0") == "1" and autocast_dtype is None
+        self.eager_seen = 0
+
+    def __call__(self, batch):
+        model, optimizers, loss_fn, scheduler, autocast_dtype = self.args
+        if self.want and batch['captions'].is_cuda:
+            from grit_amd.engine import graph_step
+            g = getattr(model, '_grit_step_graph', None)
+            if g is not None and g.graph is not None and g.loss_fn_ignore == loss_fn.ignore_index and g.matches(batch):
+                g.scheduler = scheduler
+                return g(batch)
+            if g is None and graph_step.supported(model, optimizers) and not getattr(model, '_grit_step_graph_taken', False):
+                if self.eager_seen >= 2:
+                    try:
+                        g = graph_step.GraphedXEStep(model, optimizers, loss_fn, batch, scheduler=scheduler, eager_steps=0)
+                        g.loss_fn_ignore = loss_fn.ignore_index
+                        model._grit_step_graph = g
+                        return g(batch)  # (a capture records, it does not run: the first replay is this batch's step)
+                    except Exception as e:  # stay on eager launches; say so once
+                        import sys
+                        sys.stderr.write("train_xe: step graph not captured (%s: %s); eager launches\n" % (type(e).__name__, str(e)[:200]))
+                        self.want = False
+                        for o in (optimizers['model'], optimizers['backbone']):
+                            if hasattr(o, 'device_hyper'):
+                                o.device_hyper = False
+                self.eager_seen += 1
+        return train_xe_step(model, batch, optimizers, loss_fn, scheduler, autocast_dtype)
+
+
 def train_xe(model, dataloaders, optimizers, text_field, epoch, rank=0, config=None, scheduler=None, writer=None,
              autocast_dtype=None, evaluate=True, checkpoint=True):
     model.train()
@@ -164,8 +203,9 @@ def train_xe(model, dataloaders, optimizers, text_field, epoch, rank=0, config=N
         scheduler.step()
     running = .0
     n = len(dataloaders['train'])
+    stepper = _XEStepper(model, optimizers, loss_fn, scheduler, autocast_dtype)
     for it, batch in enumerate(_progress(dataloaders['train'], desc=f'Epoch {epoch} - train', unit='it')):
-        loss = train_xe_step(model, batch, optimizers, loss_fn, scheduler, autocast_dtype)
+        loss = stepper(batch)
         running += loss.item()  # the reference syncs to the host every step as well (:343)
         if rank == 0 and writer is not None:
             writer.add_scalar('backbone_lr', optimizers['backbone'].param_groups[0]['lr'], epoch * n + it)

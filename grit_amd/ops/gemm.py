@@ -46,11 +46,20 @@ def gemm_nt(a, b, epilogue=NONE, bias=None, aux=None, colsum=None, out=None, var
     return out
 
 
+def _fused_variant(M, N, K):
+    """Tile variant of the fused Mlp GEMMs: the four-wave persistent kernel where a tile has >= 16 K steps to amortise its exposed
+    GELU epilogue (stage 3, K = 1 024: fc1 + GELU 134 -> 118 us, fc2-dgrad x GELU' 152 -> 134), the eight-wave one elsewhere
+    (stage 2: 146 / 186 against 167 / 182; profiles/r04/fused_variants.txt).  GRIT_GEMM_VARIANT overrides."""
+    if VARIANT:
+        return VARIANT
+    return 7 if (OWN and K >= 1024 and K % 64 == 0 and N % 256 == 0 and M >= 256 and M * K * 2 < 2 ** 31 and N * K * 2 < 2 ** 31) else 0
+
+
 def linear_bias_gelu(x2, weight, bias):
     """(pre, act) = (x2 @ weight^T + bias, gelu(x2 @ weight^T + bias)), both [M, N] bf16, one kernel."""
     M, N = x2.shape[0], weight.shape[0]
     pre = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
-    act = gemm_nt(x2, weight, BIAS_GELU, bias=bias, aux=pre)
+    act = gemm_nt(x2, weight, BIAS_GELU, bias=bias, aux=pre, variant=_fused_variant(M, N, x2.shape[1]))
     return pre, act
 
 
@@ -59,8 +68,10 @@ def input_grad_dgelu(dy2, weight_t, pre):
     weight transposed; colsum_partial [ceil(M / 128), N_hidden] f32 sums to the bias gradient of the Linear that produced pre."""
     M = dy2.shape[0]
     N = weight_t.shape[0]
-    partial = torch.empty((-(-M // COLSUM_ROWS), N), dtype=torch.float32, device=dy2.device)
-    d_pre = gemm_nt(dy2, weight_t, DGELU, aux=pre, colsum=partial)
+    v = _fused_variant(M, N, dy2.shape[1])
+    # (the four-wave kernel writes one row of sums per 128-row wave block of its 256-row tiles: 2 ceil(M / 256) rows, all written)
+    partial = torch.empty((2 * -(-M // 256) if v == 7 else -(-M // COLSUM_ROWS), N), dtype=torch.float32, device=dy2.device)
+    d_pre = gemm_nt(dy2, weight_t, DGELU, aux=pre, colsum=partial, variant=v)
     return d_pre, partial
 
 

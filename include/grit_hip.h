@@ -367,9 +367,11 @@ int grit_wgrad_group_splits(int M);
 int grit_wgrad_small_grouped(const grit_wgrad_job* jobs, int n_jobs, void* stream);
 /* The same job table through the long-map kernel (grit_wgrad_tn's 256 x 256 tiles, one launch for all jobs): for jobs with
  * N % 256 == 0, K % 256 == 0, M % 32 == 0 (grit_wgrad_tn_group_ok), db_partial [splits, N] (column sums per slice) or NULL,
- * splits = any number of row slices such that every slice owns at least one 32-row step -- the caller picks it so that the tiles of
- * all jobs together fill the chip with LONG loops (thirty M = 4 800 problems are 128 tiles x 2 slices of 75 steps).  dW_partial
- * [splits, N, K] fp32 as above. */
+ * splits = any number of row slices such that every slice owns at least one step (64 rows when M % 64 == 0, else 32; slice s =
+ * rows [s * ceil(steps / splits) * step_rows, ...)) -- the caller picks it so that the tiles of all jobs together fill the chip with
+ * LONG loops (thirty M = 4 800 problems are 128 tiles x 2 slices of 38 steps).  dW_partial [splits, N, K] fp32 as above.  When every
+ * job has M % 64 == 0 the launch runs the four-wave kernel (wgrad_tn4_256_grouped), else the eight-wave one; in both the workgroups
+ * of one XCD (block % 8) take a contiguous band of a job's (slice, tile) pairs. */
 int grit_wgrad_tn_group_ok(int M, int N, int K);
 int grit_wgrad_tn_grouped(const grit_wgrad_job* jobs, int n_jobs, void* stream);
 /* Column sums of up to GRIT_COLSUM_GROUP_MAX bf16 matrices x [M, N] (leading dimension ld) in one launch:
@@ -399,8 +401,10 @@ int grit_transpose_bf16_grouped(const grit_transpose_job* jobs, int n_jobs, void
  * operands; the transpose happens in the LDS reads (ds_read_b64_tr_b16 on both MFMA operands, grit_amd/csrc/wgrad_tn.hip).
  * Replaces the batched library GEMM over row slices of autograd's Linear backward (models/common/swin_model.py:26-35, 147-149).
  * N, K multiples of 256, M a multiple of 32 (grit_wgrad_tn_splits returns 0 otherwise: use the library), 16-byte aligned bases,
- * leading dimensions multiples of 8.  db_partial != NULL: [S, N] fp32 column sums of dY per slice (the bias gradient) as a
- * by-product of the workgroups of k-tile 0 (v_dot2 on the dY^T fragments they hold anyway + LDS adds, in the MFMAs' shadow). */
+ * leading dimensions multiples of 8.  Slices are whole steps of 64 rows when M % 64 == 0 (the four-wave kernel: 128 x 128 wave
+ * tiles, AGPR accumulators; GRIT_WGRAD_TN_W4=0 selects the eight-wave kernel for A/B runs), of 32 rows otherwise (eight waves).
+ * db_partial != NULL: [S, N] fp32 column sums of dY per slice (the bias gradient) as a by-product of the workgroups of k-tile 0
+ * (four waves: one extra MFMA per dY^T fragment against a block of ones; eight waves: v_dot2 on the fragments + LDS adds). */
 int grit_wgrad_tn_splits(int M, int N, int K);
 int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial,
                   float* db_partial, void* stream);
@@ -465,7 +469,11 @@ int grit_image_batch_fwd(const uint8_t* src, const int64_t* desc, const int32_t*
  *                        (fp32, before the bf16 rounding of C), s < ceil(M / GRIT_GEMM_COLSUM_ROWS): fully overwritten, to be summed over s
  *                        with grit_slab_sum (the bias gradient of the Linear that produced aux)
  * Needs N % 128 == 0, K % 32 == 0, 16-byte aligned bases; M is free.  variant 0 = tile configuration chosen from the
- * shape (1..4 = explicit configurations for A/B runs; results are identical).
+ * shape; 1..4 = explicit eight-wave configurations, 5 = persistent ping-pong, 6 = persistent stream with a trickled epilogue
+ * (gemm_ps.hip; kept for A/B: slower), 7 = persistent FOUR-wave kernel with 128 x 128 wave tiles (gemm_w4.hip: N % 256 == 0,
+ * K % 64 == 0, M >= 256, operands below 2 GiB; what the long-map forward / input-gradient GEMMs run where it beats the library).
+ * Results are bit-identical across variants; variant 7 writes its GRIT_GEMM_DGELU column sums as 2 * ceil(M / 256) rows (one per
+ * 128-row wave block of its 256-row tiles; every row written).
  * ------------------------------------------------------------------------------------------------------ */
 #define GRIT_GEMM_NONE 0
 #define GRIT_GEMM_BIAS 1

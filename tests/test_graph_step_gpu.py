@@ -136,3 +136,40 @@ def test_batch_that_does_not_fit_is_refused():
         step(other)
     step.release()
     assert float(train_xe_step(wrapped, a, opts, loss_fn)) > 0  # eager steps work again after the graph is dropped
+
+
+def test_train_xe_uses_the_step_graph_when_asked(monkeypatch):
+    """engine.caption_engine.train_xe with GRIT_TRAIN_STEP_GRAPH=1: two eager steps, one capture, replays for the batches of the captured
+    shape, eager launches for a batch of another shape; the epoch's mean loss equals the eager epoch's within the tolerance of
+    test_replayed_steps_equal_eager_steps; without the variable no graph is taken."""
+    from grit_amd.engine.caption_engine import train_xe
+    from grit_amd.utils.misc import NestedTensor
+    a, b = _batches()
+    odd = {'samples': NestedTensor(a['samples'].tensors[:1].contiguous(), a['samples'].mask[:1].contiguous()), 'captions': a['captions'][:1].contiguous()}
+    order = [a, b, a, b, odd, a]
+
+    class Field(object):
+        class vocab(object):
+            stoi = {'<pad>': 1}
+
+    def epoch():
+        wrapped, opts, _ = _setup()
+        init = _masters(wrapped, PICKS)
+        res = train_xe(wrapped, {'train': order}, opts, Field(), 0, evaluate=False, checkpoint=False)
+        return wrapped, res['loss'], init
+
+    monkeypatch.delenv("GRIT_TRAIN_STEP_GRAPH", raising=False)
+    w0, eager, m_init = epoch()
+    assert getattr(w0, '_grit_step_graph', None) is None
+    m_eager = _masters(w0, PICKS)
+    del w0
+    torch.cuda.empty_cache()
+    monkeypatch.setenv("GRIT_TRAIN_STEP_GRAPH", "1")
+    w1, graphed, _ = epoch()
+    g = getattr(w1, '_grit_step_graph', None)
+    assert g is not None and g.replays == 3, None if g is None else g.replays  # steps 3, 4 and 6 (the capture's own replay included)
+    assert np.isfinite(graphed) and abs(graphed - eager) < 8e-3 * abs(eager), (eager, graphed)
+    m_graph = _masters(w1, PICKS)
+    for n in PICKS:  # (same bar as test_replayed_steps_equal_eager_steps: Adam turns gradient noise into differences of the step's size)
+        moved = float(torch.linalg.norm(m_eager[n] - m_init[n]))
+        assert float(torch.linalg.norm(m_graph[n] - m_eager[n])) < 0.25 * moved, n

@@ -838,6 +838,11 @@ def linear(x, weight, bias, single_use=False):
             and x.dtype in (torch.bfloat16, torch.float32) and weight.shape[0] % 8 == 0
             and x.numel() // x.shape[-1] >= MIN_ROWS)
     if not fits:
+        if (backend.override() is None and x.is_cuda and not torch.is_autocast_enabled() and x.dtype == torch.bfloat16
+                and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad))):
+            own = _own_linear(x, weight, bias)  # frozen stage / inference: the long-map kernels where the policy prefers them
+            if own is not None:
+                return own
         return F.linear(x, weight, bias)
     return _LinearFn.apply(x, weight, bias, single_use_now(single_use))
 

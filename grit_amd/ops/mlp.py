@@ -194,7 +194,10 @@ def mlp(x, module):
     fc1, fc2 = module.fc1, module.fc2
     if not (torch.is_grad_enabled() and (x.requires_grad or fc1.weight.requires_grad or fc2.weight.requires_grad)):
         act = G.gemm_nt(_rows(x), fc1.weight, G.BIAS_GELU, bias=fc1.bias)  # frozen stage / inference: no pre-activation kept
-        return F.linear(act, fc2.weight, fc2.bias).view(x.shape[:-1] + (fc2.weight.shape[0],))
+        out = G.long_linear(act, fc2.weight, fc2.bias)  # (stage-0 map: the own narrow-output kernel)
+        if out is None:
+            out = F.linear(act, fc2.weight, fc2.bias)
+        return out.view(x.shape[:-1] + (fc2.weight.shape[0],))
     return _MlpFn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias,
                         single_use_now(getattr(fc1, "single_use", False) and getattr(fc2, "single_use", False)))
 

@@ -15,9 +15,11 @@ What makes the step capturable (everything else already was -- no host read, no 
     fused decoder glue take part in the capture (backend.capturing_train_step) -- the graph's private pool owns every tensor
     whose raw address a deferred job keeps.
 
-Scope: a static-shape step -- same batch shape, same `any_padding` flag, same live parameter set -- on ONE rank (no collective is
-captured: with world > 1 the eager step keeps the RCCL overlap that was tested on gloo; GRIT_STEP_GRAPH_COLLECTIVES=1 captures
-them too, untested on hardware).  `GraphedXEStep.matches(batch)` says whether a batch fits; callers fall back to the eager step
+Scope: a static-shape step -- same batch shape, same `any_padding` flag, same live parameter set -- on ONE rank.  No collective is
+captured: with world > 1 the eager step keeps the RCCL overlap that was tested on gloo.  (Tried on hardware with a one-rank RCCL
+group, round 4: torch's ProcessGroupNCCL watchdog thread queries the collectives' events while the stream is capturing --
+hipErrorStreamCaptureUnsupported invalidates the capture and the watchdog's exception terminates the process.  `supported()`
+therefore refuses any wrapper whose gradient sync issues collectives.)  `GraphedXEStep.matches(batch)` says whether a batch fits; callers fall back to the eager step
 for the odd batch (the last one of an epoch) or keep one graph per shape.
 """
 import os
@@ -35,7 +37,7 @@ def supported(model, optimizers):
     ddp = getattr(model, 'ddp', None)
     if ddp is None or not getattr(model, 'flat_optimizer', False):
         return False
-    if ddp.collective and os.environ.get("GRIT_STEP_GRAPH_COLLECTIVES") != "1":
+    if ddp.collective:
         return False
     return all(hasattr(optimizers[k], 'prepare_replay') for k in ('model', 'backbone'))
 

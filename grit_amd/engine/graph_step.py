@@ -15,11 +15,14 @@ What makes the step capturable (everything else already was -- no host read, no 
     fused decoder glue take part in the capture (backend.capturing_train_step) -- the graph's private pool owns every tensor
     whose raw address a deferred job keeps.
 
-Scope: a static-shape step -- same batch shape, same `any_padding` flag, same live parameter set -- on ONE rank.  No collective is
-captured: with world > 1 the eager step keeps the RCCL overlap that was tested on gloo.  (Tried on hardware with a one-rank RCCL
-group, round 4: torch's ProcessGroupNCCL watchdog thread queries the collectives' events while the stream is capturing --
-hipErrorStreamCaptureUnsupported invalidates the capture and the watchdog's exception terminates the process.  `supported()`
-therefore refuses any wrapper whose gradient sync issues collectives.)  `GraphedXEStep.matches(batch)` says whether a batch fits; callers fall back to the eager step
+Scope: a static-shape step -- same batch shape, same `any_padding` flag, same live parameter set.  By default on ONE rank without
+collectives: with world > 1 the eager step keeps the RCCL overlap that was tested on gloo.  GRIT_STEP_GRAPH_COLLECTIVES=1
+(experimental) captures the bucketed all-reduces too: run on hardware with a one-rank RCCL group (tests/test_graph_step_gpu.py,
+profiles/r04/bench_rccl_one_rank_graph.json: 52.3 ms against 53.6 ms eager on one box), never with N > 1.  It needs the capture in
+thread-local error mode -- torch's ProcessGroupNCCL watchdog thread keeps querying the events of earlier collectives, which the
+default global mode forbids during a capture (hipErrorStreamCaptureUnsupported invalidates the capture and the watchdog's
+exception terminates the process).  The sharded optimizer's cross-step all-gather is not capturable this way.
+`GraphedXEStep.matches(batch)` says whether a batch fits; callers fall back to the eager step
 for the odd batch (the last one of an epoch) or keep one graph per shape.
 """
 import os
@@ -37,7 +40,7 @@ def supported(model, optimizers):
     ddp = getattr(model, 'ddp', None)
     if ddp is None or not getattr(model, 'flat_optimizer', False):
         return False
-    if ddp.collective:
+    if ddp.collective and os.environ.get("GRIT_STEP_GRAPH_COLLECTIVES") != "1":
         return False
     return all(hasattr(optimizers[k], 'prepare_replay') for k in ('model', 'backbone'))
 
@@ -72,7 +75,9 @@ class GraphedXEStep(object):
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
         with backend.capturing_train_step(self.device) as seeds:
-            with torch.cuda.graph(self.graph):
+            # (a wrapper with collectives -- GRIT_STEP_GRAPH_COLLECTIVES=1, experimental -- captures in thread-local error mode: the process
+            # group's watchdog thread keeps querying the events of earlier collectives, which global mode forbids during a capture)
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local" if model.ddp.collective else "global"):
                 seeds.begin_captured_step(self.device)
                 self.loss = train_xe_step(model, self.static, optimizers, loss_fn)
         model._grit_step_graph_taken = True

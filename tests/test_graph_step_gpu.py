@@ -173,3 +173,48 @@ def test_train_xe_uses_the_step_graph_when_asked(monkeypatch):
     for n in PICKS:  # (same bar as test_replayed_steps_equal_eager_steps: Adam turns gradient noise into differences of the step's size)
         moved = float(torch.linalg.norm(m_eager[n] - m_init[n]))
         assert float(torch.linalg.norm(m_graph[n] - m_eager[n])) < 0.25 * moved, n
+
+
+def _rccl_graph_worker(rank, port, ret):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GRIT_DDP_SELF_COLLECTIVES="1", GRIT_STEP_GRAPH_COLLECTIVES="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from grit_amd.engine import graph_step
+    from grit_amd.engine.caption_engine import train_xe_step
+    a, b = _batches()
+    wrapped, opts, loss_fn = _setup()
+    assert wrapped.ddp.collective and graph_step.supported(wrapped, opts)
+    issued = []
+
+    def spy(*args, _f=dist.all_reduce, **kw):
+        issued.append(int(args[0].numel()))
+        return _f(*args, **kw)
+    dist.all_reduce = spy
+    losses = [float(train_xe_step(wrapped, a, opts, loss_fn)), float(train_xe_step(wrapped, b, opts, loss_fn))]
+    eager_calls = len(issued)
+    step = graph_step.GraphedXEStep(wrapped, opts, loss_fn, a, eager_steps=0)
+    captured_calls = len(issued) - eager_calls
+    for x in (a, b, a, b):
+        losses.append(float(step(x)))
+    torch.cuda.synchronize()
+    ret["losses"], ret["eager_calls"], ret["captured_calls"], ret["replay_calls"] = losses, eager_calls, captured_calls, len(issued) - eager_calls - captured_calls
+    dist.destroy_process_group()
+
+
+def test_step_graph_with_one_rank_rccl_collectives():
+    """GRIT_STEP_GRAPH_COLLECTIVES=1 (experimental): the step of a wrapper whose gradient sync goes through a ONE-RANK RCCL group is
+    captured with its all-reduces (thread-local capture error mode: the process group's watchdog keeps querying events) and replayed:
+    no Python-side collective call during replays, finite losses that go down like the eager steps'."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_rccl_graph_worker, args=(port, ret), nprocs=1, join=True)
+        ret = dict(ret)
+    assert ret["eager_calls"] >= 2 and ret["captured_calls"] >= 1 and ret["replay_calls"] == 0, ret
+    assert all(np.isfinite(ret["losses"])) and ret["losses"][-1] < ret["losses"][0] - 0.02, ret["losses"]

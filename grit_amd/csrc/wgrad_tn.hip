@@ -432,8 +432,10 @@ __device__ __forceinline__ void tn4_run(const TnArgs& g, int split, int n0, int 
         GRIT_TN4_TIE(x0l); GRIT_TN4_TIE(x0h); GRIT_TN4_TIE(y0l); GRIT_TN4_TIE(y0h);
         GRIT_TN4_JOIN(X0, x0l, x0h); GRIT_TN4_JOIN(Y0, y0l, y0h);
     };
+    const unsigned long long t_loop0 = (g.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
     kstep(std::true_type{}, 0);
     for (int s = 1; s < nsteps; ++s) kstep(std::false_type{}, s);
+    const unsigned long long t_loop1 = (g.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
     wait_vm<0>();  // the transfers issued past the end must not land in another workgroup's LDS
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last asm MFMAs retire before their accumulators are read
 
@@ -450,6 +452,8 @@ __device__ __forceinline__ void tn4_run(const TnArgs& g, int split, int n0, int 
             else out[(size_t)(16 * i + r) * g.K + 16 * j] = v[r];
         }
     }, std::make_integer_sequence<int, 64>{});
+    if ((g.dbg & 16) && blockIdx.x == 0 && tid == 0)  // diagnostic (corrupts one element): counter cycles of the main loop per K step
+        g.partial[0] = (float)(t_loop1 - t_loop0) / (float)nsteps;
     if constexpr (CS != 0) {
         // lanes l15 = 0 write the sums into copy 0 of the column-sum block, lanes 1..3 zero copies 1..3 (tn4_body adds the four)
         asm volatile("s_nop 15" ::: "memory");

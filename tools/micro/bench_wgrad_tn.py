@@ -54,6 +54,11 @@ def main():
         err = float((got - ref).abs().max() / ref.abs().max())
         t_own, t_own_sum = timed(own), timed(lambda: slab_sum(part.unsqueeze(0), torch.bfloat16))
         t_own_b = timed(own_b)
+        if int(os.environ.get("GRIT_WGRAD_TN_DBG", "0")) & 16:
+            own()
+            torch.cuda.synchronize()
+            print(f"    counter cycles per 64-row K step (workgroup 0, wave 0): {float(part[0, 0, 0]):.0f}; {M // 64 // S} steps per workgroup"
+                  f" -> loop {float(part[0, 0, 0]) * (M // 64 // S):.0f} cycles of a {t_own:.0f} us launch", flush=True)
         fl = 2.0 * M * N * K
         print(f"M{M} N{N} K{K}: library S{S0} {t_lib:.0f} us ({fl / t_lib / 1e9:.2f} PF/s) + sum {t_lib_sum:.0f} | own S{S} {t_own:.0f} us "
               f"({fl / t_own / 1e9:.2f} PF/s) + sum {t_own_sum:.0f} | with bias by-product {t_own_b:.0f} us | rel err {err:.1e}", flush=True)

@@ -211,7 +211,7 @@ def msda_spread_microbench(device, iters=30):
 def build(device, config):
     from grit_amd.models.caption import Transformer
     from grit_amd.models.caption.detector import build_detector
-    torch.manual_seed(config.exp.seed)
+    torch.manual_seed(config.exp.seed + int(os.environ.get('GRIT_BENCH_SEED', '0')))  # (GRIT_BENCH_SEED: diagnostic -- other weights / masks)
     model = Transformer(build_detector(config), config).to(device)
     model.cached_features = False
     return model

@@ -114,15 +114,32 @@ class FlatAdam(torch.optim.Optimizer):
         this before every replay of a captured step; step() calls it itself when it is not being captured."""
         lr, b1, b2, _ = self._hyper()
         n = max(1, len(self._runs))
-        if getattr(self, '_hyper_host', None) is None or self._hyper_host.shape[0] < n:
+        if getattr(self, '_hyper_host', None) is None or self._hyper_host.shape[1] < n:
             dev = self._runs[0][0][2].device if self._runs else torch.device('cpu')
-            self._hyper_host = torch.zeros((n, 2), dtype=torch.float32).pin_memory() if dev.type == 'cuda' else torch.zeros((n, 2))
+            # The staging copy is a RING of pinned tables: an asynchronous H2D copy reads the pinned memory when it EXECUTES, and a
+            # host that runs ahead of the device (no host sync per step) would otherwise overwrite step k's scalars with step k+1's
+            # before step k's copy has run.  A slot is rewritten only after the copy that read it last has completed (its event).
+            shape = (self._HYPER_SLOTS, n, 2)
+            self._hyper_host = torch.zeros(shape, dtype=torch.float32).pin_memory() if dev.type == 'cuda' else torch.zeros(shape)
             self._hyper_dev = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+            self._hyper_events = [None] * self._HYPER_SLOTS
+            self._hyper_slot = 0
+        slot = self._hyper_slot
+        self._hyper_slot = (slot + 1) % self._HYPER_SLOTS
+        if self._hyper_events[slot] is not None:
+            self._hyper_events[slot].synchronize()
+        host = self._hyper_host[slot]
         for i, (_, _, age) in enumerate(self._runs):
             t = age + 1
-            self._hyper_host[i, 0] = lr / (1.0 - b1 ** t)
-            self._hyper_host[i, 1] = 1.0 / math.sqrt(1.0 - b2 ** t)
-        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+            host[i, 0] = lr / (1.0 - b1 ** t)
+            host[i, 1] = 1.0 / math.sqrt(1.0 - b2 ** t)
+        self._hyper_dev[:host.shape[0]].copy_(host, non_blocking=True)
+        if self._hyper_dev.is_cuda:
+            if self._hyper_events[slot] is None:
+                self._hyper_events[slot] = torch.cuda.Event()
+            self._hyper_events[slot].record()
+
+    _HYPER_SLOTS = 8
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -125,3 +125,37 @@ def test_flat_adam_step_counts_survive_freeze_save_load_unfreeze():
         _step(wrapped, opt2, x, y)  # (the step in which det's gradient arrives late does not step it: it rejoins the runs after it)
         after = {n: int(float(opt2.state[m]['step'])) for n, m in masters.items()}
         assert after["head.weight"] == 6 and det_age < after["det.weight"] <= det_age + 2, after
+
+
+def test_replay_scalars_are_staged_through_a_ring():
+    """FlatAdam.prepare_replay (the per-step scalars a captured step reads from device memory): consecutive calls stage through
+    DIFFERENT pinned tables, so that a host running ahead of the device cannot overwrite the scalars of a step whose asynchronous
+    copy has not executed yet (seen in a 300-step soak of bench.py: the replayed steps read later steps' bias corrections and the
+    loss curve left the eager one); the values are those of the step about to be taken."""
+    import math
+    from grit_amd.amp import Bf16Compute
+    from tests.helpers import oracle_ops
+    torch.manual_seed(0)
+    model = Net()
+    wrapped = Bf16Compute(model, bucket_mb=0.0002, flat_optimizer=True)
+    masters = dict(wrapped.named_master_parameters())
+    opt = wrapped.flat_adam(list(masters.values()), lr=1e-2)
+    x, y = torch.randn(4, 8).bfloat16(), torch.randn(4, 4)
+    with oracle_ops():
+        _step(wrapped, opt, x, y)
+    b1, b2 = opt.param_groups[0]['betas']
+    seen = []
+    for k in range(opt._HYPER_SLOTS + 2):
+        opt.prepare_replay()
+        slot = (opt._hyper_slot - 1) % opt._HYPER_SLOTS
+        t = opt._runs[0][2] + 1
+        want = (1e-2 / (1.0 - b1 ** t), 1.0 / math.sqrt(1.0 - b2 ** t))
+        got = opt._hyper_host[slot, 0]
+        assert abs(float(got[0]) - want[0]) < 1e-6 * want[0] and abs(float(got[1]) - want[1]) < 1e-6 * want[1]
+        assert torch.equal(opt._hyper_dev[0], got)
+        seen.append((slot, opt._hyper_host[slot].clone()))
+        if k >= 1:  # the previous call's table is untouched by this one
+            ps, pv = seen[k - 1]
+            assert ps != slot and torch.equal(opt._hyper_host[ps], pv)
+        opt.advance()
+    assert len({s for s, _ in seen}) == opt._HYPER_SLOTS

@@ -100,7 +100,7 @@ def test_replay_reads_learning_rate_and_step_count_at_replay_time():
     # bias corrections follow the step count: the table holds lr / (1 - beta1^t) for the step just taken (t = 4)
     o = opts['model']
     b1 = o.param_groups[0]['betas'][0]
-    assert abs(float(o._hyper_host[0, 0]) - lrs['model'] / (1 - b1 ** 4)) < 1e-6 * lrs['model'] / (1 - b1 ** 4)
+    assert abs(float(o._hyper_dev[0, 0]) - lrs['model'] / (1 - b1 ** 4)) < 1e-6 * lrs['model'] / (1 - b1 ** 4)
 
 
 def test_replays_draw_fresh_dropout_masks():

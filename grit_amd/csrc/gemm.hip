@@ -7,6 +7,8 @@
 //   GRIT_GEMM_BIAS        C = acc + bias                                   (any Linear)
 //   GRIT_GEMM_BIAS_GELU   aux = acc + bias ; C = gelu(aux)                 (fc1 + exact-erf GELU; aux = pre-activation kept for backward)
 //   GRIT_GEMM_DGELU       C = acc * gelu'(aux) ; colsum[slab, n] = sum_rows C   (fc2 input gradient x GELU' + fc1 bias gradient)
+//   GRIT_GEMM_BIAS_GELU_DACT  aux = gelu'(acc + bias) ; C = gelu(acc + bias)   (the derivative saved instead of the pre-activation)
+//   GRIT_GEMM_MUL_AUX     C = acc * aux ; colsum as above                       (... and the backward is a plain product)
 // so the [M, 4C] hidden map is written once per pass instead of written, re-read and re-written by GELU / GeluBackward / column-sum kernels.
 //
 // Structure (MI355X_MICROARCH.md / cdna_hip_programming.md section 5):
@@ -235,7 +237,7 @@ void gemm_nt_bf16(const GemmArgs g) {
     const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
 
     v4f bias4[NTL];
-    if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU) {
+    if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU || EPI == GRIT_GEMM_BIAS_GELU_DACT) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
             const v4bf b = *reinterpret_cast<const v4bf*>(g.bias + nw + 16 * j + 4 * lq);
@@ -309,7 +311,40 @@ void gemm_nt_bf16(const GemmArgs g) {
                 put(i, j, v4f{lo[0], lo[1], hi[0], hi[1]});
             }
         flush(g.C, g.ldc, (g.nt_aux & 2) != 0);
-    } else {  // GRIT_GEMM_DGELU
+    } else if constexpr (EPI == GRIT_GEMM_BIAS_GELU_DACT) {
+        // activation and its derivative from one sigmoid; the derivative goes to aux (what the backward multiplies by), the
+        // accumulators are overwritten with the activation, which leaves in a second pass through the image
+        if (g.aux) {  // (workgroup-uniform, hoisted: as a test per piece it costs 32 branches and 30 spilled registers)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) {
+                    const v4f x = acc[i][j] + bias4[j];
+                    v2f glo, ghi, dlo, dhi;
+                    gelu_dgelu2(v2f{x[0], x[1]}, glo, dlo);
+                    gelu_dgelu2(v2f{x[2], x[3]}, ghi, dhi);
+                    acc[i][j] = v4f{glo[0], glo[1], ghi[0], ghi[1]};
+                    put(i, j, v4f{dlo[0], dlo[1], dhi[0], dhi[1]});
+                    __builtin_amdgcn_sched_barrier(0);  // one quad at a time: interleaved, the two-output temporaries of 32 quads spill
+                }
+            }
+        } else {  // frozen stage / inference: the activation alone
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) {
+                    const v4f x = acc[i][j] + bias4[j];
+                    const v2f lo = gelu2(v2f{x[0], x[1]}), hi = gelu2(v2f{x[2], x[3]});
+                    acc[i][j] = v4f{lo[0], lo[1], hi[0], hi[1]};
+                }
+        }
+        if (g.aux) flush(g.aux, g.ldaux, (g.nt_aux & 1) != 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) put(i, j, acc[i][j]);
+        flush(g.C, g.ldc, (g.nt_aux & 2) != 0);
+    } else {  // GRIT_GEMM_DGELU, GRIT_GEMM_MUL_AUX
         // the pre-activation tile comes in the way the result goes out: whole 128-byte row segments (one DMA piece = 8 rows) into
         // the wave's transpose image, from where every lane picks its 8-byte pieces -- accumulator-shaped global loads (16 rows x
         // 32 bytes per instruction) cost 11k cycles per tile more (tools/micro/gemm_stamps.hip)
@@ -339,7 +374,8 @@ void gemm_nt_bf16(const GemmArgs g) {
             for (int j = 0; j < NTL; ++j) {
                 const int chunk = (2 * j + (lq >> 1)) ^ (row & 7);
                 const v4bf x = *reinterpret_cast<const v4bf*>(eb + row * 128 + chunk * 16 + (lq & 1) * 8);
-                const v2f dlo = dgelu2(v2f{(float)x[0], (float)x[1]}), dhi = dgelu2(v2f{(float)x[2], (float)x[3]});
+                v2f dlo = v2f{(float)x[0], (float)x[1]}, dhi = v2f{(float)x[2], (float)x[3]};
+                if constexpr (EPI == GRIT_GEMM_DGELU) { dlo = dgelu2(dlo); dhi = dgelu2(dhi); }  // (MUL_AUX: aux IS the factor)
                 const v4f v = {acc[i][j][0] * dlo[0], acc[i][j][1] * dlo[1], acc[i][j][2] * dhi[0], acc[i][j][3] * dhi[1]};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cs[j][r] += live ? v[r] : 0.f;  // bias gradient from the unrounded products
@@ -713,6 +749,8 @@ int launch(const GemmArgs& a, int epilogue, hipStream_t st) {
         case GRIT_GEMM_BIAS: GRIT_GEMM_LAUNCH(GRIT_GEMM_BIAS) break;
         case GRIT_GEMM_BIAS_GELU: GRIT_GEMM_LAUNCH(GRIT_GEMM_BIAS_GELU) break;
         case GRIT_GEMM_DGELU: GRIT_GEMM_LAUNCH(GRIT_GEMM_DGELU) break;
+        case GRIT_GEMM_BIAS_GELU_DACT: GRIT_GEMM_LAUNCH(GRIT_GEMM_BIAS_GELU_DACT) break;
+        case GRIT_GEMM_MUL_AUX: GRIT_GEMM_LAUNCH(GRIT_GEMM_MUL_AUX) break;
         default: return GRIT_ERR_BAD_ARG;
     }
 #undef GRIT_GEMM_LAUNCH
@@ -725,9 +763,9 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
                                  int epilogue, const void* bias, void* aux, long ldaux, float* colsum, int variant,
                                  void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return GRIT_ERR_BAD_ARG;
-    if ((epilogue == GRIT_GEMM_BIAS || epilogue == GRIT_GEMM_BIAS_GELU) && !bias) return GRIT_ERR_BAD_ARG;
-    if (epilogue == GRIT_GEMM_DGELU && !aux) return GRIT_ERR_BAD_ARG;
-    if (epilogue == GRIT_GEMM_DGELU && !colsum) return GRIT_ERR_BAD_ARG;
+    if ((epilogue == GRIT_GEMM_BIAS || epilogue == GRIT_GEMM_BIAS_GELU || epilogue == GRIT_GEMM_BIAS_GELU_DACT) && !bias) return GRIT_ERR_BAD_ARG;
+    if ((epilogue == GRIT_GEMM_DGELU || epilogue == GRIT_GEMM_MUL_AUX) && (!aux || !colsum)) return GRIT_ERR_BAD_ARG;
+    if (epilogue > GRIT_GEMM_DGELU && variant > 4) return GRIT_ERR_UNSUPPORTED;  // the round-4 epilogues: eight-wave per-tile kernel only
     // 16-byte DMA pieces and row stores: leading dimensions in multiples of 8 elements, 16-byte aligned bases
     if ((lda | ldb | ldc | (aux ? ldaux : 0)) & 7) return GRIT_ERR_UNSUPPORTED;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)aux | (uintptr_t)bias) & 15) return GRIT_ERR_UNSUPPORTED;

@@ -72,6 +72,22 @@ __device__ __forceinline__ v2f dgelu2(v2f x) {
     return s * __builtin_elementwise_fma(x * q, v2f{1.0f, 1.0f} - s, v2f{1.0f, 1.0f});
 }
 
+// gelu2 and dgelu2 of the same argument, sharing the sigmoid: the same operations in the same order as the two functions above
+// (identical results), one exp2 + one rcp per element instead of two each.
+__device__ __forceinline__ void gelu_dgelu2(v2f x, v2f& gelu, v2f& dgelu) {
+    v2f xx = x * x;
+    xx = v2f{fminf(xx[0], 50.0f), fminf(xx[1], 50.0f)};
+    v2f p = __builtin_elementwise_fma(v2f{kNegLog2e * kGeluC2, kNegLog2e * kGeluC2}, xx, v2f{kNegLog2e * kGeluC1, kNegLog2e * kGeluC1});
+    p = __builtin_elementwise_fma(p, xx, v2f{kNegLog2e * kGeluC0, kNegLog2e * kGeluC0});
+    const v2f t = x * p;
+    const v2f d = v2f{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + v2f{1.0f, 1.0f};
+    const v2f s = v2f{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    gelu = x * s;
+    v2f q = __builtin_elementwise_fma(v2f{5.0f * kGeluC2, 5.0f * kGeluC2}, xx, v2f{3.0f * kGeluC1, 3.0f * kGeluC1});
+    q = __builtin_elementwise_fma(q, xx, v2f{kGeluC0, kGeluC0});
+    dgelu = s * __builtin_elementwise_fma(x * q, v2f{1.0f, 1.0f} - s, v2f{1.0f, 1.0f});
+}
+
 // Sum over the 16 lanes of a DPP row (the 16 token lanes of an accumulator quarter) by row rotations: plain VALU.  As four
 // __shfl_xor steps it is four ds_bpermute round trips with a full lgkmcnt wait each -- 64 of them per wave in the column-sum
 // epilogue of the GELU' GEMM.

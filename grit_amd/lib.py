@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64

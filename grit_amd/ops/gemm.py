@@ -12,7 +12,12 @@ import torch
 from grit_amd import lib as _lib
 from grit_amd.ops.profiling import gemm_work, timed
 
-NONE, BIAS, BIAS_GELU, DGELU = 0, 1, 2, 3
+NONE, BIAS, BIAS_GELU, DGELU, BIAS_GELU_DACT, MUL_AUX = 0, 1, 2, 3, 4, 5
+# GRIT_MLP_SAVE_DGELU=1 (default 0): the fused Mlp forward saves GELU'(pre-activation) -- computed from the sigmoid the activation needs
+# anyway -- instead of the pre-activation, and the fc2 input gradient multiplies by it (GRIT_GEMM_BIAS_GELU_DACT / GRIT_GEMM_MUL_AUX).
+# Measured (profiles/r04/saved_dgelu.txt, stage 2): the product epilogue saves 33 us (181 -> 148), the two-output forward epilogue
+# costs 48 (149 -> 197: its temporaries spill beside the 128 accumulators); in the step 52.79 -> 53.14 ms.  Kept, tested, not the default.
+SAVE_DGELU = os.environ.get("GRIT_MLP_SAVE_DGELU", "0") == "1"
 COLSUM_ROWS = 128
 VARIANT = int(os.environ.get("GRIT_GEMM_VARIANT", "0"))  # tuning alternatives of the same kernel (A/B runs)
 
@@ -37,7 +42,8 @@ def gemm_nt(a, b, epilogue=NONE, bias=None, aux=None, colsum=None, out=None, var
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     v = VARIANT if variant is None else variant
-    work = gemm_work(M, N, K, outputs=2 if (epilogue == BIAS_GELU and aux is not None) else 1, extra_in=1 if epilogue == DGELU else 0)
+    work = gemm_work(M, N, K, outputs=2 if (epilogue in (BIAS_GELU, BIAS_GELU_DACT) and aux is not None) else 1,
+                     extra_in=1 if epilogue in (DGELU, MUL_AUX) else 0)
     with _lib.device_guard(a.device), timed("gemm_own", epilogue=epilogue, kernel="gemm_w4" if v == 7 else "gemm_nt_bf16", **work):
         st = _lib.load().grit_gemm_bf16_nt(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0), M, N, K,
                                            epilogue, _ptr(bias), _ptr(aux), aux.stride(0) if aux is not None else 0,
@@ -56,18 +62,27 @@ def _fused_variant(M, N, K):
 
 
 def linear_bias_gelu(x2, weight, bias):
-    """(pre, act) = (x2 @ weight^T + bias, gelu(x2 @ weight^T + bias)), both [M, N] bf16, one kernel."""
+    """(saved, act), both [M, N] bf16, one kernel: act = gelu(x2 @ weight^T + bias); saved = what input_grad_dgelu needs of the
+    pre-activation h = x2 @ weight^T + bias -- gelu'(h) (GRIT_MLP_SAVE_DGELU, default) or h itself."""
     M, N = x2.shape[0], weight.shape[0]
     pre = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
+    if SAVE_DGELU:  # `pre` then holds gelu'(x2 @ weight^T + bias): what input_grad_dgelu multiplies by
+        act = gemm_nt(x2, weight, BIAS_GELU_DACT, bias=bias, aux=pre, variant=VARIANT if VARIANT in (1, 2, 3, 4) else 0)
+        return pre, act
     act = gemm_nt(x2, weight, BIAS_GELU, bias=bias, aux=pre, variant=_fused_variant(M, N, x2.shape[1]))
     return pre, act
 
 
 def input_grad_dgelu(dy2, weight_t, pre):
-    """(d_pre, colsum_partial): d_pre = (dy2 @ weight_t^T) * gelu'(pre) with weight_t [N_hidden, K] = the following Linear's
-    weight transposed; colsum_partial [ceil(M / 128), N_hidden] f32 sums to the bias gradient of the Linear that produced pre."""
+    """(d_pre, colsum_partial): d_pre = (dy2 @ weight_t^T) * gelu'(h) with weight_t [N_hidden, K] = the following Linear's
+    weight transposed and `pre` = the tensor linear_bias_gelu saved (gelu'(h), or h with GRIT_MLP_SAVE_DGELU=0); colsum_partial
+    [ceil(M / 128), N_hidden] f32 sums to the bias gradient of the Linear that produced h."""
     M = dy2.shape[0]
     N = weight_t.shape[0]
+    if SAVE_DGELU:  # `pre` is the saved derivative (linear_bias_gelu above): a plain product in the epilogue
+        partial = torch.empty((-(-M // COLSUM_ROWS), N), dtype=torch.float32, device=dy2.device)
+        d_pre = gemm_nt(dy2, weight_t, MUL_AUX, aux=pre, colsum=partial, variant=VARIANT if VARIANT in (1, 2, 3, 4) else 0)
+        return d_pre, partial
     v = _fused_variant(M, N, dy2.shape[1])
     # (the four-wave kernel writes one row of sums per 128-row wave block of its 256-row tiles: 2 ceil(M / 256) rows, all written)
     partial = torch.empty((2 * -(-M // 256) if v == 7 else -(-M // COLSUM_ROWS), N), dtype=torch.float32, device=dy2.device)

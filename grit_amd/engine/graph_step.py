@@ -17,7 +17,7 @@ What makes the step capturable (everything else already was -- no host read, no 
 
 Scope: a static-shape step -- same batch shape, same `any_padding` flag, same live parameter set.  By default on ONE rank without
 collectives: with world > 1 the eager step keeps the RCCL overlap that was tested on gloo.  GRIT_STEP_GRAPH_COLLECTIVES=1
-(experimental) captures the bucketed all-reduces too: run on hardware with a one-rank RCCL group (tests/test_graph_step_gpu.py,
+(experimental) captures the bucketed all-reduces too: run on hardware with a one-rank RCCL group (tests/test_graph_step_gpu.py with GRIT_TEST_RCCL_GRAPH=1: 6 of 7 runs passed, one unexplained failure inside a full-suite run;
 profiles/r04/bench_rccl_one_rank_graph.json: 52.3 ms against 53.6 ms eager on one box), never with N > 1.  It needs the capture in
 thread-local error mode -- torch's ProcessGroupNCCL watchdog thread keeps querying the events of earlier collectives, which the
 default global mode forbids during a capture (hipErrorStreamCaptureUnsupported invalidates the capture and the watchdog's

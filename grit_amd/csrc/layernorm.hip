@@ -103,13 +103,29 @@ __device__ __forceinline__ float row_sum(float v) {
     }
 }
 
+// Patch-merging view (reference models/common/swin_model.py:279-287, PatchMerging.forward): row r of the [B * H/2 * W/2, 4 Cs] map the
+// LayerNorm sees is the concatenation of the four pixels (2 hh + dy, 2 ww + dx), (dy, dx) = (0,0), (1,0), (0,1), (1,1), of the
+// [B, H, W, Cs] token map.  With Cs > 0 the kernels address x (forward, backward) and dx (backward) THROUGH that view: the
+// permute + reshape copy of the map (and the scatter of its gradient) never exists.  H, W even; Cs a multiple of 8.
+struct MergeView {
+    int H = 0, W = 0, Cs = 0;
+};
+
+// element offset of channel chunk `col` (a multiple of 8, < 4 Cs) of merged row r
+__device__ __forceinline__ size_t merged_offset(const MergeView& mv, int r, int col) {
+    const int Wh = mv.W >> 1, per_img = (mv.H >> 1) * Wh;
+    const int b = r / per_img, rem = r - b * per_img, hh = rem / Wh, ww = rem - hh * Wh;
+    const int q = col / mv.Cs, cc = col - q * mv.Cs;
+    return ((size_t)(b * mv.H + 2 * hh + (q & 1)) * mv.W + 2 * ww + (q >> 1)) * mv.Cs + cc;
+}
+
 // LPR lanes per row, CH chunks of 8 channels per lane: C = LPR * 8 * CH
 template <typename T, typename WT, int LPR, int CH>
 __global__ __launch_bounds__(256)
 void ln_fwd(const T* __restrict__ x, const WT* __restrict__ w, const WT* __restrict__ b, int rows, float eps,
             T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
             const T* __restrict__ branch, const float* __restrict__ row_scale, int rows_per_sample, T* __restrict__ sum_out,
-            float drop_p, const unsigned long long* __restrict__ seed_dev, bool nt) {
+            float drop_p, const unsigned long long* __restrict__ seed_dev, bool nt, MergeView mv) {
     constexpr int C = LPR * 8 * CH, R = 64 / LPR;
     const unsigned long long seed = (branch && drop_p > 0.f) ? *seed_dev : 0ull;
     const float inv_keep = 1.0f / (1.0f - drop_p);
@@ -121,7 +137,7 @@ void ln_fwd(const T* __restrict__ x, const WT* __restrict__ w, const WT* __restr
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        Vec8<T>::load(x + (size_t)rc * C + (c * LPR + sub) * 8, v[c]);
+        Vec8<T>::load(x + (mv.Cs ? merged_offset(mv, rc, (c * LPR + sub) * 8) : (size_t)rc * C + (c * LPR + sub) * 8), v[c]);
         if (branch) {  // x <- shortcut + scale * branch, rounded to T exactly as the unfused add / addcmul would store it
             float br[8];
             Vec8<T>::load(branch + (size_t)rc * C + (c * LPR + sub) * 8, br);
@@ -164,7 +180,7 @@ __global__ __launch_bounds__(256)
 void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restrict__ dy, const float* __restrict__ mean,
             const float* __restrict__ rstd, int rows, T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
             const T* __restrict__ dres, const float* __restrict__ row_scale, int rows_per_sample, T* __restrict__ dbranch,
-            float* __restrict__ dsum, float drop_p, const unsigned long long* __restrict__ seed_dev, bool nt) {
+            float* __restrict__ dsum, float drop_p, const unsigned long long* __restrict__ seed_dev, bool nt, MergeView mv) {
     constexpr int C = LPR * 8 * CH, R = 64 / LPR;
     const unsigned long long seed = (dbranch && drop_p > 0.f) ? *seed_dev : 0ull;
     const float inv_keep = 1.0f / (1.0f - drop_p);
@@ -194,7 +210,7 @@ void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restri
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            Vec8<T>::load(x + (size_t)rc * C + (c * LPR + sub) * 8, xh[c]);
+            Vec8<T>::load(x + (mv.Cs ? merged_offset(mv, rc, (c * LPR + sub) * 8) : (size_t)rc * C + (c * LPR + sub) * 8), xh[c]);
             Vec8<T>::load(dy + (size_t)rc * C + (c * LPR + sub) * 8, g[c]);
             if (dres) {
                 Vec8<T>::load(dres + (size_t)rc * C + (c * LPR + sub) * 8, skip[c]);
@@ -222,7 +238,7 @@ void ln_bwd(const T* __restrict__ x, const WT* __restrict__ w, const T* __restri
                     aw[c][i] = fmaf(g[c][i], xh[c][i], aw[c][i]);
                     ab[c][i] += g[c][i];
                 }
-                Vec8<T>::store(dx + (size_t)row * C + (c * LPR + sub) * 8, o, nt);
+                Vec8<T>::store(dx + (mv.Cs ? merged_offset(mv, row, (c * LPR + sub) * 8) : (size_t)row * C + (c * LPR + sub) * 8), o, nt);
                 if (dbranch) {  // gradient of the branch: the rounded dx times the sample's drop-path factor and/or the
                                 // element's dropout keep factor
                     const float sc = row_scale ? row_scale[row / rows_per_sample] : 1.0f;
@@ -281,6 +297,7 @@ struct Fused {  // optional residual operands (all null / 0 for the plain LayerN
     float* dsum = nullptr;            // backward: per-workgroup partial column sums of the branch gradient, or null
     float drop_p = 0.f;               // element dropout probability applied to the branch (0: none)
     const unsigned long long* seed_dev = nullptr;  // device-resident dropout seed (read when drop_p > 0)
+    MergeView merge;                  // patch-merging view of x (and of dx): grit_merge_layernorm_*
 };
 
 template <typename T, typename WT>
@@ -294,11 +311,11 @@ int launch(bool fwd, const void* x, const void* w, const void* b_or_dy, const fl
         if (fwd)                                                                                                       \
             hipLaunchKernelGGL((ln_fwd<T, WT, LPR_, CH_>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const WT*)w,  \
                                (const WT*)b_or_dy, rows, eps, (T*)out, o1, o2, (const T*)fu.branch, fu.row_scale,        \
-                               fu.rows_per_sample, (T*)fu.sum_out, fu.drop_p, fu.seed_dev, nt);                       \
+                               fu.rows_per_sample, (T*)fu.sum_out, fu.drop_p, fu.seed_dev, nt, fu.merge);             \
         else                                                                                                           \
             hipLaunchKernelGGL((ln_bwd<T, WT, LPR_, CH_>), dim3(blocks < kBwdBlocks ? blocks : kBwdBlocks), dim3(256), 0, st, \
                                (const T*)x, (const WT*)w, (const T*)b_or_dy, mean_in, rstd_in, rows, (T*)out, o1, o2,  \
-                               (const T*)fu.dres, fu.row_scale, fu.rows_per_sample, (T*)fu.dbranch, fu.dsum, fu.drop_p, fu.seed_dev, nt); \
+                               (const T*)fu.dres, fu.row_scale, fu.rows_per_sample, (T*)fu.dbranch, fu.dsum, fu.drop_p, fu.seed_dev, nt, fu.merge); \
         return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;                                            \
     }
     switch (C) {
@@ -336,6 +353,32 @@ int grit_layernorm_bwd(const void* x, const void* weight, const void* dy, const 
                        int C, int x_is_bf16, int w_is_bf16, void* dx, float* dweight, float* dbias, void* stream) {
     if (!mean || !rstd) return GRIT_ERR_BAD_ARG;
     return dispatch(false, x, weight, dy, mean, rstd, rows, C, 0.f, x_is_bf16, w_is_bf16, dx, dweight, dbias, (hipStream_t)stream);
+}
+
+static bool merge_ok(int B, int H, int W, int Cs, int rows, int C) {
+    return B > 0 && H > 0 && W > 0 && Cs > 0 && H % 2 == 0 && W % 2 == 0 && Cs % 8 == 0 && C == 4 * Cs &&
+           (long long)B * (H / 2) * (W / 2) == rows;
+}
+
+int grit_merge_layernorm_fwd(const void* x, int B, int H, int W, int Cs, const void* weight, const void* bias, float eps,
+                             int x_is_bf16, int w_is_bf16, void* y, float* mean, float* rstd, void* stream) {
+    const long long rows = (long long)B * (H / 2) * (W / 2);
+    if (rows <= 0 || rows > 0x7fffffffLL || !merge_ok(B, H, W, Cs, (int)rows, 4 * Cs)) return GRIT_ERR_BAD_ARG;
+    Fused fu;
+    fu.merge.H = H; fu.merge.W = W; fu.merge.Cs = Cs;
+    return dispatch(true, x, weight, bias, nullptr, nullptr, (int)rows, 4 * Cs, eps, x_is_bf16, w_is_bf16, y, mean, rstd,
+                    (hipStream_t)stream, fu);
+}
+
+int grit_merge_layernorm_bwd(const void* x, int B, int H, int W, int Cs, const void* weight, const void* dy, const float* mean,
+                             const float* rstd, int x_is_bf16, int w_is_bf16, void* dx, float* dweight, float* dbias,
+                             void* stream) {
+    const long long rows = (long long)B * (H / 2) * (W / 2);
+    if (!mean || !rstd || rows <= 0 || rows > 0x7fffffffLL || !merge_ok(B, H, W, Cs, (int)rows, 4 * Cs)) return GRIT_ERR_BAD_ARG;
+    Fused fu;
+    fu.merge.H = H; fu.merge.W = W; fu.merge.Cs = Cs;
+    return dispatch(false, x, weight, dy, mean, rstd, (int)rows, 4 * Cs, 0.f, x_is_bf16, w_is_bf16, dx, dweight, dbias,
+                    (hipStream_t)stream, fu);
 }
 
 int grit_add_layernorm_fwd(const void* shortcut, const void* branch, const float* row_scale, int rows_per_sample,

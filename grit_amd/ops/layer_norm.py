@@ -87,6 +87,65 @@ def layer_norm(x, weight, bias, eps=1e-5):
     return _LayerNormFn.apply(x, weight.contiguous(), bias.contiguous(), float(eps))
 
 
+class _MergeLayerNormFn(Function):
+    """LayerNorm(4C) of the 2 x 2 patch-merged view of a token map [B, H, W, C] (H, W even) without materialising the view
+    (grit_merge_layernorm_{fwd,bwd}; reference models/common/swin_model.py:279-288)."""
+
+    @staticmethod
+    def forward(ctx, x, H, W, weight, bias, eps):
+        B, C = x.shape[0], x.shape[-1]
+        x4 = x.reshape(B, H, W, C)
+        if not x4.is_contiguous():
+            x4 = x4.contiguous()
+        rows = B * (H // 2) * (W // 2)
+        y = torch.empty((rows, 4 * C), dtype=x.dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        xb, wb = int(x.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
+        with _lib.device_guard(x.device):
+            st = _lib.load().grit_merge_layernorm_fwd(_ptr(x4), B, H, W, C, _ptr(weight), _ptr(bias), eps, xb, wb, _ptr(y), _ptr(mean),
+                                                      _ptr(rstd), _lib.current_stream_ptr())
+        _lib.check(st, "grit_merge_layernorm_fwd")
+        ctx.save_for_backward(x4, weight, mean, rstd)
+        ctx.shape = x.shape
+        return y.view(B, (H // 2) * (W // 2), 4 * C)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x4, weight, mean, rstd = ctx.saved_tensors
+        B, H, W, C = x4.shape
+        rows = B * (H // 2) * (W // 2)
+        dy2 = dy.reshape(rows, 4 * C)
+        if not dy2.is_contiguous() or dy2.dtype != x4.dtype:
+            dy2 = dy2.to(x4.dtype).contiguous()
+        dx = torch.empty_like(x4)
+        rows_per_block = 4 * (64 // min(4 * C // 8, 64))
+        nblk = min(-(-rows // rows_per_block), LN_BWD_PARTIALS)
+        base = torch.empty(2, LN_BWD_PARTIALS, 4 * C, dtype=torch.float32, device=x4.device)
+        xb, wb = int(x4.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
+        with _lib.device_guard(x4.device):
+            st = _lib.load().grit_merge_layernorm_bwd(_ptr(x4), B, H, W, C, _ptr(weight), _ptr(dy2), _ptr(mean), _ptr(rstd), xb, wb,
+                                                      _ptr(dx), _ptr(base[0]), _ptr(base[1]), _lib.current_stream_ptr())
+        _lib.check(st, "grit_merge_layernorm_bwd")
+        sums = slab_sum(base, weight.dtype, slabs=nblk)
+        return dx.view(ctx.shape), None, None, sums[0], sums[1], None
+
+
+def merge_layer_norm(x, H, W, weight, bias, eps=1e-5):
+    """LayerNorm(4C)(patch_merge(x)) for x [B, H*W, C] (or [B, H, W, C]), or None when the fused form does not apply (odd H / W, a
+    channel count or dtype outside the kernels, an injected backend): the caller then builds the merged view itself."""
+    if backend.override() is not None:
+        return None
+    C = x.shape[-1]
+    fits = (x.is_cuda and H % 2 == 0 and W % 2 == 0 and C % 8 == 0 and 4 * C in SUPPORTED_C and weight is not None and bias is not None
+            and x.dtype in (torch.float32, torch.bfloat16) and weight.dtype == bias.dtype
+            and (weight.dtype == x.dtype or (x.dtype == torch.bfloat16 and weight.dtype == torch.float32)))
+    if not fits:
+        return None
+    return _MergeLayerNormFn.apply(x, H, W, weight.contiguous(), bias.contiguous(), float(eps))
+
+
 class _AddLayerNormFn(Function):
     """(shortcut, branch, scale) -> (x, LayerNorm(x)) with x = shortcut + scale * branch; scale [B] f32 or None."""
 

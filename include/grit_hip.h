@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 33
+#define GRIT_ABI_VERSION 34
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -278,6 +278,16 @@ int grit_relbias_bwd(const float* dbias, const int32_t* order, const int32_t* of
  * gradient as stored -- the bias gradient of the Linear that produced `branch` (attn.proj / mlp.fc2), for free.
  * Other arguments as in grit_layernorm_{fwd,bwd}.
  * ------------------------------------------------------------------------------------------------------ */
+/* LayerNorm of the PATCH-MERGED map without the map (reference models/common/swin_model.py:279-288, PatchMerging.forward: 2 x 2
+ * neighbourhood concat in the order (0,0), (1,0), (0,1), (1,1) -> LayerNorm(4 Cs)): x is the token map [B, H, W, Cs] (H, W even, Cs a
+ * multiple of 8, 4 Cs in the supported widths); row r of the [B * H/2 * W/2, 4 Cs] view is gathered on load.  y, mean, rstd as in
+ * grit_layernorm_fwd on that view.  Backward: dy [rows, 4 Cs] contiguous, dx is written straight in the token-map layout
+ * [B, H, W, Cs] (every element exactly once).  Replaces the permute + reshape copy and the scatter of its gradient. */
+int grit_merge_layernorm_fwd(const void* x, int B, int H, int W, int Cs, const void* weight, const void* bias, float eps,
+                             int x_is_bf16, int w_is_bf16, void* y, float* mean, float* rstd, void* stream);
+int grit_merge_layernorm_bwd(const void* x, int B, int H, int W, int Cs, const void* weight, const void* dy, const float* mean,
+                             const float* rstd, int x_is_bf16, int w_is_bf16, void* dx, float* dweight, float* dbias,
+                             void* stream);
 int grit_add_layernorm_fwd(const void* shortcut, const void* branch, const float* row_scale, int rows_per_sample,
                            float drop_p, const uint64_t* seed_dev, const void* weight, const void* bias, int rows, int C,
                            float eps, int x_is_bf16, int w_is_bf16, void* sum_out, void* y, float* mean, float* rstd,

@@ -601,3 +601,37 @@ def test_grouped_weight_transposes_and_their_cache():
     assert all(T.lookup(w) is None for w in ws)
     T.refresh(ws)
     assert torch.equal(T.lookup(ws[2]), ws[2].t().contiguous())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,C,dtype", [(2, 8, 12, 128, torch.bfloat16), (3, 20, 20, 256, torch.bfloat16), (1, 10, 6, 512, torch.float32),
+                                           (32, 80, 80, 128, torch.bfloat16), (2, 4, 2, 1024, torch.bfloat16)])
+def test_patch_merging_layer_norm_through_the_view(B, H, W, C, dtype):
+    """grit_merge_layernorm_{fwd,bwd} (reference models/common/swin_model.py:279-288): LayerNorm(4C) of the 2 x 2 patch-merged view
+    addressed directly against the materialised permute + reshape followed by the plain kernels: forward bit-identical (same rows,
+    same arithmetic), input gradient equal element for element in the token-map layout, dgamma / dbeta equal within the order of the
+    partial sums; odd sizes are not taken (the caller pads and copies)."""
+    from grit_amd.ops.layer_norm import layer_norm, merge_layer_norm
+    g = torch.Generator(device=DEV).manual_seed(B * H + C)
+    x = torch.randn(B, H * W, C, device=DEV, generator=g).to(dtype)
+    w = (1.0 + 0.1 * torch.randn(4 * C, device=DEV, generator=g)).to(dtype)
+    b = (0.1 * torch.randn(4 * C, device=DEV, generator=g)).to(dtype)
+    cot = torch.randn(B, (H // 2) * (W // 2), 4 * C, device=DEV, generator=g).to(dtype)
+    outs = []
+    for fused in (True, False):
+        xi, wi, bi = (t_.clone().requires_grad_(True) for t_ in (x, w, b))
+        if fused:
+            y = merge_layer_norm(xi, H, W, wi, bi, 1e-5)
+            assert y is not None
+        else:
+            v = xi.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, (H // 2) * (W // 2), 4 * C)
+            y = layer_norm(v, wi, bi, 1e-5)
+        (y.float() * cot.float()).sum().backward()
+        outs.append((y.detach(), xi.grad, wi.grad, bi.grad))
+    (y1, dx1, dw1, db1), (y0, dx0, dw0, db0) = outs
+    assert torch.equal(y1, y0)
+    assert torch.equal(dx1, dx0)
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    assert float((dw1.float() - dw0.float()).abs().max()) <= tol * float(dw0.float().abs().max()) + 1e-6
+    assert float((db1.float() - db0.float()).abs().max()) <= tol * float(db0.float().abs().max()) + 1e-6
+    assert merge_layer_norm(x[:, :(H - 1) * W].contiguous(), H - 1, W, w, b, 1e-5) is None  # odd height: not taken

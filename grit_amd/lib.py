@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -44,6 +44,7 @@ SIGNATURES = {
     "grit_winattn_bwd_f32": [_ptr] * 4 + [_int] + [_ptr] * 3 + [_int] * 7 + [_f32] + [_ptr] * 4,
     "grit_layernorm_fwd": [_ptr] * 3 + [_int, _int, _f32, _int, _int] + [_ptr] * 4,
     "grit_layernorm_bwd": [_ptr] * 5 + [_int] * 4 + [_ptr] * 4,
+    "grit_patch_embed_ln_fwd": [_ptr, _int, _int, _int, _int, _int] + [_ptr] * 4 + [_f32, _ptr, _ptr],
     "grit_merge_layernorm_fwd": [_ptr] + [_int] * 4 + [_ptr] * 2 + [_f32, _int, _int] + [_ptr] * 4,
     "grit_merge_layernorm_bwd": [_ptr] + [_int] * 4 + [_ptr] * 4 + [_int, _int] + [_ptr] * 4,
     "grit_relbias_fwd": [_ptr, _ptr, _int, _int, _int, _int, _ptr, _ptr],

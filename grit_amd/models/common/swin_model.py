@@ -26,6 +26,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
+import ctypes
+
+from grit_amd import lib as _lib
+from grit_amd.ops import backend as _backend
 from grit_amd.ops.layer_norm import LayerNorm, add_layer_norm, linear_add_layer_norm, merge_layer_norm
 from grit_amd.ops import transposed as _transposed
 from grit_amd.ops.linear import Linear, linear, mark_single_use, park_weight_grad_for_partner
@@ -39,6 +43,7 @@ def to_2tuple(x):
 
 
 _POOLED_DROP_PATH = os.environ.get('GRIT_POOLED_DROP_PATH', '1') != '0'  # A/B knob
+_PATCH_EMBED_FUSED = os.environ.get('GRIT_PATCH_EMBED_FUSED', '1') != '0'  # A/B knob: conv + bias + LayerNorm of PatchEmbed in one pass
 _MERGE_LN = os.environ.get('GRIT_MERGE_LN', '1') != '0'  # A/B knob: patch-merging LayerNorm on the gathering kernels
 _FUSED_MLP = os.environ.get('GRIT_FUSED_MLP', '1') != '0'  # A/B knob: Mlp on the fused-epilogue GEMM (grit_amd/ops/mlp.py)
 
@@ -359,6 +364,10 @@ class PatchEmbed(nn.Module):
         convolution for this shape is two orders of magnitude slower than the GEMM on MI355X."""
         ph, pw = self.patch_size
         H, W = x.shape[-2:]
+        fused = self._fused_tokens(x)
+        if fused is not None:
+            return fused, H // ph, W // pw
+        x = x.to(self.proj.weight.dtype)
         if W % pw or H % ph:
             x = F.pad(x, (0, (pw - W % pw) % pw, 0, (ph - H % ph) % ph))
         B, Cin, H, W = x.shape
@@ -368,6 +377,29 @@ class PatchEmbed(nn.Module):
         if self.norm is not None:
             t = self.norm(t)
         return t, Wh, Ww
+
+    def _fused_tokens(self, x):
+        """conv + bias + LayerNorm in one pass over the image (grit_patch_embed_ln_fwd) where it applies: a frozen / no-grad bf16
+        patch embedding on the device with a 4 x 4 patch, 3 input channels, W a multiple of 64; None otherwise."""
+        w = self.proj.weight
+        if not (_PATCH_EMBED_FUSED and x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and self.patch_size == (4, 4) and self.in_chans == 3
+                and isinstance(self.norm, LayerNorm) and self.embed_dim in (96, 128, 192) and w.dtype == torch.bfloat16
+                and self.proj.bias is not None and self.norm.weight.dtype == torch.bfloat16 and x.dtype in (torch.float32, torch.bfloat16)
+                and x.shape[2] % 4 == 0 and x.shape[3] % 64 == 0 and x.is_contiguous() and _backend.override() is None
+                and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or self.norm.weight.requires_grad))):
+            return None
+        B, _, H, W = x.shape
+        out = torch.empty((B, (H // 4) * (W // 4), self.embed_dim), dtype=torch.bfloat16, device=x.device)
+        w2 = w.view(self.embed_dim, 48)
+        ptr = lambda t_: ctypes.c_void_p(t_.data_ptr())
+        with _lib.device_guard(x.device):
+            st = _lib.load().grit_patch_embed_ln_fwd(ptr(x), int(x.dtype == torch.bfloat16), B, H, W, self.embed_dim, ptr(w2), ptr(self.proj.bias),
+                                                     ptr(self.norm.weight), ptr(self.norm.bias), float(self.norm.eps), ptr(out),
+                                                     _lib.current_stream_ptr())
+        if st == 2:  # GRIT_ERR_UNSUPPORTED (shape outside the kernel): the GEMM path
+            return None
+        _lib.check(st, "grit_patch_embed_ln_fwd")
+        return out
 
     def forward(self, x):
         t, Wh, Ww = self.tokens(x)
@@ -453,7 +485,7 @@ class SwinTransformer(nn.Module):
             _transposed.refresh([w for stage in self.layers for blk in stage.blocks
                                  for w in (blk.mlp.fc2.weight, blk.attn.proj.weight, blk.attn.qkv.weight, blk.mlp.fc1.weight)
                                  if w.requires_grad])
-        x, Wh, Ww = self.patch_embed.tokens(x.to(self.patch_embed.proj.weight.dtype))
+        x, Wh, Ww = self.patch_embed.tokens(x)  # (casts to the weights' dtype itself unless the fused pass reads the image as it is)
         if self.ape:
             pos = F.interpolate(self.absolute_pos_embed, size=(Wh, Ww), mode='bicubic')
             x = x + pos.flatten(2).transpose(1, 2)

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 34
+#define GRIT_ABI_VERSION 35
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -278,6 +278,15 @@ int grit_relbias_bwd(const float* dbias, const int32_t* order, const int32_t* of
  * gradient as stored -- the bias gradient of the Linear that produced `branch` (attn.proj / mlp.fc2), for free.
  * Other arguments as in grit_layernorm_{fwd,bwd}.
  * ------------------------------------------------------------------------------------------------------ */
+/* Patch embedding of the Swin backbone in one pass (reference models/common/swin_model.py:336-365, PatchEmbed: Conv2d(3, C, kernel 4,
+ * stride 4) -> flatten(2).transpose(1, 2) -> LayerNorm(C)): out[b, hh * W/4 + ww, :] = LayerNorm(conv(img)[b, :, hh, ww] + bias),
+ * bf16.  img [B, 3, H, W] fp32 (img_is_bf16 = 0: rounded to bf16 on load, as the unfused cast does) or bf16; weight [C, 48] bf16 =
+ * the conv weight flattened in its own (c, kh, kw) order; bias, gamma, beta [C] bf16; C in {96, 128, 192}; H % 4 == 0, W % 64 == 0
+ * (GRIT_ERR_UNSUPPORTED otherwise: the caller keeps its GEMM path); 16-byte aligned bases.  The conv output is rounded to bf16
+ * before the statistics, like the tensor the unfused GEMM stores.  Forward only: PatchEmbed is frozen in GRIT (frozen_stages = 2). */
+int grit_patch_embed_ln_fwd(const void* img, int img_is_bf16, int B, int H, int W, int C, const void* weight, const void* bias,
+                            const void* gamma, const void* beta, float eps, void* out, void* stream);
+
 /* LayerNorm of the PATCH-MERGED map without the map (reference models/common/swin_model.py:279-288, PatchMerging.forward: 2 x 2
  * neighbourhood concat in the order (0,0), (1,0), (0,1), (1,1) -> LayerNorm(4 Cs)): x is the token map [B, H, W, Cs] (H, W even, Cs a
  * multiple of 8, 4 Cs in the supported widths); row r of the [B * H/2 * W/2, 4 Cs] view is gathered on load.  y, mean, rstd as in

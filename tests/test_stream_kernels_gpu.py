@@ -635,3 +635,47 @@ def test_patch_merging_layer_norm_through_the_view(B, H, W, C, dtype):
     assert float((dw1.float() - dw0.float()).abs().max()) <= tol * float(dw0.float().abs().max()) + 1e-6
     assert float((db1.float() - db0.float()).abs().max()) <= tol * float(db0.float().abs().max()) + 1e-6
     assert merge_layer_norm(x[:, :(H - 1) * W].contiguous(), H - 1, W, w, b, 1e-5) is None  # odd height: not taken
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,C,img_dtype", [(2, 64, 128, 128, torch.float32), (1, 128, 64, 96, torch.bfloat16), (3, 32, 192, 192, torch.float32),
+                                               (32, 640, 640, 128, torch.float32)])
+def test_patch_embedding_in_one_pass(B, H, W, C, img_dtype):
+    """grit_patch_embed_ln_fwd (reference models/common/swin_model.py:336-365): conv 4 x 4 / 4 + bias + LayerNorm against the
+    reference composition evaluated in fp32 on the same bf16-rounded image and weights, and against this repository's unfused path
+    (cast, im2col copy, GEMM, LayerNorm kernels): the bf16 results may differ by the rounding of differently ordered fp32 sums
+    (one bf16 ulp of the conv output moves the normalised value by ~2^-8 of its scale)."""
+    from grit_amd.models.common.swin_model import PatchEmbed
+    from grit_amd.ops.layer_norm import LayerNorm
+    import grit_amd.models.common.swin_model as SM
+    torch.manual_seed(C + H)
+    pe = PatchEmbed(patch_size=4, in_chans=3, embed_dim=C, norm_layer=LayerNorm).to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        pe.norm.weight.copy_(1.0 + 0.1 * torch.randn(C, device=DEV))
+        pe.norm.bias.copy_(0.1 * torch.randn(C, device=DEV))
+    for p in pe.parameters():
+        p.requires_grad_(False)
+    img = torch.randn(B, 3, H, W, device=DEV).to(img_dtype)
+    with torch.no_grad():
+        fused, Wh, Ww = pe.tokens(img)
+        assert (Wh, Ww) == (H // 4, W // 4) and fused.shape == (B, Wh * Ww, C) and fused.dtype == torch.bfloat16
+        unfused = None
+        if C == 128:  # (the streaming LayerNorm kernels of the unfused path cover the widths GRIT uses: 128 ... 4096)
+            old = SM._PATCH_EMBED_FUSED
+            SM._PATCH_EMBED_FUSED = False
+            try:
+                unfused, _, _ = pe.tokens(img)
+            finally:
+                SM._PATCH_EMBED_FUSED = old
+        x32 = img.to(torch.bfloat16).float()
+        conv = torch.nn.functional.conv2d(x32, pe.proj.weight.float(), pe.proj.bias.float(), stride=4)
+        tok = conv.flatten(2).transpose(1, 2).to(torch.bfloat16).float()
+        ref = torch.nn.functional.layer_norm(tok, (C,), pe.norm.weight.float(), pe.norm.bias.float(), pe.norm.eps)
+    err = (fused.float() - ref).abs()
+    assert float(err.max()) <= 0.06 and float(err.mean()) <= 4e-3, (float(err.max()), float(err.mean()))
+    if unfused is not None:
+        d = (fused.float() - unfused.float()).abs()
+        assert float(d.max()) <= 0.06 and float((d > 0).float().mean()) < 0.2, (float(d.max()), float((d > 0).float().mean()))
+    # a width outside the kernel's tiling keeps the GEMM path
+    with torch.no_grad():
+        assert pe._fused_tokens(img[..., :W - 4].contiguous()) is None

@@ -43,6 +43,8 @@ struct GemmArgs {
                  // whole-tile outputs streamed past L2 leave the operand panels resident -- 63.4 -> 62.0 ms per training step)
     float* colsum;
     int M, N, K, tiles_m, tiles_n;
+    const float* row_scale;    // GRIT_GEMM_DGELU / MUL_AUX, optional: per-sample factors that were applied to the rows of A (drop path);
+    int rows_per_sample;       //   a tile whose rows all belong to ONE sample with factor 0 has A = 0: its result is written as zeros
 #ifdef GRIT_GEMM_STAMPS
     unsigned long long* stamps;  // diagnostic build only (tools/micro/gemm_stamps.hip): [workgroup][wave][16] s_memtime values
 #endif
@@ -83,6 +85,29 @@ void gemm_nt_bf16(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, lq = lane >> 4;
+
+    if constexpr (EPI == GRIT_GEMM_DGELU || EPI == GRIT_GEMM_MUL_AUX) {
+        // Rows of a sample that drop path removed from this branch arrive as exact zeros (dbranch = 0 * dx): the product is zero whatever
+        // the weights are -- no K loop, no GELU', just the zero tile and zero column sums (every output stays fully written).
+        if (g.row_scale != nullptr) {
+            const int s_lo = m0 / g.rows_per_sample, s_hi = (min(m0 + BM, g.M) - 1) / g.rows_per_sample;
+            if (s_lo == s_hi && g.row_scale[s_lo] == 0.f) {  // workgroup-uniform
+                const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+                const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int it = 0; it < WTM / 8; ++it) {
+                    const int m = mw + it * 8 + (lane >> 3);
+                    if (m < g.M) __builtin_nontemporal_store(z, reinterpret_cast<u32x4*>(g.C + (size_t)m * g.ldc + nw + (lane & 7) * 8));
+                }
+                if (l15 == 0 && mw < g.M) {
+                    float* dst = g.colsum + (size_t)(mw / WTM) * g.N + nw + 4 * lq;
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) *reinterpret_cast<v4f*>(dst + 16 * j) = v4f{0.f, 0.f, 0.f, 0.f};
+                }
+                return;
+            }
+        }
+    }
 
     // ---- DMA source pointers (one per round) and LDS destinations -------------------------------------------------
     const __bf16* asrc[LA];
@@ -759,6 +784,10 @@ int launch(const GemmArgs& a, int epilogue, hipStream_t st) {
 
 }  // namespace
 
+// (set by grit_gemm_bf16_nt_rows around its call: the plain entry point keeps its signature)
+static thread_local const float* g_row_scale = nullptr;
+static thread_local int g_rows_per_sample = 0;
+
 extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                                  int epilogue, const void* bias, void* aux, long ldaux, float* colsum, int variant,
                                  void* stream) {
@@ -776,6 +805,7 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
     static const int nt_aux = [] { const char* e = getenv("GRIT_GEMM_NT_AUX"); return e ? atoi(e) : 15; }();
     a.nt_aux = nt_aux;
     a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
+    a.row_scale = g_row_scale; a.rows_per_sample = g_rows_per_sample;
 #ifdef GRIT_GEMM_STAMPS
     a.stamps = nullptr;  // diagnostic builds set it through launch<>() directly
 #endif
@@ -797,4 +827,16 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
                                                epilogue == GRIT_GEMM_BIAS ? 0 : nt_aux, stream);
         default: return GRIT_ERR_BAD_ARG;
     }
+}
+
+// GRIT_GEMM_DGELU / GRIT_GEMM_MUL_AUX with the per-sample factors of the rows of A (see GemmArgs::row_scale): eight-wave variants only.
+extern "C" int grit_gemm_bf16_nt_rows(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                                      int epilogue, void* aux, long ldaux, float* colsum, const float* row_scale, int rows_per_sample,
+                                      int variant, void* stream) {
+    if (epilogue != GRIT_GEMM_DGELU && epilogue != GRIT_GEMM_MUL_AUX) return GRIT_ERR_BAD_ARG;
+    if (row_scale && (rows_per_sample <= 0 || variant > 4)) return GRIT_ERR_BAD_ARG;
+    g_row_scale = row_scale; g_rows_per_sample = rows_per_sample;
+    const int st = grit_gemm_bf16_nt(A, lda, B, ldb, C, ldc, M, N, K, epilogue, nullptr, aux, ldaux, colsum, variant, stream);
+    g_row_scale = nullptr; g_rows_per_sample = 0;
+    return st;
 }

@@ -18,6 +18,8 @@ NONE, BIAS, BIAS_GELU, DGELU, BIAS_GELU_DACT, MUL_AUX = 0, 1, 2, 3, 4, 5
 # Measured (profiles/r04/saved_dgelu.txt, stage 2): the product epilogue saves 33 us (181 -> 148), the two-output forward epilogue
 # costs 48 (149 -> 197: its temporaries spill beside the 128 accumulators); in the step 52.79 -> 53.14 ms.  Kept, tested, not the default.
 SAVE_DGELU = os.environ.get("GRIT_MLP_SAVE_DGELU", "0") == "1"
+# GRIT_GEMM_ROW_SKIP (default 1): the fc2 input gradient skips the tiles of samples that drop path removed from the branch (exact zeros)
+ROW_SKIP = os.environ.get("GRIT_GEMM_ROW_SKIP", "1") != "0"
 COLSUM_ROWS = 128
 VARIANT = int(os.environ.get("GRIT_GEMM_VARIANT", "0"))  # tuning alternatives of the same kernel (A/B runs)
 
@@ -73,12 +75,24 @@ def linear_bias_gelu(x2, weight, bias):
     return pre, act
 
 
-def input_grad_dgelu(dy2, weight_t, pre):
+def input_grad_dgelu(dy2, weight_t, pre, row_scale=None, rows_per_sample=0):
     """(d_pre, colsum_partial): d_pre = (dy2 @ weight_t^T) * gelu'(h) with weight_t [N_hidden, K] = the following Linear's
     weight transposed and `pre` = the tensor linear_bias_gelu saved (gelu'(h), or h with GRIT_MLP_SAVE_DGELU=0); colsum_partial
     [ceil(M / 128), N_hidden] f32 sums to the bias gradient of the Linear that produced h."""
     M = dy2.shape[0]
     N = weight_t.shape[0]
+    if ROW_SKIP and row_scale is not None and rows_per_sample > 0 and row_scale.dtype == torch.float32 and row_scale.is_cuda:
+        # drop path: rows of dropped samples are exact zeros in dy2 -- their tiles need no K loop (grit_gemm_bf16_nt_rows, eight-wave kernel)
+        partial = torch.empty((-(-M // COLSUM_ROWS), N), dtype=torch.float32, device=dy2.device)
+        d_pre = torch.empty((M, N), dtype=torch.bfloat16, device=dy2.device)
+        K = dy2.shape[1]
+        epi = MUL_AUX if SAVE_DGELU else DGELU
+        with _lib.device_guard(dy2.device), timed("gemm_own", epilogue=epi, kernel="gemm_nt_bf16", **gemm_work(M, N, K, extra_in=1)):
+            st = _lib.load().grit_gemm_bf16_nt_rows(_ptr(dy2), dy2.stride(0), _ptr(weight_t), weight_t.stride(0), _ptr(d_pre), d_pre.stride(0),
+                                                    M, N, K, epi, _ptr(pre), pre.stride(0), _ptr(partial), _ptr(row_scale), int(rows_per_sample),
+                                                    VARIANT if VARIANT in (1, 2, 3, 4) else 0, _lib.current_stream_ptr())
+        _lib.check(st, "grit_gemm_bf16_nt_rows")
+        return d_pre, partial
     if SAVE_DGELU:  # `pre` is the saved derivative (linear_bias_gelu above): a plain product in the epilogue
         partial = torch.empty((-(-M // COLSUM_ROWS), N), dtype=torch.float32, device=dy2.device)
         d_pre = gemm_nt(dy2, weight_t, MUL_AUX, aux=pre, colsum=partial, variant=VARIANT if VARIANT in (1, 2, 3, 4) else 0)

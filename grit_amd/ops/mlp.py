@@ -37,7 +37,7 @@ def _rows(t):
     return t2 if t2.is_contiguous() else t2.contiguous()
 
 
-def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=None, params=None):
+def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=None, params=None, row_scale=None, rows_per_sample=0):
     """Gradients of branch = fc2(gelu(fc1(n2))) w.r.t. (n2, w1, b1, w2[, b2]) given d_branch [M, C].  The chain of input
     gradients runs on the current stream, the weight / bias gradients beside it on the side stream (linear.fork).  `group`:
     the caller's SlabGroup -- every partial sum of the node (dW2, db1, dW1[, db2]) is then reduced by the caller's one launch
@@ -62,7 +62,8 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=No
             d_b2 = column_sum(d_branch, w2.dtype, group)
     if chain:
         w2t = _transposed.lookup(params[1] if params is not None else w2)  # made for all blocks at once by the backbone's forward
-        d_pre, partial = G.input_grad_dgelu(d_branch, w2t if w2t is not None else w2.t().contiguous(), pre)
+        # (row_scale: the drop-path factors already applied to the rows of d_branch -- tiles of dropped samples are zeros without a K loop)
+        d_pre, partial = G.input_grad_dgelu(d_branch, w2t if w2t is not None else w2.t().contiguous(), pre, row_scale, rows_per_sample)
         join(side, d_w2, d_b2)
         side = fork(d_pre, partial, n2) if (need_x and (need_w1 or need_b1)) else None
         if side is not None:
@@ -165,7 +166,8 @@ class _MlpAddLayerNormFn(Function):
         ni = ctx.needs_input_grad
         ps = ctx.params
         d_x, d_w1, d_b1, d_w2, _ = _mlp_backward(d_branch, x2, w1, pre, act, w2, (ni[0], ni[1], ni[2], ni[3]), group=group,
-                                                 params=None if ps is None else (ps[0], ps[2]))
+                                                 params=None if ps is None else (ps[0], ps[2]), row_scale=scale,
+                                                 rows_per_sample=x2.shape[0] // ctx.shape[0] if scale is not None else 0)
         # (sums in another dtype than the parameters would be converted -- read -- below, before a deferred launch has run)
         finish_group(group, ps is not None and not WGRAD_STREAM and sums.dtype == w2.dtype and ni[4] and ni[7] and ni[8],
                      [] if ps is None else [(ps[0], d_w1), (ps[1], d_b1), (ps[2], d_w2), (ps[3], sums[2]), (ps[4], sums[0]),

@@ -319,6 +319,31 @@ def test_saved_derivative_epilogues(M, N, K, variant):
             G.gemm_nt(x, w, G.MUL_AUX, aux=aux, colsum=part, variant=v)
 
 
+@pytest.mark.parametrize("M,per,N,K", [(51200, 1600, 2048, 512), (4096 + 300, 550, 256, 128), (12800, 400, 1024, 256)])
+def test_dropped_samples_are_skipped_not_computed(M, per, N, K):
+    """grit_gemm_bf16_nt_rows: with the per-sample drop-path factors at hand, the GELU' GEMM writes the tiles of dropped samples as
+    zeros without a K loop.  Bit-identical to the dense kernel on the same (zeroed) rows -- result and column sums -- whatever the
+    alignment of samples and 256-row tiles; a NaN planted in the pre-activation of a skipped tile is never read."""
+    from grit_amd.ops import gemm as G
+    torch.manual_seed(M + N)
+    B = -(-M // per)
+    scale = (torch.rand(B, device='cuda') > 0.4).float() / 0.6
+    scale[0] = 0.0
+    dy = torch.randn(M, K, device='cuda').bfloat16()
+    rows = torch.arange(M, device='cuda') // per
+    dy = (dy.float() * scale[rows].unsqueeze(1)).bfloat16()          # dbranch = scale * dx: exact zero rows for dropped samples
+    w = (torch.randn(N, K, device='cuda') * K ** -0.5).bfloat16()
+    pre = torch.randn(M, N, device='cuda').bfloat16()
+    dense, part_dense = G.input_grad_dgelu(dy, w, pre)
+    pre_nan = pre.clone()
+    if per >= 512:
+        pre_nan[256:512] = float('nan')  # rows of sample 0 (dropped), a tile that lies inside it
+    skip, part_skip = G.input_grad_dgelu(dy, w, pre_nan, scale, per)
+    assert torch.equal(skip, dense)
+    assert torch.equal(part_skip, part_dense)
+    assert float(skip[:per].abs().max()) == 0.0
+
+
 def test_saved_derivative_equals_the_derivative_epilogue_over_the_whole_range():
     """Every bf16 value of [-9, 9] through an identity GEMM: the tensor GRIT_GEMM_BIAS_GELU_DACT saves is what GRIT_GEMM_DGELU
     computes from the pre-activation (same expression, same order: bit-identical after the bf16 rounding of the store), so

@@ -186,6 +186,7 @@ int main(int argc, char** argv) {
         if (N % 256 == 0) {  // the ping-pong kernel's phases on the same box (its epilogue is the fifth figure, per K step)
             hipMemset(stamps, 0, (size_t)256 * 8 * 16 * 8);
             v45::GemmArgs a;
+            a.row_scale = nullptr; a.rows_per_sample = 0;
             a.A = (const __bf16*)A; a.lda = K; a.B = (const __bf16*)B; a.ldb = K; a.C = (__bf16*)C; a.ldc = N; a.bias = (const __bf16*)bias;
             a.aux = nullptr; a.ldaux = N; a.colsum = nullptr; a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0; a.nt_aux = 0;
             a.stamps = stamps;

@@ -24,6 +24,7 @@ int main(int argc, char** argv) {
     hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice); hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(bias, hbias.data(), N * 2, hipMemcpyHostToDevice); hipMemset(aux, 0, (size_t)M * N * 2);
     GemmArgs a;
+    a.row_scale = nullptr; a.rows_per_sample = 0;
     a.A = (const __bf16*)A; a.lda = K; a.B = (const __bf16*)B; a.ldb = K; a.C = (__bf16*)C; a.ldc = N; a.bias = (const __bf16*)bias;
     a.aux = (__bf16*)aux; a.ldaux = N; a.colsum = cs; a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0; a.stamps = nullptr;
     auto run = [&](unsigned long long* st) {

@@ -78,17 +78,28 @@ void gemm_nt_bf16(const GemmArgs g) {
     const int nwg = g.tiles_m * g.tiles_n;
     const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
     const int qd = nwg >> 3, rm = nwg & 7;
-    const int tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
-    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    int tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    if (g.row_scale != nullptr && (g.tiles_m & 7) == 0) {
+        // With tiles that may be skipped (samples removed by drop path: a run of ~6 consecutive row panels) a contiguous band of row
+        // panels per XCD leaves the skipping to the one XCD that owns the sample, and the launch waits for the others.  Deal the row
+        // panels round-robin instead -- panel 8 p + xcd -- : every XCD still runs whole panels (the 8 tiles that share an A panel), and
+        // a dropped sample thins out all of them.
+        const int pl = idx / g.tiles_n;
+        tn = idx - pl * g.tiles_n;
+        tm = 8 * pl + xcd;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, lq = lane >> 4;
 
-    if constexpr (EPI == GRIT_GEMM_DGELU || EPI == GRIT_GEMM_MUL_AUX) {
-        // Rows of a sample that drop path removed from this branch arrive as exact zeros (dbranch = 0 * dx): the product is zero whatever
-        // the weights are -- no K loop, no GELU', just the zero tile and zero column sums (every output stays fully written).
+    if constexpr (EPI == GRIT_GEMM_DGELU || EPI == GRIT_GEMM_MUL_AUX || EPI == GRIT_GEMM_BIAS_GELU) {
+        // Backward (DGELU / MUL_AUX): rows of a sample that drop path removed from this branch arrive as exact zeros (dbranch = 0 * dx):
+        // the product is zero whatever the weights are -- no K loop, no GELU', just the zero tile and zero column sums.
+        // Forward (BIAS_GELU): the branch output of such a sample is multiplied by 0 and the tensors saved here meet only zero gradients
+        // in the backward: the tile is not computed, activation and saved pre-activation are written as zeros (finite: 0 * x stays 0).
         if (g.row_scale != nullptr) {
             const int s_lo = m0 / g.rows_per_sample, s_hi = (min(m0 + BM, g.M) - 1) / g.rows_per_sample;
             if (s_lo == s_hi && g.row_scale[s_lo] == 0.f) {  // workgroup-uniform
@@ -97,8 +108,14 @@ void gemm_nt_bf16(const GemmArgs g) {
 #pragma unroll
                 for (int it = 0; it < WTM / 8; ++it) {
                     const int m = mw + it * 8 + (lane >> 3);
-                    if (m < g.M) __builtin_nontemporal_store(z, reinterpret_cast<u32x4*>(g.C + (size_t)m * g.ldc + nw + (lane & 7) * 8));
+                    if (m < g.M) {
+                        __builtin_nontemporal_store(z, reinterpret_cast<u32x4*>(g.C + (size_t)m * g.ldc + nw + (lane & 7) * 8));
+                        if constexpr (EPI == GRIT_GEMM_BIAS_GELU) {
+                            if (g.aux) __builtin_nontemporal_store(z, reinterpret_cast<u32x4*>(g.aux + (size_t)m * g.ldaux + nw + (lane & 7) * 8));
+                        }
+                    }
                 }
+                if constexpr (EPI != GRIT_GEMM_BIAS_GELU)
                 if (l15 == 0 && mw < g.M) {
                     float* dst = g.colsum + (size_t)(mw / WTM) * g.N + nw + 4 * lq;
 #pragma unroll
@@ -831,12 +848,12 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
 
 // GRIT_GEMM_DGELU / GRIT_GEMM_MUL_AUX with the per-sample factors of the rows of A (see GemmArgs::row_scale): eight-wave variants only.
 extern "C" int grit_gemm_bf16_nt_rows(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
-                                      int epilogue, void* aux, long ldaux, float* colsum, const float* row_scale, int rows_per_sample,
-                                      int variant, void* stream) {
-    if (epilogue != GRIT_GEMM_DGELU && epilogue != GRIT_GEMM_MUL_AUX) return GRIT_ERR_BAD_ARG;
+                                      int epilogue, const void* bias, void* aux, long ldaux, float* colsum, const float* row_scale,
+                                      int rows_per_sample, int variant, void* stream) {
+    if (epilogue != GRIT_GEMM_DGELU && epilogue != GRIT_GEMM_MUL_AUX && epilogue != GRIT_GEMM_BIAS_GELU) return GRIT_ERR_BAD_ARG;
     if (row_scale && (rows_per_sample <= 0 || variant > 4)) return GRIT_ERR_BAD_ARG;
     g_row_scale = row_scale; g_rows_per_sample = rows_per_sample;
-    const int st = grit_gemm_bf16_nt(A, lda, B, ldb, C, ldc, M, N, K, epilogue, nullptr, aux, ldaux, colsum, variant, stream);
+    const int st = grit_gemm_bf16_nt(A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, colsum, variant, stream);
     g_row_scale = nullptr; g_rows_per_sample = 0;
     return st;
 }

@@ -63,11 +63,22 @@ def _fused_variant(M, N, K):
     return 7 if (OWN and K >= 1024 and K % 64 == 0 and N % 256 == 0 and M >= 256 and M * K * 2 < 2 ** 31 and N * K * 2 < 2 ** 31) else 0
 
 
-def linear_bias_gelu(x2, weight, bias):
+def linear_bias_gelu(x2, weight, bias, row_scale=None, rows_per_sample=0):
     """(saved, act), both [M, N] bf16, one kernel: act = gelu(x2 @ weight^T + bias); saved = what input_grad_dgelu needs of the
     pre-activation h = x2 @ weight^T + bias -- gelu'(h) (GRIT_MLP_SAVE_DGELU, default) or h itself."""
     M, N = x2.shape[0], weight.shape[0]
     pre = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
+    if (ROW_SKIP and not SAVE_DGELU and row_scale is not None and rows_per_sample > 0 and row_scale.dtype == torch.float32
+            and row_scale.is_cuda):
+        # drop path: the tiles of samples whose branch is multiplied by 0 are not computed (zeros in `act` and `pre`)
+        act = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
+        K = x2.shape[1]
+        with _lib.device_guard(x2.device), timed("gemm_own", epilogue=BIAS_GELU, kernel="gemm_nt_bf16", **gemm_work(M, N, K, outputs=2)):
+            st = _lib.load().grit_gemm_bf16_nt_rows(_ptr(x2), x2.stride(0), _ptr(weight), weight.stride(0), _ptr(act), act.stride(0), M, N, K,
+                                                    BIAS_GELU, _ptr(bias), _ptr(pre), pre.stride(0), None, _ptr(row_scale),
+                                                    int(rows_per_sample), VARIANT if VARIANT in (1, 2, 3, 4) else 0, _lib.current_stream_ptr())
+        _lib.check(st, "grit_gemm_bf16_nt_rows")
+        return pre, act
     if SAVE_DGELU:  # `pre` then holds gelu'(x2 @ weight^T + bias): what input_grad_dgelu multiplies by
         act = gemm_nt(x2, weight, BIAS_GELU_DACT, bias=bias, aux=pre, variant=VARIANT if VARIANT in (1, 2, 3, 4) else 0)
         return pre, act
@@ -89,7 +100,7 @@ def input_grad_dgelu(dy2, weight_t, pre, row_scale=None, rows_per_sample=0):
         epi = MUL_AUX if SAVE_DGELU else DGELU
         with _lib.device_guard(dy2.device), timed("gemm_own", epilogue=epi, kernel="gemm_nt_bf16", **gemm_work(M, N, K, extra_in=1)):
             st = _lib.load().grit_gemm_bf16_nt_rows(_ptr(dy2), dy2.stride(0), _ptr(weight_t), weight_t.stride(0), _ptr(d_pre), d_pre.stride(0),
-                                                    M, N, K, epi, _ptr(pre), pre.stride(0), _ptr(partial), _ptr(row_scale), int(rows_per_sample),
+                                                    M, N, K, epi, None, _ptr(pre), pre.stride(0), _ptr(partial), _ptr(row_scale), int(rows_per_sample),
                                                     VARIANT if VARIANT in (1, 2, 3, 4) else 0, _lib.current_stream_ptr())
         _lib.check(st, "grit_gemm_bf16_nt_rows")
         return d_pre, partial

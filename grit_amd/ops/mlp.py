@@ -134,7 +134,8 @@ class _MlpAddLayerNormFn(Function):
     def forward(ctx, x_in, w1, b1, w2, b2, shortcut, scale, weight, bias, eps, single_use=False):
         ctx.params = (w1, b1, w2, b2, weight, bias) if single_use else None
         x2 = _rows(x_in)
-        pre, act = G.linear_bias_gelu(x2, w1, b1)
+        # (scale: the drop-path factors of this branch -- the fc1 tiles of samples it removes are not computed)
+        pre, act = G.linear_bias_gelu(x2, w1, b1, scale, x2.shape[0] // shortcut.shape[0] if scale is not None else 0)
         branch = G.long_linear(act, w2, b2)  # (the stage-0 map: the own narrow-output kernel; None elsewhere)
         if branch is None:
             with timed("gemm_lib", **gemm_work(act.numel() // act.shape[-1], w2.shape[0], w2.shape[1])):

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 36
+#define GRIT_ABI_VERSION 37
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -509,13 +509,16 @@ int grit_image_batch_fwd(const uint8_t* src, const int64_t* desc, const int32_t*
 #define GRIT_GEMM_COLSUM_ROWS 128
 int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                       int epilogue, const void* bias, void* aux, long ldaux, float* colsum, int variant, void* stream);
-/* GRIT_GEMM_DGELU / GRIT_GEMM_MUL_AUX for an A whose rows carry per-sample factors that are already applied (drop path in the Swin
- * blocks, models/common/swin_model.py:289-298: the gradient of a dropped sample's branch is exactly zero): row_scale [ceil(M /
- * rows_per_sample)] f32 on the device; a 256-row tile that lies inside ONE sample with factor 0 is written as zeros (C and its column
- * sums) without a K loop.  Same results as grit_gemm_bf16_nt on that A.  Eight-wave variants (0..4); row_scale NULL = no skipping. */
+/* The fused Mlp GEMMs with the per-sample drop-path factors of the Swin blocks at hand (models/common/swin_model.py:289-298:
+ * x = shortcut + drop_path(mlp(norm2(x))); a dropped sample's branch contributes nothing forward and receives an exactly zero
+ * gradient): row_scale [ceil(M / rows_per_sample)] f32 on the device; a 256-row tile that lies inside ONE sample with factor 0 is
+ * not computed.  GRIT_GEMM_DGELU / GRIT_GEMM_MUL_AUX (backward: the rows of A are already zero): C and its column sums are written as
+ * zeros -- the same results as grit_gemm_bf16_nt.  GRIT_GEMM_BIAS_GELU (forward): C and aux are written as zeros instead of the values
+ * nobody will use (the caller multiplies the branch by the same factor 0; the saved tensors meet zero gradients).  Eight-wave
+ * variants (0..4); row_scale NULL = no skipping. */
 int grit_gemm_bf16_nt_rows(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K, int epilogue,
-                           void* aux, long ldaux, float* colsum, const float* row_scale, int rows_per_sample, int variant,
-                           void* stream);
+                           const void* bias, void* aux, long ldaux, float* colsum, const float* row_scale, int rows_per_sample,
+                           int variant, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Beam-search candidate selection (reference models/caption/transformer.py:184-188: descending sort of the flattened

@@ -217,6 +217,34 @@ def test_fused_mlp_matches_module(with_norm):
         _close(a, b, 2.0 ** -5)
 
 
+def test_fused_mlp_node_with_and_without_the_dropped_sample_shortcut(monkeypatch):
+    """The Mlp + residual + LayerNorm node with drop-path factors: not computing the fc1 tiles of dropped samples (forward) and the
+    GELU' tiles (backward) leaves every output and every gradient of the node bit-identical (GRIT_GEMM_ROW_SKIP on / off)."""
+    from grit_amd.models.common.swin_model import Mlp
+    from grit_amd.ops.layer_norm import LayerNorm
+    from grit_amd.ops import gemm as G
+    from grit_amd.ops import mlp as M
+    torch.manual_seed(1)
+    B, T, C = 4, 1600, 256
+    mod = Mlp(C, 4 * C).cuda().bfloat16()
+    norm = LayerNorm(C).cuda().bfloat16()
+    x = torch.randn(B, T, C, device='cuda').bfloat16().requires_grad_(True)
+    sc = torch.randn(B, T, C, device='cuda').bfloat16().requires_grad_(True)
+    scale = torch.tensor([0.0, 1.25, 0.0, 1.25], device='cuda')
+    cot = torch.randn(B, T, C, device='cuda').bfloat16()
+
+    def run(skip):
+        monkeypatch.setattr(G, "ROW_SKIP", skip)
+        for p in list(mod.parameters()) + list(norm.parameters()) + [x, sc]:
+            p.grad = None
+        out, y = M.mlp_add_layer_norm(x, mod, sc, scale, norm)
+        (out * cot + y * cot.flip(0)).sum().backward()
+        return [out.detach().clone(), y.detach().clone()] + [p.grad.clone() for p in list(mod.parameters()) + list(norm.parameters()) + [x, sc]]
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("M,N,K", [(4800, 512, 512), (4800, 128, 512), (4800, 1024, 512), (640, 512, 512), (3200, 2048, 512),
                                    (777, 64, 192), (33, 128, 64), (16000, 256, 1024), (4801, 64, 64)])
 @pytest.mark.parametrize("strided", [False, True])

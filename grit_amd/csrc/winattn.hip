@@ -71,7 +71,6 @@ struct Geom {
     int B, H, W, C, nH, shift, nWh, nWw, Hp, Wp, T, nWm;
     float scale;
     int xcd_pairs;  // 1: workgroup id -> (head, window group) keeps heads 2j / 2j+1 on one XCD (head_and_group)
-    int skip_zero;  // backward: 1 = a window whose dO tile is all zeros is answered with zeros (GRIT_WINATTN_BWD_SKIP, default 1)
     float inv_img, inv_nww;  // 1 / (windows per image), 1 / nWw: window_of
 };
 
@@ -765,7 +764,7 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
 //     single (consumed at the top of their window): 18 432 B;  statistics 3 552 B (the row log-sum-exps, the region ids and the token indices of the
 //     144 window positions double buffered: they arrive with the tiles).
 constexpr int kBP2 = 152;
-constexpr size_t kBwdDmaLds = (size_t)kN * kBP2 * 2 + (size_t)kN * kSP * 2 + 8 * (size_t)kN * kTP * 2 + 3 * kN * 4 + 3 * kHd * 4 + 2 * kN + 2 * kN * 4 + 16;  // (+ 16: the two "this window has a gradient" words)
+constexpr size_t kBwdDmaLds = (size_t)kN * kBP2 * 2 + (size_t)kN * kSP * 2 + 8 * (size_t)kN * kTP * 2 + 3 * kN * 4 + 3 * kHd * 4 + 2 * kN + 2 * kN * 4;
 static_assert(kBwdDmaLds <= 160 * 1024, "one workgroup per CU");
 
 template <bool kExplicitMask>
@@ -785,7 +784,6 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     float* pad_s = delta_s + kN;                                            // [96]
     uint8_t* rid = reinterpret_cast<uint8_t*>(pad_s + 3 * kHd);             // [2][144]
     int* tok_s = reinterpret_cast<int*>(rid + 2 * kN);                      // [2][144] token index of a window position, -1: padding
-    int* work_s = tok_s + 2 * kN;                                           // [2] "the dO tile of the window in buffer i is not all zeros"
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -804,7 +802,6 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
         bT[ki * kBP2 + qi] = (__bf16)rel_bias[(size_t)h * kN * kN + i];
     }
     if (tid < 3 * kHd) pad_s[tid] = 0.f;
-    if (tid < 2) work_s[tid] = 0;
 
     v4f dB[kTiles];  // d(bias)[query 16qt + 4lg + r][key 16w + l15], summed over this workgroup's windows
 #pragma unroll
@@ -904,43 +901,22 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs (and its stores of the previous window) are done
         __syncthreads();  // ... everybody's: the tiles of this window are complete (first time: so is the bias slab)
         float dpart = 0.f;  // delta = rowsum(dO * O): 8 channels per thread, 4 threads per token
-        int do_nonzero;     // any element of this thread's 16 bytes of dO other than +-0
         {
-            const uint4 araw = *reinterpret_cast<const uint4*>(&dOs[sn * kTP + sc * 8]);
-            do_nonzero = ((araw.x | araw.y | araw.z | araw.w) & 0x7fff7fffu) != 0u;
-            const v8bf a = as_v8bf(araw);
+            const v8bf a = as_v8bf(*reinterpret_cast<const uint4*>(&dOs[sn * kTP + sc * 8]));
             const v8bf c = as_v8bf(*reinterpret_cast<const uint4*>(&Os1[sn * kTP + sc * 8]));
 #pragma unroll
             for (int e = 0; e < 8; ++e) dpart = fmaf((float)a[e], (float)c[e], dpart);
             dpart = sum_quad(dpart);
         }
         if (sc == 0) delta_s[sn] = dpart;
-        if (__any(do_nonzero) && lane == 0) work_s[cur] = 1;  // (every wave that sees a non-zero writes the same 1)
         // this lane's key in phase 1: its token (-1: window padding) and shift-mask region, as the loaders left them
         const int tkk = tok_s[cur * kN + 16 * w + l15], kreg = rid[cur * kN + 16 * w + l15];
         // this lane's K / V fragments (B operands of phase 1): key 16 w + l15, channels 8 lg ..
         const int swr = ((l15 & 8) ? 3 : 0) ^ ((l15 & 4) ? 2 : 0);   // chunk permutation of row l15 of a 16-row block (see fetch_rows)
         const v8bf kf = as_v8bf(*reinterpret_cast<const uint4*>(&Ks[(16 * w + l15) * kTP + ((lg ^ swr) << 3)]));
         const v8bf vf = as_v8bf(*reinterpret_cast<const uint4*>(&Vs1[(16 * w + l15) * kTP + ((lg ^ swr) << 3)]));
-        // statistics visible; the V / O tiles and the other tile buffer are free for the next window's DMA -- and, in the same
-        // barrier: is there anything to do?  A window whose dO tile is all zeros (a sample that drop path removed from this branch:
-        // its gradient is exactly 0 * dx) has dS = P (dP - delta) = 0, i.e. dQ = dK = dV = 0 and no d(bias): three zero stores
-        // per token instead of five matrix products (11 % of the (window, head) units at GRIT's drop-path rates)
-        __syncthreads();
-        const int work = work_s[cur];
-        if (tid == 0) work_s[cur ^ 1] = 0;  // (last read behind the previous window's barrier; set again behind the next window's first)
+        __syncthreads();  // statistics visible; the V / O tiles and the other tile buffer are free for the next window's DMA
         if (win + ngrp < NW) nxt = prefetch(win + ngrp, cur ^ 1);  // lands under phases 1 and 2 of this window
-        if (!work && g.skip_zero) {
-            const int tk = tok_s[cur * kN + sn];
-            if (tk >= 0) {
-                __bf16* base = dqkv + (img + tk) * C3 + hoff + sc * 8;
-                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-                *reinterpret_cast<uint4*>(base) = z;
-                *reinterpret_cast<uint4*>(base + g.C) = z;
-                *reinterpret_cast<uint4*>(base + 2 * g.C) = z;
-            }
-            continue;
-        }
 
         // Per-lane LDS offsets, made opaque once per window: without this hipcc hoists ~90 loop-invariant LDS
         // addresses out of the window loop, runs out of registers and reloads them from scratch before every read.
@@ -1314,7 +1290,6 @@ Geom make_geom(int B, int H, int W, int C, int nH, int shift, float scale, int n
     g.nWh = (H + kWs - 1) / kWs; g.nWw = (W + kWs - 1) / kWs;
     g.Hp = g.nWh * kWs; g.Wp = g.nWw * kWs; g.T = H * W; g.nWm = nWm > 0 ? nWm : 1; g.scale = scale;
     g.xcd_pairs = 0;
-    g.skip_zero = 0;
     g.inv_img = 1.0f / (float)(g.nWh * g.nWw); g.inv_nww = 1.0f / (float)g.nWw;
     return g;
 }
@@ -1336,7 +1311,6 @@ Geom with_xcd_mapping(Geom g, int blocks) {
     const int groups = blocks / g.nH;
     g.xcd_pairs = (g.nH % 8 == 0 && g.nH >= 16) || (g.nH == 8 && groups % 2 == 0) || (g.nH == 4 && groups % 4 == 0);
     if (getenv("GRIT_WINATTN_PLAIN_MAP")) g.xcd_pairs = 0;  // A/B knob for tools/bench_kernels.py
-    g.skip_zero = !(getenv("GRIT_WINATTN_BWD_SKIP") && atoi(getenv("GRIT_WINATTN_BWD_SKIP")) == 0);
     return g;
 }
 

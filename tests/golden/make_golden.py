@@ -650,5 +650,58 @@ def make_h5():
 
 MAKERS.update({'h5': make_h5})
 
+
+
+def make_g15():
+    """Beam search that REACHES EOS, with a real batch (reference models/caption/transformer.py:204-254: the `seq_mask`
+    product, the -999 fill, the index-0 survivor of a finished beam; :184-188 the full descending sort).  The closed-form fill
+    never emits token 3 (G7 / G9 / G13 contain none), so row 3 of `cap_generator.fc.weight` is scaled: x6 makes the eight images
+    finish at different steps (one never, two with all five beams finished), x10 adds EOS as the very first word.  Decoder only
+    (model.cached_features = True) from seeded features with RAGGED grid masks (padded grid tokens zeroed, as the detector's
+    padded positions are masked keys); 3-layer decoder = BASELINE config 5's model, beam 5 x 20 steps, out_size 5 (every beam,
+    best first).  Stored per variant: tokens, log-probs and the per-step top-6 candidate scores (the margin record)."""
+    import_reference()
+    model, cfg = _ref_model(3)
+    model.eval()
+    B, Ng, beam, T = 8, 100, 5, 20
+    gen = torch.Generator().manual_seed(15)
+    gri = torch.randn(B, Ng, 1024, generator=gen)
+    reg = torch.randn(B, 150, 512, generator=gen)
+    gri_mask = torch.zeros(B, 1, 1, Ng, dtype=torch.bool)
+    for i, n in enumerate([100, 100, 80, 70, 100, 49, 90, 64]):
+        gri_mask[i, ..., n:] = True
+        gri[i, n:] = 0
+    reg_mask = torch.zeros(B, 1, 1, 150, dtype=torch.bool)
+    out = {'gri_feat': gri.numpy(), 'reg_feat': reg.numpy(), 'gri_mask': gri_mask.numpy(), 'reg_mask': reg_mask.numpy(),
+           'eos_row_scales': np.array([6.0, 10.0], dtype=np.float32)}
+    w0 = model.cap_generator.fc.weight.data.clone()
+    model.cached_features = True
+    for scale in (6, 10):
+        model.cap_generator.fc.weight.data.copy_(w0)
+        model.cap_generator.fc.weight.data[3] *= float(scale)
+        record = []
+        orig = model.select
+
+        def select(t, cand, beam_size, _orig=orig, _rec=record, **kw):
+            flat = cand.reshape(cand.shape[0], -1)
+            _rec.append(torch.sort(flat, -1, descending=True)[0][:, :beam_size + 1].clone())
+            return _orig(t, cand, beam_size, **kw)
+
+        model.select = select
+        with torch.no_grad():
+            toks, lps = model({'gri_feat': gri.clone(), 'gri_mask': gri_mask.clone(), 'reg_feat': reg.clone(),
+                               'reg_mask': reg_mask.clone()}, seq=None, use_beam_search=True, max_len=T, eos_idx=3,
+                              beam_size=beam, out_size=beam)
+        model.select = orig
+        top6 = torch.stack(record, 1)  # [B, steps, beam + 1]
+        out.update({f's{scale}_tokens': toks.numpy(), f's{scale}_logprobs': lps.numpy(), f's{scale}_top': top6.numpy()})
+        first = [[int((toks[b, k] == 3).nonzero()[0]) if (toks[b, k] == 3).any() else -1 for k in range(beam)] for b in range(B)]
+        d = (top6[..., :-1] - top6[..., 1:]).abs()
+        print(f'g15 x{scale}: first EOS per (image, beam)', first, 'min margin per image', d.amin((1, 2)).tolist())
+    np.savez_compressed(os.path.join(HERE, 'beam_g15.npz'), **out)
+
+
+MAKERS.update({'g15': make_g15})
+
 if __name__ == "__main__":
     main()

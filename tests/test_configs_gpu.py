@@ -227,21 +227,36 @@ def test_config5_batch64_beam5_equals_single_image_decodes_and_reference_order_l
     singles = [decode({k: v[i:i + 1].contiguous() for k, v in feats.items()}) for i in range(B)]
     single_tokens = torch.cat([s[0] for s in singles], 0)
     single_lps = torch.cat([s[1] for s in singles], 0)
-    # batched == per image.  fp32 GEMMs of 320 rows and of 5 rows run different library kernels (summation order): where a pair of
-    # candidates is closer than that round-off the beam may legitimately take the other one -- allowed only as an exact tie in score
-    same = (tokens == single_tokens).all(1)
-    score_b, score_s = lps.sum(-1), single_lps.sum(-1)
-    assert int(same.sum()) >= B - 2, int(same.sum())
-    assert torch.allclose(score_b[same], score_s[same], rtol=1e-4, atol=1e-4)
-    assert torch.allclose(score_b[~same], score_s[~same], rtol=0, atol=2e-4)  # a flipped near-tie changes the score by < 2e-4
-    # ... == the loop composed of the reference's operations (every inference restructuring off, eager)
+    # ... == the loop composed of the reference's operations (every inference restructuring off, eager), which also records the
+    # per-step candidate margins the way fixtures G7 / G15 do: the top beam + 1 scores of every selection
     monkeypatch.setattr(T, "_GRAPH_DECODE", False)
     monkeypatch.setattr(T, "_FUSED_BEAM_STEP", False)
     monkeypatch.setattr(A, "_KV_CACHE", False)
     monkeypatch.setattr(A, "_KV_FUSED_APPEND", False)
     monkeypatch.setattr(CG, "_FUSED_STEP_INPUTS", False)
     monkeypatch.setattr(gate_ops, "supported", lambda *a, **k: False)
+    record, orig = [], model.select
+
+    def select(step, cand, beam_size, **kw):
+        flat = cand.reshape(cand.shape[0], -1)
+        record.append(torch.topk(flat, beam_size + 1, -1).values)
+        return orig(step, cand, beam_size, **kw)
+
+    monkeypatch.setattr(model, "select", select)
     ref_tokens, ref_lps = decode(feats)
+    top = torch.stack(record, 1)  # [B, steps, beam + 1]
+    margin = (top[..., :-1] - top[..., 1:]).abs().amin((1, 2))
+    # fp32 GEMMs of 320 rows and of 5 rows run different library kernels (summation order): where two candidates are closer than
+    # that round-off a beam may legitimately take the other one.  Allowed ONLY for an image whose recorded margin is below 1e-4
+    # (G15's pinned margins start at 1.2e-4); every other image must agree bit for bit, with the single-image decodes and with the
+    # reference-order loop
+    pinned = margin >= 1e-4
+    assert int(pinned.sum()) >= B // 2, margin.sort().values[:8]  # the criterion must not be vacuous
+    same = (tokens == single_tokens).all(1)
     same_ref = (tokens == ref_tokens).all(1)
-    assert int(same_ref.sum()) >= B - 2, int(same_ref.sum())
+    assert bool(same[pinned].all()), (margin[~same], (~same).nonzero().flatten())
+    assert bool(same_ref[pinned].all()), (margin[~same_ref], (~same_ref).nonzero().flatten())
+    score_b, score_s = lps.sum(-1), single_lps.sum(-1)
+    assert torch.allclose(score_b[same], score_s[same], rtol=1e-4, atol=1e-4)
+    assert torch.allclose(score_b[~same], score_s[~same], rtol=0, atol=2e-4)  # a flipped near-tie changes the score by < 2e-4
     assert torch.allclose(lps.sum(-1), ref_lps.sum(-1), rtol=1e-4, atol=2e-4)

@@ -500,9 +500,7 @@ def main():
         except Exception as e:  # stay on the eager HIP path and say so in the line (config.step_graph_error)
             graph_error = "%s: %s" % (type(e).__name__, str(e)[:300])
             sys.stderr.write("bench.py: step graph not captured (%s); running eager launches\n" % graph_error)
-            torch.cuda.synchronize()
-            for o in (optimizers['model'], optimizers['backbone']):
-                o.device_hyper = False
+            # (GraphedXEStep leaves nothing of the failed capture behind: graph_step.abandon_capture)
 
     def step(i):
         if graphed is not None:

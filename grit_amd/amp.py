@@ -62,7 +62,10 @@ class FlatAdam(torch.optim.Optimizer):
         slice when the optimizer is sharded."""
         self._runs = self._owner._runs(self._mine, key=self._steps.get)
         self._layout_version = self._owner.ddp.layout_version
-        self._hyper_host = None  # the device table of per-step scalars has one row per run
+        # A step captured in a HIP graph holds, per run, the run's (start, n) and the ADDRESS of its row of the device table of
+        # per-step scalars: a captured step is valid for exactly one value of `runs_version` (grit_amd/engine/graph_step.py checks it),
+        # and the table itself is allocated once, with room to spare, so that re-deriving the runs never frees memory a graph reads
+        self.runs_version = getattr(self, 'runs_version', 0) + 1
         # parameters of this optimizer outside every run (outside the live set) that share their age -- and therefore their
         # state['step'] tensor -- with a parameter that WILL be stepped: the next step must give the two groups tensors of their own
         stepped = {id(p) for _, params, _ in self._runs for p in params}
@@ -113,9 +116,10 @@ class FlatAdam(torch.optim.Optimizer):
         the launches read (pinned host copy -> one asynchronous H2D copy on the current stream).  grit_amd.engine.graph_step calls
         this before every replay of a captured step; step() calls it itself when it is not being captured."""
         lr, b1, b2, _ = self._hyper()
-        n = max(1, len(self._runs))
-        if getattr(self, '_hyper_host', None) is None or self._hyper_host.shape[1] < n:
-            dev = self._runs[0][0][2].device if self._runs else torch.device('cpu')
+        n = max(self._HYPER_ROWS, len(self._runs))
+        dev = self._runs[0][0][2].device if self._runs else torch.device('cpu')
+        if getattr(self, '_hyper_host', None) is None or self._hyper_host.shape[1] < len(self._runs) or \
+                (self._runs and self._hyper_dev.device != dev):
             # The staging copy is a RING of pinned tables: an asynchronous H2D copy reads the pinned memory when it EXECUTES, and a
             # host that runs ahead of the device (no host sync per step) would otherwise overwrite step k's scalars with step k+1's
             # before step k's copy has run.  A slot is rewritten only after the copy that read it last has completed (its event).
@@ -133,13 +137,14 @@ class FlatAdam(torch.optim.Optimizer):
             t = age + 1
             host[i, 0] = lr / (1.0 - b1 ** t)
             host[i, 1] = 1.0 / math.sqrt(1.0 - b2 ** t)
-        self._hyper_dev[:host.shape[0]].copy_(host, non_blocking=True)
+        self._hyper_dev.copy_(host, non_blocking=True)
         if self._hyper_dev.is_cuda:
             if self._hyper_events[slot] is None:
                 self._hyper_events[slot] = torch.cuda.Event()
             self._hyper_events[slot].record()
 
     _HYPER_SLOTS = 8
+    _HYPER_ROWS = 64  # rows of the device table (one per run; a handful in practice): re-derived runs keep the allocation
 
     @torch.no_grad()
     def step(self, closure=None):

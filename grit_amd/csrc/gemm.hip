@@ -7,8 +7,6 @@
 //   GRIT_GEMM_BIAS        C = acc + bias                                   (any Linear)
 //   GRIT_GEMM_BIAS_GELU   aux = acc + bias ; C = gelu(aux)                 (fc1 + exact-erf GELU; aux = pre-activation kept for backward)
 //   GRIT_GEMM_DGELU       C = acc * gelu'(aux) ; colsum[slab, n] = sum_rows C   (fc2 input gradient x GELU' + fc1 bias gradient)
-//   GRIT_GEMM_BIAS_GELU_DACT  aux = gelu'(acc + bias) ; C = gelu(acc + bias)   (the derivative saved instead of the pre-activation)
-//   GRIT_GEMM_MUL_AUX     C = acc * aux ; colsum as above                       (... and the backward is a plain product)
 // so the [M, 4C] hidden map is written once per pass instead of written, re-read and re-written by GELU / GeluBackward / column-sum kernels.
 //
 // Structure (MI355X_MICROARCH.md / cdna_hip_programming.md section 5):
@@ -28,7 +26,7 @@
 #include <type_traits>
 #include "../../include/grit_hip.h"
 #include "gemm_math.h"
-#include "gemm_ps.h"
+#include "gemm_launchers.h"
 
 namespace {
 
@@ -43,7 +41,7 @@ struct GemmArgs {
                  // whole-tile outputs streamed past L2 leave the operand panels resident -- 63.4 -> 62.0 ms per training step)
     float* colsum;
     int M, N, K, tiles_m, tiles_n;
-    const float* row_scale;    // GRIT_GEMM_DGELU / MUL_AUX, optional: per-sample factors that were applied to the rows of A (drop path);
+    const float* row_scale;    // GRIT_GEMM_DGELU, optional: per-sample factors that were applied to the rows of A (drop path);
     int rows_per_sample;       //   a tile whose rows all belong to ONE sample with factor 0 has A = 0: its result is written as zeros
 #ifdef GRIT_GEMM_STAMPS
     unsigned long long* stamps;  // diagnostic build only (tools/micro/gemm_stamps.hip): [workgroup][wave][16] s_memtime values
@@ -95,8 +93,8 @@ void gemm_nt_bf16(const GemmArgs g) {
     const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, lq = lane >> 4;
 
-    if constexpr (EPI == GRIT_GEMM_DGELU || EPI == GRIT_GEMM_MUL_AUX || EPI == GRIT_GEMM_BIAS_GELU) {
-        // Backward (DGELU / MUL_AUX): rows of a sample that drop path removed from this branch arrive as exact zeros (dbranch = 0 * dx):
+    if constexpr (EPI == GRIT_GEMM_DGELU || EPI == GRIT_GEMM_BIAS_GELU) {
+        // Backward (DGELU): rows of a sample that drop path removed from this branch arrive as exact zeros (dbranch = 0 * dx):
         // the product is zero whatever the weights are -- no K loop, no GELU', just the zero tile and zero column sums.
         // Forward (BIAS_GELU): the branch output of such a sample is multiplied by 0 and the tensors saved here meet only zero gradients
         // in the backward: the tile is not computed, activation and saved pre-activation are written as zeros (finite: 0 * x stays 0).
@@ -279,7 +277,7 @@ void gemm_nt_bf16(const GemmArgs g) {
     const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
 
     v4f bias4[NTL];
-    if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU || EPI == GRIT_GEMM_BIAS_GELU_DACT) {
+    if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
             const v4bf b = *reinterpret_cast<const v4bf*>(g.bias + nw + 16 * j + 4 * lq);
@@ -353,40 +351,7 @@ void gemm_nt_bf16(const GemmArgs g) {
                 put(i, j, v4f{lo[0], lo[1], hi[0], hi[1]});
             }
         flush(g.C, g.ldc, (g.nt_aux & 2) != 0);
-    } else if constexpr (EPI == GRIT_GEMM_BIAS_GELU_DACT) {
-        // activation and its derivative from one sigmoid; the derivative goes to aux (what the backward multiplies by), the
-        // accumulators are overwritten with the activation, which leaves in a second pass through the image
-        if (g.aux) {  // (workgroup-uniform, hoisted: as a test per piece it costs 32 branches and 30 spilled registers)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-#pragma unroll
-                for (int j = 0; j < NTL; ++j) {
-                    const v4f x = acc[i][j] + bias4[j];
-                    v2f glo, ghi, dlo, dhi;
-                    gelu_dgelu2(v2f{x[0], x[1]}, glo, dlo);
-                    gelu_dgelu2(v2f{x[2], x[3]}, ghi, dhi);
-                    acc[i][j] = v4f{glo[0], glo[1], ghi[0], ghi[1]};
-                    put(i, j, v4f{dlo[0], dlo[1], dhi[0], dhi[1]});
-                    __builtin_amdgcn_sched_barrier(0);  // one quad at a time: interleaved, the two-output temporaries of 32 quads spill
-                }
-            }
-        } else {  // frozen stage / inference: the activation alone
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NTL; ++j) {
-                    const v4f x = acc[i][j] + bias4[j];
-                    const v2f lo = gelu2(v2f{x[0], x[1]}), hi = gelu2(v2f{x[2], x[3]});
-                    acc[i][j] = v4f{lo[0], lo[1], hi[0], hi[1]};
-                }
-        }
-        if (g.aux) flush(g.aux, g.ldaux, (g.nt_aux & 1) != 0);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) put(i, j, acc[i][j]);
-        flush(g.C, g.ldc, (g.nt_aux & 2) != 0);
-    } else {  // GRIT_GEMM_DGELU, GRIT_GEMM_MUL_AUX
+    } else {  // GRIT_GEMM_DGELU
         // the pre-activation tile comes in the way the result goes out: whole 128-byte row segments (one DMA piece = 8 rows) into
         // the wave's transpose image, from where every lane picks its 8-byte pieces -- accumulator-shaped global loads (16 rows x
         // 32 bytes per instruction) cost 11k cycles per tile more (tools/micro/gemm_stamps.hip)
@@ -417,7 +382,7 @@ void gemm_nt_bf16(const GemmArgs g) {
                 const int chunk = (2 * j + (lq >> 1)) ^ (row & 7);
                 const v4bf x = *reinterpret_cast<const v4bf*>(eb + row * 128 + chunk * 16 + (lq & 1) * 8);
                 v2f dlo = v2f{(float)x[0], (float)x[1]}, dhi = v2f{(float)x[2], (float)x[3]};
-                if constexpr (EPI == GRIT_GEMM_DGELU) { dlo = dgelu2(dlo); dhi = dgelu2(dhi); }  // (MUL_AUX: aux IS the factor)
+                dlo = dgelu2(dlo); dhi = dgelu2(dhi);
                 const v4f v = {acc[i][j][0] * dlo[0], acc[i][j][1] * dlo[1], acc[i][j][2] * dhi[0], acc[i][j][3] * dhi[1]};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cs[j][r] += live ? v[r] : 0.f;  // bias gradient from the unrounded products
@@ -791,8 +756,6 @@ int launch(const GemmArgs& a, int epilogue, hipStream_t st) {
         case GRIT_GEMM_BIAS: GRIT_GEMM_LAUNCH(GRIT_GEMM_BIAS) break;
         case GRIT_GEMM_BIAS_GELU: GRIT_GEMM_LAUNCH(GRIT_GEMM_BIAS_GELU) break;
         case GRIT_GEMM_DGELU: GRIT_GEMM_LAUNCH(GRIT_GEMM_DGELU) break;
-        case GRIT_GEMM_BIAS_GELU_DACT: GRIT_GEMM_LAUNCH(GRIT_GEMM_BIAS_GELU_DACT) break;
-        case GRIT_GEMM_MUL_AUX: GRIT_GEMM_LAUNCH(GRIT_GEMM_MUL_AUX) break;
         default: return GRIT_ERR_BAD_ARG;
     }
 #undef GRIT_GEMM_LAUNCH
@@ -809,9 +772,8 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
                                  int epilogue, const void* bias, void* aux, long ldaux, float* colsum, int variant,
                                  void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return GRIT_ERR_BAD_ARG;
-    if ((epilogue == GRIT_GEMM_BIAS || epilogue == GRIT_GEMM_BIAS_GELU || epilogue == GRIT_GEMM_BIAS_GELU_DACT) && !bias) return GRIT_ERR_BAD_ARG;
-    if ((epilogue == GRIT_GEMM_DGELU || epilogue == GRIT_GEMM_MUL_AUX) && (!aux || !colsum)) return GRIT_ERR_BAD_ARG;
-    if (epilogue > GRIT_GEMM_DGELU && variant > 4) return GRIT_ERR_UNSUPPORTED;  // the round-4 epilogues: eight-wave per-tile kernel only
+    if ((epilogue == GRIT_GEMM_BIAS || epilogue == GRIT_GEMM_BIAS_GELU) && !bias) return GRIT_ERR_BAD_ARG;
+    if (epilogue == GRIT_GEMM_DGELU && (!aux || !colsum)) return GRIT_ERR_BAD_ARG;
     // 16-byte DMA pieces and row stores: leading dimensions in multiples of 8 elements, 16-byte aligned bases
     if ((lda | ldb | ldc | (aux ? ldaux : 0)) & 7) return GRIT_ERR_UNSUPPORTED;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)aux | (uintptr_t)bias) & 15) return GRIT_ERR_UNSUPPORTED;
@@ -834,11 +796,6 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
         case 3: return launch<256, 128, 32, 2, 2, 4>(a, epilogue, st);  // deeper ring, 96 KB
         case 4: return (K % 64 || N % 256) ? GRIT_ERR_UNSUPPORTED : launch<256, 256, 64, 2, 4, 2>(a, epilogue, st);  // 8 waves, 128 KB
         case 5: return (N % 256) ? GRIT_ERR_UNSUPPORTED : launch_pp(a, epilogue, st);  // persistent ping-pong, 160 KB
-        case 6: {  // persistent stream with the trickled epilogue (gemm_ps.hip); GRIT_GEMM_PS_NT overrides the store policy (A/B)
-            static const int ps_nt = [] { const char* e = getenv("GRIT_GEMM_PS_NT"); return e ? atoi(e) : -1; }();
-            const int nt = ps_nt >= 0 ? ps_nt : (epilogue == GRIT_GEMM_BIAS_GELU ? (nt_aux & 3) : 0);
-            return grit_detail::gemm_ps_launch(A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, nt, stream, nullptr);
-        }
         case 7:  // four waves, 128 x 128 wave tiles (gemm_w4.hip)
             return grit_detail::gemm_w4_launch(A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, colsum,
                                                epilogue == GRIT_GEMM_BIAS ? 0 : nt_aux, stream);
@@ -846,11 +803,11 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
     }
 }
 
-// GRIT_GEMM_DGELU / GRIT_GEMM_MUL_AUX with the per-sample factors of the rows of A (see GemmArgs::row_scale): eight-wave variants only.
+// GRIT_GEMM_DGELU / GRIT_GEMM_BIAS_GELU with the per-sample factors of the rows of A (see GemmArgs::row_scale): eight-wave variants only.
 extern "C" int grit_gemm_bf16_nt_rows(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                                       int epilogue, const void* bias, void* aux, long ldaux, float* colsum, const float* row_scale,
                                       int rows_per_sample, int variant, void* stream) {
-    if (epilogue != GRIT_GEMM_DGELU && epilogue != GRIT_GEMM_MUL_AUX && epilogue != GRIT_GEMM_BIAS_GELU) return GRIT_ERR_BAD_ARG;
+    if (epilogue != GRIT_GEMM_DGELU && epilogue != GRIT_GEMM_BIAS_GELU) return GRIT_ERR_BAD_ARG;
     if (row_scale && (rows_per_sample <= 0 || variant > 4)) return GRIT_ERR_BAD_ARG;
     g_row_scale = row_scale; g_rows_per_sample = rows_per_sample;
     const int st = grit_gemm_bf16_nt(A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, colsum, variant, stream);

@@ -27,7 +27,7 @@
 #include <utility>
 #include "../../include/grit_hip.h"
 #include "gemm_math.h"
-#include "gemm_ps.h"
+#include "gemm_launchers.h"
 
 namespace {
 

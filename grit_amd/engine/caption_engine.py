@@ -157,7 +157,7 @@ def train_xe_step(model, batch, optimizers, loss_fn, scheduler=None, autocast_dt
 
 
 class _XEStepper(object):
-    """train_xe's step: eager launches, or -- GRIT_TRAIN_STEP_GRAPH=1, one rank, Bf16Compute + FlatAdam, no autocast -- the step
+    """train_xe's step: the step graph (GRIT_TRAIN_STEP_GRAPH, default 1 since round 5: what bench.py times is what training runs), i.e. -- one rank, Bf16Compute + FlatAdam, no autocast -- the step
     captured ONCE as a HIP graph (grit_amd/engine/graph_step.py) after two eager steps on the first batch shape and replayed for
     every batch of that shape (collators that pad to a fixed size make that every batch but an epoch's last); other batches, and
     everything once the wrapper's live parameter set changed, run eagerly.  The captured graph is kept on the wrapper across epochs
@@ -166,7 +166,7 @@ class _XEStepper(object):
     def __init__(self, model, optimizers, loss_fn, scheduler, autocast_dtype):
         import os
         self.args = (model, optimizers, loss_fn, scheduler, autocast_dtype)
-        self.want = os.environ.get("GRIT_TRAIN_STEP_GRAPH", "0") == "1" and autocast_dtype is None
+        self.want = os.environ.get("GRIT_TRAIN_STEP_GRAPH", "1") != "0" and autocast_dtype is None
         self.eager_seen = 0
 
     def __call__(self, batch):
@@ -174,9 +174,16 @@ class _XEStepper(object):
         if self.want and batch['captions'].is_cuda:
             from grit_amd.engine import graph_step
             g = getattr(model, '_grit_step_graph', None)
-            if g is not None and g.graph is not None and g.loss_fn_ignore == loss_fn.ignore_index and g.matches(batch):
-                g.scheduler = scheduler
-                return g(batch)
+            if g is not None and g.graph is not None:
+                if g.loss_fn_ignore == loss_fn.ignore_index and g.matches(batch, optimizers):
+                    g.scheduler = scheduler
+                    return g(batch)
+                if not g.matches(batch, optimizers) and g.matches_shapes(batch):
+                    # same batch shape, yet the graph no longer fits: the optimizers were rebuilt (XE -> SC -> XE) or their runs
+                    # re-derived (load_state_dict, a changed live set).  The recorded launches are stale for good: drop the graph
+                    # (one capture per wrapper and process) and stay on eager launches
+                    g.release()
+                    self.want = False
             if g is None and graph_step.supported(model, optimizers) and not getattr(model, '_grit_step_graph_taken', False):
                 if self.eager_seen >= 2:
                     try:
@@ -187,10 +194,7 @@ class _XEStepper(object):
                     except Exception as e:  # stay on eager launches; say so once
                         import sys
                         sys.stderr.write("train_xe: step graph not captured (%s: %s); eager launches\n" % (type(e).__name__, str(e)[:200]))
-                        self.want = False
-                        for o in (optimizers['model'], optimizers['backbone']):
-                            if hasattr(o, 'device_hyper'):
-                                o.device_hyper = False
+                        self.want = False  # (GraphedXEStep cleaned up after itself: graph_step.abandon_capture)
                 self.eager_seen += 1
         return train_xe_step(model, batch, optimizers, loss_fn, scheduler, autocast_dtype)
 

@@ -45,6 +45,28 @@ def supported(model, optimizers):
     return all(hasattr(optimizers[k], 'prepare_replay') for k in ('model', 'backbone'))
 
 
+def abandon_capture(model, opts, iteration=None):
+    """After a capture that died part-way (inside forward, backward or the optimizers): leave nothing of the phantom step behind.
+    Deferred / parked weight-gradient jobs hold raw addresses into the discarded graph pool; the bucket wrapper's books (closed
+    gradient slots, packed flags, iteration count) describe a pass that never ran; the optimizers would keep reading their
+    per-step scalars from the device table.  The next step then runs as an ordinary eager step."""
+    from grit_amd.ops import linear as _linear
+    _linear.abandon_deferred()
+    _linear._deferral["active"] = False
+    _linear._deferral["pending"].clear()
+    ddp = model.ddp
+    for b in ddp.buckets:
+        b.work = b.wire = None
+    ddp.release_gradients()
+    if iteration is not None:
+        ddp._iteration = iteration
+    for o in opts:
+        if hasattr(o, 'device_hyper'):
+            o.device_hyper = False
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 class GraphedXEStep(object):
 
     def __init__(self, model, optimizers, loss_fn, batch, scheduler=None, eager_steps=2):
@@ -69,29 +91,49 @@ class GraphedXEStep(object):
             train_xe_step(model, self.static, optimizers, loss_fn)
         self._layout = model.ddp.layout_version
         self._opts = [optimizers['model'], optimizers['backbone']]
-        for o in self._opts:
-            o.device_hyper = True
-            o.prepare_replay()
-        torch.cuda.synchronize(self.device)
-        self.graph = torch.cuda.CUDAGraph()
-        with backend.capturing_train_step(self.device) as seeds:
-            # (a wrapper with collectives -- GRIT_STEP_GRAPH_COLLECTIVES=1, experimental -- captures in thread-local error mode: the process
-            # group's watchdog thread keeps querying the events of earlier collectives, which global mode forbids during a capture)
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local" if model.ddp.collective else "global"):
-                seeds.begin_captured_step(self.device)
-                self.loss = train_xe_step(model, self.static, optimizers, loss_fn)
+        iteration = model.ddp._iteration
+        try:
+            for o in self._opts:
+                o.device_hyper = True
+                o.prepare_replay()
+            torch.cuda.synchronize(self.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with backend.capturing_train_step(self.device) as seeds:
+                # (a wrapper with collectives -- GRIT_STEP_GRAPH_COLLECTIVES=1, experimental -- captures in thread-local error mode: the
+                # process group's watchdog thread keeps querying the events of earlier collectives, which global mode forbids during a capture)
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local" if model.ddp.collective else "global"):
+                    seeds.begin_captured_step(self.device)
+                    self.loss = train_xe_step(model, self.static, optimizers, loss_fn)
+        except BaseException:
+            self.graph = None
+            model._grit_step_graph_taken = True  # (a second capture attempt on this wrapper is not safe on this ROCm either)
+            abandon_capture(model, self._opts, iteration)
+            raise
+        # what the recorded launches depend on beyond the batch: THESE optimizer objects, each with the run layout (start / length per
+        # launch, row of the device table of per-step scalars) it had at capture time -- FlatAdam._derive_runs bumps runs_version
+        self._opt_state = tuple((id(o), o.runs_version) for o in self._opts)
         model._grit_step_graph_taken = True
         self.replays = 0
 
-    def matches(self, batch):
+    def matches(self, batch, optimizers=None):
+        """Does `batch` (and, when given, the `optimizers` dict of the caller) fit the captured step?"""
         s = batch['samples']
+        if optimizers is not None and tuple(id(optimizers[k]) for k in ('model', 'backbone')) != tuple(i for i, _ in self._opt_state):
+            return False  # rebuilt between phases (XE -> SC): the replay would step the captured objects, not the caller's
+        if self.graph is None or tuple((id(o), o.runs_version) for o in self._opts) != self._opt_state:
+            return False  # load_state_dict / a changed live set re-derived the runs: the recorded (start, n) per launch are stale
         return (s.tensors.shape == self.images.shape and s.tensors.dtype == self.images.dtype and s.any_padding == self.any_padding
                 and (s.mask is None) == (self.mask is None) and batch['captions'].shape == self.captions.shape
                 and self.model.ddp.layout_version == self._layout)
 
+    def matches_shapes(self, batch):
+        s = batch['samples']
+        return (s.tensors.shape == self.images.shape and s.tensors.dtype == self.images.dtype and s.any_padding == self.any_padding
+                and (s.mask is None) == (self.mask is None) and batch['captions'].shape == self.captions.shape)
+
     def __call__(self, batch):
         if not self.matches(batch):
-            raise ValueError("batch does not fit the captured step (shape / padding flag / live parameter set changed)")
+            raise ValueError("batch does not fit the captured step (shape / padding flag / live parameter set / optimizer runs changed)")
         s = batch['samples']
         if s.tensors.data_ptr() != self.images.data_ptr():
             self.images.copy_(s.tensors, non_blocking=True)

@@ -469,7 +469,14 @@ class SwinTransformer(nn.Module):
         if keep is None or keep.device != device or keep.shape[0] != 2 * len(blocks):
             probs = [1.0 - blk.drop_path.drop_prob for blk in blocks for _ in range(2)]
             keep = self._drop_path_keep = torch.tensor(probs, dtype=torch.float32).to(device)[:, None]  # once per device
-        scales = (torch.rand(keep.shape[0], B, device=device) < keep).to(torch.float32) / keep
+        # `drop_path_uniforms` ([2 * blocks, B] in [0, 1), attention row then Mlp row per block): the draw itself, injectable so that two
+        # runs -- bf16 with the skipped tiles, fp32 kernels, skip paths off -- see the SAME per-sample keep mask (tests/test_drop_path_gpu.py)
+        u = getattr(self, 'drop_path_uniforms', None)
+        if u is None:
+            u = torch.rand(keep.shape[0], B, device=device)
+        elif tuple(u.shape) != (keep.shape[0], B):
+            raise ValueError("drop_path_uniforms must be [%d, %d], got %s" % (keep.shape[0], B, tuple(u.shape)))
+        scales = (u.to(device=device, dtype=torch.float32) < keep).to(torch.float32) / keep
         for j, blk in enumerate(blocks):
             blk._drop_path_ready = [scales[2 * j + 1], scales[2 * j]]  # popped from the end: attention first
 

@@ -12,12 +12,7 @@ import torch
 from grit_amd import lib as _lib
 from grit_amd.ops.profiling import gemm_work, timed
 
-NONE, BIAS, BIAS_GELU, DGELU, BIAS_GELU_DACT, MUL_AUX = 0, 1, 2, 3, 4, 5
-# GRIT_MLP_SAVE_DGELU=1 (default 0): the fused Mlp forward saves GELU'(pre-activation) -- computed from the sigmoid the activation needs
-# anyway -- instead of the pre-activation, and the fc2 input gradient multiplies by it (GRIT_GEMM_BIAS_GELU_DACT / GRIT_GEMM_MUL_AUX).
-# Measured (profiles/r04/saved_dgelu.txt, stage 2): the product epilogue saves 33 us (181 -> 148), the two-output forward epilogue
-# costs 48 (149 -> 197: its temporaries spill beside the 128 accumulators); in the step 52.79 -> 53.14 ms.  Kept, tested, not the default.
-SAVE_DGELU = os.environ.get("GRIT_MLP_SAVE_DGELU", "0") == "1"
+NONE, BIAS, BIAS_GELU, DGELU = 0, 1, 2, 3
 # GRIT_GEMM_ROW_SKIP (default 1): the fc2 input gradient skips the tiles of samples that drop path removed from the branch (exact zeros)
 ROW_SKIP = os.environ.get("GRIT_GEMM_ROW_SKIP", "1") != "0"
 COLSUM_ROWS = 128
@@ -44,8 +39,8 @@ def gemm_nt(a, b, epilogue=NONE, bias=None, aux=None, colsum=None, out=None, var
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     v = VARIANT if variant is None else variant
-    work = gemm_work(M, N, K, outputs=2 if (epilogue in (BIAS_GELU, BIAS_GELU_DACT) and aux is not None) else 1,
-                     extra_in=1 if epilogue in (DGELU, MUL_AUX) else 0)
+    work = gemm_work(M, N, K, outputs=2 if (epilogue == BIAS_GELU and aux is not None) else 1,
+                     extra_in=1 if epilogue == DGELU else 0)
     with _lib.device_guard(a.device), timed("gemm_own", epilogue=epilogue, kernel="gemm_w4" if v == 7 else "gemm_nt_bf16", **work):
         st = _lib.load().grit_gemm_bf16_nt(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0), M, N, K,
                                            epilogue, _ptr(bias), _ptr(aux), aux.stride(0) if aux is not None else 0,
@@ -64,11 +59,13 @@ def _fused_variant(M, N, K):
 
 
 def linear_bias_gelu(x2, weight, bias, row_scale=None, rows_per_sample=0):
-    """(saved, act), both [M, N] bf16, one kernel: act = gelu(x2 @ weight^T + bias); saved = what input_grad_dgelu needs of the
-    pre-activation h = x2 @ weight^T + bias -- gelu'(h) (GRIT_MLP_SAVE_DGELU, default) or h itself."""
+    """(pre, act), both [M, N] bf16, one kernel: pre = x2 @ weight^T + bias (what input_grad_dgelu needs), act = gelu(pre).
+    With drop-path factors (`row_scale`, one per sample of `rows_per_sample` rows) the tiles of dropped samples are skipped; that path
+    always runs the eight-wave kernel, so at K >= 1 024 (stage 3) an active drop path forgoes the four-wave variant's ~12 % there --
+    2 of the 22 trainable blocks, against ~11 % of ALL fused-Mlp tiles not computed."""
     M, N = x2.shape[0], weight.shape[0]
     pre = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
-    if (ROW_SKIP and not SAVE_DGELU and row_scale is not None and rows_per_sample > 0 and row_scale.dtype == torch.float32
+    if (ROW_SKIP and row_scale is not None and rows_per_sample > 0 and row_scale.dtype == torch.float32
             and row_scale.is_cuda):
         # drop path: the tiles of samples whose branch is multiplied by 0 are not computed (zeros in `act` and `pre`)
         act = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
@@ -79,16 +76,13 @@ def linear_bias_gelu(x2, weight, bias, row_scale=None, rows_per_sample=0):
                                                     int(rows_per_sample), VARIANT if VARIANT in (1, 2, 3, 4) else 0, _lib.current_stream_ptr())
         _lib.check(st, "grit_gemm_bf16_nt_rows")
         return pre, act
-    if SAVE_DGELU:  # `pre` then holds gelu'(x2 @ weight^T + bias): what input_grad_dgelu multiplies by
-        act = gemm_nt(x2, weight, BIAS_GELU_DACT, bias=bias, aux=pre, variant=VARIANT if VARIANT in (1, 2, 3, 4) else 0)
-        return pre, act
     act = gemm_nt(x2, weight, BIAS_GELU, bias=bias, aux=pre, variant=_fused_variant(M, N, x2.shape[1]))
     return pre, act
 
 
 def input_grad_dgelu(dy2, weight_t, pre, row_scale=None, rows_per_sample=0):
     """(d_pre, colsum_partial): d_pre = (dy2 @ weight_t^T) * gelu'(h) with weight_t [N_hidden, K] = the following Linear's
-    weight transposed and `pre` = the tensor linear_bias_gelu saved (gelu'(h), or h with GRIT_MLP_SAVE_DGELU=0); colsum_partial
+    weight transposed and `pre` = the pre-activation h linear_bias_gelu saved; colsum_partial
     [ceil(M / 128), N_hidden] f32 sums to the bias gradient of the Linear that produced h."""
     M = dy2.shape[0]
     N = weight_t.shape[0]
@@ -97,16 +91,12 @@ def input_grad_dgelu(dy2, weight_t, pre, row_scale=None, rows_per_sample=0):
         partial = torch.empty((-(-M // COLSUM_ROWS), N), dtype=torch.float32, device=dy2.device)
         d_pre = torch.empty((M, N), dtype=torch.bfloat16, device=dy2.device)
         K = dy2.shape[1]
-        epi = MUL_AUX if SAVE_DGELU else DGELU
+        epi = DGELU
         with _lib.device_guard(dy2.device), timed("gemm_own", epilogue=epi, kernel="gemm_nt_bf16", **gemm_work(M, N, K, extra_in=1)):
             st = _lib.load().grit_gemm_bf16_nt_rows(_ptr(dy2), dy2.stride(0), _ptr(weight_t), weight_t.stride(0), _ptr(d_pre), d_pre.stride(0),
                                                     M, N, K, epi, None, _ptr(pre), pre.stride(0), _ptr(partial), _ptr(row_scale), int(rows_per_sample),
                                                     VARIANT if VARIANT in (1, 2, 3, 4) else 0, _lib.current_stream_ptr())
         _lib.check(st, "grit_gemm_bf16_nt_rows")
-        return d_pre, partial
-    if SAVE_DGELU:  # `pre` is the saved derivative (linear_bias_gelu above): a plain product in the epilogue
-        partial = torch.empty((-(-M // COLSUM_ROWS), N), dtype=torch.float32, device=dy2.device)
-        d_pre = gemm_nt(dy2, weight_t, MUL_AUX, aux=pre, colsum=partial, variant=VARIANT if VARIANT in (1, 2, 3, 4) else 0)
         return d_pre, partial
     v = _fused_variant(M, N, dy2.shape[1])
     # (the four-wave kernel writes one row of sums per 128-row wave block of its 256-row tiles: 2 ceil(M / 256) rows, all written)

@@ -487,15 +487,8 @@ int grit_image_batch_fwd(const uint8_t* src, const int64_t* desc, const int32_t*
  *   GRIT_GEMM_DGELU      C = acc * gelu'(aux[m, n]) (aux read; the exact derivative of the same expression); colsum[s, n] = sum over rows [128 s, 128 s + 128) of C
  *                        (fp32, before the bf16 rounding of C), s < ceil(M / GRIT_GEMM_COLSUM_ROWS): fully overwritten, to be summed over s
  *                        with grit_slab_sum (the bias gradient of the Linear that produced aux)
- *   GRIT_GEMM_BIAS_GELU_DACT  like GRIT_GEMM_BIAS_GELU, but aux receives gelu'(acc + bias[n]) -- the DERIVATIVE at the pre-activation,
- *                        from the same sigmoid (one exp2 + one rcp per element for both outputs) -- instead of the pre-activation:
- *                        what the backward pass multiplies by, computed once where it is cheap (round 4)
- *   GRIT_GEMM_MUL_AUX    C = acc * aux[m, n] (aux read); colsum as GRIT_GEMM_DGELU: the fc2 input gradient times the saved
- *                        derivative -- 2 VALU operations per element in the epilogue instead of GELU' (13 + two transcendentals)
- *                        (both: eight-wave variants 0..4 only)
  * Needs N % 128 == 0, K % 32 == 0, 16-byte aligned bases; M is free.  variant 0 = tile configuration chosen from the
- * shape; 1..4 = explicit eight-wave configurations, 5 = persistent ping-pong, 6 = persistent stream with a trickled epilogue
- * (gemm_ps.hip; kept for A/B: slower), 7 = persistent FOUR-wave kernel with 128 x 128 wave tiles (gemm_w4.hip: N % 256 == 0,
+ * shape; 1..4 = explicit eight-wave configurations, 5 = persistent ping-pong, 7 = persistent FOUR-wave kernel with 128 x 128 wave tiles (gemm_w4.hip: N % 256 == 0,
  * K % 64 == 0, M >= 256, operands below 2 GiB; what the long-map forward / input-gradient GEMMs run where it beats the library).
  * Results are bit-identical across variants; variant 7 writes its GRIT_GEMM_DGELU column sums as 2 * ceil(M / 256) rows (one per
  * 128-row wave block of its 256-row tiles; every row written).
@@ -504,15 +497,13 @@ int grit_image_batch_fwd(const uint8_t* src, const int64_t* desc, const int32_t*
 #define GRIT_GEMM_BIAS 1
 #define GRIT_GEMM_BIAS_GELU 2
 #define GRIT_GEMM_DGELU 3
-#define GRIT_GEMM_BIAS_GELU_DACT 4
-#define GRIT_GEMM_MUL_AUX 5
 #define GRIT_GEMM_COLSUM_ROWS 128
 int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                       int epilogue, const void* bias, void* aux, long ldaux, float* colsum, int variant, void* stream);
 /* The fused Mlp GEMMs with the per-sample drop-path factors of the Swin blocks at hand (models/common/swin_model.py:289-298:
  * x = shortcut + drop_path(mlp(norm2(x))); a dropped sample's branch contributes nothing forward and receives an exactly zero
  * gradient): row_scale [ceil(M / rows_per_sample)] f32 on the device; a 256-row tile that lies inside ONE sample with factor 0 is
- * not computed.  GRIT_GEMM_DGELU / GRIT_GEMM_MUL_AUX (backward: the rows of A are already zero): C and its column sums are written as
+ * not computed.  GRIT_GEMM_DGELU (backward: the rows of A are already zero): C and its column sums are written as
  * zeros -- the same results as grit_gemm_bf16_nt.  GRIT_GEMM_BIAS_GELU (forward): C and aux are written as zeros instead of the values
  * nobody will use (the caller multiplies the branch by the same factor 0; the saved tensors meet zero gradients).  Eight-wave
  * variants (0..4); row_scale NULL = no skipping. */

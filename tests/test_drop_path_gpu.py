@@ -1,0 +1,114 @@
+"""A whole training step with stochastic depth ON (timm DropPath as the reference's Swin blocks use it,
+reference models/common/swin_model.py:289-298: per-sample keep w.p. 1 - p, kept branches scaled by 1 / (1 - p)).
+
+Every other model-level comparison turns DropPath off (tests/helpers.py disable_drop_path); the step the benchmark times has it on
+and takes shortcuts because of it: 256-row tiles inside a dropped sample are not computed by the fused Mlp GEMMs (forward: fc1 + GELU;
+backward: the fc2 input gradient x GELU'), the row panels are dealt round-robin over the XCDs, `add_layernorm` multiplies by the
+per-sample factor.  Here the per-sample draw is INJECTED (`SwinTransformer.drop_path_uniforms`) so that different runs see the same
+keep mask, at BASELINE config 3's size (16 images of 640 x 640):
+
+  * bf16 step with the skip paths  vs  the fp32-kernel step, same mask: loss and picked gradients at config 3's tolerances;
+  * skip paths on  vs  off (GRIT_GEMM_ROW_SKIP=0): the loss and every gradient downstream of deterministic kernels bit-equal; with the
+    region branch cut off the backbone (the MSDeformAttn backward sums a cell's terms in LDS-counter order, the only run-to-run
+    non-determinism of the step) EVERY picked gradient, backbone included, bit-equal.
+"""
+import os
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.helpers import build_model
+from tests.test_configs_gpu import DETERMINISTIC, PICKS, _free_port
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BACKBONE_PICKS = tuple(n for n in PICKS if 'backbone' in n) + ('detector.backbone.layers.3.blocks.1.mlp.fc2.weight',
+                                                               'detector.backbone.layers.2.blocks.9.mlp.fc2.bias',
+                                                               'detector.backbone.layers.2.blocks.4.norm2.weight')
+
+
+def _worker(rank, port, mode, cut_regions, n_images, ret):
+    """mode: 'skip' (bf16, default paths), 'noskip' (bf16, GRIT_GEMM_ROW_SKIP=0), 'fp32' (fp32 weights and kernels)."""
+    if mode == 'noskip':
+        os.environ["GRIT_GEMM_ROW_SKIP"] = "0"  # read when grit_amd.ops.gemm is imported: this is a fresh process
+    from grit_amd.amp import Bf16Compute
+    from grit_amd.data import synthetic_batch
+    from grit_amd.models.common.swin_model import DropPath
+    from grit_amd.ops import gemm as gemm_ops
+    assert gemm_ops.ROW_SKIP == (mode != 'noskip')
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    model, cfg = build_model(3, fill=False, **{'model.dropout': 0.0, 'model.detector.dropout': 0.0})
+    model.train().to(DEV)
+    backbone = model.detector.backbone
+    blocks = [blk for stage in backbone.layers for blk in stage.blocks
+              if blk.training and isinstance(blk.drop_path, DropPath) and blk.drop_path.drop_prob > 0.]
+    assert len(blocks) >= 18  # DropPath is ON in every trainable block
+    u = torch.rand(2 * len(blocks), n_images, generator=torch.Generator().manual_seed(77))
+    backbone.drop_path_uniforms = u.to(DEV)
+    keep = torch.tensor([1.0 - b.drop_path.drop_prob for b in blocks for _ in range(2)])[:, None]
+    ret["dropped"] = int((u >= keep).sum())
+    ret["dropped_mlp"] = int((u >= keep)[1::2].sum())
+    if cut_regions:  # gradients reach the backbone through the grid feature only: every kernel on that path is deterministic
+        det = model.detector.det_module
+        orig = det.forward
+        det.forward = lambda *a, src_flatten=None, **k: orig(*a, src_flatten=src_flatten.detach(), **k)
+    loss_fn = torch.nn.NLLLoss(ignore_index=1)
+    batch = synthetic_batch(n_images, 640, 640, 20, device=DEV, seed=4)
+    if mode == 'fp32':
+        out = model(batch['samples'], batch['captions'])
+        loss = loss_fn(out[:, :-1].reshape(-1, out.shape[-1]), batch['captions'][:, 1:].reshape(-1))
+        loss.backward()
+    else:
+        wrapped = Bf16Compute(model, bucket_mb=64)
+        out = wrapped(batch['samples'], batch['captions'])
+        loss = loss_fn(out[:, :-1].reshape(-1, out.shape[-1]).float(), batch['captions'][:, 1:].reshape(-1))
+        loss.backward()
+        wrapped.finish_gradient_sync()
+    named = dict(model.named_parameters())
+    torch.cuda.synchronize()
+    ret["loss"] = float(loss)
+    ret["grads"] = {n: named[n].grad.detach().float().cpu() for n in PICKS + BACKBONE_PICKS if named[n].grad is not None}
+    ret["finite"] = all(bool(torch.isfinite(p.grad).all()) for p in named.values() if p.grad is not None)
+
+
+def _run(*args):
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(_free_port(),) + args + (ret,), nprocs=1, join=True)
+        return dict(ret)
+
+
+def test_step_with_drop_path_on_against_fp32_kernels_and_skip_paths_off():
+    B = 16
+    skip = _run('skip', False, B)
+    noskip = _run('noskip', False, B)
+    fp32 = _run('fp32', False, B)
+    assert skip["finite"] and noskip["finite"] and fp32["finite"]
+    assert skip["dropped_mlp"] >= 20 and skip["dropped"] == fp32["dropped"]  # ~11 % of 40 x 16 (block, sample) branches
+    # (1) same mask, fp32 kernels: config 3's tolerances (tests/test_configs_gpu.py::test_config3_bs16_step_against_the_fp32_kernels)
+    assert abs(skip["loss"] - fp32["loss"]) < 2e-2 * fp32["loss"], (skip["loss"], fp32["loss"])
+    rels = {n: float(torch.linalg.norm(skip["grads"][n] - fp32["grads"][n]) / torch.linalg.norm(fp32["grads"][n])) for n in PICKS}
+    for n, rel in rels.items():
+        assert rel < (0.6 if 'cross_attn' in n else 0.3), rels
+    assert sorted(rels.values())[len(rels) // 2] < 0.12, rels
+    # (2) skip-on == skip-off where the arithmetic is deterministic
+    assert skip["loss"] == noskip["loss"]
+    for n in DETERMINISTIC:
+        assert torch.equal(skip["grads"][n], noskip["grads"][n]), n
+
+
+def test_skipped_tiles_change_no_bit_of_any_gradient():
+    B = 16
+    skip = _run('skip', True, B)
+    noskip = _run('noskip', True, B)
+    assert skip["finite"] and noskip["finite"] and skip["dropped_mlp"] >= 20
+    assert skip["loss"] == noskip["loss"]
+    compared = 0
+    for n in DETERMINISTIC + BACKBONE_PICKS:  # (the detection module's own parameters still sit behind its MSDeformAttn backward)
+        assert torch.equal(skip["grads"][n], noskip["grads"][n]), n
+        compared += 1
+    assert compared == len(BACKBONE_PICKS) + 3
+    for n in BACKBONE_PICKS:
+        assert float(skip["grads"][n].abs().max()) > 0, n

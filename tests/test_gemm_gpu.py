@@ -310,43 +310,6 @@ def test_small_map_gradient_rejects_what_it_does_not_cover(monkeypatch):
     assert small_weight_bias_grad(dy, x, True, torch.float32) is None
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1000, 512, 128), (4096 + 17, 256, 512), (37, 1024, 192)])
-def test_saved_derivative_epilogues(M, N, K, variant):
-    """GRIT_GEMM_BIAS_GELU_DACT / GRIT_GEMM_MUL_AUX (round 4: the Mlp forward saves gelu'(h) instead of h).  The activation is
-    bit-identical to GRIT_GEMM_BIAS_GELU's; the saved tensor is GRIT_GEMM_DGELU's factor (the same sigmoid form) rounded to bf16;
-    the product epilogue multiplies exactly and sums the columns of the unrounded products; rows past M leave the partials alone."""
-    from grit_amd.ops import gemm as G
-    from grit_amd.ops.linear import slab_sum
-    if variant in (2, 4) and K % 64:
-        pytest.skip("BK = 64 configuration")
-    if variant == 4 and N % 256:
-        pytest.skip("256-column tiles")
-    x, w, b = _inputs(M, N, K)
-    ref = x.float() @ w.float().t() + b.float()
-    dact = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
-    act = G.gemm_nt(x, w, G.BIAS_GELU_DACT, bias=b, aux=dact, variant=variant)
-    assert torch.equal(act, G.gemm_nt(x, w, G.BIAS_GELU, bias=b, variant=variant))
-    assert torch.equal(act, G.gemm_nt(x, w, G.BIAS_GELU_DACT, bias=b, variant=variant))  # no saved tensor: same activation
-    h = ref.clone().requires_grad_(True)
-    F.gelu(h).sum().backward()
-    _close(dact, h.grad)
-    # the product epilogue against (x w^T) * aux in fp32
-    aux = torch.randn(M, N, device='cuda').bfloat16()
-    slabs = -(-M // 128)
-    fenced = torch.full((slabs + 2, N), float('nan'), device='cuda')
-    part = fenced[1:1 + slabs]
-    d = G.gemm_nt(x, w, G.MUL_AUX, aux=aux, colsum=part, variant=variant)
-    assert torch.isnan(fenced[0]).all() and torch.isnan(fenced[-1]).all() and torch.isfinite(part).all()
-    want = (x.float() @ w.float().t()) * aux.float()
-    _close(d, want)
-    db = slab_sum(part.unsqueeze(0), torch.float32)[0]
-    assert (db - want.sum(0)).abs().max().item() <= 2e-3 * want.sum(0).abs().max().item() + 1e-3
-    for v in (5, 6, 7):  # the persistent kernels do not carry the round-4 epilogues: refused, not mis-computed
-        with pytest.raises(Exception):
-            G.gemm_nt(x, w, G.MUL_AUX, aux=aux, colsum=part, variant=v)
-
-
 @pytest.mark.parametrize("M,per,N,K", [(51200, 1600, 2048, 512), (4096 + 300, 550, 256, 128), (12800, 400, 1024, 256)])
 def test_dropped_samples_are_skipped_not_computed(M, per, N, K):
     """grit_gemm_bf16_nt_rows: with the per-sample drop-path factors at hand, the GELU' GEMM writes the tiles of dropped samples as
@@ -370,34 +333,6 @@ def test_dropped_samples_are_skipped_not_computed(M, per, N, K):
     assert torch.equal(skip, dense)
     assert torch.equal(part_skip, part_dense)
     assert float(skip[:per].abs().max()) == 0.0
-
-
-def test_saved_derivative_equals_the_derivative_epilogue_over_the_whole_range():
-    """Every bf16 value of [-9, 9] through an identity GEMM: the tensor GRIT_GEMM_BIAS_GELU_DACT saves is what GRIT_GEMM_DGELU
-    computes from the pre-activation (same expression, same order: bit-identical after the bf16 rounding of the store), so
-    forward + backward through the saved derivative reproduce the old pair up to ONE extra bf16 rounding of the factor."""
-    from grit_amd.ops import gemm as G
-    N = 128
-    vals = torch.linspace(-9, 9, 256 * 1024, device='cuda').bfloat16().unique()
-    M = (vals.numel() + N - 1) // N * N
-    x = torch.zeros(M, device='cuda', dtype=torch.bfloat16)
-    x[:vals.numel()] = vals
-    x = x.view(-1, N).contiguous()
-    eye = torch.eye(N, device='cuda', dtype=torch.bfloat16)
-    zero_b = torch.zeros(N, device='cuda', dtype=torch.bfloat16)
-    dact = torch.empty_like(x)
-    act = G.gemm_nt(x, eye, G.BIAS_GELU_DACT, bias=zero_b, aux=dact)
-    assert torch.equal(act, G.gemm_nt(x, eye, G.BIAS_GELU, bias=zero_b))
-    ones = torch.ones_like(x)
-    part = torch.empty((-(-x.shape[0] // 128), N), device='cuda')
-    d_old = G.gemm_nt(ones, eye, G.DGELU, aux=x, colsum=part)       # 1 * gelu'(x), rounded once
-    assert torch.equal(dact, d_old)
-    d_new = G.gemm_nt(ones, eye, G.MUL_AUX, aux=dact, colsum=part)  # 1 * bf16(gelu'(x))
-    assert torch.equal(d_new, dact)
-    xr = x.float().requires_grad_(True)
-    F.gelu(xr).sum().backward()
-    derr = (dact.float() - xr.grad).abs()
-    assert float((derr - xr.grad.abs() * 2.0 ** -8).max()) <= 1.5e-4, float(derr.max())
 
 
 def test_fused_gelu_epilogues_against_erf_gelu_over_the_whole_range():

@@ -140,10 +140,35 @@ def test_batch_that_does_not_fit_is_refused():
     assert float(train_xe_step(wrapped, a, opts, loss_fn)) > 0  # eager steps work again after the graph is dropped
 
 
+def test_captured_step_goes_stale_with_its_optimizers():
+    """the recorded Adam launches hold (start, n) per run and the address of a row of the device table of per-step scalars.
+    Re-derived runs (load_state_dict) and rebuilt optimizers (XE -> SC -> XE) must make the graph refuse; the device table itself is
+    allocated once (re-deriving does not free what a graph reads)."""
+    from grit_amd.engine.caption_engine import build_optimizers, train_xe_step
+    from grit_amd.engine.graph_step import GraphedXEStep
+    from grit_amd.config import default_config
+    a, _ = _batches()
+    wrapped, opts, loss_fn = _setup()
+    train_xe_step(wrapped, a, opts, loss_fn)
+    step = GraphedXEStep(wrapped, opts, loss_fn, a, eager_steps=0)
+    step(a)
+    assert step.matches(a) and step.matches(a, opts)
+    table = opts['model']._hyper_dev.data_ptr()
+    rebuilt = build_optimizers(wrapped, default_config(), mode='xe')
+    assert not step.matches(a, rebuilt)  # other optimizer objects than the captured ones
+    opts['model'].load_state_dict(opts['model'].state_dict())
+    assert opts['model']._hyper_dev.data_ptr() == table
+    assert not step.matches(a) and step.matches_shapes(a)
+    with pytest.raises(ValueError):
+        step(a)
+    step.release()
+    assert float(train_xe_step(wrapped, a, opts, loss_fn)) > 0
+
+
 def test_train_xe_uses_the_step_graph_when_asked(monkeypatch):
-    """engine.caption_engine.train_xe with GRIT_TRAIN_STEP_GRAPH=1: two eager steps, one capture, replays for the batches of the captured
+    """engine.caption_engine.train_xe (GRIT_TRAIN_STEP_GRAPH, default 1): two eager steps, one capture, replays for the batches of the captured
     shape, eager launches for a batch of another shape; the epoch's mean loss equals the eager epoch's within the tolerance of
-    test_replayed_steps_equal_eager_steps; without the variable no graph is taken."""
+    test_replayed_steps_equal_eager_steps; with GRIT_TRAIN_STEP_GRAPH=0 no graph is taken."""
     from grit_amd.engine.caption_engine import train_xe
     from grit_amd.utils.misc import NestedTensor
     a, b = _batches()
@@ -160,13 +185,13 @@ def test_train_xe_uses_the_step_graph_when_asked(monkeypatch):
         res = train_xe(wrapped, {'train': order}, opts, Field(), 0, evaluate=False, checkpoint=False)
         return wrapped, res['loss'], init
 
-    monkeypatch.delenv("GRIT_TRAIN_STEP_GRAPH", raising=False)
+    monkeypatch.setenv("GRIT_TRAIN_STEP_GRAPH", "0")
     w0, eager, m_init = epoch()
     assert getattr(w0, '_grit_step_graph', None) is None
     m_eager = _masters(w0, PICKS)
     del w0
     torch.cuda.empty_cache()
-    monkeypatch.setenv("GRIT_TRAIN_STEP_GRAPH", "1")
+    monkeypatch.delenv("GRIT_TRAIN_STEP_GRAPH")  # the default since round 5 (bench.py times the graphed step: the two agree)
     w1, graphed, _ = epoch()
     g = getattr(w1, '_grit_step_graph', None)
     assert g is not None and g.replays == 3, None if g is None else g.replays  # steps 3, 4 and 6 (the capture's own replay included)

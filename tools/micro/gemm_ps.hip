@@ -1,3 +1,5 @@
+// NEGATIVE RESULT of round 4 (bit-exact, 154 vs 134 us against the per-tile kernel; profiles/r04/README.md): kept here, outside the
+// product library, for the record and for tools/micro/gemm_ps_bench.hip.
 // Persistent bf16 MFMA GEMM for the long token maps with a TRICKLED epilogue (gfx950) -- variant 6 of grit_gemm_bf16_nt.
 //
 //   C[M, N] = epilogue( A[M, K] . B[N, K]^T )      A, B, C bf16 row-major (K-contiguous operands), fp32 accumulation
@@ -31,8 +33,11 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../include/grit_hip.h"
-#include "gemm_math.h"
-#include "gemm_ps.h"
+#include "../../grit_amd/csrc/gemm_math.h"
+namespace grit_detail {
+int gemm_ps_launch(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K, int epilogue,
+                   const void* bias, void* aux, long ldaux, int nt, void* stream, unsigned long long* stamps);
+}
 
 namespace {
 

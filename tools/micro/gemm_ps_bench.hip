@@ -1,4 +1,4 @@
-// Stand-alone check + timing of the persistent stream GEMM (grit_amd/csrc/gemm_ps.hip) next to the per-tile and ping-pong kernels of
+// Stand-alone check + timing of the persistent stream GEMM (tools/micro/gemm_ps.hip) next to the per-tile and ping-pong kernels of
 // gemm.hip, no torch:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGRIT_GEMM_STAMPS tools/micro/gemm_ps_bench.hip -o tools/micro/bin/gemm_ps_bench
 //   tools/micro/bin/gemm_ps_bench            (all Swin shapes: correctness on sampled rows against a naive fp32 kernel, us per launch,
@@ -9,11 +9,11 @@
 #include <type_traits>
 #include "../../include/grit_hip.h"
 #include "../../grit_amd/csrc/gemm_math.h"
-#include "../../grit_amd/csrc/gemm_ps.h"
+#include "../../grit_amd/csrc/gemm_launchers.h"
 namespace v45 {
 #include "../../grit_amd/csrc/gemm.hip"
 }
-#include "../../grit_amd/csrc/gemm_ps.hip"
+#include "gemm_ps.hip"
 #include "../../grit_amd/csrc/gemm_w4.hip"
 #include <algorithm>
 #include <cmath>

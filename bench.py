@@ -665,18 +665,38 @@ def main():
             "wgrad_small": "wgrad_small (grit_amd/csrc/wgrad.hip): 64 x 64-tile grouped weight gradients of shapes outside 256-multiples",
             "gemm_lib": "hipBLASLt / rocBLAS through torch (tuned table grit_amd/tunableop_gfx950.csv): K >= 1024 long-map GEMMs with <= 512 "
                         "output columns (stream-K), the value projection, every GEMM of the two decoders",
+            "gemm_lib_long": "NOT an own kernel -- hipBLASLt through torch on the long token maps (>= 8192 rows): the stream-K "
+                             "Custom_Cijk...SK3_MT256x256x64 for K >= 1024 with <= 512 output columns (fc2 forward, fc1 / qkv input "
+                             "gradients), the stacked value projection, PatchMerging reductions, input_proj",
+            "gemm_lib_short": "NOT an own kernel -- hipBLASLt / rocBLAS through torch on the short maps (< 8192 rows): the Linears of the "
+                              "deformable decoder, the grid net and the caption decoder",
         }
         n_an = 2  # analysis steps the events cover
         gemm, families = None, {}
+        skipped_flops = skippable_flops = 0.0
         if gemm_events:
-            def fam_of(kind, pl):
-                return "gemm_lib" if kind == "gemm_lib" else pl.get("kernel", "gemm_nt_bf16")
+            def fams_of(kind, pl):
+                if kind == "gemm_lib":  # the aggregate AND its long-map / short-map halves (different regimes: MFMA-bound vs latency)
+                    return ("gemm_lib", "gemm_lib_long" if pl.get("rows", 0) >= 8192 else "gemm_lib_short")
+                return (pl.get("kernel", "gemm_nt_bf16"),)
             for kind, a, b, pl in gemm_events:
-                f = families.setdefault(fam_of(kind, pl), {"t": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
-                f["t"] += a.elapsed_time(b) * 1e-3
-                f["flops"] += pl.get("flops", 0.0)
-                f["bytes"] += pl.get("bytes", 0.0)
-                f["n"] += 1
+                dt = a.elapsed_time(b) * 1e-3
+                scale = pl.get("row_scale")
+                if scale is not None:  # drop path: 256-row tiles that lie inside dropped samples were not computed
+                    rows, per = int(pl["rows"]), int(pl["rows_per_sample"])
+                    zero = (scale.detach().float().cpu() == 0)
+                    first = torch.arange(0, rows, 256)
+                    last = torch.clamp(first + 255, max=rows - 1)
+                    lo, hi = first // per, last // per
+                    tile_skipped = (lo == hi) & zero[lo]  # the kernel's rule (gemm.hip): the tile lies inside ONE sample, and it is dropped
+                    skipped_flops += pl.get("flops", 0.0) * float(tile_skipped.float().mean())
+                    skippable_flops += pl.get("flops", 0.0)
+                for name in fams_of(kind, pl):
+                    f = families.setdefault(name, {"t": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+                    f["t"] += dt
+                    f["flops"] += pl.get("flops", 0.0)
+                    f["bytes"] += pl.get("bytes", 0.0)
+                    f["n"] += 1
             gemm = {"note": "every GEMM family of the step against BOTH bounds: `frac_mfma` = algorithmic flops / time / 2.5 PFLOP/s (dense bf16), "
                             "`frac_hbm` = algorithmic bytes (operands once + outputs once + fp32 split partials) / time / 8 TB/s; `bound` names "
                             "the larger one, `frac` is its value.  Per-launch HIP events on the launch stream in %d eager steps right behind "
@@ -691,8 +711,9 @@ def main():
                               "algorithmic_bytes_per_launch": f["bytes"] / f["n"], "TFLOPs": f["flops"] / tt / 1e12,
                               "GBps": f["bytes"] / tt / 1e9, "frac_mfma": fm, "frac_hbm": fh, "bound": "mfma" if fm >= fh else "hbm",
                               "frac": max(fm, fh), "traffic": traffic, "traffic_source": tsrc}
-            own = [v for k, v in gemm.items() if isinstance(v, dict) and k != "gemm_lib"]
-            for label, sel in (("gemm_own", own), ("all", [v for v in gemm.values() if isinstance(v, dict)])):
+            own = [v for k, v in gemm.items() if isinstance(v, dict) and not k.startswith("gemm_lib")]
+            for label, sel in (("gemm_own", own), ("all", [v for k, v in gemm.items() if isinstance(v, dict)
+                                                           and k not in ("gemm_lib_long", "gemm_lib_short")])):
                 if sel:
                     tt = sum(v["ms_per_step"] for v in sel) * 1e-3
                     ff = sum(v["algorithmic_flops_per_launch"] * v["launches_per_step"] for v in sel)
@@ -714,9 +735,16 @@ def main():
                     "traffic": v["traffic"], "traffic_source": v["traffic_source"],
                     "timing": "per-launch HIP events on the launch stream in %d eager steps right behind the timed region" % n_an}
         roof_wgrad = family_roofline("wgrad_tn")
-        # the hand-written kernel family with the most time per step (of the GEMM families and the two window-attention kernels)
-        candidates = [r for r in (family_roofline("gemm_nt_bf16"), roof_wgrad, family_roofline("gemm_w4"),
+        roof_lib_long = family_roofline("gemm_lib_long")
+        # the kernel family with the most time per step -- ALL of them compete: the own GEMM families, the two
+        # window-attention kernels AND the library's long-map GEMMs, which the line marks as not an own kernel when they win
+        for r, own_kernel in ((roof_lib_long, False), (roof_wgrad, True)):
+            if r:
+                r["own_kernel"] = own_kernel
+        candidates = [r for r in (family_roofline("gemm_nt_bf16"), roof_wgrad, family_roofline("gemm_w4"), roof_lib_long,
                                   window_attention.get("winattn_bwd"), window_attention.get("winattn_fwd")) if r]
+        for r in candidates:
+            r.setdefault("own_kernel", True)
         dominant = max(candidates, key=lambda r: r["ms_per_step"]) if candidates else roof
         if roof:  # MSDeformAttn forward: both denominators side by side
             roof["frac_touched"] = roof["frac"]
@@ -746,14 +774,27 @@ def main():
                                           "without a wire, not a multi-GPU number"),
                        "grad_sync": grad_sync if (world > 1 or self_coll) else None, "self_collectives": bool(self_coll),
                        "step_graph": graphed is not None, "step_graph_error": graph_error,
-                       "step_enqueue": ("one captured HIP graph replayed per step (grit_amd/engine/graph_step.py); per-launch kernel "
-                                        "events come from %d eager steps behind the timed region" % event_steps) if graphed is not None
+                       "step_graph_segments": (sum(1 for k, _ in graphed.plan if k == 'graph') if graphed.plan is not None else 1)
+                       if graphed is not None else 0,
+                       "step_enqueue": (("one captured HIP graph replayed per step" if graphed.plan is None else
+                                         "%d captured graph segments per step, the %d bucket all-reduces issued eagerly between them on the "
+                                         "process group's stream" % (sum(1 for k, _ in graphed.plan if k == 'graph'),
+                                                                     sum(1 for k, _ in graphed.plan if k == 'collective')))
+                                        + " (grit_amd/engine/graph_step.py); per-launch kernel events come from %d eager steps behind "
+                                          "the timed region" % event_steps) if graphed is not None
                        else "eager launches",
+                       "step_forks": bool(graphed is not None and graphed.plan is None and __import__('grit_amd.ops.streams', fromlist=['x']).ENABLED),
                        "rccl_env": rccl_env,
                        "points": args.points, "ragged": bool(args.ragged),
                        "msda_backward_accumulation": ("f32" if args.fp32 else ("f32 (" + msda_op.F32_METHOD + ")") if msda_op.F32_ACCUMULATE
                                                       else "bf16 (packed atomics)")},
             "mfma_roofline_frac_bf16": value / world * FLOP_PER_IMAGE_FWD_BWD / MFMA_PEAK_BF16,
+            # ... the same with the flops the step EXECUTES: the fused Mlp GEMMs do not compute the 256-row tiles inside samples that drop path
+            # removed from the branch (counted per launch from the drawn factors of the analysis steps)
+            "flops_per_image": {"nominal": FLOP_PER_IMAGE_FWD_BWD,
+                                "executed": FLOP_PER_IMAGE_FWD_BWD - skipped_flops / n_an / args.batch,
+                                "skipped_fraction_of_skippable_gemms": (skipped_flops / skippable_flops) if skippable_flops else 0.0},
+            "mfma_roofline_frac_bf16_executed": value / world * (FLOP_PER_IMAGE_FWD_BWD - skipped_flops / n_an / args.batch) / MFMA_PEAK_BF16,
             "final_loss": final_loss,
             # the hand-written kernel with the most time per step (profiles/r03/*steady_state.txt): the long-map weight-gradient GEMM
             # (MFMA-bound) once the analysis steps ran, else the window-attention backward (HBM-bound); both are always reported below
@@ -761,6 +802,7 @@ def main():
             "roofline_gemm_nt_bf16": family_roofline("gemm_nt_bf16"),
             "roofline_gemm_w4": family_roofline("gemm_w4"),
             "roofline_wgrad_tn": roof_wgrad,
+            "roofline_gemm_lib_long": roof_lib_long,
             "roofline_msda": roof,
             "msda_backward": msda_bwd,
             "roofline_winattn_bwd": window_attention.get("winattn_bwd"),

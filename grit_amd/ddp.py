@@ -45,10 +45,11 @@ import torch.distributed as dist
 from torch import nn
 
 from grit_amd.ops import linear as _linear_ops
+from grit_amd.ops import streams as _streams
 
 
 class _Bucket(object):
-    __slots__ = ('params', 'views', 'flat', 'pending', 'expected', 'work', 'wire', 'packed', 'lo', 'hi', 'rs_out')
+    __slots__ = ('params', 'views', 'flat', 'pending', 'expected', 'work', 'wire', 'packed', 'lo', 'hi', 'rs_out', 'cut')
 
     def __init__(self, params, views, flat, lo=0, hi=None):
         self.params, self.views, self.flat = params, views, flat
@@ -59,6 +60,7 @@ class _Bucket(object):
         self.work = None
         self.wire = None
         self.packed = False
+        self.cut = False  # segmented capture: the capture was cut behind this bucket's pack
 
 
 class BucketedDataParallel(nn.Module):
@@ -95,6 +97,7 @@ class BucketedDataParallel(nn.Module):
         self._decided = False     # the live set has been agreed at least once
         self.layout_version = 0   # bumped whenever the live set changes (FlatAdam re-derives its runs)
         self._iteration = 0
+        self._cutter = None       # set by grit_amd.engine.graph_step while it captures the step in segments around the collectives
         if self.world > 1 and broadcast_parameters:
             for p in module.parameters():
                 dist.broadcast(p.data, src=0, group=process_group)
@@ -191,6 +194,9 @@ class BucketedDataParallel(nn.Module):
         parameters without a gradient are zeroed (the flat buffer still holds the previous step's values there)."""
         if b.packed:
             return
+        # (captured step with forked branches, grit_amd/ops/streams.py: the gradients of this bucket and the operands of the deferred
+        # jobs were produced on whichever stream ran their node -- this stream waits for all of them, and they for the pack)
+        _streams.rendezvous()
         _linear_ops.wait_deferred()  # small-map weight gradients computed beside the backward chain (grit_amd/ops/linear.py)
         src, dst, stale = [], [], []
         for p, view in zip(b.params, b.views):
@@ -202,6 +208,7 @@ class BucketedDataParallel(nn.Module):
                 dst.append(view)
         if src:
             torch._foreach_copy_(dst, src)
+            _streams.keep_for_current_stream(src)  # (gradients produced on a forked stream, dropped right below)
         if stale:
             torch._foreach_zero_(stale)
         for p, view in zip(b.params, b.views):
@@ -209,10 +216,22 @@ class BucketedDataParallel(nn.Module):
             if p.grad is not None:
                 p.grad = view
         b.packed = True
+        _streams.release()
 
     def _launch(self, b):
         if not self.collective or b.work is not None:
             return
+        if self._cutter is not None:
+            # segmented capture of the step (grit_amd/engine/graph_step.py): the capture is CUT here -- the segment recorded so far ends
+            # with this bucket packed, the collective itself is issued eagerly between the replays of this segment and the next
+            if not b.cut:
+                b.cut = True
+                self._cutter.collective(b)
+            return
+        self.issue(b)
+
+    def issue(self, b):
+        """The bucket's collective, asynchronously on the process group's stream (ordered behind the current stream)."""
         src = b.flat
         if self.wire_dtype is not None and self.wire_dtype != b.flat.dtype:
             src = b.wire = b.flat.to(self.wire_dtype)
@@ -224,9 +243,41 @@ class BucketedDataParallel(nn.Module):
         else:
             b.work = dist.all_reduce(src, group=self.group, async_op=True)
 
+    def capture_ready(self):
+        """May the step be captured in segments around the bucket collectives?  Steady state only: the live set agreed, no late
+        gradient in the last step, no per-step agreement, plain in-place all-reduce of the buckets' own dtype."""
+        return (self.collective and self._decided and not self._late and not self.agree_every_step and not self.check_agreement
+                and not self.shard_grads and self.wire_dtype is None)
+
+    def _finish_captured(self):
+        """finish_gradient_sync() while a segmented capture records the step: the steady-state path only (capture_ready()) -- pack and
+        cut what backward left, a 'wait for every collective' cut, then the device-side tail.  The host-side books of a replayed step
+        are kept by the replaying caller (GraphedXEStep.__call__)."""
+        _streams.rendezvous()
+        _linear_ops.end_deferral()
+        if self._late:
+            raise RuntimeError("segmented capture: a gradient arrived outside the bucket reductions (the live set changed)")
+        for b in self.buckets:
+            if b.expected == 0:
+                continue
+            if not b.packed:
+                self._pack(b)
+            self._launch(b)
+        self._cutter.wait_all()
+        if self.average and self.world > 1:
+            for b in self.buckets:
+                b.flat[b.lo:b.hi].mul_(1.0 / self.world)
+        for b in self.buckets:
+            b.cut = False
+        self._refresh_expected()
+        self._iteration += 1
+
     def finish_gradient_sync(self):
         """Launch what is still pending, agree on the used / late parameters, wait, reduce late gradients, average,
         and re-derive the live set if it changed."""
+        if self._cutter is not None:
+            return self._finish_captured()
+        _streams.rendezvous()
         _linear_ops.end_deferral()
         for b in self.buckets:
             if b.expected == 0 and self._decided:

@@ -130,8 +130,9 @@ def evaluate_loss(model, dataloader, loss_fn, text_field, epoch, writer):
     return val_loss
 
 
-def train_xe_step(model, batch, optimizers, loss_fn, scheduler=None, autocast_dtype=None):
-    """One optimisation step in the reference's order; returns the (rank-averaged) loss tensor, no host sync."""
+def train_xe_step(model, batch, optimizers, loss_fn, scheduler=None, autocast_dtype=None, gather=True):
+    """One optimisation step in the reference's order; returns the (rank-averaged) loss tensor, no host sync.
+    gather=False leaves the rank average of the loss to the caller (the segmented capture of the step issues it between replays)."""
     dev = batch['captions'].device.type
     with torch.autocast(dev, dtype=autocast_dtype, enabled=autocast_dtype is not None):
         out = model(batch['samples'], batch['captions'])
@@ -149,7 +150,7 @@ def train_xe_step(model, batch, optimizers, loss_fn, scheduler=None, autocast_dt
     post = getattr(model, 'after_optimizer_step', None)
     if post is not None:
         post()
-    loss = gather_result(loss.detach())
+    loss = gather_result(loss.detach()) if gather else loss.detach()
     if scheduler is not None:
         lr = scheduler.step()
         assert optimizers['model'].param_groups[0]['lr'] == lr, "LR scheduler doesn't work properly."

@@ -15,24 +15,31 @@ What makes the step capturable (everything else already was -- no host read, no 
     fused decoder glue take part in the capture (backend.capturing_train_step) -- the graph's private pool owns every tensor
     whose raw address a deferred job keeps.
 
-Scope: a static-shape step -- same batch shape, same `any_padding` flag, same live parameter set.  By default on ONE rank without
-collectives: with world > 1 the eager step keeps the RCCL overlap that was tested on gloo.  GRIT_STEP_GRAPH_COLLECTIVES=1
-(experimental) captures the bucketed all-reduces too: run on hardware with a one-rank RCCL group (tests/test_graph_step_gpu.py with GRIT_TEST_RCCL_GRAPH=1: 6 of 7 runs passed, one unexplained failure inside a full-suite run;
-profiles/r04/bench_rccl_one_rank_graph.json: 52.3 ms against 53.6 ms eager on one box), never with N > 1.  It needs the capture in
-thread-local error mode -- torch's ProcessGroupNCCL watchdog thread keeps querying the events of earlier collectives, which the
-default global mode forbids during a capture (hipErrorStreamCaptureUnsupported invalidates the capture and the watchdog's
-exception terminates the process).  The sharded optimizer's cross-step all-gather is not capturable this way.
-`GraphedXEStep.matches(batch)` says whether a batch fits; callers fall back to the eager step
-for the odd batch (the last one of an epoch) or keep one graph per shape.
+Scope: a static-shape step -- same batch shape, same `any_padding` flag, same live parameter set, same optimizer objects and runs.
+`GraphedXEStep.matches(batch)` says whether a batch fits; callers fall back to the eager step for the odd batch (the last one of an
+epoch).
+
+With collectives (N > 1 ranks; round 5) the step is captured in SEGMENTS: the capture is cut behind every bucket's pack (from the autograd
+hook that completes the bucket -- the engine's device thread, hence torch's "relaxed" capture-error mode, which is also what keeps
+ProcessGroupNCCL's watchdog thread, querying the events of earlier collectives, from invalidating the capture) and once more where the
+step waits for the collectives.  A replayed step is then: segment 0 (forward + backward up to the first full bucket) -> all-reduce of
+bucket 0 issued EAGERLY on the process group's stream -> segment 1 -> all-reduce 1 -> ... -> wait -> last segment (both Adam steps) ->
+the scalar all-reduce of the loss.  ~2 300 launches become ~7 graph launches + ~7 collective calls per step, the all-reduces overlap the
+rest of backward exactly as in the eager step, and no collective is ever part of a capture (round 4's experiment captured them: one
+unexplained failure in seven runs; removed).  Independent-branch forks (grit_amd/ops/streams.py) are off inside a segmented capture: a cut
+must happen on the capture's origin stream.  Not capturable this way: the sharded optimizer's cross-step all-gather, wire-dtype
+conversion of the buckets, per-step agreement of the live set (supported() says no; the eager step runs).
 """
 import os
 
 import torch
 
 from grit_amd.ops import backend
+from grit_amd.ops import streams
 from grit_amd.utils.misc import NestedTensor
 
 ENABLED = os.environ.get("GRIT_STEP_GRAPH", "1") != "0"
+SEGMENTS = os.environ.get("GRIT_STEP_GRAPH_SEGMENTS", "1") != "0"
 
 
 def supported(model, optimizers):
@@ -40,9 +47,53 @@ def supported(model, optimizers):
     ddp = getattr(model, 'ddp', None)
     if ddp is None or not getattr(model, 'flat_optimizer', False):
         return False
-    if ddp.collective and os.environ.get("GRIT_STEP_GRAPH_COLLECTIVES") != "1":
-        return False
+    if ddp.collective:  # captured in segments around the collectives (GRIT_STEP_GRAPH_SEGMENTS=0: eager launches with N > 1)
+        if not SEGMENTS or getattr(model, 'shard_optimizer', False) or ddp.shard_grads or ddp.wire_dtype is not None \
+                or ddp.agree_every_step or ddp.check_agreement:
+            return False
     return all(hasattr(optimizers[k], 'prepare_replay') for k in ('model', 'backbone'))
+
+
+def _debug(msg):
+    if os.environ.get("GRIT_GRAPH_DEBUG") == "1":
+        import sys
+        import threading
+        sys.stderr.write("[graph_step %s] %s\n" % (threading.current_thread().name, msg))
+        sys.stderr.flush()
+
+
+class _Cutter(object):
+    """The segments of a step captured around its collectives: `plan` is the replay order -- ('graph', CUDAGraph), ('collective', bucket),
+    ('wait', None).  begin() / end() may be called from different threads (autograd hooks run on the engine's device thread)."""
+
+    def __init__(self):
+        self.pool = torch.cuda.graph_pool_handle()
+        self.plan, self.cur = [], None
+
+    def begin(self):
+        self.cur = torch.cuda.CUDAGraph()
+        self.cur.capture_begin(pool=self.pool, capture_error_mode="relaxed")
+        _debug("segment %d begins" % sum(1 for k, _ in self.plan if k == 'graph'))
+
+    def end(self):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # ("The CUDA Graph is empty": two cuts with nothing in between)
+            _debug("segment ends ...")
+            self.cur.capture_end()
+            _debug("... ended")
+        self.plan.append(('graph', self.cur))
+        self.cur = None
+
+    def collective(self, bucket):
+        self.end()
+        self.plan.append(('collective', bucket))
+        self.begin()
+
+    def wait_all(self):
+        self.end()
+        self.plan.append(('wait', None))
+        self.begin()
 
 
 def abandon_capture(model, opts, iteration=None):
@@ -74,7 +125,7 @@ class GraphedXEStep(object):
         caching allocator), then captures one.  Call it like train_xe_step's result: `loss = step(batch)`."""
         from grit_amd.engine.caption_engine import train_xe_step
         if not supported(model, optimizers):
-            raise ValueError("GraphedXEStep needs a Bf16Compute wrapper with FlatAdam optimizers and no collectives in the step")
+            raise ValueError("GraphedXEStep needs a Bf16Compute wrapper with FlatAdam optimizers (and, with collectives, the plain bucketed all-reduce)")
         if getattr(model, '_grit_step_graph_taken', False):
             # a second capture on a wrapper whose first graph was released dies in hipStreamEndCapture (ROCm 7.2, seen in bench.py):
             # refuse here, callers stay on eager launches
@@ -92,18 +143,25 @@ class GraphedXEStep(object):
         self._layout = model.ddp.layout_version
         self._opts = [optimizers['model'], optimizers['backbone']]
         iteration = model.ddp._iteration
+        self.plan = None
         try:
             for o in self._opts:
                 o.device_hyper = True
                 o.prepare_replay()
             torch.cuda.synchronize(self.device)
-            self.graph = torch.cuda.CUDAGraph()
-            with backend.capturing_train_step(self.device) as seeds:
-                # (a wrapper with collectives -- GRIT_STEP_GRAPH_COLLECTIVES=1, experimental -- captures in thread-local error mode: the
-                # process group's watchdog thread keeps querying the events of earlier collectives, which global mode forbids during a capture)
-                with torch.cuda.graph(self.graph, capture_error_mode="thread_local" if model.ddp.collective else "global"):
-                    seeds.begin_captured_step(self.device)
-                    self.loss = train_xe_step(model, self.static, optimizers, loss_fn)
+            if model.ddp.collective:
+                self._capture_segments(model, optimizers, loss_fn, train_xe_step)
+            else:
+                self.graph = torch.cuda.CUDAGraph()
+                with backend.capturing_train_step(self.device) as seeds:
+                    with torch.cuda.graph(self.graph):
+                        seeds.begin_captured_step(self.device)
+                        streams.begin_capture(self.device)  # independent branches fork from here on (grit_amd/ops/streams.py)
+                        try:
+                            self.loss = train_xe_step(model, self.static, optimizers, loss_fn)
+                            streams.rendezvous(self.device)  # (every fork is joined already; cheap insurance before the capture ends)
+                        finally:
+                            streams.end_capture(self.device)
         except BaseException:
             self.graph = None
             model._grit_step_graph_taken = True  # (a second capture attempt on this wrapper is not safe on this ROCm either)
@@ -114,6 +172,61 @@ class GraphedXEStep(object):
         self._opt_state = tuple((id(o), o.runs_version) for o in self._opts)
         model._grit_step_graph_taken = True
         self.replays = 0
+
+    def _capture_segments(self, model, optimizers, loss_fn, train_xe_step):
+        """The step with collectives: one capture per stretch between two collectives (module docstring)."""
+        import gc
+        ddp = model.ddp
+        if not ddp.capture_ready():
+            raise RuntimeError("segmented capture needs the bucket wrapper in steady state (live set agreed, no late gradients): "
+                               "run eager steps first")
+        cutter = _Cutter()
+        gc.collect()
+        torch.cuda.empty_cache()
+        cur = torch.cuda.current_stream(self.device)
+        cap = torch.cuda.Stream(device=self.device)
+        cap.wait_stream(cur)
+        ddp._cutter = cutter
+        try:
+            with backend.capturing_train_step(self.device) as seeds, streams.suspended(), torch.cuda.stream(cap):
+                cutter.begin()
+                try:
+                    seeds.begin_captured_step(self.device)
+                    self.loss = train_xe_step(model, self.static, optimizers, loss_fn, gather=False)
+                except BaseException as e:
+                    import sys
+                    import traceback
+                    sys.stderr.write("graph_step: exception inside the segmented capture: %s\n%s\n" % (repr(e)[:500], traceback.format_exc()[-3000:]))
+                    sys.stderr.flush()
+                    raise
+                finally:
+                    if cutter.cur is not None:
+                        cutter.end()
+        finally:
+            ddp._cutter = None
+            for b in ddp.buckets:
+                b.cut = False
+        cur.wait_stream(cap)
+        self.graph = cutter.plan[0][1]  # (`graph is None` means released)
+        self.plan, self._pool = cutter.plan, cutter.pool
+
+    def _replay(self):
+        if self.plan is None:
+            self.graph.replay()
+            return
+        from grit_amd.engine.caption_engine import gather_result
+        ddp = self.model.ddp
+        for kind, arg in self.plan:
+            if kind == 'graph':
+                arg.replay()
+            elif kind == 'collective':
+                ddp.issue(arg)  # asynchronously on the process group's stream, behind the segment just enqueued
+            else:
+                for b in ddp.buckets:
+                    if b.work is not None:
+                        b.work.wait()  # (the current stream waits; the host does not)
+                        b.work = None
+        gather_result(self.loss)  # the rank average of the loss, in place on the graph's output (reference caption_engine.py:340)
 
     def matches(self, batch, optimizers=None):
         """Does `batch` (and, when given, the `optimizers` dict of the caller) fit the captured step?"""
@@ -142,7 +255,7 @@ class GraphedXEStep(object):
             self.captions.copy_(batch['captions'], non_blocking=True)
         for o in self._opts:
             o.prepare_replay()
-        self.graph.replay()
+        self._replay()
         for o in self._opts:
             o.advance()
         self.model.ddp._iteration += 1
@@ -156,4 +269,4 @@ class GraphedXEStep(object):
         """Back to eager steps: the optimizers take their scalars from the launch arguments again."""
         for o in self._opts:
             o.device_hyper = False
-        self.graph = None
+        self.graph = self.plan = None

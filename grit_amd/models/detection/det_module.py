@@ -280,8 +280,10 @@ class DetectionModule(nn.Module):
             return [(maps, l) for l in range(n)]
         return shared_input_linears(src, projs)
 
-    def forward(self, srcs, masks, no_padding=False, src_flatten=None, shapes=None):
-        """no_padding=True (caller knows every mask is all-False) drops the padding mask handed to MSDeformAttn, whose
+    def forward(self, srcs, masks, no_padding=False, src_flatten=None, shapes=None, last_only=False):
+        """last_only=True (the captioner: it consumes hs[-1] alone, reference models/caption/detector.py:73): returns (hs[-1], None, None)
+        without stacking the intermediate outputs and without the last layer's box refinement, whose result nobody reads.
+        no_padding=True (caller knows every mask is all-False) drops the padding mask handed to MSDeformAttn, whose
         masked_fill would be a full copy of each value map that changes nothing.  `src_flatten` / `shapes`: the levels
         already flattened into one [B, S, C] map (grit_amd.ops.group_norm writes it directly), `srcs` is then unused."""
         od = self.prepare_od_inputs(srcs, masks, src_flatten, shapes, no_padding)
@@ -292,8 +294,11 @@ class DetectionModule(nn.Module):
             values = self.project_values(od['src'], od['src_padding_mask'])
         if od['reference_points'].shape[-1] == 4:  # the (w, h) part of the ratios once, not once per layer
             od['src_valid_ratios'] = torch.cat([od['src_valid_ratios'], od['src_valid_ratios']], -1)
+        n = len(self.decoder_layers)
         for lid, layer in enumerate(self.decoder_layers):
             od['tgt'] = layer(**od) if values is None else layer(value=values[lid], **od)
+            if last_only and lid == n - 1:
+                return od['tgt'], None, None
             refine = self.bbox_embed[lid + 1] if self.bbox_embed is not None else None
             od['reference_points'] = self.bbox_refine(refine, od['tgt'], od['reference_points'])
             hs.append(od['tgt'])

@@ -70,7 +70,8 @@ def linear_bias_gelu(x2, weight, bias, row_scale=None, rows_per_sample=0):
         # drop path: the tiles of samples whose branch is multiplied by 0 are not computed (zeros in `act` and `pre`)
         act = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
         K = x2.shape[1]
-        with _lib.device_guard(x2.device), timed("gemm_own", epilogue=BIAS_GELU, kernel="gemm_nt_bf16", **gemm_work(M, N, K, outputs=2)):
+        with _lib.device_guard(x2.device), timed("gemm_own", epilogue=BIAS_GELU, kernel="gemm_nt_bf16", row_scale=row_scale,
+                                                  rows_per_sample=int(rows_per_sample), **gemm_work(M, N, K, outputs=2)):
             st = _lib.load().grit_gemm_bf16_nt_rows(_ptr(x2), x2.stride(0), _ptr(weight), weight.stride(0), _ptr(act), act.stride(0), M, N, K,
                                                     BIAS_GELU, _ptr(bias), _ptr(pre), pre.stride(0), None, _ptr(row_scale),
                                                     int(rows_per_sample), VARIANT if VARIANT in (1, 2, 3, 4) else 0, _lib.current_stream_ptr())
@@ -92,7 +93,8 @@ def input_grad_dgelu(dy2, weight_t, pre, row_scale=None, rows_per_sample=0):
         d_pre = torch.empty((M, N), dtype=torch.bfloat16, device=dy2.device)
         K = dy2.shape[1]
         epi = DGELU
-        with _lib.device_guard(dy2.device), timed("gemm_own", epilogue=epi, kernel="gemm_nt_bf16", **gemm_work(M, N, K, extra_in=1)):
+        with _lib.device_guard(dy2.device), timed("gemm_own", epilogue=epi, kernel="gemm_nt_bf16", row_scale=row_scale,
+                                                   rows_per_sample=int(rows_per_sample), **gemm_work(M, N, K, extra_in=1)):
             st = _lib.load().grit_gemm_bf16_nt_rows(_ptr(dy2), dy2.stride(0), _ptr(weight_t), weight_t.stride(0), _ptr(d_pre), d_pre.stride(0),
                                                     M, N, K, epi, None, _ptr(pre), pre.stride(0), _ptr(partial), _ptr(row_scale), int(rows_per_sample),
                                                     VARIANT if VARIANT in (1, 2, 3, 4) else 0, _lib.current_stream_ptr())

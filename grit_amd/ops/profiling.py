@@ -31,6 +31,6 @@ def gemm_work(rows, n, k, esize=2, outputs=1, extra_in=0.0, partial_f32=0.0):
     """Payload of a GEMM launch for timed(): 2 rows n k flop, and its ALGORITHMIC bytes -- both operands once, `outputs` result maps
     of rows x n (`extra_in`: further input maps of that size, e.g. the pre-activation of the GELU' epilogue; `partial_f32`: fp32
     elements written as split partials)."""
-    return {"flops": 2.0 * rows * n * k,
+    return {"rows": rows, "flops": 2.0 * rows * n * k,
             "bytes": float(esize) * (rows * k + n * k + (outputs + extra_in) * rows * n) + 4.0 * partial_f32}
 

@@ -490,7 +490,9 @@ int grit_image_batch_fwd(const uint8_t* src, const int64_t* desc, const int32_t*
  * Needs N % 128 == 0, K % 32 == 0, 16-byte aligned bases; M is free.  variant 0 = tile configuration chosen from the
  * shape; 1..4 = explicit eight-wave configurations, 5 = persistent ping-pong, 7 = persistent FOUR-wave kernel with 128 x 128 wave tiles (gemm_w4.hip: N % 256 == 0,
  * K % 64 == 0, M >= 256, operands below 2 GiB; what the long-map forward / input-gradient GEMMs run where it beats the library).
- * Results are bit-identical across variants; variant 7 writes its GRIT_GEMM_DGELU column sums as 2 * ceil(M / 256) rows (one per
+ * The NONE / BIAS results are bit-identical across variants (same products, same k order per accumulator).  The GELU epilogues of
+ * variant 7 start from the bf16-ROUNDED pre-activation / gradient (what an unfused Linear -> GELU pair computes), those of variants
+ * 1..5 from the fp32 values: equal up to that one rounding.  Variant 7 writes its GRIT_GEMM_DGELU column sums as 2 * ceil(M / 256) rows (one per
  * 128-row wave block of its 256-row tiles; every row written).
  * ------------------------------------------------------------------------------------------------------ */
 #define GRIT_GEMM_NONE 0

@@ -133,6 +133,8 @@ def _small_batch(n, seed):
 
 
 def _a14_worker(rank, world, port, ret):
+    import faulthandler
+    faulthandler.enable()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     if world > 1:
@@ -165,9 +167,21 @@ def _a14_worker(rank, world, port, ret):
     losses = [float(loss)]
     for _ in range(2):
         losses.append(float(train_xe_step(wrapped, mine, opts, loss_fn)))  # (rank-averaged by gather_result)
+    # steps 4-6 through the step graph: with two ranks captured in SEGMENTS around the bucket all-reduces (graph_step.py), in the
+    # single process as one graph
+    from grit_amd.engine import graph_step
+    assert graph_step.supported(wrapped, opts)
+    # (nothing may keep the autograd graph of an EAGER step alive across the capture: its AccumulateGrad nodes would be reused, and
+    # they run on the stream they were created on -- the default stream, which a capture on another stream must not touch)
+    del out, loss
+    step = graph_step.GraphedXEStep(wrapped, opts, loss_fn, mine, eager_steps=0)
+    assert (step.plan is not None) == (world > 1)
+    for _ in range(3):
+        losses.append(float(step(mine)))
     torch.cuda.synchronize()
     if rank == 0:
         ret["grads"], ret["losses"] = grads, losses
+        ret["plan"] = None if step.plan is None else [k for k, _ in step.plan]
         ret["unused"] = len(wrapped.unused_parameters)
     if world > 1:
         dist.barrier()
@@ -185,9 +199,12 @@ def test_a14_two_ranks_on_the_hip_path_equal_one_process_on_the_whole_batch():
         one = dict(ret)
     assert two["unused"] == one["unused"] == 80  # the reference's static unused set
     # step-1 loss of rank 0 is its half batch's; steps 2-3 are rank averages = the whole-batch loss of the single process
-    for a, b in zip(two["losses"][1:], one["losses"][1:]):
-        assert abs(a - b) < 5e-3 * abs(b), (two["losses"], one["losses"])
-    assert one["losses"][-1] < one["losses"][0]
+    for i, (a, b) in enumerate(zip(two["losses"][1:], one["losses"][1:])):
+        # (steps 4-6 run through the step graphs; the two trajectories drift apart with every Adam step on bf16-rounded sums:
+        # 0.2 % / 0.2 % eager, then 0.3 % / 0.3 % / 0.6 % measured)
+        assert abs(a - b) < (5e-3 if i < 2 else 1.5e-2) * abs(b), (two["losses"], one["losses"])
+    assert one["losses"][-1] < one["losses"][0] and len(one["losses"]) == 6
+    assert two["plan"].count('collective') >= 2 and two["plan"].count('wait') == 1 and one["plan"] is None, two["plan"]
     for n in PICKS:
         a, b = two["grads"][n], one["grads"][n]
         rel = float(torch.linalg.norm(a - b) / torch.linalg.norm(b))

@@ -8,9 +8,12 @@ per-sample factor.  Here the per-sample draw is INJECTED (`SwinTransformer.drop_
 keep mask, at BASELINE config 3's size (16 images of 640 x 640):
 
   * bf16 step with the skip paths  vs  the fp32-kernel step, same mask: loss and picked gradients at config 3's tolerances;
-  * skip paths on  vs  off (GRIT_GEMM_ROW_SKIP=0): the loss and every gradient downstream of deterministic kernels bit-equal; with the
-    region branch cut off the backbone (the MSDeformAttn backward sums a cell's terms in LDS-counter order, the only run-to-run
-    non-determinism of the step) EVERY picked gradient, backbone included, bit-equal.
+  * skip paths on  vs  off (GRIT_GEMM_ROW_SKIP=0), both on the eight-wave fused-Mlp kernel (GRIT_GEMM_VARIANT=4): the loss bit-equal,
+    and with the region branch cut off the backbone (the MSDeformAttn backward sums a cell's terms in LDS-counter order, the only
+    run-to-run non-determinism of the step) EVERY picked gradient, backbone included, bit-equal.
+    (Why the variant is pinned: without drop-path factors the stage-3 Mlp runs the four-wave kernel, whose GELU epilogue evaluates
+    GELU of the bf16-ROUNDED pre-activation -- what an unfused Linear -> GELU pair computes -- while the eight-wave kernel, which the
+    skip path always runs, evaluates it on the fp32 sum: two correct roundings, 1.5e-5 apart in the loss.  First run of this test.)
 """
 import os
 
@@ -28,10 +31,12 @@ BACKBONE_PICKS = tuple(n for n in PICKS if 'backbone' in n) + ('detector.backbon
                                                                'detector.backbone.layers.2.blocks.4.norm2.weight')
 
 
-def _worker(rank, port, mode, cut_regions, n_images, ret):
+def _worker(rank, port, mode, cut_regions, pin_variant, n_images, ret):
     """mode: 'skip' (bf16, default paths), 'noskip' (bf16, GRIT_GEMM_ROW_SKIP=0), 'fp32' (fp32 weights and kernels)."""
     if mode == 'noskip':
         os.environ["GRIT_GEMM_ROW_SKIP"] = "0"  # read when grit_amd.ops.gemm is imported: this is a fresh process
+    if pin_variant:
+        os.environ["GRIT_GEMM_VARIANT"] = "4"
     from grit_amd.amp import Bf16Compute
     from grit_amd.data import synthetic_batch
     from grit_amd.models.common.swin_model import DropPath
@@ -80,35 +85,27 @@ def _run(*args):
         return dict(ret)
 
 
-def test_step_with_drop_path_on_against_fp32_kernels_and_skip_paths_off():
+def test_step_with_drop_path_on_against_fp32_kernels():
     B = 16
-    skip = _run('skip', False, B)
-    noskip = _run('noskip', False, B)
-    fp32 = _run('fp32', False, B)
-    assert skip["finite"] and noskip["finite"] and fp32["finite"]
-    assert skip["dropped_mlp"] >= 20 and skip["dropped"] == fp32["dropped"]  # ~11 % of 40 x 16 (block, sample) branches
-    # (1) same mask, fp32 kernels: config 3's tolerances (tests/test_configs_gpu.py::test_config3_bs16_step_against_the_fp32_kernels)
+    skip = _run('skip', False, False, B)
+    fp32 = _run('fp32', False, False, B)
+    assert skip["finite"] and fp32["finite"]
+    assert skip["dropped_mlp"] >= 20 and skip["dropped"] == fp32["dropped"]  # ~16 % of 44 x 16 (branch, sample) pairs
+    # same mask, fp32 kernels: config 3's tolerances (tests/test_configs_gpu.py::test_config3_bs16_step_against_the_fp32_kernels)
     assert abs(skip["loss"] - fp32["loss"]) < 2e-2 * fp32["loss"], (skip["loss"], fp32["loss"])
     rels = {n: float(torch.linalg.norm(skip["grads"][n] - fp32["grads"][n]) / torch.linalg.norm(fp32["grads"][n])) for n in PICKS}
     for n, rel in rels.items():
         assert rel < (0.6 if 'cross_attn' in n else 0.3), rels
     assert sorted(rels.values())[len(rels) // 2] < 0.12, rels
-    # (2) skip-on == skip-off where the arithmetic is deterministic
-    assert skip["loss"] == noskip["loss"]
-    for n in DETERMINISTIC:
-        assert torch.equal(skip["grads"][n], noskip["grads"][n]), n
 
 
-def test_skipped_tiles_change_no_bit_of_any_gradient():
+def test_skipped_tiles_change_no_bit_of_the_loss_or_of_any_gradient():
     B = 16
-    skip = _run('skip', True, B)
-    noskip = _run('noskip', True, B)
+    skip = _run('skip', True, True, B)
+    noskip = _run('noskip', True, True, B)
     assert skip["finite"] and noskip["finite"] and skip["dropped_mlp"] >= 20
     assert skip["loss"] == noskip["loss"]
-    compared = 0
     for n in DETERMINISTIC + BACKBONE_PICKS:  # (the detection module's own parameters still sit behind its MSDeformAttn backward)
         assert torch.equal(skip["grads"][n], noskip["grads"][n]), n
-        compared += 1
-    assert compared == len(BACKBONE_PICKS) + 3
     for n in BACKBONE_PICKS:
         assert float(skip["grads"][n].abs().max()) > 0, n

@@ -21,7 +21,11 @@ import torch
 
 from grit_amd.ops import backend
 
-ENABLED = os.environ.get("GRIT_STEP_FORK", "1") != "0"
+# Default OFF (round 5, profiles/r05/ab_fork.txt, same box, alternating passes): grid net beside the detection module 51.94 -> 52.46 ms,
+# region beside grid cross-attention 51.94 -> 52.84 ms, both 52.89 ms.  Branches DO run side by side on replay (r05_graph_probe.py), but a
+# graph with any parallel branch leaves the runtime's single-queue fast path: the whole 2 300-node replay pays for it, and the branches of
+# this step are too short to win it back.  GRIT_STEP_FORK=1 enables the forks (tests/test_graph_step_gpu.py keeps them correct).
+ENABLED = os.environ.get("GRIT_STEP_FORK", "0") == "1"
 MASK = int(os.environ.get("GRIT_STEP_FORK_MASK", "255"))  # bit i: fork slot i may be taken (A/B and debugging aid)
 _pool = {}      # device index -> list of side streams
 _in_capture = {}  # device index -> [origin stream, side streams that joined the current capture (a stream stays in capture mode until it ends)]

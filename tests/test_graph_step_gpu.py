@@ -219,16 +219,19 @@ def _rccl_segments_worker(rank, port, steps, ret):
         issued.append(int(args[0].numel()))
         return _f(*args, **kw)
     dist.all_reduce = spy
-    losses = [float(train_xe_step(wrapped, a, opts, loss_fn)), float(train_xe_step(wrapped, b, opts, loss_fn))]
-    eager_calls = len(issued) // 2
+    losses = [float(train_xe_step(wrapped, a, opts, loss_fn))]  # (the first step also agrees on the live parameter set: one more call)
+    first = len(issued)
+    losses.append(float(train_xe_step(wrapped, b, opts, loss_fn)))
+    eager_calls = len(issued) - first
     step = graph_step.GraphedXEStep(wrapped, opts, loss_fn, a, eager_steps=0)
-    captured_calls = len(issued) - 2 * eager_calls
+    captured_calls = len(issued) - first - eager_calls
+    before = len(issued)
     order = [a, b] * (steps // 2)
     for x in order:
         losses.append(float(step(x)))
     torch.cuda.synchronize()
     ret["losses"], ret["eager_calls"], ret["captured_calls"] = losses, eager_calls, captured_calls
-    ret["replay_calls"] = (len(issued) - 2 * eager_calls - captured_calls) / len(order)
+    ret["replay_calls"] = (len(issued) - before) / len(order)
     ret["plan"] = [k for k, _ in step.plan]
     ret["masters"] = {n: v.cpu() for n, v in _masters(wrapped, PICKS).items()}
     dist.destroy_process_group()

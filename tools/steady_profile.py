@@ -63,6 +63,14 @@ def main(out_dir, nwin=2):
         n = len(spans)
         print(f"\ndecoder phase (first msda_fwd .. last msda_bwd), mean of {n}: span {tot_span / n / 1e6:.2f} ms, GPU busy "
               f"{tot_busy / n / 1e6:.2f} ms in {n_k / n:.0f} kernels, of which {tot_small / n / 1e6:.2f} ms in kernels < 20 us")
+        import os
+        if os.environ.get("GRIT_PROFILE_SEQUENCE"):  # the ordered kernel list of ONE decoder phase (what runs after what, how long)
+            a, b = spans[-1]
+            with open(os.environ["GRIT_PROFILE_SEQUENCE"], "w") as fh:
+                for r in win_rows:
+                    s0 = int(r["Start_Timestamp"])
+                    if a <= s0 < b:
+                        fh.write("%9.1f us  +%7.1f  %s\n" % ((s0 - a) / 1e3, (int(r["End_Timestamp"]) - s0) / 1e3, r["Kernel_Name"][:110]))
         inside = collections.defaultdict(lambda: [0, 0])
         for a, b in spans:
             for r in win_rows:

@@ -273,7 +273,8 @@ def test_step_in_segments_around_one_rank_rccl_collectives():
     assert seg["replay_calls"] == seg["eager_calls"], seg
     assert all(np.isfinite(seg["losses"])) and len(seg["losses"]) == len(ref["losses"]) == steps + 2
     for e, r in zip(ref["losses"], seg["losses"]):
-        assert abs(e - r) < 3e-2 * abs(e), (ref["losses"], seg["losses"])
+        # (two batches, 22 Adam steps: the loss falls from 9.5 to ~0.2, where two EAGER runs are ~0.01 apart as well)
+        assert abs(e - r) < 3e-2 * abs(e) + 2e-2, (ref["losses"], seg["losses"])
     assert seg["losses"][-1] < seg["losses"][0] - 0.02
     for n in PICKS:
         moved = float(torch.linalg.norm(ref["masters"][n] - ref["init"][n]))

@@ -489,7 +489,7 @@ def main():
     # region -- is a device-to-device copy of the batch into the graph's input buffers, the optimizers' per-step scalars and one
     # hipGraphLaunch.  What is timed is the same work (forward, backward, gradient buckets, both Adam steps), enqueued differently.
     from grit_amd.engine import graph_step
-    graphed, graph_error = None, None
+    graphed, graph_error, graph_plan = None, None, None
     want_graph = graph_step.ENABLED and not args.fp32 and args.warmup >= 1 and graph_step.supported(wrapped, optimizers)
     eager_warmup = min(2, args.warmup) if want_graph else args.warmup
     for i in range(eager_warmup):
@@ -497,6 +497,7 @@ def main():
     if want_graph:
         try:
             graphed = graph_step.GraphedXEStep(wrapped, optimizers, loss_fn, batches[eager_warmup % len(batches)], eager_steps=0)
+            graph_plan = None if graphed.plan is None else [k for k, _ in graphed.plan]  # (release() below forgets it)
         except Exception as e:  # stay on the eager HIP path and say so in the line (config.step_graph_error)
             graph_error = "%s: %s" % (type(e).__name__, str(e)[:300])
             sys.stderr.write("bench.py: step graph not captured (%s); running eager launches\n" % graph_error)
@@ -774,16 +775,14 @@ def main():
                                           "without a wire, not a multi-GPU number"),
                        "grad_sync": grad_sync if (world > 1 or self_coll) else None, "self_collectives": bool(self_coll),
                        "step_graph": graphed is not None, "step_graph_error": graph_error,
-                       "step_graph_segments": (sum(1 for k, _ in graphed.plan if k == 'graph') if graphed.plan is not None else 1)
-                       if graphed is not None else 0,
-                       "step_enqueue": (("one captured HIP graph replayed per step" if graphed.plan is None else
+                       "step_graph_segments": (graph_plan.count('graph') if graph_plan is not None else 1) if graphed is not None else 0,
+                       "step_enqueue": (("one captured HIP graph replayed per step" if graph_plan is None else
                                          "%d captured graph segments per step, the %d bucket all-reduces issued eagerly between them on the "
-                                         "process group's stream" % (sum(1 for k, _ in graphed.plan if k == 'graph'),
-                                                                     sum(1 for k, _ in graphed.plan if k == 'collective')))
+                                         "process group's stream" % (graph_plan.count('graph'), graph_plan.count('collective')))
                                         + " (grit_amd/engine/graph_step.py); per-launch kernel events come from %d eager steps behind "
                                           "the timed region" % event_steps) if graphed is not None
                        else "eager launches",
-                       "step_forks": bool(graphed is not None and graphed.plan is None and __import__('grit_amd.ops.streams', fromlist=['x']).ENABLED),
+                       "step_forks": bool(graphed is not None and graph_plan is None and __import__('grit_amd.ops.streams', fromlist=['x']).ENABLED),
                        "rccl_env": rccl_env,
                        "points": args.points, "ragged": bool(args.ragged),
                        "msda_backward_accumulation": ("f32" if args.fp32 else ("f32 (" + msda_op.F32_METHOD + ")") if msda_op.F32_ACCUMULATE

@@ -49,6 +49,19 @@ struct TnArgs {
     int M, N, K, S, rows_per_split, tiles_n, tiles_k;
     float* db_partial;        // [S][N] fp32 column sums of dY per slice (the bias gradient), or nullptr
     int dbg;                  // diagnostics of the four-wave kernel (GRIT_WGRAD_TN_DBG): 1 = every workgroup of a slice LOADS tile (0, 0)
+    // Drop path (round 5; four-wave kernel only): per-sample factors of the branch dY is the gradient of.  The rows of a sample with
+    // factor 0 are exact zeros in dY -- they add nothing to dW -- so the 64-row steps inside such samples are not loaded at all and the
+    // S slices share the LIVE steps equally (a slice is then a run of live steps, not a fixed row range).  nullptr / 0: every row.
+    const float* row_scale;
+    int rows_per_sample;      // a multiple of 64; M / rows_per_sample <= 64 samples
+};
+
+// Position of a slice in the LIVE 64-row steps of a problem whose dropped samples are skipped (tn4_body computes it, wave-uniform).
+struct TnRuns {
+    int sps;                      // steps per sample; 0 = no skipping (plain consecutive steps)
+    int run_left;                 // steps left in the current sample, the one being loaded included
+    unsigned long long rest;      // kept samples from the current one on (bit b = sample b)
+    int gap_bytes_y, gap_bytes_x; // bytes of one skipped SAMPLE in dY / X
 };
 
 typedef int v2i __attribute__((ext_vector_type(2)));
@@ -289,7 +302,7 @@ constexpr int k4Lds = 2 * k4Buf + kColBytes;
 
 // CS: 0 no bias by-product; 1 / 2: this wave folds the even / odd dY fragments into column sums (waves wn = 0 / 1 of k-tile 0)
 template <int CS>
-__device__ __forceinline__ void tn4_run(const TnArgs& g, int split, int n0, int k0, int m_begin, int nsteps, char* lds) {
+__device__ __forceinline__ void tn4_run(const TnArgs& g, int split, int n0, int k0, int m_begin, int nsteps, TnRuns runs, char* lds) {
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -317,7 +330,19 @@ __device__ __forceinline__ void tn4_run(const TnArgs& g, int split, int n0, int 
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lptr_t)(lds + buf * k4Buf + k4Op + (wave + 4 * p) * 1024), 16, voffX, p * pieceX + soffX, 0, 0);
     };
     auto advance_load = [&]() {
-        if (lks + 1 < nsteps) { ++lks; soffY += stepY; soffX += stepX; }
+        if (lks + 1 < nsteps) {
+            ++lks;
+            // drop path: leaving the last step of a sample, the next step is the first one of the next KEPT sample (scalar arithmetic,
+            // branch-free: ~10 SALU operations per 128-MFMA step)
+            runs.run_left -= 1;
+            const bool cross = runs.sps != 0 && runs.run_left == 0;
+            const unsigned long long next = runs.rest & (runs.rest - 1ull);
+            const int skipped = cross ? (__builtin_ctzll(next | (1ull << 63)) - __builtin_ctzll(runs.rest | (1ull << 63)) - 1) : 0;
+            runs.rest = cross ? next : runs.rest;
+            runs.run_left = cross ? runs.sps : runs.run_left;
+            soffY += stepY + skipped * runs.gap_bytes_y;
+            soffX += stepX + skipped * runs.gap_bytes_x;
+        }
     };
 
     // ---- fragment addresses (buffer 0): row 4 lg + trq of a 16-row group, 32-byte group (block ^ (row & 7)), 8 bytes at trp;
@@ -471,16 +496,40 @@ __device__ __forceinline__ void tn4_body(const TnArgs& g, int logical, char* lds
     const int tiles = g.tiles_n * g.tiles_k;
     const int split = logical / tiles, tile = logical - split * tiles;
     const int tn = tile / g.tiles_k, tk = tile - tn * g.tiles_k;
-    const int m_begin = split * g.rows_per_split, m_end = min(g.M, m_begin + g.rows_per_split);
-    const int nsteps = (m_end - m_begin) / k4Rows;
+    int m_begin = split * g.rows_per_split;
+    int nsteps = (min(g.M, m_begin + g.rows_per_split) - m_begin) / k4Rows;
+    TnRuns runs = {0, 0, 0ull, 0, 0};
+    if (g.row_scale != nullptr) {
+        // the live 64-row steps of the problem, shared equally by the S slices (all of this is wave-uniform scalar work, once per
+        // workgroup: <= 64 factor loads and a few bit operations)
+        const int samples = g.M / g.rows_per_sample, sps = g.rows_per_sample / k4Rows;
+        unsigned long long keep = 0ull;
+        for (int b = 0; b < samples; ++b) keep |= (unsigned long long)(g.row_scale[b] != 0.f) << b;
+        const int live = __builtin_popcountll(keep) * sps;
+        if (live >= g.S && live < samples * sps) {  // (nothing dropped: the plain slices; fewer live steps than slices: likewise -- zeros add up to zero)
+            const int j0 = (int)((long)split * live / g.S), j1 = (int)((long)(split + 1) * live / g.S);
+            int q = j0 / sps;
+            const int r = j0 - q * sps;
+            unsigned long long rest = keep;
+            for (; q > 0; --q) rest &= rest - 1ull;  // drop the kept samples in front of this slice
+            const int first = __builtin_ctzll(rest);
+            m_begin = first * g.rows_per_sample + r * k4Rows;
+            nsteps = j1 - j0;
+            runs.sps = sps;
+            runs.run_left = sps - r;
+            runs.rest = rest;
+            runs.gap_bytes_y = (int)((long)g.rows_per_sample * g.ldy * 2);
+            runs.gap_bytes_x = (int)((long)g.rows_per_sample * g.ldx * 2);
+        }
+    }
     const bool colsum = g.db_partial != nullptr && tk == 0;  // workgroup-uniform
     // (GRIT_WGRAD_TN_DBG & 2: EVERY workgroup of a problem with a by-product runs its MFMAs, so that all run at one pace; measured
     // equal to k-tile 0 alone, stand-alone and in the step -- profiles/r04/wgrad_tn_notes.txt)
     const bool cs_code = (g.dbg & 2) ? g.db_partial != nullptr : colsum;
     const int mode = cs_code ? 1 + (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) : 0;  // wave-uniform; same barriers on all paths
-    if (mode == 0) tn4_run<0>(g, split, tn * kT, tk * kT, m_begin, nsteps, lds);
-    else if (mode == 1) tn4_run<1>(g, split, tn * kT, tk * kT, m_begin, nsteps, lds);
-    else tn4_run<2>(g, split, tn * kT, tk * kT, m_begin, nsteps, lds);
+    if (mode == 0) tn4_run<0>(g, split, tn * kT, tk * kT, m_begin, nsteps, runs, lds);
+    else if (mode == 1) tn4_run<1>(g, split, tn * kT, tk * kT, m_begin, nsteps, runs, lds);
+    else tn4_run<2>(g, split, tn * kT, tk * kT, m_begin, nsteps, runs, lds);
     if (colsum) {
         __syncthreads();
         const float* colacc = reinterpret_cast<const float*>(lds + 2 * k4Buf);
@@ -522,6 +571,20 @@ bool tn4_fits(const TnArgs& a) {
     return a.M % k4Rows == 0 && a.rows_per_split % k4Rows == 0 && (long)(a.rows_per_split + 8) * a.ldy * 2 < 0x7fffffffL &&
            (long)(a.rows_per_split + 8) * a.ldx * 2 < 0x7fffffffL;
 }
+// GRIT_WGRAD_ROW_SKIP=0: never skip the rows of dropped samples (A/B switch; the slices are then fixed row ranges as before)
+bool tn_row_skip_enabled() {
+    static const bool on = [] { const char* e = getenv("GRIT_WGRAD_ROW_SKIP"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// the factors are used only where the four-wave kernel's skipping applies: whole 64-row steps per sample, <= 64 samples, and a slice
+// (which may now span the whole map) addressable with 32-bit byte offsets; anywhere else every row is processed (equally correct)
+void tn_set_rows(TnArgs& a, const float* row_scale, int rows_per_sample) {
+    a.row_scale = nullptr; a.rows_per_sample = 0;
+    if (!row_scale || rows_per_sample <= 0 || !tn_row_skip_enabled() || !tn4_enabled()) return;
+    if (rows_per_sample % k4Rows || a.M % rows_per_sample || a.M / rows_per_sample > 64 || a.M / rows_per_sample < 2) return;
+    if ((long)(a.M + 8) * a.ldy * 2 >= 0x7fffffffL || (long)(a.M + 8) * a.ldx * 2 >= 0x7fffffffL) return;
+    a.row_scale = row_scale; a.rows_per_sample = rows_per_sample;
+}
 
 bool tn_shape_ok(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && N % kT == 0 && K % kT == 0 && M % kBK == 0; }
 
@@ -532,6 +595,7 @@ bool tn_fill(TnArgs& a, const void* dY, long ldy, const void* X, long ldx, int M
              float* db_partial = nullptr) {
     a.db_partial = db_partial;
     a.dbg = tn4_dbg();
+    a.row_scale = nullptr; a.rows_per_sample = 0;
     if (!dY || !X || !partial || splits <= 0 || !tn_shape_ok(M, N, K)) return false;
     if (ldy % 8 || ldx % 8 || ldy < N || ldx < K || ((uintptr_t)dY % 16) || ((uintptr_t)X % 16) || ((uintptr_t)partial % 16)) return false;
     const int gr = tn_granule(M), steps = M / gr;
@@ -558,8 +622,8 @@ extern "C" int grit_wgrad_tn_splits(int M, int N, int K) {
     return (M + rows - 1) / rows;
 }
 
-extern "C" int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial,
-                             float* db_partial, void* stream) {
+static int wgrad_tn_launch(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial,
+                           float* db_partial, const float* row_scale, int rows_per_sample, void* stream) {
     if (!dY || !X || !partial || M <= 0 || N <= 0 || K <= 0 || splits <= 0) return GRIT_ERR_BAD_ARG;
     if (N % kT || K % kT || M % kBK || ldy % 8 || ldx % 8 || ldy < N || ldx < K || ((uintptr_t)dY % 16) || ((uintptr_t)X % 16) ||
         ((uintptr_t)partial % 16))
@@ -573,7 +637,9 @@ extern "C" int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, 
     const int gr = tn_granule(M), steps = M / gr;
     a.rows_per_split = ((steps + splits - 1) / splits) * gr;
     a.tiles_n = N / kT; a.tiles_k = K / kT;
+    a.row_scale = nullptr; a.rows_per_sample = 0;
     if (tn4_enabled() && tn4_fits(a)) {
+        tn_set_rows(a, row_scale, rows_per_sample);
         static bool attr4_set = false;
         if (!attr4_set) {
             if (hipFuncSetAttribute((const void*)wgrad_tn4_256, hipFuncAttributeMaxDynamicSharedMemorySize, k4Lds) != hipSuccess)
@@ -594,6 +660,17 @@ extern "C" int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, 
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 
+extern "C" int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial,
+                             float* db_partial, void* stream) {
+    return wgrad_tn_launch(dY, ldy, X, ldx, M, N, K, splits, partial, db_partial, nullptr, 0, stream);
+}
+
+extern "C" int grit_wgrad_tn_rows(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial,
+                                  float* db_partial, const float* row_scale, int rows_per_sample, void* stream) {
+    if (row_scale && rows_per_sample <= 0) return GRIT_ERR_BAD_ARG;
+    return wgrad_tn_launch(dY, ldy, X, ldx, M, N, K, splits, partial, db_partial, row_scale, rows_per_sample, stream);
+}
+
 extern "C" int grit_wgrad_tn_group_ok(int M, int N, int K) { return tn_shape_ok(M, N, K) ? 1 : 0; }
 
 extern "C" int grit_wgrad_tn_grouped(const grit_wgrad_job* jobs, int n_jobs, void* stream) {
@@ -612,6 +689,8 @@ extern "C" int grit_wgrad_tn_grouped(const grit_wgrad_job* jobs, int n_jobs, voi
     a.first_block[n_jobs] = (unsigned)total;
     bool four = tn4_enabled();
     for (int j = 0; j < n_jobs && four; ++j) four = tn4_fits(a.job[j]);
+    if (four)
+        for (int j = 0; j < n_jobs; ++j) tn_set_rows(a.job[j], jobs[j].row_scale, jobs[j].rows_per_sample);
     if (four) {
         static bool attr4_set = false;
         if (!attr4_set) {

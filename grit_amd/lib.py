@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -36,6 +36,7 @@ SIGNATURES = {
     "grit_transpose_bf16_grouped": [_ptr, _int, _ptr],
     "grit_wgrad_tn_splits": [_int] * 3,
     "grit_wgrad_tn": [_ptr, _c.c_long, _ptr, _c.c_long] + [_int] * 4 + [_ptr, _ptr, _ptr],
+    "grit_wgrad_tn_rows": [_ptr, _c.c_long, _ptr, _c.c_long] + [_int] * 4 + [_ptr, _ptr, _ptr, _int, _ptr],
     "grit_msda_bwd_sorted_supported": [_int] * 6,
     "grit_msda_bwd_bf16_sorted": [_ptr, _c.c_long] + [_ptr] * 5 + [_int] * 7 + [_ptr] * 4,
     "grit_winattn_fwd_bf16": [_ptr] * 4 + [_int] * 8 + [_f32, _ptr, _ptr, _ptr],
@@ -100,7 +101,8 @@ class SlabJob(_c.Structure):
 class WgradJob(_c.Structure):
     """grit_wgrad_job of include/grit_hip.h."""
     _fields_ = [("dY", _c.c_void_p), ("ldy", _c.c_long), ("X", _c.c_void_p), ("ldx", _c.c_long), ("M", _c.c_int), ("N", _c.c_int),
-                ("K", _c.c_int), ("splits", _c.c_int), ("dW_partial", _c.c_void_p), ("db_partial", _c.c_void_p)]
+                ("K", _c.c_int), ("splits", _c.c_int), ("dW_partial", _c.c_void_p), ("db_partial", _c.c_void_p),
+                ("row_scale", _c.c_void_p), ("rows_per_sample", _c.c_int)]
 
 
 class ColsumJob(_c.Structure):

@@ -158,9 +158,11 @@ class WindowAttention(nn.Module):
             return torch.zeros(3 * self.dim, dtype=dtype, device=self.qkv.weight.device)
         return self.qkv.bias.to(dtype)
 
-    def attend_heads(self, x, H, W, shift):
-        """x: normalised tokens [B, H*W, C] in map order -> concatenated head outputs [B, H*W, C] (before proj)."""
-        qkv = self.qkv(x)
+    def attend_heads(self, x, H, W, shift, row_scale=None):
+        """x: normalised tokens [B, H*W, C] in map order -> concatenated head outputs [B, H*W, C] (before proj).
+        row_scale: (drop-path factors [B], rows per sample) of the attention branch, when the caller multiplies the branch by them: the
+        gradient that comes back to qkv is then zero in the rows of dropped samples and its weight gradient skips them."""
+        qkv = self.qkv(x, row_scale=row_scale) if row_scale is not None else self.qkv(x)
         return window_attention(qkv, self.relative_position_bias(), self.pad_qkv(qkv.dtype), H, W, self.num_heads,
                                 self.window_size[0], shift, self.scale)
 
@@ -214,7 +216,9 @@ class SwinTransformerBlock(nn.Module):
         if self.attn.proj_drop.p == 0. and self.mlp.drop.p == 0.:
             # output projection + residual + following LayerNorm as one node (the norm's backward kernel then also
             # yields the projection's bias gradient): attn.proj -> norm2, mlp.fc2 -> the next block's norm1
-            x, n2 = self._residual_linear_norm(x, self.attn.attend_heads(n1, H, W, self.shift_size), self.attn.proj, self.norm2)
+            scale_a = self._drop_path_scale(x, torch.float32)  # (drawn BEFORE the attention runs: its qkv Linear is told about it)
+            heads = self.attn.attend_heads(n1, H, W, self.shift_size, row_scale=None if scale_a is None else (scale_a, L))
+            x, n2 = self._residual_linear_norm(x, heads, self.attn.proj, self.norm2, scale=scale_a, drawn=True)
             if next_norm is None:
                 return self._residual(x, self.mlp.run(n2))
             # fc1 + GELU + fc2 + drop-path + residual + the next block's norm1 as one node (fused-epilogue GEMMs)

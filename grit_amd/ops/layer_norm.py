@@ -264,7 +264,9 @@ class _LinearAddLayerNormFn(Function):
         if not inp2.is_contiguous():
             inp2 = inp2.contiguous()
         d_inp = d_lin_w = None
-        deferred = defer_weight_bias_grad(d_branch, inp2, lin_w, None, ctx.needs_input_grad[1], False, ctx.single_use)
+        # drop path: d_branch = scale[b] * dx is exactly zero in the rows of dropped samples -- the projection's weight gradient skips them
+        rs = (scale, d_branch.shape[0] // ctx.shape[0]) if (scale is not None and ctx.drop_p == 0) else None
+        deferred = defer_weight_bias_grad(d_branch, inp2, lin_w, None, ctx.needs_input_grad[1], False, ctx.single_use, row_scale=rs)
         if deferred is not None:  # short map: the projection's weight gradient joins the scope's grouped launch
             esz = sums.element_size() * sums.shape[-1]
             if not (ctx.sum_params is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[5] and ctx.needs_input_grad[6]
@@ -292,7 +294,7 @@ class _LinearAddLayerNormFn(Function):
                 with timed("gemm_lib", **gemm_work(d_branch.shape[0], lin_w.shape[1], lin_w.shape[0])):
                     d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
         if d_lin_w is None:
-            d_lin_w = weight_grad(d_branch, inp2, group, param=lin_w) if ctx.needs_input_grad[1] else None
+            d_lin_w = weight_grad(d_branch, inp2, group, param=lin_w, row_scale=rs) if ctx.needs_input_grad[1] else None
             sp = ctx.sum_params
             # long maps: the node's reductions (weight-gradient partials, LayerNorm / bias sums) join the scope's grouped launch
             finish_group(group, side is None and sp is not None and sums.dtype == lin_w.dtype and ctx.needs_input_grad[2]

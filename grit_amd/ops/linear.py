@@ -106,7 +106,7 @@ def park_weight_grad_for_partner(first, partner):
     partner.weight._grit_wgrad_pickup = True
 
 
-def defer_weight_bias_grad(dy2, x2, weight, bias, need_dw, need_db, single_use):
+def defer_weight_bias_grad(dy2, x2, weight, bias, need_dw, need_db, single_use, row_scale=None):
     """(dW, db) as empty tensors that flush_deferred() will fill, or None when the job must be done by the node itself."""
     if not (WGRAD_DEFER and single_use and need_dw and _deferral["active"] and dy2.is_cuda and dy2.dtype == torch.bfloat16
             and x2.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.grad is None
@@ -132,7 +132,7 @@ def defer_weight_bias_grad(dy2, x2, weight, bias, need_dw, need_db, single_use):
     db = torch.empty((N,), dtype=torch.bfloat16, device=dy2.device) if need_db else None
     # no reference to dw / db is kept (autograd only adopts a gradient tensor nobody else holds): addresses only
     _deferral["parked" if park else "jobs"].append((dy2, x2, weight, bias if need_db else None, dw.data_ptr(),
-                                                    db.data_ptr() if need_db else 0, M, N, K))
+                                                    db.data_ptr() if need_db else 0, M, N, K, row_scale))
     return dw, db
 
 
@@ -219,7 +219,7 @@ def flush_deferred(final=False):
     lib = _lib.load()
     dev = jobs[0][0].device
     _streams.keep_for_current_stream([t for j in jobs for t in (j[0], j[1])])  # operands produced on forked streams of a captured step
-    for dy2, x2, w, b, pw, pb, M, N, K in jobs:
+    for dy2, x2, w, b, pw, pb, M, N, K, _rs in jobs:
         _verify(w, pw, "weight gradient [%d, %d]" % (N, K), final)
         if b is not None:
             _verify(b, pb, "bias gradient [%d]" % N, final)
@@ -249,7 +249,7 @@ def flush_deferred(final=False):
                 slabs = splits
             sizes, total = [], 0
             for job, S, sl in zip(chunk, splits, slabs):
-                dy2, x2, w, b, pw, pb, M, N, K = job
+                dy2, x2, w, b, pw, pb, M, N, K, _rs = job
                 sizes.append((S, sl, total, total + S * N * K))
                 total += S * N * K + (sl * N if b is not None else 0)
             work = torch.empty(total, dtype=torch.float32, device=dev)
@@ -259,10 +259,10 @@ def flush_deferred(final=False):
             nc = 0
             group = SlabGroup()
             for t, (job, (S, sl, woff, boff)) in enumerate(zip(chunk, sizes)):
-                dy2, x2, w, b, pw, pb, M, N, K = job
+                dy2, x2, w, b, pw, pb, M, N, K, rs = job
                 bias_here = (base + 4 * boff) if b is not None else None
                 table[t] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, base + 4 * woff,
-                                         None if (kind == "tn" and not WGRAD_TN_BIAS) else bias_here)
+                                         None if (kind == "tn" and not WGRAD_TN_BIAS) else bias_here, *_rows_arg(rs, M))
                 if kind == "tn" and b is not None and not WGRAD_TN_BIAS:
                     ctable[nc] = _lib.ColsumJob(dy2.data_ptr(), dy2.stride(0), M, N, sl, bias_here)
                     nc += 1
@@ -549,7 +549,23 @@ WGRAD_TN_GROUPED = os.environ.get("GRIT_WGRAD_TN_GROUPED", "1") != "0"
 WGRAD_TN_BIAS = os.environ.get("GRIT_WGRAD_TN_BIAS", "1") != "0"
 
 
-def long_weight_grad_partials(dy2, x2, need_db=False):
+# GRIT_WGRAD_ROW_SKIP (default 1): the long-map weight gradients do not load the rows of samples that drop path removed from the branch
+# (exact zeros in dY); the row slices share the live rows equally (grit_wgrad_tn_rows, wgrad_tn.hip).  Also read by the library itself.
+WGRAD_ROW_SKIP = os.environ.get("GRIT_WGRAD_ROW_SKIP", "1") != "0"
+
+
+def _rows_arg(row_scale, M):
+    """(pointer or None, rows per sample) of a (factors, rows_per_sample) pair for an M-row problem; (None, 0) when it does not apply."""
+    if not WGRAD_ROW_SKIP or row_scale is None:
+        return None, 0
+    scale, per = row_scale
+    if (scale is None or per <= 0 or not scale.is_cuda or scale.dtype != torch.float32 or not scale.is_contiguous()
+            or scale.numel() * per != M):
+        return None, 0
+    return scale.data_ptr(), int(per)
+
+
+def long_weight_grad_partials(dy2, x2, need_db=False, row_scale=None):
     """fp32 partials [S, N, K] of dW = dy2^T x2 from the own kernel, or None where it does not apply (the library path runs).
     need_db: returns (partials, [S, N] fp32 column sums of dy2 per slice) -- the bias gradient as a by-product of the same launch."""
     if not (WGRAD_TN and dy2.is_cuda and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16):
@@ -565,10 +581,11 @@ def long_weight_grad_partials(dy2, x2, need_db=False):
     part = torch.empty((S, N, K), dtype=torch.float32, device=dy2.device)
     bpart = torch.empty((S, N), dtype=torch.float32, device=dy2.device) if need_db else None
     with _lib.device_guard(dy2.device), timed("gemm_own", flops=2.0 * M * N * K, kernel="wgrad_tn", bytes=2.0 * M * (N + K) + 4.0 * S * N * K):
-        st = lib.grit_wgrad_tn(ctypes.c_void_p(dy2.data_ptr()), dy2.stride(0), ctypes.c_void_p(x2.data_ptr()), x2.stride(0), M, N, K, S,
-                               ctypes.c_void_p(part.data_ptr()), ctypes.c_void_p(bpart.data_ptr()) if need_db else None,
-                               _lib.current_stream_ptr())
-    _lib.check(st, "grit_wgrad_tn")
+        rs, per = _rows_arg(row_scale, M)
+        st = lib.grit_wgrad_tn_rows(ctypes.c_void_p(dy2.data_ptr()), dy2.stride(0), ctypes.c_void_p(x2.data_ptr()), x2.stride(0), M, N, K, S,
+                                    ctypes.c_void_p(part.data_ptr()), ctypes.c_void_p(bpart.data_ptr()) if need_db else None,
+                                    ctypes.c_void_p(rs) if rs else None, per, _lib.current_stream_ptr())
+    _lib.check(st, "grit_wgrad_tn_rows")
     return (part, bpart) if need_db else part
 
 
@@ -585,7 +602,7 @@ def tn_slices(M, want):
     return -(-steps // per)
 
 
-def long_weight_grad_with_parked(dy2, x2, group, weight):
+def long_weight_grad_with_parked(dy2, x2, group, weight, row_scale=None):
     """(partials [S, N, K], bias column sums [S, N]) of this node's long-map Linear like long_weight_grad_partials(.., True), from a
     grouped launch that also computes the parked weight gradients (park_weight_grad_for_partner); their slice sums join `group`.
     None when nothing is parked or it does not apply (the parked jobs then stay for the scope's flush)."""
@@ -609,13 +626,15 @@ def long_weight_grad_with_parked(dy2, x2, group, weight):
     part = torch.empty((S, N, K), dtype=torch.float32, device=dy2.device)
     bpart = torch.empty((S, N), dtype=torch.float32, device=dy2.device)
     table = (_lib.WgradJob * (len(parked) + 1))()
-    table[0] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, part.data_ptr(), bpart.data_ptr())
+    table[0] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, part.data_ptr(), bpart.data_ptr(),
+                             *_rows_arg(row_scale, M))
     flops = 2.0 * M * N * K
     nbytes = 2.0 * M * (N + K) + 4.0 * S * N * K
-    for t, (pdy, px, pw_param, _, pw, _, pM, pN, pK) in enumerate(parked):
+    for t, (pdy, px, pw_param, _, pw, _, pM, pN, pK, prs) in enumerate(parked):
         pS = tn_slices(pM, want)
         work = torch.empty(pS * pN * pK, dtype=torch.float32, device=dy2.device)
-        table[t + 1] = _lib.WgradJob(pdy.data_ptr(), pdy.stride(0), px.data_ptr(), px.stride(0), pM, pN, pK, pS, work.data_ptr(), None)
+        table[t + 1] = _lib.WgradJob(pdy.data_ptr(), pdy.stride(0), px.data_ptr(), px.stride(0), pM, pN, pK, pS, work.data_ptr(), None,
+                                     *_rows_arg(prs, pM))
         group.add_raw(work, 1, 0, pS, pN * pK, pw, True)
         _deferral["unverified"].append((pw_param, pw, "parked weight gradient [%d, %d]" % (pN, pK)))
         flops += 2.0 * pM * pN * pK
@@ -626,7 +645,7 @@ def long_weight_grad_with_parked(dy2, x2, group, weight):
     return part, bpart
 
 
-def long_weight_grads_together(pairs):
+def long_weight_grads_together(pairs, row_scale=None):
     """[fp32 partials [S_j, N_j, K_j]] of dW_j = dy_j^T x_j for several long-map problems of ONE backward node from one grouped launch
     of the long-map kernel -- together their tiles fill the chip with fewer row slices each (fc1 + fc2 of a Swin Mlp: 16 + 16 tiles,
     8 slices of 200 steps instead of 16 of 100: half the fp32 slices to write and to sum).  None when it does not apply."""
@@ -654,7 +673,8 @@ def long_weight_grads_together(pairs):
         S = tn_slices(M, want)
         part = torch.empty((S, N, K), dtype=torch.float32, device=dy2.device)
         parts.append(part)
-        table[t] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, part.data_ptr(), None)
+        table[t] = _lib.WgradJob(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, S, part.data_ptr(), None,
+                                 *_rows_arg(row_scale, M))
     with _lib.device_guard(pairs[0][0].device), timed("gemm_own", flops=2.0 * sum(d.shape[0] * d.shape[1] * x.shape[1] for d, x in pairs), kernel="wgrad_tn",
                                                       bytes=sum(2.0 * d.shape[0] * (d.shape[1] + x.shape[1]) + 4.0 * p.numel() for (d, x), p in zip(pairs, parts))):
         st = lib.grit_wgrad_tn_grouped(table, len(pairs), _lib.current_stream_ptr())
@@ -662,7 +682,7 @@ def long_weight_grads_together(pairs):
     return parts
 
 
-def weight_grad(dy2, x2, group=None, param=None):
+def weight_grad(dy2, x2, group=None, param=None, row_scale=None):
     """dW [N, K] = dy2^T [N, M] @ x2 [M, K], split over M into one batched GEMM with fp32 partial sums.  With `group` (a
     SlabGroup) the sum over the partials is left to the group's launch.  param: the weight this is the gradient of -- inside a
     gradient-bucket scope the sum is then written straight into the parameter's bucket slot (grad_slot)."""
@@ -670,7 +690,7 @@ def weight_grad(dy2, x2, group=None, param=None):
     if small is not None:
         return small[0]
     M, N = dy2.shape
-    own = long_weight_grad_partials(dy2, x2)
+    own = long_weight_grad_partials(dy2, x2, row_scale=row_scale)
     if own is not None:
         slot = grad_slot(param, dy2.dtype, dy2.device)
         out = None if slot is None else slot.view(1, N, x2.shape[1])
@@ -687,18 +707,18 @@ def weight_grad(dy2, x2, group=None, param=None):
     return slab_sum(part.unsqueeze(0), dy2.dtype)[0]
 
 
-def weight_bias_grad(dy2, x2, group, need_w, need_b, weight):
+def weight_bias_grad(dy2, x2, group, need_w, need_b, weight, row_scale=None):
     """(dW, db) of a Linear from dy2 [M, N], x2 [M, K]; either may be None when not wanted.  Long maps with both wanted: ONE launch of
     the own kernel yields the weight-gradient slices and, as a by-product, the bias gradient's column sums (no pass over dy2 of its
     own); otherwise weight_grad / column_sum.  group: the node's SlabGroup (the sums are left to its launch)."""
-    pair = long_weight_grad_with_parked(dy2, x2, group, weight) if (need_w and need_b) else None
+    pair = long_weight_grad_with_parked(dy2, x2, group, weight, row_scale) if (need_w and need_b) else None
     if pair is None:
-        pair = long_weight_grad_partials(dy2, x2, True) if (WGRAD_TN_BIAS and need_w and need_b and group is not None) else None
+        pair = long_weight_grad_partials(dy2, x2, True, row_scale) if (WGRAD_TN_BIAS and need_w and need_b and group is not None) else None
     if pair is not None:
         slot = grad_slot(weight, dy2.dtype, dy2.device)
         dw = group.add(pair[0].unsqueeze(0), dy2.dtype, out=None if slot is None else slot.view(1, dy2.shape[1], x2.shape[1]))[0]
         return dw, group.add(pair[1].unsqueeze(0), weight.dtype)[0]
-    dw = weight_grad(dy2, x2, group, param=weight) if need_w else None
+    dw = weight_grad(dy2, x2, group, param=weight, row_scale=row_scale) if need_w else None
     db = column_sum(dy2 if dy2.is_contiguous() else dy2.contiguous(), weight.dtype, group) if need_b else None
     return dw, db
 
@@ -724,10 +744,13 @@ def _own_input_grad(dy2, weight, shape):
 class _LinearFn(Function):
 
     @staticmethod
-    def forward(ctx, x, weight, bias, single_use=False):
+    def forward(ctx, x, weight, bias, single_use=False, row_scale=None):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.single_use = single_use
+        # drop path: (per-sample factors [B] f32, rows per sample) of the branch this Linear feeds -- the caller's promise that the rows
+        # of a sample with factor 0 come back as exact zeros in dy (wgrad_tn.hip then skips them in the weight gradient)
+        ctx.row_scale = row_scale
         ctx.bias_param = bias if single_use else None  # the parameter itself: the deferred path checks its .grad
         ctx.weight_param = weight if single_use else None
         ctx.weight_obj = weight  # the tensor object the forward was called with: transposed copies are attached to IT
@@ -755,7 +778,7 @@ class _LinearFn(Function):
             if ctx.needs_input_grad[0]:
                 with timed("gemm_lib", **gemm_work(dy2.shape[0], weight.shape[1], weight.shape[0])):
                     dx = torch.mm(dy2, weight).view(x.shape)
-            return dx, dw, db, None
+            return dx, dw, db, None, None
         side = fork(dy2, x2, rows=dy2.shape[0], single_use=ctx.single_use) \
             if (ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or need_b)) else None
         group = SlabGroup() if dy2.is_cuda else None  # dW's and db's partial sums: one reduction launch
@@ -764,7 +787,7 @@ class _LinearFn(Function):
             if both is not None:  # short map: dW and db partials from one launch
                 dw, db = both
             else:
-                dw, db = weight_bias_grad(dy2, x2, group, ctx.needs_input_grad[1], need_b, weight)
+                dw, db = weight_bias_grad(dy2, x2, group, ctx.needs_input_grad[1], need_b, weight, row_scale=ctx.row_scale)
             if side is None:
                 finish_group(group, ctx.single_use, [(ctx.weight_param, dw), (ctx.bias_param, db)])
             elif group is not None:
@@ -775,7 +798,7 @@ class _LinearFn(Function):
                 with timed("gemm_lib", **gemm_work(dy2.shape[0], weight.shape[1], weight.shape[0])):
                     dx = torch.mm(dy2, weight).view(x.shape)
         join(side, dw, db)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class _SharedInputLinearsFn(Function):
@@ -832,9 +855,11 @@ def shared_input_linears(x, linears):
     return list(_SharedInputLinearsFn.apply(x, len(linears), *[lin.weight for lin in linears], *[lin.bias for lin in linears]))
 
 
-def linear(x, weight, bias, single_use=False):
+def linear(x, weight, bias, single_use=False, row_scale=None):
     """F.linear with the backward of this module.  single_use=True: the caller guarantees `weight` / `bias` receive exactly one
-    gradient per backward pass (not shared between call sites), which lets small maps compute them beside the chain (fork)."""
+    gradient per backward pass (not shared between call sites), which lets small maps compute them beside the chain (fork).
+    row_scale = (factors [B] float32 on the device, rows per sample) or None: drop-path factors of the branch the result feeds; the caller
+    guarantees that the gradient of the result is exactly zero in the rows of samples whose factor is 0 (the weight gradient skips them)."""
     fits = (backend.override() is None and x.is_cuda and torch.is_grad_enabled()
             and not torch.is_autocast_enabled()
             and (x.requires_grad or weight.requires_grad) and x.dtype == weight.dtype
@@ -847,7 +872,7 @@ def linear(x, weight, bias, single_use=False):
             if own is not None:
                 return own
         return F.linear(x, weight, bias)
-    return _LinearFn.apply(x, weight, bias, single_use_now(single_use))
+    return _LinearFn.apply(x, weight, bias, single_use_now(single_use), row_scale)
 
 
 class Linear(nn.Linear):
@@ -855,5 +880,5 @@ class Linear(nn.Linear):
 
     single_use = False
 
-    def forward(self, input):
-        return linear(input, self.weight, self.bias, self.single_use)
+    def forward(self, input, row_scale=None):
+        return linear(input, self.weight, self.bias, self.single_use, row_scale)

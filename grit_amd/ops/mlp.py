@@ -50,14 +50,15 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=No
         group = None
     # params = (fc1.weight, fc2.weight) as Parameters when the module is declared single-use: inside a gradient-bucket scope the two
     # weight gradients then join the scope's grouped launch (ops.linear.defer_weight_bias_grad) instead of running here
-    dfr2 = defer_weight_bias_grad(d_branch, act, params[1], None, need_w2, False, True) if (params is not None and side is None) else None
+    rs = (row_scale, rows_per_sample) if (row_scale is not None and rows_per_sample > 0) else None  # (the weight gradients skip dropped samples)
+    dfr2 = defer_weight_bias_grad(d_branch, act, params[1], None, need_w2, False, True, row_scale=rs) if (params is not None and side is None) else None
     # both weight gradients of the node in one grouped launch (after d_pre exists): see linear.long_weight_grads_together
     together = dfr2 is None and side is None and group is not None and need_w2 and need_w1 and chain
     with on_stream(side):
         if dfr2 is not None:
             d_w2 = dfr2[0]
         elif need_w2 and not together:
-            d_w2 = weight_grad(d_branch, act, group, param=w2)
+            d_w2 = weight_grad(d_branch, act, group, param=w2, row_scale=rs)
         if need_b2:
             d_b2 = column_sum(d_branch, w2.dtype, group)
     if chain:
@@ -71,8 +72,8 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=No
         with on_stream(side):
             if need_b1:
                 d_b1 = (group.add(partial.unsqueeze(0), w1.dtype) if group is not None else slab_sum(partial.unsqueeze(0), w1.dtype))[0]
-            dfr1 = defer_weight_bias_grad(d_pre, n2, params[0], None, need_w1, False, True) if (params is not None and side is None) else None
-            parts = long_weight_grads_together([(d_branch, act), (d_pre, n2)]) if (together and dfr1 is None) else None
+            dfr1 = defer_weight_bias_grad(d_pre, n2, params[0], None, need_w1, False, True, row_scale=rs) if (params is not None and side is None) else None
+            parts = long_weight_grads_together([(d_branch, act), (d_pre, n2)], row_scale=rs) if (together and dfr1 is None) else None
             if parts is not None:
                 outs = []
                 for part, (wt, dyt, xt) in zip(parts, ((w2, d_branch, act), (w1, d_pre, n2))):
@@ -82,11 +83,11 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=No
                 d_w2, d_w1 = outs
             else:
                 if together:
-                    d_w2 = weight_grad(d_branch, act, group, param=w2)
+                    d_w2 = weight_grad(d_branch, act, group, param=w2, row_scale=rs)
                 if dfr1 is not None:
                     d_w1 = dfr1[0]
                 elif need_w1:
-                    d_w1 = weight_grad(d_pre, n2, group, param=w1)
+                    d_w1 = weight_grad(d_pre, n2, group, param=w1, row_scale=rs)
         if need_x:
             d_n2 = G.long_input_grad(d_pre, params[0] if params is not None else w1)  # NT on fc1.weight^T (own kernel / library NT)
             if d_n2 is None:

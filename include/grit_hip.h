@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 37
+#define GRIT_ABI_VERSION 38
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -381,6 +381,10 @@ typedef struct grit_wgrad_job {
     int M, N, K, splits;
     float* dW_partial;
     float* db_partial;
+    /* grit_wgrad_tn_grouped only (grit_wgrad_small_grouped ignores them): per-sample factors of the branch whose gradient dY is -- see
+     * grit_wgrad_tn_rows.  NULL / 0: every row is processed. */
+    const float* row_scale;
+    int rows_per_sample;
 } grit_wgrad_job;
 int grit_wgrad_group_splits(int M);
 int grit_wgrad_small_grouped(const grit_wgrad_job* jobs, int n_jobs, void* stream);
@@ -427,6 +431,14 @@ int grit_transpose_bf16_grouped(const grit_transpose_job* jobs, int n_jobs, void
 int grit_wgrad_tn_splits(int M, int N, int K);
 int grit_wgrad_tn(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial,
                   float* db_partial, void* stream);
+/* The same with the drop-path factors of the branch whose gradient dY is (reference timm DropPath, models/common/swin_model.py:289-298:
+ * per-sample keep w.p. 1 - p): row_scale[b] == 0 promises that rows [b * rows_per_sample, (b + 1) * rows_per_sample) of dY are exact
+ * zeros.  Those rows add nothing to dW, so their 64-row steps are never loaded and the S slices share the LIVE steps equally (a slice is
+ * a run of live steps instead of a fixed row range: the slice partials differ from grit_wgrad_tn's, their sum only by fp32 summation
+ * order).  Applies on the four-wave kernel when rows_per_sample % 64 == 0 and M / rows_per_sample is 2..64; otherwise -- and with
+ * GRIT_WGRAD_ROW_SKIP=0 -- every row is processed, which is equally correct.  X may hold anything in skipped rows (never read). */
+int grit_wgrad_tn_rows(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, int splits, float* partial,
+                       float* db_partial, const float* row_scale, int rows_per_sample, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Adam step on one flat range of the fp32-master / bf16-compute training state (torch.optim.Adam as configured by the

@@ -35,6 +35,7 @@ def _worker(rank, port, mode, cut_regions, pin_variant, n_images, ret):
     """mode: 'skip' (bf16, default paths), 'noskip' (bf16, GRIT_GEMM_ROW_SKIP=0), 'fp32' (fp32 weights and kernels)."""
     if mode == 'noskip':
         os.environ["GRIT_GEMM_ROW_SKIP"] = "0"  # read when grit_amd.ops.gemm is imported: this is a fresh process
+        os.environ["GRIT_WGRAD_ROW_SKIP"] = "0"  # ... and by libgrit_hip.so / grit_amd.ops.linear: the weight gradients load every row
     if pin_variant:
         os.environ["GRIT_GEMM_VARIANT"] = "4"
     from grit_amd.amp import Bf16Compute
@@ -105,7 +106,20 @@ def test_skipped_tiles_change_no_bit_of_the_loss_or_of_any_gradient():
     noskip = _run('noskip', True, True, B)
     assert skip["finite"] and noskip["finite"] and skip["dropped_mlp"] >= 20
     assert skip["loss"] == noskip["loss"]
-    for n in DETERMINISTIC + BACKBONE_PICKS:  # (the detection module's own parameters still sit behind its MSDeformAttn backward)
+    for n in DETERMINISTIC:
         assert torch.equal(skip["grads"][n], noskip["grads"][n]), n
-    for n in BACKBONE_PICKS:
-        assert float(skip["grads"][n].abs().max()) > 0, n
+    exact = 0
+    for n in BACKBONE_PICKS:  # (the detection module's own parameters still sit behind its MSDeformAttn backward)
+        a, b = skip["grads"][n], noskip["grads"][n]
+        assert float(a.abs().max()) > 0, n
+        if 'norm' in n:  # LayerNorm sums: untouched by any skip path -- bit for bit
+            assert torch.equal(a, b), n
+            exact += 1
+            continue
+        # Weight (and, as the kernel's by-product, bias) gradients of the long maps: the skipped GEMM tiles change no bit of their
+        # operands, but the weight-gradient kernel shares the LIVE rows among its slices (grit_wgrad_tn_rows), so the fp32 slice sums are
+        # taken in another order: equal up to that -- a bf16 ulp on a few elements (measured below), nowhere near a missing sample
+        diff = (a - b).abs()
+        assert float(torch.linalg.norm(a - b)) <= 2e-3 * float(torch.linalg.norm(b)), n
+        assert float((diff > 0).float().mean()) < 0.2 and float(diff.max()) <= 2.0 ** -7 * float(b.abs().max()), n
+    assert exact >= 1

@@ -460,3 +460,58 @@ def test_grouped_long_kernel_and_grouped_column_sums():
     table[2] = _lib.WgradJob(keep[2][0].data_ptr(), keep[2][0].stride(0), keep[2][1].data_ptr(), keep[2][1].stride(0), 640, 512, 2048, 21,
                              keep[2][2].data_ptr(), None)
     assert lib.grit_wgrad_tn_grouped(table, len(problems), _lib.current_stream_ptr()) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,per,N,K,drop", [(32, 1600, 512, 2048, (0, 3, 4, 17, 31)), (32, 1600, 2048, 512, (5,)), (8, 6400, 256, 1024, (1, 2, 6)),
+                                            (32, 1600, 512, 512, tuple(range(1, 32))), (32, 1600, 512, 512, ()), (16, 400, 1024, 1024, (2, 9))])
+def test_weight_gradient_skips_the_rows_of_dropped_samples(B, per, N, K, drop):
+    """grit_wgrad_tn_rows / the row_scale fields of grit_wgrad_tn_grouped (round 5): with the drop-path factors of the branch at hand the
+    64-row steps inside dropped samples (exact zero rows of dY) are never loaded -- NaNs planted in X there are not seen -- and the slices
+    share the live steps: the SUM of the slice partials equals the plain kernel's up to fp32 summation order, the bias by-product too.
+    Nothing dropped: the very same slices, bit for bit.  rows_per_sample % 64 != 0 (stage 3: 400 rows): every row is processed."""
+    import ctypes
+    from grit_amd import lib as _lib
+    lib = _lib.load()
+    M = B * per
+    g = torch.Generator(device=DEV).manual_seed(B + N + len(drop))
+    dy = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    scale = torch.full((B,), 1.25, device=DEV)
+    for b in drop:
+        scale[b] = 0.0
+        dy[b * per:(b + 1) * per] = 0
+    skipping = per % 64 == 0
+    x_nan = x.clone()
+    if skipping and 0 < len(drop) and (B - len(drop)) * (per // 64) >= lib.grit_wgrad_tn_splits(M, N, K):
+        for b in drop:
+            x_nan[b * per:(b + 1) * per] = float("nan")
+    S = lib.grit_wgrad_tn_splits(M, N, K)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    plain = torch.empty((S, N, K), dtype=torch.float32, device=DEV)
+    bplain = torch.empty((S, N), dtype=torch.float32, device=DEV)
+    assert lib.grit_wgrad_tn(p(dy), dy.stride(0), p(x), x.stride(0), M, N, K, S, p(plain), p(bplain), _lib.current_stream_ptr()) == 0
+    part = torch.full((S, N, K), float("nan"), dtype=torch.float32, device=DEV)
+    bpart = torch.full((S, N), float("nan"), dtype=torch.float32, device=DEV)
+    assert lib.grit_wgrad_tn_rows(p(dy), dy.stride(0), p(x_nan), x.stride(0), M, N, K, S, p(part), p(bpart), p(scale), per,
+                                  _lib.current_stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(part).all()) and bool(torch.isfinite(bpart).all())
+    if not drop or not skipping:
+        assert torch.equal(part, plain) and torch.equal(bpart, bplain)
+    ref = dy.double().t() @ x.double()
+    tol = 2e-5 * float(ref.abs().max()) + 1e-4
+    assert float((part.double().sum(0) - ref).abs().max()) <= tol
+    assert float((part.double().sum(0) - plain.double().sum(0)).abs().max()) <= tol
+    refb = dy.double().sum(0)
+    assert float((bpart.double().sum(0) - refb).abs().max()) <= 1e-5 * float(refb.abs().max()) + 1e-3
+    # the same through the grouped launch, next to a job without factors
+    table = (_lib.WgradJob * 2)()
+    gpart = torch.full((S, N, K), float("nan"), dtype=torch.float32, device=DEV)
+    other = torch.full((S, N, K), float("nan"), dtype=torch.float32, device=DEV)
+    table[0] = _lib.WgradJob(dy.data_ptr(), dy.stride(0), x_nan.data_ptr(), x.stride(0), M, N, K, S, gpart.data_ptr(), None, scale.data_ptr(), per)
+    table[1] = _lib.WgradJob(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K, S, other.data_ptr(), None, None, 0)
+    assert lib.grit_wgrad_tn_grouped(table, 2, _lib.current_stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(gpart, part) and torch.equal(other, plain)
+    assert lib.grit_wgrad_tn_rows(p(dy), dy.stride(0), p(x), x.stride(0), M, N, K, S, p(part), None, p(scale), 0, _lib.current_stream_ptr()) != 0

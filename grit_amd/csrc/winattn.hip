@@ -764,15 +764,21 @@ void winattn_bwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
 //     single (consumed at the top of their window): 18 432 B;  statistics 3 552 B (the row log-sum-exps, the region ids and the token indices of the
 //     144 window positions double buffered: they arrive with the tiles).
 constexpr int kBP2 = 152;
-constexpr size_t kBwdDmaLds = (size_t)kN * kBP2 * 2 + (size_t)kN * kSP * 2 + 8 * (size_t)kN * kTP * 2 + 3 * kN * 4 + 3 * kHd * 4 + 2 * kN + 2 * kN * 4;
+constexpr size_t kBwdDmaLds = (size_t)kN * kBP2 * 2 + (size_t)kN * kSP * 2 + 8 * (size_t)kN * kTP * 2 + 3 * kN * 4 + 3 * kHd * 4 + 2 * kN + 2 * kN * 4
+                              + 64;  // (+ the kept-sample table of the drop-path variant)
 static_assert(kBwdDmaLds <= 160 * 1024, "one workgroup per CU");
 
-template <bool kExplicitMask>
+// kRows (round 5): drop path.  row_scale[b] == 0 promises dO == 0 for image b (the branch was multiplied by 0): its windows contribute
+// nothing to dq / dk / dv, d(bias) or the padding gradient.  The workgroup then walks the windows of the KEPT images only -- through a
+// live-index -> window map, so the window loop itself is the same code with the same single exit (round 4 answered such windows from
+// inside the loop: a second exit, 14 more registers in an issue-bound kernel, slower) -- after a store-only pre-loop that writes
+// the zeros of the dropped images' dq / dk / dv slices.
+template <bool kExplicitMask, bool kRows = false>
 __global__ __launch_bounds__(kThreads)
 void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ rel_bias, const __bf16* __restrict__ pad_qkv,
                  const float* __restrict__ mask, Geom g, const __bf16* __restrict__ out, const __bf16* __restrict__ dout,
                  const float* __restrict__ lse2, __bf16* __restrict__ dqkv, float* __restrict__ dbias,
-                 float* __restrict__ dpad) {
+                 float* __restrict__ dpad, const float* __restrict__ row_scale = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* bT = reinterpret_cast<__bf16*>(smem_raw);                       // [144][kBP2]  bias^T, bf16 (see header comment)
     __bf16* dSt = bT + kN * kBP2;                                           // [144][kSP]   [key][query]
@@ -784,6 +790,7 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     float* pad_s = delta_s + kN;                                            // [96]
     uint8_t* rid = reinterpret_cast<uint8_t*>(pad_s + 3 * kHd);             // [2][144]
     int* tok_s = reinterpret_cast<int*>(rid + 2 * kN);                      // [2][144] token index of a window position, -1: padding
+    uint8_t* kept_s = reinterpret_cast<uint8_t*>(tok_s + 2 * kN);           // [64] kRows: j-th kept image
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -791,7 +798,7 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     int h, grp;
     head_and_group(g, h, grp);
     const int ngrp = gridDim.x / g.nH;
-    const int NW = g.B * g.nWh * g.nWw;
+    int NW = g.B * g.nWh * g.nWw;  // (kRows: the windows of the kept images)
     const int C3 = 3 * g.C;
     const int hoff = h * kHd;
     const float c2 = g.scale * kLog2e;
@@ -802,6 +809,31 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
         bT[ki * kBP2 + qi] = (__bf16)rel_bias[(size_t)h * kN * kN + i];
     }
     if (tid < 3 * kHd) pad_s[tid] = 0.f;
+    if constexpr (kRows) {
+        unsigned long long keep = 0ull;  // wave-uniform (scalar loads): bit b = image b is kept; B <= 64 (host)
+        for (int b = 0; b < g.B; ++b) keep |= (unsigned long long)(row_scale[b] != 0.f) << b;
+        if (tid < g.B && ((keep >> tid) & 1ull)) kept_s[__builtin_popcountll(keep & ((1ull << tid) - 1ull))] = (uint8_t)tid;
+        NW = __builtin_popcountll(keep) * g.nWh * g.nWw;
+        // dq / dk / dv of the dropped images: zeros (this head's three 64-byte slices of every token; 12 threads per token, the
+        // workgroups of a head share an image's tokens)
+        const int slice = (tid % 12) >> 2, chunk = tid & 3;  // (576 = 48 x 12)
+        for (unsigned long long gone = ~keep & (g.B == 64 ? ~0ull : (1ull << g.B) - 1ull); gone; gone &= gone - 1ull) {
+            const size_t row0 = (size_t)__builtin_ctzll(gone) * g.T;
+            for (int t = grp * 48 + tid / 12; t < g.T; t += ngrp * 48)
+                *reinterpret_cast<uint4*>(dqkv + (row0 + t) * C3 + slice * g.C + hoff + chunk * 8) = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();  // the table is read by the first prefetch
+    }
+    // live index -> window id (kRows; identity otherwise)
+    auto window_id = [&](int lv) {
+        if constexpr (kRows) {
+            const int wpi = g.nWh * g.nWw;
+            const int q = (int)(((float)lv + 0.5f) * g.inv_img);
+            return (int)kept_s[q] * wpi + (lv - q * wpi);
+        } else {
+            return lv;
+        }
+    };
 
     v4f dB[kTiles];  // d(bias)[query 16qt + 4lg + r][key 16w + l15], summed over this workgroup's windows
 #pragma unroll
@@ -891,8 +923,9 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     };
     Next nxt;
     int cur = 0;
-    if (grp < NW) nxt = prefetch(grp, 0);
-    for (int win = grp; win < NW; win += ngrp, cur ^= 1) {
+    if (grp < NW) nxt = prefetch(window_id(grp), 0);
+    for (int lv = grp; lv < NW; lv += ngrp, cur ^= 1) {
+        [[maybe_unused]] const int win = lv;  // (the explicit-mask variant indexes its mask by window id; it never runs with kRows)
         const int wy = nxt.wy, wx = nxt.wx;
         const size_t img = nxt.img;
         __bf16* Qs = tiles + cur * 3 * kN * kTP;
@@ -916,7 +949,7 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
         const v8bf kf = as_v8bf(*reinterpret_cast<const uint4*>(&Ks[(16 * w + l15) * kTP + ((lg ^ swr) << 3)]));
         const v8bf vf = as_v8bf(*reinterpret_cast<const uint4*>(&Vs1[(16 * w + l15) * kTP + ((lg ^ swr) << 3)]));
         __syncthreads();  // statistics visible; the V / O tiles and the other tile buffer are free for the next window's DMA
-        if (win + ngrp < NW) nxt = prefetch(win + ngrp, cur ^ 1);  // lands under phases 1 and 2 of this window
+        if (lv + ngrp < NW) nxt = prefetch(window_id(lv + ngrp), cur ^ 1);  // lands under phases 1 and 2 of this window
 
         // Per-lane LDS offsets, made opaque once per window: without this hipcc hoists ~90 loop-invariant LDS
         // addresses out of the window loop, runs out of registers and reloads them from scratch before every read.
@@ -1347,6 +1380,14 @@ int grit_winattn_fwd_bf16(const void* qkv, const float* rel_bias, const void* pa
 int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pad_qkv, const float* mask, int n_mask_windows,
                           const void* out, const void* dout, const float* lse, int B, int H, int W, int C, int num_heads,
                           int window, int shift, float scale, void* dqkv, float* drel_bias, float* dpad, void* stream) {
+    return grit_winattn_bwd_bf16_rows(qkv, rel_bias, pad_qkv, mask, n_mask_windows, out, dout, lse, B, H, W, C, num_heads, window, shift,
+                                      scale, dqkv, drel_bias, dpad, nullptr, stream);
+}
+
+int grit_winattn_bwd_bf16_rows(const void* qkv, const float* rel_bias, const void* pad_qkv, const float* mask, int n_mask_windows,
+                               const void* out, const void* dout, const float* lse, int B, int H, int W, int C, int num_heads,
+                               int window, int shift, float scale, void* dqkv, float* drel_bias, float* dpad, const float* row_scale,
+                               void* stream) {
     if (!qkv || !rel_bias || !pad_qkv || !out || !dout || !lse || !dqkv || !drel_bias || !dpad) return GRIT_ERR_BAD_ARG;
     const int st = check_geom(B, H, W, C, num_heads, window, shift);
     if (st != GRIT_OK) return st;
@@ -1358,10 +1399,13 @@ int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pa
         if (hipFuncSetAttribute((const void*)winattn_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds) != hipSuccess ||
             hipFuncSetAttribute((const void*)winattn_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds) != hipSuccess ||
             hipFuncSetAttribute((const void*)winattn_bwd_dma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdDmaLds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)winattn_bwd_dma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdDmaLds) != hipSuccess)
+            hipFuncSetAttribute((const void*)winattn_bwd_dma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdDmaLds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)winattn_bwd_dma<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdDmaLds) != hipSuccess)
             return GRIT_ERR_LAUNCH;
         lds_attr_set = true;
     }
+    // drop path: the windows of images whose branch was multiplied by 0 are not computed (GRIT_WINATTN_ROW_SKIP=0: A/B switch)
+    static const bool row_skip = !(getenv("GRIT_WINATTN_ROW_SKIP") && atoi(getenv("GRIT_WINATTN_ROW_SKIP")) == 0);
     // The DMA-staged variant is the default since its transfers are issued as asm (before that the compiler's `vmcnt(0)` behind
     // every issue made it 3-9 % SLOWER on stages 2 / 3, profiles/r03/negative_results.txt #3): -3 % on stages 0 / 1, -2 % on
     // stage 2, equal on stage 3, step -0.1 ms (profiles/r03/winattn_dma_asm.txt).  GRIT_WINATTN_BWD_DMA=0: register staging.
@@ -1370,11 +1414,15 @@ int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pa
         if (mask)
             hipLaunchKernelGGL(winattn_bwd_dma<true>, dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdDmaLds, (hipStream_t)stream,
                                (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
-                               (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad);
+                               (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad, (const float*)nullptr);
+        else if (row_scale && row_skip && B >= 2 && B <= 64)
+            hipLaunchKernelGGL((winattn_bwd_dma<false, true>), dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdDmaLds, (hipStream_t)stream,
+                               (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
+                               (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad, row_scale);
         else
             hipLaunchKernelGGL(winattn_bwd_dma<false>, dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdDmaLds, (hipStream_t)stream,
                                (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
-                               (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad);
+                               (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad, (const float*)nullptr);
         return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
     }
     if (mask)

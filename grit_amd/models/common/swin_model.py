@@ -164,7 +164,7 @@ class WindowAttention(nn.Module):
         gradient that comes back to qkv is then zero in the rows of dropped samples and its weight gradient skips them."""
         qkv = self.qkv(x, row_scale=row_scale) if row_scale is not None else self.qkv(x)
         return window_attention(qkv, self.relative_position_bias(), self.pad_qkv(qkv.dtype), H, W, self.num_heads,
-                                self.window_size[0], shift, self.scale)
+                                self.window_size[0], shift, self.scale, row_scale=None if row_scale is None else row_scale[0])
 
     def attend_map(self, x, H, W, shift):
         """x: normalised tokens [B, H*W, C] in map order -> attention output [B, H*W, C] (after proj)."""

@@ -65,7 +65,7 @@ def _ptr(t):
 class _WindowAttentionFn(Function):
 
     @staticmethod
-    def forward(ctx, qkv, rel_bias, pad_qkv, mask, H, W, num_heads, window, shift, scale):
+    def forward(ctx, qkv, rel_bias, pad_qkv, mask, H, W, num_heads, window, shift, scale, row_scale=None):
         B, T, C3 = qkv.shape
         C = C3 // 3
         nWh, nWw = -(-H // window), -(-W // window)
@@ -82,6 +82,9 @@ class _WindowAttentionFn(Function):
         _lib.check(st, "grit_winattn_fwd")
         ctx.save_for_backward(qkv, rel_bias, pad_qkv, mask, out, lse)
         ctx.geom = (H, W, num_heads, window, shift, scale)
+        # drop path: per-image factors [B] float32 of the attention branch (the caller multiplies the branch by them): the gradient
+        # that comes back is zero for images with factor 0 -- the backward kernel does not compute their windows
+        ctx.row_scale = row_scale
         return out
 
     @staticmethod
@@ -98,18 +101,27 @@ class _WindowAttentionFn(Function):
         dbias, dpad = acc[:rel_bias.numel()].view_as(rel_bias), acc[rel_bias.numel():]
         nWm = 0 if mask is None else mask.shape[0]
         flops = _core_flops(B, -(-H // window), -(-W // window), num_heads, window * window, 5)
+        rs = ctx.row_scale
+        rows = (rs is not None and qkv.dtype == torch.bfloat16 and rs.is_cuda and rs.dtype == torch.float32 and rs.is_contiguous()
+                and rs.numel() == B)
         bwd = _lib.load().grit_winattn_bwd_f32 if qkv.dtype == torch.float32 else _lib.load().grit_winattn_bwd_bf16
         with _lib.device_guard(qkv.device), _Timed("bwd" if qkv.dtype == torch.bfloat16 else "bwd_f32", flops):
-            st = bwd(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, _ptr(out),
+            if rows:
+                st = _lib.load().grit_winattn_bwd_bf16_rows(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, _ptr(out),
+                                                            _ptr(dout), _ptr(lse), B, H, W, C, num_heads, window, shift, scale,
+                                                            _ptr(dqkv), _ptr(dbias), _ptr(dpad), _ptr(rs), _lib.current_stream_ptr())
+            else:
+                st = bwd(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, _ptr(out),
                                                    _ptr(dout), _ptr(lse), B, H, W, C, num_heads, window, shift, scale,
                                                    _ptr(dqkv), _ptr(dbias), _ptr(dpad), _lib.current_stream_ptr())
         _lib.check(st, "grit_winattn_bwd")
-        return dqkv, dbias, dpad.to(pad_qkv.dtype), None, None, None, None, None, None, None
+        return dqkv, dbias, dpad.to(pad_qkv.dtype), None, None, None, None, None, None, None, None
 
 
-def window_attention(qkv, rel_bias, pad_qkv, H, W, num_heads, window, shift, scale, mask=None):
+def window_attention(qkv, rel_bias, pad_qkv, H, W, num_heads, window, shift, scale, mask=None, row_scale=None):
     """qkv [B, H*W, 3C] (q|k|v, each head-major), rel_bias [nH, N, N] fp32, pad_qkv [3C], optional explicit
-    additive mask [nW_mask, N, N] (replaces the analytic shift mask).  Returns [B, H*W, C] in qkv's dtype."""
+    additive mask [nW_mask, N, N] (replaces the analytic shift mask).  Returns [B, H*W, C] in qkv's dtype.
+    row_scale: drop-path factors [B] of the branch this attention is part of (see _WindowAttentionFn.forward) or None."""
     ov = backend.override()
     if ov is not None:
         return ov.window_attention(qkv, rel_bias, pad_qkv, H, W, num_heads, window, shift, scale, mask=mask)
@@ -124,5 +136,5 @@ def window_attention(qkv, rel_bias, pad_qkv, H, W, num_heads, window, shift, sca
     cdt = torch.float32 if in_dtype in (torch.float32, torch.float64) else torch.bfloat16
     out = _WindowAttentionFn.apply(qkv.to(cdt).contiguous(), rel_bias.float().contiguous(), pad_qkv.to(cdt).contiguous(),
                                    None if mask is None else mask.float().contiguous(), H, W, num_heads, window, shift,
-                                   float(scale))
+                                   float(scale), row_scale)
     return out.to(in_dtype)

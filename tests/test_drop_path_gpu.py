@@ -36,6 +36,7 @@ def _worker(rank, port, mode, cut_regions, pin_variant, n_images, ret):
     if mode == 'noskip':
         os.environ["GRIT_GEMM_ROW_SKIP"] = "0"  # read when grit_amd.ops.gemm is imported: this is a fresh process
         os.environ["GRIT_WGRAD_ROW_SKIP"] = "0"  # ... and by libgrit_hip.so / grit_amd.ops.linear: the weight gradients load every row
+        os.environ["GRIT_WINATTN_ROW_SKIP"] = "0"  # ... the window-attention backward computes every window
     if pin_variant:
         os.environ["GRIT_GEMM_VARIANT"] = "4"
     from grit_amd.amp import Bf16Compute

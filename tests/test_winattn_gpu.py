@@ -231,3 +231,43 @@ def test_dma_and_register_staged_kernels_agree_bit_for_bit_on_random_geometries(
         assert fa == fb and qa == qb, (a, b)
         da, db = float(a.split(" dbias ")[1].split()[0]), float(b.split(" dbias ")[1].split()[0])
         assert abs(da - db) <= 1e-5 * abs(db) + 1e-9, (a, b)
+
+
+@pytest.mark.parametrize("B,H,W,nH,shift,drop", [(8, 20, 20, 4, 6, (1, 5)), (4, 24, 36, 8, 0, (0,)), (6, 40, 40, 16, 6, (0, 2, 3, 5)),
+                                                 (5, 13, 30, 2, 6, (0, 1, 2, 3, 4)), (3, 20, 20, 4, 6, ())])
+def test_backward_skips_the_windows_of_dropped_images(B, H, W, nH, shift, drop):
+    """Drop path (round 5): with the per-image factors of the attention branch the backward does not compute the windows of images
+    whose factor is 0 (their dO is zero: the promise of the caller).  Against the plain backward on the same dO: dq / dk / dv of the kept
+    images bit for bit, exact zeros for the dropped ones, d(bias) / d(pad) equal up to the order of the float atomics; the operands of
+    dropped images are never read (NaNs planted in their q / k / v, O and log-sum-exp rows do not show)."""
+    from grit_amd.ops.window_attention import _WindowAttentionFn
+    qkv, bias, pad = _inputs(B, H, W, nH, seed=B + H)
+    cot = torch.randn(B, H * W, 32 * nH, generator=torch.Generator().manual_seed(2)).bfloat16()
+    scale = torch.full((B,), 1.0 / 0.8)
+    for b in drop:
+        scale[b] = 0.0
+        cot[b] = 0
+    args = (None, H, W, nH, 12, shift, 32**-0.5)
+
+    def run(row_scale, poison):
+        x, y, z = qkv.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True), pad.to(DEV).requires_grad_(True)
+        out = _WindowAttentionFn.apply(x, y, z, *args, row_scale)
+        if poison:  # what the backward would read for the dropped images: saved q / k / v, O and the log-sum-exps
+            with torch.no_grad():
+                saved = out.grad_fn.saved_tensors
+                for b in drop:
+                    saved[0][b] = float("nan")
+                    saved[4][b] = float("nan")
+                    nw = saved[5].shape[0] // B
+                    saved[5][b * nw:(b + 1) * nw] = float("nan")
+        out.backward(cot.to(DEV))
+        return x.grad, y.grad, z.grad
+
+    plain = run(None, False)
+    skipped = run(scale.to(DEV), len(drop) > 0)
+    assert all(bool(torch.isfinite(t_).all()) for t_ in skipped)
+    assert torch.equal(skipped[0], plain[0])
+    for b in drop:
+        assert not bool(skipped[0][b].any())
+    for got, ref in zip(skipped[1:], plain[1:]):
+        assert float((got.float() - ref.float()).abs().max()) <= 1e-4 * float(ref.float().abs().max()) + 1e-5

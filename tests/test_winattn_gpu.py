@@ -263,8 +263,10 @@ def test_backward_skips_the_windows_of_dropped_images(B, H, W, nH, shift, drop):
         out.backward(cot.to(DEV))
         return x.grad, y.grad, z.grad
 
+    import os
+    skipping = os.environ.get("GRIT_WINATTN_BWD_DMA") != "0" and os.environ.get("GRIT_WINATTN_ROW_SKIP") != "0"  # (else: every window is computed)
     plain = run(None, False)
-    skipped = run(scale.to(DEV), len(drop) > 0)
+    skipped = run(scale.to(DEV), len(drop) > 0 and skipping)
     assert all(bool(torch.isfinite(t_).all()) for t_ in skipped)
     assert torch.equal(skipped[0], plain[0])
     for b in drop:

@@ -303,24 +303,54 @@ void winattn_fwd(const __bf16* __restrict__ qkv, const float* __restrict__ rel_b
 //     MI355X_MICROARCH.md "LDS").
 constexpr unsigned kFTile = kN * 64, kFVTile = kRows * 64;
 constexpr unsigned kFOffQ = 0, kFOffK = 2 * kFTile, kFOffV = 4 * kFTile, kFOffTok = kFOffV + 2 * kFVTile, kFOffRid = kFOffTok + 2 * kN * 4;
-constexpr size_t kFwdDmaLds = kFOffRid + 2 * kN;
+constexpr size_t kFwdDmaLds = kFOffRid + 2 * kN + 64;  // (+ the kept-image table of the drop-path variant)
 
+// kSkip (round 5): drop path, training forward.  The branch this attention belongs to is multiplied by row_scale[b] afterwards: the
+// windows of images with factor 0 are not computed -- out receives zeros for their tokens (finite: 0 * x stays 0 in the residual add),
+// their log-sum-exps zeros (the backward that gets the same factors never reads them) -- and the workgroups share the windows of the
+// kept images through the live-index map of winattn_bwd_dma<.., true>.  Same window loop, same single exit.
+template <bool kSkip = false>
 __global__ __launch_bounds__(kThreads)
 void winattn_fwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ rel_bias, const __bf16* __restrict__ pad_qkv, Geom g,
-                     __bf16* __restrict__ out, float* __restrict__ lse2) {
+                     __bf16* __restrict__ out, float* __restrict__ lse2, const float* __restrict__ row_scale = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     int* tok_s = reinterpret_cast<int*>(smem_raw + kFOffTok);       // [2][144]
     uint8_t* rid = smem_raw + kFOffRid;                              // [2][144]
+    uint8_t* kept_s = rid + 2 * kN;                                  // [64] kSkip: j-th kept image
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     int h, grp;
     head_and_group(g, h, grp);
     const int ngrp = gridDim.x / g.nH;
-    const int NW = g.B * g.nWh * g.nWw;
+    int NW = g.B * g.nWh * g.nWw;  // (kSkip: the windows of the kept images)
     const int C3 = 3 * g.C;
     const int hoff = h * kHd;
     const float c2 = g.scale * kLog2e;
+    if constexpr (kSkip) {
+        unsigned long long keep = 0ull;  // wave-uniform: bit b = image b is kept; B <= 64 (host)
+        for (int b = 0; b < g.B; ++b) keep |= (unsigned long long)(row_scale[b] != 0.f) << b;
+        if (tid < g.B && ((keep >> tid) & 1ull)) kept_s[__builtin_popcountll(keep & ((1ull << tid) - 1ull))] = (uint8_t)tid;
+        NW = __builtin_popcountll(keep) * g.nWh * g.nWw;
+        const int wpi = g.nWh * g.nWw, chunk = tid & 3;  // out: this head's 64-byte slice of a token = 4 threads; 576 = 144 x 4
+        for (unsigned long long gone = ~keep & (g.B == 64 ? ~0ull : (1ull << g.B) - 1ull); gone; gone &= gone - 1ull) {
+            const int b = __builtin_ctzll(gone);
+            for (int t = grp * 144 + (tid >> 2); t < g.T; t += ngrp * 144)
+                *reinterpret_cast<uint4*>(out + ((size_t)b * g.T + t) * g.C + hoff + chunk * 8) = make_uint4(0, 0, 0, 0);
+            for (int i = grp * kThreads + tid; i < wpi * kN; i += ngrp * kThreads)
+                lse2[(((size_t)b * wpi + i / kN) * g.nH + h) * kN + i % kN] = 0.f;
+        }
+        __syncthreads();  // the table is read by the first prefetch
+    }
+    auto window_id = [&](int lv) {  // live index -> window id (identity without kSkip)
+        if constexpr (kSkip) {
+            const int wpi = g.nWh * g.nWw;
+            const int q = (int)(((float)lv + 0.5f) * g.inv_img);
+            return (int)kept_s[q] * wpi + (lv - q * wpi);
+        } else {
+            return lv;
+        }
+    };
 
     // rows 144 .. 159 of both V buffers: the k-padding of the last PV step, never written by the transfers
     for (int i = tid; i < 2 * (kRows - kN) * 16; i += kThreads) {
@@ -365,11 +395,12 @@ void winattn_fwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
             dma16(src + 2 * g.C + c * 8, kFOffV + buf * kFVTile, group);
         }
     };
-    struct Next { int wy, wx; size_t img; };
+    struct Next { int wy, wx, win; size_t img; };
     auto prefetch = [&](int win, int buf) {
         Next f;
         int b;
         window_of(win, g, b, f.wy, f.wx);
+        f.win = win;
         f.img = (size_t)b * g.T;
         if (li >= 0) {  // wave-uniform
             fetch_rows(li, f.wy, f.wx, f.img, buf, true, true);
@@ -382,9 +413,9 @@ void winattn_fwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     const int trq = l15 >> 2, trp = l15 & 3;
     Next nxt;
     int cur = 0;
-    if (grp < NW) nxt = prefetch(grp, 0);
-    for (int win = grp; win < NW; win += ngrp, cur ^= 1) {
-        const int wy = nxt.wy, wx = nxt.wx;
+    if (grp < NW) nxt = prefetch(window_id(grp), 0);
+    for (int lv = grp; lv < NW; lv += ngrp, cur ^= 1) {
+        const int wy = nxt.wy, wx = nxt.wx, win = kSkip ? nxt.win : lv;
         const size_t img = nxt.img;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's transfers (and its stores of the previous window)
         __syncthreads();  // everybody's: the tiles of this window are complete, and nobody reads the other buffers any more
@@ -397,7 +428,7 @@ void winattn_fwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
         asm volatile("" : "+v"(oFrag), "+v"(oTrV), "+v"(oId));
         const int tq = tok_s[oId + 16 * w + l15], qreg = rid[oId + 16 * w + l15];
         const v8bf qf = as_v8bf(*reinterpret_cast<const uint4*>(&Qs[oFrag + 16 * w * 32]));
-        if (win + ngrp < NW) nxt = prefetch(win + ngrp, cur ^ 1);  // lands under this window's compute
+        if (lv + ngrp < NW) nxt = prefetch(window_id(lv + ngrp), cur ^ 1);  // lands under this window's compute
 
         // ---- S^T = K Q^T : acc[kt][r] = <q(16w + l15), k(16kt + 4lg + r)>
         v4f acc[kTiles];
@@ -768,12 +799,12 @@ constexpr size_t kBwdDmaLds = (size_t)kN * kBP2 * 2 + (size_t)kN * kSP * 2 + 8 *
                               + 64;  // (+ the kept-sample table of the drop-path variant)
 static_assert(kBwdDmaLds <= 160 * 1024, "one workgroup per CU");
 
-// kRows (round 5): drop path.  row_scale[b] == 0 promises dO == 0 for image b (the branch was multiplied by 0): its windows contribute
+// kSkip (round 5): drop path.  row_scale[b] == 0 promises dO == 0 for image b (the branch was multiplied by 0): its windows contribute
 // nothing to dq / dk / dv, d(bias) or the padding gradient.  The workgroup then walks the windows of the KEPT images only -- through a
 // live-index -> window map, so the window loop itself is the same code with the same single exit (round 4 answered such windows from
 // inside the loop: a second exit, 14 more registers in an issue-bound kernel, slower) -- after a store-only pre-loop that writes
 // the zeros of the dropped images' dq / dk / dv slices.
-template <bool kExplicitMask, bool kRows = false>
+template <bool kExplicitMask, bool kSkip = false>
 __global__ __launch_bounds__(kThreads)
 void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ rel_bias, const __bf16* __restrict__ pad_qkv,
                  const float* __restrict__ mask, Geom g, const __bf16* __restrict__ out, const __bf16* __restrict__ dout,
@@ -790,7 +821,7 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     float* pad_s = delta_s + kN;                                            // [96]
     uint8_t* rid = reinterpret_cast<uint8_t*>(pad_s + 3 * kHd);             // [2][144]
     int* tok_s = reinterpret_cast<int*>(rid + 2 * kN);                      // [2][144] token index of a window position, -1: padding
-    uint8_t* kept_s = reinterpret_cast<uint8_t*>(tok_s + 2 * kN);           // [64] kRows: j-th kept image
+    uint8_t* kept_s = reinterpret_cast<uint8_t*>(tok_s + 2 * kN);           // [64] kSkip: j-th kept image
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -798,7 +829,7 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     int h, grp;
     head_and_group(g, h, grp);
     const int ngrp = gridDim.x / g.nH;
-    int NW = g.B * g.nWh * g.nWw;  // (kRows: the windows of the kept images)
+    int NW = g.B * g.nWh * g.nWw;  // (kSkip: the windows of the kept images)
     const int C3 = 3 * g.C;
     const int hoff = h * kHd;
     const float c2 = g.scale * kLog2e;
@@ -809,7 +840,7 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
         bT[ki * kBP2 + qi] = (__bf16)rel_bias[(size_t)h * kN * kN + i];
     }
     if (tid < 3 * kHd) pad_s[tid] = 0.f;
-    if constexpr (kRows) {
+    if constexpr (kSkip) {
         unsigned long long keep = 0ull;  // wave-uniform (scalar loads): bit b = image b is kept; B <= 64 (host)
         for (int b = 0; b < g.B; ++b) keep |= (unsigned long long)(row_scale[b] != 0.f) << b;
         if (tid < g.B && ((keep >> tid) & 1ull)) kept_s[__builtin_popcountll(keep & ((1ull << tid) - 1ull))] = (uint8_t)tid;
@@ -824,9 +855,9 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
         }
         __syncthreads();  // the table is read by the first prefetch
     }
-    // live index -> window id (kRows; identity otherwise)
+    // live index -> window id (kSkip; identity otherwise)
     auto window_id = [&](int lv) {
-        if constexpr (kRows) {
+        if constexpr (kSkip) {
             const int wpi = g.nWh * g.nWw;
             const int q = (int)(((float)lv + 0.5f) * g.inv_img);
             return (int)kept_s[q] * wpi + (lv - q * wpi);
@@ -925,7 +956,7 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
     int cur = 0;
     if (grp < NW) nxt = prefetch(window_id(grp), 0);
     for (int lv = grp; lv < NW; lv += ngrp, cur ^= 1) {
-        [[maybe_unused]] const int win = lv;  // (the explicit-mask variant indexes its mask by window id; it never runs with kRows)
+        [[maybe_unused]] const int win = lv;  // (the explicit-mask variant indexes its mask by window id; it never runs with kSkip)
         const int wy = nxt.wy, wx = nxt.wx;
         const size_t img = nxt.img;
         __bf16* Qs = tiles + cur * 3 * kN * kTP;
@@ -1354,6 +1385,21 @@ extern "C" {
 int grit_winattn_fwd_bf16(const void* qkv, const float* rel_bias, const void* pad_qkv, const float* mask, int n_mask_windows,
                           int B, int H, int W, int C, int num_heads, int window, int shift, float scale,
                           void* out, float* lse, void* stream) {
+    return grit_winattn_fwd_bf16_rows(qkv, rel_bias, pad_qkv, mask, n_mask_windows, B, H, W, C, num_heads, window, shift, scale, out, lse,
+                                      nullptr, stream);
+}
+
+// (one rule for both directions: a forward that skipped an image must meet a backward that skips it too)
+static bool winattn_rows_apply(const float* row_scale, const float* mask, int B) {
+    static const bool row_skip = !(getenv("GRIT_WINATTN_ROW_SKIP") && atoi(getenv("GRIT_WINATTN_ROW_SKIP")) == 0);
+    static const bool fwd_dma = !(getenv("GRIT_WINATTN_FWD_DMA") && atoi(getenv("GRIT_WINATTN_FWD_DMA")) == 0);
+    static const bool bwd_dma = !(getenv("GRIT_WINATTN_BWD_DMA") && atoi(getenv("GRIT_WINATTN_BWD_DMA")) == 0);
+    return row_scale && !mask && row_skip && fwd_dma && bwd_dma && B >= 2 && B <= 64;
+}
+
+int grit_winattn_fwd_bf16_rows(const void* qkv, const float* rel_bias, const void* pad_qkv, const float* mask, int n_mask_windows,
+                               int B, int H, int W, int C, int num_heads, int window, int shift, float scale,
+                               void* out, float* lse, const float* row_scale, void* stream) {
     if (!qkv || !rel_bias || !pad_qkv || !out || !lse) return GRIT_ERR_BAD_ARG;
     const int st = check_geom(B, H, W, C, num_heads, window, shift);
     if (st != GRIT_OK) return st;
@@ -1364,12 +1410,17 @@ int grit_winattn_fwd_bf16(const void* qkv, const float* rel_bias, const void* pa
     if (use_dma && !mask) {
         static bool attr_done = false;
         if (!attr_done) {
-            if (hipFuncSetAttribute((const void*)winattn_fwd_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdDmaLds) != hipSuccess)
+            if (hipFuncSetAttribute((const void*)winattn_fwd_dma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdDmaLds) != hipSuccess ||
+                hipFuncSetAttribute((const void*)winattn_fwd_dma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdDmaLds) != hipSuccess)
                 return GRIT_ERR_LAUNCH;
             attr_done = true;
         }
-        hipLaunchKernelGGL(winattn_fwd_dma, dim3(grid_blocks(g, 256)), dim3(kThreads), kFwdDmaLds, (hipStream_t)stream,
-                           (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, g, (__bf16*)out, lse);
+        if (winattn_rows_apply(row_scale, mask, B))
+            hipLaunchKernelGGL(winattn_fwd_dma<true>, dim3(grid_blocks(g, 256)), dim3(kThreads), kFwdDmaLds, (hipStream_t)stream,
+                               (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, g, (__bf16*)out, lse, row_scale);
+        else
+            hipLaunchKernelGGL(winattn_fwd_dma<false>, dim3(grid_blocks(g, 256)), dim3(kThreads), kFwdDmaLds, (hipStream_t)stream,
+                               (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, g, (__bf16*)out, lse, (const float*)nullptr);
         return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(winattn_fwd, dim3(grid_blocks(g, 256)), dim3(kThreads), 0, (hipStream_t)stream,
@@ -1405,7 +1456,6 @@ int grit_winattn_bwd_bf16_rows(const void* qkv, const float* rel_bias, const voi
         lds_attr_set = true;
     }
     // drop path: the windows of images whose branch was multiplied by 0 are not computed (GRIT_WINATTN_ROW_SKIP=0: A/B switch)
-    static const bool row_skip = !(getenv("GRIT_WINATTN_ROW_SKIP") && atoi(getenv("GRIT_WINATTN_ROW_SKIP")) == 0);
     // The DMA-staged variant is the default since its transfers are issued as asm (before that the compiler's `vmcnt(0)` behind
     // every issue made it 3-9 % SLOWER on stages 2 / 3, profiles/r03/negative_results.txt #3): -3 % on stages 0 / 1, -2 % on
     // stage 2, equal on stage 3, step -0.1 ms (profiles/r03/winattn_dma_asm.txt).  GRIT_WINATTN_BWD_DMA=0: register staging.
@@ -1415,7 +1465,7 @@ int grit_winattn_bwd_bf16_rows(const void* qkv, const float* rel_bias, const voi
             hipLaunchKernelGGL(winattn_bwd_dma<true>, dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdDmaLds, (hipStream_t)stream,
                                (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
                                (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad, (const float*)nullptr);
-        else if (row_scale && row_skip && B >= 2 && B <= 64)
+        else if (winattn_rows_apply(row_scale, mask, B))
             hipLaunchKernelGGL((winattn_bwd_dma<false, true>), dim3(grid_blocks(g, 256)), dim3(kThreads), kBwdDmaLds, (hipStream_t)stream,
                                (const __bf16*)qkv, rel_bias, (const __bf16*)pad_qkv, mask, g, (const __bf16*)out,
                                (const __bf16*)dout, lse, (__bf16*)dqkv, drel_bias, dpad, row_scale);

@@ -40,6 +40,7 @@ SIGNATURES = {
     "grit_msda_bwd_sorted_supported": [_int] * 6,
     "grit_msda_bwd_bf16_sorted": [_ptr, _c.c_long] + [_ptr] * 5 + [_int] * 7 + [_ptr] * 4,
     "grit_winattn_fwd_bf16": [_ptr] * 4 + [_int] * 8 + [_f32, _ptr, _ptr, _ptr],
+    "grit_winattn_fwd_bf16_rows": [_ptr] * 4 + [_int] * 8 + [_f32, _ptr, _ptr, _ptr, _ptr],
     "grit_winattn_bwd_bf16": [_ptr] * 4 + [_int] + [_ptr] * 3 + [_int] * 7 + [_f32] + [_ptr] * 4,
     "grit_winattn_bwd_bf16_rows": [_ptr] * 4 + [_int] + [_ptr] * 3 + [_int] * 7 + [_f32] + [_ptr] * 5,
     "grit_winattn_fwd_f32": [_ptr] * 4 + [_int] * 8 + [_f32, _ptr, _ptr, _ptr],

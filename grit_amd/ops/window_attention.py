@@ -74,9 +74,17 @@ class _WindowAttentionFn(Function):
         lse = torch.empty((B * nWh * nWw, num_heads, N), dtype=torch.float32, device=qkv.device)
         nWm = 0 if mask is None else mask.shape[0]
         fwd = _lib.load().grit_winattn_fwd_f32 if qkv.dtype == torch.float32 else _lib.load().grit_winattn_fwd_bf16
+        # (the factors reach the forward kernel only when a backward -- which gets the same factors -- will follow)
+        rows = (row_scale is not None and qkv.dtype == torch.bfloat16 and row_scale.is_cuda and row_scale.dtype == torch.float32
+                and row_scale.is_contiguous() and row_scale.numel() == B and torch.is_grad_enabled() and qkv.requires_grad)
         with _lib.device_guard(qkv.device), _Timed("fwd" if qkv.dtype == torch.bfloat16 else "fwd_f32",
                                                    _core_flops(B, nWh, nWw, num_heads, N, 2)):
-            st = fwd(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, B, H, W, C,
+            if rows:
+                st = _lib.load().grit_winattn_fwd_bf16_rows(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, B, H, W, C,
+                                                            num_heads, window, shift, scale, _ptr(out), _ptr(lse), _ptr(row_scale),
+                                                            _lib.current_stream_ptr())
+            else:
+                st = fwd(_ptr(qkv), _ptr(rel_bias), _ptr(pad_qkv), _ptr(mask), nWm, B, H, W, C,
                                                    num_heads, window, shift, scale, _ptr(out), _ptr(lse),
                                                    _lib.current_stream_ptr())
         _lib.check(st, "grit_winattn_fwd")
@@ -84,7 +92,7 @@ class _WindowAttentionFn(Function):
         ctx.geom = (H, W, num_heads, window, shift, scale)
         # drop path: per-image factors [B] float32 of the attention branch (the caller multiplies the branch by them): the gradient
         # that comes back is zero for images with factor 0 -- the backward kernel does not compute their windows
-        ctx.row_scale = row_scale
+        ctx.row_scale = row_scale if rows else None
         return out
 
     @staticmethod

@@ -224,10 +224,18 @@ int grit_winattn_bwd_bf16(const void* qkv, const float* rel_bias, const void* pa
                           const void* out, const void* dout, const float* lse,
                           int B, int H, int W, int C, int num_heads, int window, int shift, float scale,
                           void* dqkv, float* drel_bias, float* dpad, void* stream);
+/* The forward with the drop-path factors of the branch the attention belongs to (training): the windows of images with
+ * row_scale[b] == 0 are not computed, out and lse receive zeros for them -- valid only because the caller multiplies the branch by the
+ * factors afterwards and hands the SAME factors to grit_winattn_bwd_bf16_rows.  Applies under the conditions listed there (both
+ * DMA-staged kernels in use); otherwise every window is computed. */
+int grit_winattn_fwd_bf16_rows(const void* qkv, const float* rel_bias, const void* pad_qkv, const float* mask, int n_mask_windows,
+                               int B, int H, int W, int C, int num_heads, int window, int shift, float scale,
+                               void* out, float* lse, const float* row_scale, void* stream);
 /* The backward with the drop-path factors of the attention branch (reference timm DropPath, models/common/swin_model.py:289-298):
  * row_scale[b] == 0 promises that dout is zero for image b.  Its windows contribute nothing to any output: they are not computed, dqkv
  * receives zeros for its tokens, the workgroups share the windows of the kept images.  row_scale == NULL, an explicit mask, B > 64,
- * the register-staged variant (GRIT_WINATTN_BWD_DMA=0) or GRIT_WINATTN_ROW_SKIP=0: every window is computed (same results). */
+ * a register-staged variant selected (GRIT_WINATTN_FWD_DMA=0 / GRIT_WINATTN_BWD_DMA=0) or GRIT_WINATTN_ROW_SKIP=0: every window is computed
+ * (same results). */
 int grit_winattn_bwd_bf16_rows(const void* qkv, const float* rel_bias, const void* pad_qkv, const float* mask, int n_mask_windows,
                                const void* out, const void* dout, const float* lse,
                                int B, int H, int W, int C, int num_heads, int window, int shift, float scale,

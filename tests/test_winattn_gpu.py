@@ -236,8 +236,8 @@ def test_dma_and_register_staged_kernels_agree_bit_for_bit_on_random_geometries(
 @pytest.mark.parametrize("B,H,W,nH,shift,drop", [(8, 20, 20, 4, 6, (1, 5)), (4, 24, 36, 8, 0, (0,)), (6, 40, 40, 16, 6, (0, 2, 3, 5)),
                                                  (5, 13, 30, 2, 6, (0, 1, 2, 3, 4)), (3, 20, 20, 4, 6, ())])
 def test_backward_skips_the_windows_of_dropped_images(B, H, W, nH, shift, drop):
-    """Drop path (round 5): with the per-image factors of the attention branch the backward does not compute the windows of images
-    whose factor is 0 (their dO is zero: the promise of the caller).  Against the plain backward on the same dO: dq / dk / dv of the kept
+    """Drop path (round 5): with the per-image factors of the attention branch neither direction computes the windows of images whose
+    factor is 0 (the caller multiplies the branch by the factors, so their dO is zero).  Against the plain backward on the same dO: dq / dk / dv of the kept
     images bit for bit, exact zeros for the dropped ones, d(bias) / d(pad) equal up to the order of the float atomics; the operands of
     dropped images are never read (NaNs planted in their q / k / v, O and log-sum-exp rows do not show)."""
     from grit_amd.ops.window_attention import _WindowAttentionFn
@@ -261,7 +261,7 @@ def test_backward_skips_the_windows_of_dropped_images(B, H, W, nH, shift, drop):
                     nw = saved[5].shape[0] // B
                     saved[5][b * nw:(b + 1) * nw] = float("nan")
         out.backward(cot.to(DEV))
-        return x.grad, y.grad, z.grad
+        return x.grad, y.grad, z.grad, out.detach()
 
     import os
     skipping = os.environ.get("GRIT_WINATTN_BWD_DMA") != "0" and os.environ.get("GRIT_WINATTN_ROW_SKIP") != "0"  # (else: every window is computed)
@@ -271,5 +271,11 @@ def test_backward_skips_the_windows_of_dropped_images(B, H, W, nH, shift, drop):
     assert torch.equal(skipped[0], plain[0])
     for b in drop:
         assert not bool(skipped[0][b].any())
-    for got, ref in zip(skipped[1:], plain[1:]):
+    # the forward with the factors: the kept images' outputs bit for bit, zeros for the dropped ones (when the skipping kernels run)
+    kept = [b for b in range(B) if b not in drop]
+    assert torch.equal(skipped[3][kept], plain[3][kept])
+    if skipping:
+        for b in drop:
+            assert not bool(skipped[3][b].any())
+    for got, ref in zip(skipped[1:3], plain[1:3]):
         assert float((got.float() - ref.float()).abs().max()) <= 1e-4 * float(ref.float().abs().max()) + 1e-5

@@ -346,7 +346,9 @@ void winattn_fwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
         if constexpr (kSkip) {
             const int wpi = g.nWh * g.nWw;
             const int q = (int)(((float)lv + 0.5f) * g.inv_img);
-            return (int)kept_s[q] * wpi + (lv - q * wpi);
+            // (readfirstlane: the table entry is the same in every lane -- as a vector value it would turn the scalar address arithmetic of
+            // the window's transfers into vector instructions on the issue-bound SIMDs)
+            return __builtin_amdgcn_readfirstlane((int)kept_s[q]) * wpi + (lv - q * wpi);
         } else {
             return lv;
         }
@@ -860,7 +862,9 @@ void winattn_bwd_dma(const __bf16* __restrict__ qkv, const float* __restrict__ r
         if constexpr (kSkip) {
             const int wpi = g.nWh * g.nWw;
             const int q = (int)(((float)lv + 0.5f) * g.inv_img);
-            return (int)kept_s[q] * wpi + (lv - q * wpi);
+            // (readfirstlane: the table entry is the same in every lane -- as a vector value it would turn the scalar address arithmetic of
+            // the window's transfers into vector instructions on the issue-bound SIMDs)
+            return __builtin_amdgcn_readfirstlane((int)kept_s[q]) * wpi + (lv - q * wpi);
         } else {
             return lv;
         }

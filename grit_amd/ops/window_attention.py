@@ -76,7 +76,7 @@ class _WindowAttentionFn(Function):
         fwd = _lib.load().grit_winattn_fwd_f32 if qkv.dtype == torch.float32 else _lib.load().grit_winattn_fwd_bf16
         # (the factors reach the forward kernel only when a backward -- which gets the same factors -- will follow)
         rows = (row_scale is not None and qkv.dtype == torch.bfloat16 and row_scale.is_cuda and row_scale.dtype == torch.float32
-                and row_scale.is_contiguous() and row_scale.numel() == B and torch.is_grad_enabled() and qkv.requires_grad)
+                and row_scale.is_contiguous() and row_scale.numel() == B and ctx.needs_input_grad[0])
         with _lib.device_guard(qkv.device), _Timed("fwd" if qkv.dtype == torch.bfloat16 else "fwd_f32",
                                                    _core_flops(B, nWh, nWw, num_heads, N, 2)):
             if rows:

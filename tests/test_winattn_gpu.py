@@ -252,16 +252,17 @@ def test_backward_skips_the_windows_of_dropped_images(B, H, W, nH, shift, drop):
     def run(row_scale, poison):
         x, y, z = qkv.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True), pad.to(DEV).requires_grad_(True)
         out = _WindowAttentionFn.apply(x, y, z, *args, row_scale)
+        result = out.detach().clone()
         if poison:  # what the backward would read for the dropped images: saved q / k / v, O and the log-sum-exps
             with torch.no_grad():
                 saved = out.grad_fn.saved_tensors
-                for b in drop:
-                    saved[0][b] = float("nan")
-                    saved[4][b] = float("nan")
+                for b in drop:  # (.data: no version bump -- autograd must not notice)
+                    saved[0].data[b] = float("nan")
+                    saved[4].data[b] = float("nan")
                     nw = saved[5].shape[0] // B
-                    saved[5][b * nw:(b + 1) * nw] = float("nan")
+                    saved[5].data[b * nw:(b + 1) * nw] = float("nan")
         out.backward(cot.to(DEV))
-        return x.grad, y.grad, z.grad, out.detach()
+        return x.grad, y.grad, z.grad, result
 
     import os
     skipping = os.environ.get("GRIT_WINATTN_BWD_DMA") != "0" and os.environ.get("GRIT_WINATTN_ROW_SKIP") != "0"  # (else: every window is computed)

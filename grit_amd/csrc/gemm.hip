@@ -21,6 +21,7 @@
 //   * XCD-aware tile order: the 8 groups of blockIdx % 8 walk disjoint bands of row panels, so an A panel is fetched from HBM
 //     by one L2 only and re-used by the N / 128 column tiles that run next to each other.
 #include <hip/hip_runtime.h>
+#include "per_device.h"
 #include <stdint.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -701,7 +702,7 @@ int launch_pp(const GemmArgs& a, int epilogue, hipStream_t st) {
     GemmArgs g = a;
     g.tiles_m = (a.M + 255) / 256;
     g.tiles_n = a.N / 256;
-    static int cus = 0;
+    static grit_detail::PerDevice<int> cus_pd; int& cus = cus_pd();
     if (cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -713,7 +714,7 @@ int launch_pp(const GemmArgs& a, int epilogue, hipStream_t st) {
 #define GRIT_GEMM_LAUNCH_PP(E)                                                                                       \
     {                                                                                                                \
         auto kern = gemm_pp_bf16<E>;                                                                                 \
-        static bool attr_done = false;                                                                               \
+        static grit_detail::PerDevice<bool> attr_done_pd; bool& attr_done = attr_done_pd();                                                                               \
         if (!attr_done) {                                                                                            \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) \
                 return GRIT_ERR_LAUNCH;                                                                              \
@@ -743,7 +744,7 @@ int launch(const GemmArgs& a, int epilogue, hipStream_t st) {
 #define GRIT_GEMM_LAUNCH(E)                                                                                          \
     {                                                                                                                \
         auto kern = gemm_nt_bf16<BM, BN, BK, WM, WN, NSTAGE, E>;                                                     \
-        static bool attr_done = false; /* idempotent: racing threads set the same value */                           \
+        static grit_detail::PerDevice<bool> attr_done_pd; bool& attr_done = attr_done_pd(); /* idempotent: racing threads set the same value */                           \
         if (!attr_done) {                                                                                            \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) \
                 return GRIT_ERR_LAUNCH;                                                                              \

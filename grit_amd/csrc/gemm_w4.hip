@@ -21,6 +21,7 @@
 //     file (942 v_accvgpr moves in the loop of the builtin version).  Every statement of a K step is volatile asm or a
 //     side-effecting builtin, so the source order IS the schedule; waits are placed by hand.
 #include <hip/hip_runtime.h>
+#include "per_device.h"
 #include <stdint.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -390,7 +391,7 @@ int gemm_w4_launch(const void* A, long lda, const void* B, long ldb, void* C, lo
     g.M = M; g.N = N; g.K = K;
     g.tiles_m = (M + 255) / 256;
     g.tiles_n = N / 256;
-    static int cus = 0;
+    static grit_detail::PerDevice<int> cus_pd; int& cus = cus_pd();
     if (cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -402,7 +403,7 @@ int gemm_w4_launch(const void* A, long lda, const void* B, long ldb, void* C, lo
 #define GRIT_W4_LAUNCH(E)                                                                                            \
     {                                                                                                                \
         auto kern = gemm_w4_bf16<E>;                                                                                 \
-        static bool attr_done = false;                                                                               \
+        static grit_detail::PerDevice<bool> attr_done_pd; bool& attr_done = attr_done_pd();                                                                               \
         if (!attr_done) {                                                                                            \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) \
                 return GRIT_ERR_LAUNCH;                                                                              \

@@ -21,6 +21,7 @@
 //
 // No hipify, no CUDA dual path: this file only builds for gfx950.
 #include <hip/hip_runtime.h>
+#include "per_device.h"
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -1401,7 +1402,7 @@ int grit_msda_bwd_bf16_sorted(const void* value, long pixel_stride, const int64_
     if (D != 64 || L * P > 16 || ((uintptr_t)value % 4) || ((uintptr_t)grad_out % 16) || ((uintptr_t)grad_value % 16))
         return GRIT_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    static bool lds_attr_set = false;  // idempotent attribute
+    static grit_detail::PerDevice<bool> lds_attr_set_pd; bool& lds_attr_set = lds_attr_set_pd();  // idempotent attribute
     if (!lds_attr_set) {
         if (hipFuncSetAttribute((const void*)msda_bwd_value, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return GRIT_ERR_LAUNCH;

@@ -18,6 +18,7 @@
 //     512 bytes;
 //   * v_mfma_f32_16x16x32_bf16 with dY^T as the A operand: accumulator rows = n, lanes = 16 consecutive k.
 #include <hip/hip_runtime.h>
+#include "per_device.h"
 #include <stdint.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -640,7 +641,7 @@ static int wgrad_tn_launch(const void* dY, long ldy, const void* X, long ldx, in
     a.row_scale = nullptr; a.rows_per_sample = 0;
     if (tn4_enabled() && tn4_fits(a)) {
         tn_set_rows(a, row_scale, rows_per_sample);
-        static bool attr4_set = false;
+        static grit_detail::PerDevice<bool> attr4_set_pd; bool& attr4_set = attr4_set_pd();
         if (!attr4_set) {
             if (hipFuncSetAttribute((const void*)wgrad_tn4_256, hipFuncAttributeMaxDynamicSharedMemorySize, k4Lds) != hipSuccess)
                 return GRIT_ERR_LAUNCH;
@@ -649,7 +650,7 @@ static int wgrad_tn_launch(const void* dY, long ldy, const void* X, long ldx, in
         hipLaunchKernelGGL(wgrad_tn4_256, dim3((unsigned)(a.tiles_n * a.tiles_k * splits)), dim3(k4Threads), k4Lds, (hipStream_t)stream, a);
         return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
     }
-    static bool attr_set = false;  // idempotent attribute
+    static grit_detail::PerDevice<bool> attr_set_pd; bool& attr_set = attr_set_pd();  // idempotent attribute
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)wgrad_tn_256, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes + kColBytes) != hipSuccess)
             return GRIT_ERR_LAUNCH;
@@ -692,7 +693,7 @@ extern "C" int grit_wgrad_tn_grouped(const grit_wgrad_job* jobs, int n_jobs, voi
     if (four)
         for (int j = 0; j < n_jobs; ++j) tn_set_rows(a.job[j], jobs[j].row_scale, jobs[j].rows_per_sample);
     if (four) {
-        static bool attr4_set = false;
+        static grit_detail::PerDevice<bool> attr4_set_pd; bool& attr4_set = attr4_set_pd();
         if (!attr4_set) {
             if (hipFuncSetAttribute((const void*)wgrad_tn4_256_grouped, hipFuncAttributeMaxDynamicSharedMemorySize, k4Lds) != hipSuccess)
                 return GRIT_ERR_LAUNCH;
@@ -701,7 +702,7 @@ extern "C" int grit_wgrad_tn_grouped(const grit_wgrad_job* jobs, int n_jobs, voi
         hipLaunchKernelGGL(wgrad_tn4_256_grouped, dim3((unsigned)total), dim3(k4Threads), k4Lds, (hipStream_t)stream, a);
         return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
     }
-    static bool attr_set = false;  // idempotent attribute
+    static grit_detail::PerDevice<bool> attr_set_pd; bool& attr_set = attr_set_pd();  // idempotent attribute
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)wgrad_tn_256_grouped, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes + kColBytes) != hipSuccess)
             return GRIT_ERR_LAUNCH;

@@ -25,6 +25,7 @@
 //     = query tile w, produces dQ^T.  dq/dk/dv of a token are written exactly once (every token belongs to one
 //     window): no global atomics except the per-launch flush of d(bias) and of the padded-token gradient.
 #include <hip/hip_runtime.h>
+#include "per_device.h"
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../include/grit_hip.h"
@@ -1412,7 +1413,7 @@ int grit_winattn_fwd_bf16_rows(const void* qkv, const float* rel_bias, const voi
     const Geom g = with_xcd_mapping(g0, grid_blocks(g0, 256));
     static const bool use_dma = [] { const char* e = getenv("GRIT_WINATTN_FWD_DMA"); return !(e && atoi(e) == 0); }();
     if (use_dma && !mask) {
-        static bool attr_done = false;
+        static grit_detail::PerDevice<bool> attr_done_pd; bool& attr_done = attr_done_pd();
         if (!attr_done) {
             if (hipFuncSetAttribute((const void*)winattn_fwd_dma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdDmaLds) != hipSuccess ||
                 hipFuncSetAttribute((const void*)winattn_fwd_dma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdDmaLds) != hipSuccess)
@@ -1449,7 +1450,7 @@ int grit_winattn_bwd_bf16_rows(const void* qkv, const float* rel_bias, const voi
     if (mask && n_mask_windows <= 0) return GRIT_ERR_BAD_ARG;
     const Geom g0 = make_geom(B, H, W, C, num_heads, shift, scale, n_mask_windows);
     const Geom g = with_xcd_mapping(g0, grid_blocks(g0, 256));
-    static bool lds_attr_set = false;  // idempotent attribute, racing first calls set the same value
+    static grit_detail::PerDevice<bool> lds_attr_set_pd; bool& lds_attr_set = lds_attr_set_pd();  // idempotent attribute, racing first calls set the same value
     if (!lds_attr_set) {
         if (hipFuncSetAttribute((const void*)winattn_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds) != hipSuccess ||
             hipFuncSetAttribute((const void*)winattn_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds) != hipSuccess ||
@@ -1515,7 +1516,7 @@ int grit_winattn_bwd_f32(const float* qkv, const float* rel_bias, const float* p
     const Geom g = make_geom(B, H, W, C, num_heads, shift, scale, n_mask_windows);
     const long long units = (long long)B * g.nWh * g.nWw * num_heads;
     if (units > 0x7fffffffLL) return GRIT_ERR_BAD_ARG;
-    static bool f32_attr_set = false;  // idempotent attribute, racing first calls set the same value
+    static grit_detail::PerDevice<bool> f32_attr_set_pd; bool& f32_attr_set = f32_attr_set_pd();  // idempotent attribute, racing first calls set the same value
     if (!f32_attr_set) {
         if (hipFuncSetAttribute((const void*)winattn_bwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdF32Lds) != hipSuccess)
             return GRIT_ERR_LAUNCH;

@@ -29,6 +29,25 @@ PICKS = ('cap_generator.fc.weight', 'grid_net.fc.weight', 'cap_generator.layers.
          'detector.det_module.decoder_layers.0.cross_attn.sampling_offsets.weight',
          'detector.backbone.layers.2.blocks.17.attn.qkv.weight', 'detector.backbone.layers.2.blocks.0.mlp.fc1.weight',
          'detector.input_proj.0.0.weight')
+# bf16 step against the fp32-kernel step: relative L2 distance of a picked gradient.  Tolerance = 2 x the largest distance measured on
+# MI355X at 16 and 32 images (profiles/r05/tolerances_measured.json: 0.012 .. 0.078, the zero-initialised sampling_offsets 0.27; the
+# bf16 step's own run-to-run floor is < 0.003).  Until round 5 the bounds were 0.3 / 0.6 for every tensor.
+GRAD_TOL = {'cap_generator.fc.weight': 0.03, 'grid_net.fc.weight': 0.12, 'cap_generator.layers.1.self_att.attention.fc_q.weight': 0.12,
+            'detector.det_module.decoder_layers.5.cross_attn.value_proj.weight': 0.125,
+            'detector.det_module.decoder_layers.0.cross_attn.sampling_offsets.weight': 0.55,
+            'detector.backbone.layers.2.blocks.17.attn.qkv.weight': 0.12, 'detector.backbone.layers.2.blocks.0.mlp.fc1.weight': 0.12,
+            'detector.input_proj.0.0.weight': 0.16}
+LOSS_TOL = 2e-4  # measured 2.1e-5 (32 images) and 3.8e-5 (16 images)
+
+
+def assert_close_to_fp32_step(bf16, fp32, grad_slack=1.0, loss_tol=LOSS_TOL):
+    assert abs(bf16["loss"] - fp32["loss"]) < loss_tol * fp32["loss"], (bf16["loss"], fp32["loss"])
+    rels = {n: float(torch.linalg.norm(bf16["grads"][n] - fp32["grads"][n]) / torch.linalg.norm(fp32["grads"][n])) for n in PICKS}
+    for n, rel in rels.items():
+        assert rel < grad_slack * GRAD_TOL[n], rels
+    return rels
+
+
 DETERMINISTIC = PICKS[:3]  # downstream of the loss only through the caption decoder / grid net: no atomics, no LDS-counter order
 
 
@@ -105,11 +124,7 @@ def test_config4_rank_workload_through_rccl_equals_no_group_and_fp32_step():
         a, b = rccl["grads"][n], plain["grads"][n]
         assert float(torch.linalg.norm(a - b)) <= 2e-2 * float(torch.linalg.norm(b)) + 1e-12, n
     # against the fp32 kernels end to end (the G8 parity path at this workload): bf16 storage of ~60 layers of activations
-    assert abs(plain["loss"] - fp32["loss"]) < 2e-2 * fp32["loss"], (plain["loss"], fp32["loss"])
-    rels = {n: float(torch.linalg.norm(plain["grads"][n] - fp32["grads"][n]) / torch.linalg.norm(fp32["grads"][n])) for n in PICKS}
-    for n, rel in rels.items():
-        assert rel < (0.6 if 'cross_attn' in n else 0.3), rels
-    assert sorted(rels.values())[len(rels) // 2] < 0.12, rels
+    assert_close_to_fp32_step(plain, fp32)
 
 
 def test_config3_bs16_step_against_the_fp32_kernels():
@@ -119,11 +134,7 @@ def test_config3_bs16_step_against_the_fp32_kernels():
     plain = _run(_config4_worker, _free_port(), 'plain', 16)
     fp32 = _run(_config4_worker, _free_port(), 'fp32', 16)
     assert plain["finite"] and fp32["finite"] and 8.0 < plain["loss"] < 10.5
-    assert abs(plain["loss"] - fp32["loss"]) < 2e-2 * fp32["loss"], (plain["loss"], fp32["loss"])
-    rels = {n: float(torch.linalg.norm(plain["grads"][n] - fp32["grads"][n]) / torch.linalg.norm(fp32["grads"][n])) for n in PICKS}
-    for n, rel in rels.items():
-        assert rel < (0.6 if 'cross_attn' in n else 0.3), rels
-    assert sorted(rels.values())[len(rels) // 2] < 0.12, rels
+    assert_close_to_fp32_step(plain, fp32)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

@@ -22,7 +22,7 @@ import torch
 import torch.multiprocessing as mp
 
 from tests.helpers import build_model
-from tests.test_configs_gpu import DETERMINISTIC, PICKS, _free_port
+from tests.test_configs_gpu import DETERMINISTIC, PICKS, _free_port, assert_close_to_fp32_step
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -94,11 +94,9 @@ def test_step_with_drop_path_on_against_fp32_kernels():
     assert skip["finite"] and fp32["finite"]
     assert skip["dropped_mlp"] >= 20 and skip["dropped"] == fp32["dropped"]  # ~16 % of 44 x 16 (branch, sample) pairs
     # same mask, fp32 kernels: config 3's tolerances (tests/test_configs_gpu.py::test_config3_bs16_step_against_the_fp32_kernels)
-    assert abs(skip["loss"] - fp32["loss"]) < 2e-2 * fp32["loss"], (skip["loss"], fp32["loss"])
-    rels = {n: float(torch.linalg.norm(skip["grads"][n] - fp32["grads"][n]) / torch.linalg.norm(fp32["grads"][n])) for n in PICKS}
-    for n, rel in rels.items():
-        assert rel < (0.6 if 'cross_attn' in n else 0.3), rels
-    assert sorted(rels.values())[len(rels) // 2] < 0.12, rels
+    # (the measured per-tensor bounds of the DropPath-off comparison, tests/test_configs_gpu.py GRAD_TOL, with 25 % slack: fewer live
+    # (sample, branch) pairs carry the same rounding noise)
+    assert_close_to_fp32_step(skip, fp32, grad_slack=1.25, loss_tol=5e-4)
 
 
 def test_skipped_tiles_change_no_bit_of_the_loss_or_of_any_gradient():

@@ -222,7 +222,10 @@ void slab_sum_grouped_kernel(const GroupedArgs a) {
 // column width (log2 of float4 groups per workgroup row) for a job: see grit_slab_sum
 int pick_cw_log2(long groups4, int groups, int slabs) {
     static const bool wide_ok = !(getenv("GRIT_SLAB_WIDE") && atoi(getenv("GRIT_SLAB_WIDE")) == 0);
-    if (wide_ok && groups4 >= 16384 && slabs >= 4 && slabs <= 512) return kWideMark;  // >= 64 workgroups of 256 column groups
+    // >= 64 workgroups of 256 column groups.  Round 5: also for 1-3 slabs (the decoders' deferred weight gradients: 2 slices of a
+    // 512 x 512 problem) -- the narrow shape below gives such a job 1 024 workgroups of which half the threads load one float4 each
+    // (99 + 87 us for two launches that move 160 MB, profiles/r05/decoder_phase_sequence.txt); same summation order either way
+    if (wide_ok && groups4 >= 16384 && slabs <= 512) return kWideMark;
     int cw_log2 = 0;
     while (cw_log2 < 6 && (1L << cw_log2) < groups4) ++cw_log2;
     // tall, narrow partials (LayerNorm: 1024 slabs x 512 columns) would leave the chip to a handful of workgroups that

@@ -186,7 +186,9 @@ class _XEStepper(object):
                     g.release()
                     self.want = False
             if g is None and graph_step.supported(model, optimizers) and not getattr(model, '_grit_step_graph_taken', False):
-                if self.eager_seen >= 2:
+                # (with collectives the capture needs the bucket wrapper in steady state -- live set agreed, no late gradient in the
+                # last step: until then the steps stay eager and the capture is simply tried again at the next batch)
+                if self.eager_seen >= 2 and (not model.ddp.collective or model.ddp.capture_ready()):
                     try:
                         g = graph_step.GraphedXEStep(model, optimizers, loss_fn, batch, scheduler=scheduler, eager_steps=0)
                         g.loss_fn_ignore = loss_fn.ignore_index

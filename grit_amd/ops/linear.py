@@ -126,10 +126,14 @@ def defer_weight_bias_grad(dy2, x2, weight, bias, need_dw, need_db, single_use, 
     if not ((M < WGRAD_SMALL_MAX_ROWS or long_ok) and N % 64 == 0 and K % 64 == 0 and dy2.stride(1) == 1 and x2.stride(1) == 1
             and dy2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0):
         return None
-    dw = grad_slot(weight, torch.bfloat16, dy2.device) if long_ok else None  # straight into the gradient bucket
+    # straight into the gradient bucket (round 5: the short maps' gradients too -- ~60 M decoder parameters were copied into their slots
+    # by the bucket pack, 12 multi-tensor launches of ~19 us per step; GRIT_DEFER_SLOT_SHORT=0 restores the copies)
+    dw = grad_slot(weight, torch.bfloat16, dy2.device) if (long_ok or DEFER_SLOT_SHORT) else None
     if dw is None:
         dw = torch.empty((N, K), dtype=torch.bfloat16, device=dy2.device)
-    db = torch.empty((N,), dtype=torch.bfloat16, device=dy2.device) if need_db else None
+    db = (grad_slot(bias, torch.bfloat16, dy2.device) if DEFER_SLOT_SHORT else None) if need_db else None
+    if need_db and db is None:
+        db = torch.empty((N,), dtype=torch.bfloat16, device=dy2.device)
     # no reference to dw / db is kept (autograd only adopts a gradient tensor nobody else holds): addresses only
     _deferral["parked" if park else "jobs"].append((dy2, x2, weight, bias if need_db else None, dw.data_ptr(),
                                                     db.data_ptr() if need_db else 0, M, N, K, row_scale))
@@ -372,6 +376,7 @@ class on_stream:
 
 
 GRAD_IN_PLACE = os.environ.get("GRIT_GRAD_IN_PLACE", "1") != "0"  # A/B knob of grad_slot
+DEFER_SLOT_SHORT = os.environ.get("GRIT_DEFER_SLOT_SHORT", "1") != "0"  # deferred short-map gradients written into their bucket slots
 
 
 def grad_slot(param, dtype, device):

@@ -490,7 +490,9 @@ def main():
     # hipGraphLaunch.  What is timed is the same work (forward, backward, gradient buckets, both Adam steps), enqueued differently.
     from grit_amd.engine import graph_step
     graphed, graph_error, graph_plan = None, None, None
-    want_graph = graph_step.ENABLED and not args.fp32 and args.warmup >= 1 and graph_step.supported(wrapped, optimizers)
+    graph_reason = ("GRIT_STEP_GRAPH=0" if not graph_step.ENABLED else "--fp32" if args.fp32 else "--warmup 0" if args.warmup < 1
+                    else graph_step.why_not(wrapped, optimizers))
+    want_graph = graph_reason is None
     eager_warmup = min(2, args.warmup) if want_graph else args.warmup
     for i in range(eager_warmup):
         loss = eager_step(i)
@@ -774,7 +776,7 @@ def main():
                                           backend + " SELF-collectives of a one-rank group (" + grad_sync + "): the sync path "
                                           "without a wire, not a multi-GPU number"),
                        "grad_sync": grad_sync if (world > 1 or self_coll) else None, "self_collectives": bool(self_coll),
-                       "step_graph": graphed is not None, "step_graph_error": graph_error,
+                       "step_graph": graphed is not None, "step_graph_error": graph_error, "step_graph_reason": graph_reason,
                        "step_graph_segments": (graph_plan.count('graph') if graph_plan is not None else 1) if graphed is not None else 0,
                        "step_enqueue": (("one captured HIP graph replayed per step" if graph_plan is None else
                                          "%d captured graph segments per step, the %d bucket all-reduces issued eagerly between them on the "
@@ -782,7 +784,6 @@ def main():
                                         + " (grit_amd/engine/graph_step.py); per-launch kernel events come from %d eager steps behind "
                                           "the timed region" % event_steps) if graphed is not None
                        else "eager launches",
-                       "step_forks": bool(graphed is not None and graph_plan is None and __import__('grit_amd.ops.streams', fromlist=['x']).ENABLED),
                        "rccl_env": rccl_env,
                        "points": args.points, "ragged": bool(args.ragged),
                        "msda_backward_accumulation": ("f32" if args.fp32 else ("f32 (" + msda_op.F32_METHOD + ")") if msda_op.F32_ACCUMULATE

@@ -45,7 +45,6 @@ import torch.distributed as dist
 from torch import nn
 
 from grit_amd.ops import linear as _linear_ops
-from grit_amd.ops import streams as _streams
 
 
 class _Bucket(object):
@@ -194,9 +193,6 @@ class BucketedDataParallel(nn.Module):
         parameters without a gradient are zeroed (the flat buffer still holds the previous step's values there)."""
         if b.packed:
             return
-        # (captured step with forked branches, grit_amd/ops/streams.py: the gradients of this bucket and the operands of the deferred
-        # jobs were produced on whichever stream ran their node -- this stream waits for all of them, and they for the pack)
-        _streams.rendezvous()
         _linear_ops.wait_deferred()  # small-map weight gradients computed beside the backward chain (grit_amd/ops/linear.py)
         src, dst, stale = [], [], []
         for p, view in zip(b.params, b.views):
@@ -208,7 +204,6 @@ class BucketedDataParallel(nn.Module):
                 dst.append(view)
         if src:
             torch._foreach_copy_(dst, src)
-            _streams.keep_for_current_stream(src)  # (gradients produced on a forked stream, dropped right below)
         if stale:
             torch._foreach_zero_(stale)
         for p, view in zip(b.params, b.views):
@@ -216,7 +211,6 @@ class BucketedDataParallel(nn.Module):
             if p.grad is not None:
                 p.grad = view
         b.packed = True
-        _streams.release()
 
     def _launch(self, b):
         if not self.collective or b.work is not None:
@@ -253,7 +247,6 @@ class BucketedDataParallel(nn.Module):
         """finish_gradient_sync() while a segmented capture records the step: the steady-state path only (capture_ready()) -- pack and
         cut what backward left, a 'wait for every collective' cut, then the device-side tail.  The host-side books of a replayed step
         are kept by the replaying caller (GraphedXEStep.__call__)."""
-        _streams.rendezvous()
         _linear_ops.end_deferral()
         if self._late:
             raise RuntimeError("segmented capture: a gradient arrived outside the bucket reductions (the live set changed)")
@@ -277,7 +270,6 @@ class BucketedDataParallel(nn.Module):
         and re-derive the live set if it changed."""
         if self._cutter is not None:
             return self._finish_captured()
-        _streams.rendezvous()
         _linear_ops.end_deferral()
         for b in self.buckets:
             if b.expected == 0 and self._decided:

@@ -26,8 +26,7 @@ step waits for the collectives.  A replayed step is then: segment 0 (forward + b
 bucket 0 issued EAGERLY on the process group's stream -> segment 1 -> all-reduce 1 -> ... -> wait -> last segment (both Adam steps) ->
 the scalar all-reduce of the loss.  ~2 300 launches become ~7 graph launches + ~7 collective calls per step, the all-reduces overlap the
 rest of backward exactly as in the eager step, and no collective is ever part of a capture (round 4's experiment captured them: one
-unexplained failure in seven runs; removed).  Independent-branch forks (grit_amd/ops/streams.py) are off inside a segmented capture: a cut
-must happen on the capture's origin stream.  Not capturable this way: the sharded optimizer's cross-step all-gather, wire-dtype
+unexplained failure in seven runs; removed).  Not capturable this way: the sharded optimizer's cross-step all-gather, wire-dtype
 conversion of the buckets, per-step agreement of the live set (supported() says no; the eager step runs).
 """
 import os
@@ -35,23 +34,38 @@ import os
 import torch
 
 from grit_amd.ops import backend
-from grit_amd.ops import streams
 from grit_amd.utils.misc import NestedTensor
 
 ENABLED = os.environ.get("GRIT_STEP_GRAPH", "1") != "0"
-SEGMENTS = os.environ.get("GRIT_STEP_GRAPH_SEGMENTS", "1") != "0"
+# Opt-in (round 6): the segmented capture begins / ends captures from autograd-hook threads in torch's relaxed capture mode; its record is
+# one RCCL rank on one GPU, two gloo ranks sharing a GPU and a 300-step soak -- no run with one RCCL rank PER GPU exists (no multi-GPU box
+# was ever available).  Until one is on record the N > 1 default is the eager step, whose launches are what the eager tests cover.
+SEGMENTS = os.environ.get("GRIT_STEP_GRAPH_SEGMENTS", "0") == "1"
+
+
+def why_not(model, optimizers):
+    """None when the step can be captured, else the reason it runs as eager launches (bench.py prints it as config.step_graph_reason).
+    The wrapper must be grit_amd.amp.Bf16Compute with the flat optimizer on a GPU; with collectives only the plain bucketed all-reduce,
+    and only when asked for."""
+    ddp = getattr(model, 'ddp', None)
+    if ddp is None or not getattr(model, 'flat_optimizer', False):
+        return "not a Bf16Compute wrapper with the flat optimizer"
+    if ddp.collective:  # GRIT_STEP_GRAPH_SEGMENTS=1: captured in segments around the collectives; default: eager launches with N > 1
+        if not SEGMENTS:
+            return "process group present and GRIT_STEP_GRAPH_SEGMENTS is not 1 (segmented capture is opt-in)"
+        if getattr(model, 'shard_optimizer', False) or ddp.shard_grads:
+            return "sharded gradients / optimizer: the cross-step all-gather is not part of the segmented plan"
+        if ddp.wire_dtype is not None:
+            return "wire-dtype conversion of the buckets is not part of the segmented plan"
+        if ddp.agree_every_step or ddp.check_agreement:
+            return "per-step agreement of the live parameter set needs the host"
+    if not all(hasattr(optimizers[k], 'prepare_replay') for k in ('model', 'backbone')):
+        return "optimizers without device-side per-step scalars (FlatAdam.prepare_replay)"
+    return None
 
 
 def supported(model, optimizers):
-    """The wrapper must be grit_amd.amp.Bf16Compute with the flat optimizer on a GPU, and no collective may be part of the step."""
-    ddp = getattr(model, 'ddp', None)
-    if ddp is None or not getattr(model, 'flat_optimizer', False):
-        return False
-    if ddp.collective:  # captured in segments around the collectives (GRIT_STEP_GRAPH_SEGMENTS=0: eager launches with N > 1)
-        if not SEGMENTS or getattr(model, 'shard_optimizer', False) or ddp.shard_grads or ddp.wire_dtype is not None \
-                or ddp.agree_every_step or ddp.check_agreement:
-            return False
-    return all(hasattr(optimizers[k], 'prepare_replay') for k in ('model', 'backbone'))
+    return why_not(model, optimizers) is None
 
 
 def _debug(msg):
@@ -156,12 +170,7 @@ class GraphedXEStep(object):
                 with backend.capturing_train_step(self.device) as seeds:
                     with torch.cuda.graph(self.graph):
                         seeds.begin_captured_step(self.device)
-                        streams.begin_capture(self.device)  # independent branches fork from here on (grit_amd/ops/streams.py)
-                        try:
-                            self.loss = train_xe_step(model, self.static, optimizers, loss_fn)
-                            streams.rendezvous(self.device)  # (every fork is joined already; cheap insurance before the capture ends)
-                        finally:
-                            streams.end_capture(self.device)
+                        self.loss = train_xe_step(model, self.static, optimizers, loss_fn)
         except BaseException:
             self.graph = None
             model._grit_step_graph_taken = True  # (a second capture attempt on this wrapper is not safe on this ROCm either)
@@ -188,7 +197,7 @@ class GraphedXEStep(object):
         cap.wait_stream(cur)
         ddp._cutter = cutter
         try:
-            with backend.capturing_train_step(self.device) as seeds, streams.suspended(), torch.cuda.stream(cap):
+            with backend.capturing_train_step(self.device) as seeds, torch.cuda.stream(cap):
                 cutter.begin()
                 try:
                     seeds.begin_captured_step(self.device)

@@ -20,7 +20,6 @@ from grit_amd.ops import backend
 from grit_amd.ops import decode_inputs
 from grit_amd.ops import gate as gate_ops
 from grit_amd.ops import glue
-from grit_amd.ops import streams
 from grit_amd.ops import weights_epoch
 from grit_amd.ops.linear import Linear, mark_single_use
 
@@ -82,11 +81,8 @@ class ParallelAttentionLayer(GeneratorLayer):
         if self.training and torch.is_grad_enabled() and self_att.is_cuda:
             # training step on the device: masks, concatenations, sigmoids, products, sum and scale of the merge below as pack /
             # ONE fc_alpha1 GEMM / fuse forward and two launches + the GEMMs backward (grit_amd/ops/glue.py)
-            # (captured step: the two cross-attentions are independent until the gated merge -- the region branch on a forked stream)
-            with streams.fork(self_att, slot=1, inputs=(y2, mask_y2)) as side:
-                e2 = self.vis_att2(self_att, y2, y2, mask_y2)
+            e2 = self.vis_att2(self_att, y2, y2, mask_y2)
             e1 = self.vis_att1(self_att, y1, y1, mask_y1)
-            side.join(e2)
             merged = glue.gated_merge_train(self_att, e1, e2, mask_pad, self.fc_alpha1)
             if merged is not None:
                 return self.pwff(merged) * mask_pad

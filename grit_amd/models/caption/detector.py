@@ -51,15 +51,6 @@ class Detector(nn.Module):
         {gri_feat [B,h*w,1024], gri_mask [B,1,1,h*w], reg_feat [B,150,512], reg_mask [B,1,1,150] (all False)}."""
         if isinstance(images, (list, tuple, torch.Tensor)):  # the reference's list branch is broken (Q13); fixed here
             images = nested_tensor_from_tensor_list(list(images))
-        out, regions = self.grid_outputs(images)
-        if regions is not None:
-            out.update(regions())
-        return out
-
-    def grid_outputs(self, images: NestedTensor):
-        """forward() in two halves: ({gri_feat, gri_mask}, `regions`) right after the backbone; `regions()` runs the detection module
-        and returns {reg_feat, reg_mask} (None without region features).  The captioner's grid network depends on the first half
-        only and runs beside the second (grit_amd/models/caption/transformer.py _visual_inputs)."""
         x, mask = images.tensors, images.mask
         features = self.backbone(x)
         if getattr(images, 'any_padding', None) is False:
@@ -73,15 +64,13 @@ class Detector(nn.Module):
             'gri_mask': masks[-1].flatten(1)[:, None, None, :],
         }
         if not self.use_reg_feat:
-            return out, None
+            return out
         no_padding = getattr(images, 'any_padding', None) is False
-
-        def regions():
-            flat, shapes = self.project_levels(features)
-            last, _, _ = self.det_module(None, masks, no_padding=no_padding, src_flatten=flat, shapes=shapes, last_only=True)
-            return {'reg_feat': last, 'reg_mask': last.new_zeros((last.shape[0], 1, 1, last.shape[1])).bool()}
-
-        return out, regions
+        flat, shapes = self.project_levels(features)
+        last, _, _ = self.det_module(None, masks, no_padding=no_padding, src_flatten=flat, shapes=shapes, last_only=True)
+        out['reg_feat'] = last
+        out['reg_mask'] = last.new_zeros((last.shape[0], 1, 1, last.shape[1])).bool()
+        return out
 
 
 def build_detector(config):

@@ -17,7 +17,6 @@ from grit_amd import lib as _lib
 from grit_amd.models.caption.base import BaseCaptioner
 from grit_amd.ops import backend
 from grit_amd.ops import beam as beam_ops
-from grit_amd.ops import streams
 from grit_amd.models.caption.cap_generator import CaptionGenerator
 from grit_amd.models.caption.grid_net import GridFeatureNetwork
 from grit_amd.utils.misc import NestedTensor
@@ -61,20 +60,6 @@ class Transformer(BaseCaptioner):
 
     # ------------------------------------------------------------------ visual side
     def _visual_inputs(self, images):
-        if (not self.cached_features and self.config.model.use_gri_feat and hasattr(self.detector, 'grid_outputs')
-                and isinstance(images, NestedTensor) and streams.active(images.tensors) and len(self.grid_net.layers) > 0
-                and type(self.grid_net).forward is GridFeatureNetwork.forward):
-            # captured training step: the grid network (3 layers on 100 tokens per image) needs the coarsest backbone map only and runs
-            # on a forked stream BESIDE the detection module's six decoder layers -- forward here, and backward too, because autograd
-            # runs a node's backward on its forward's stream (grit_amd/ops/streams.py)
-            vis, regions = self.detector.grid_outputs(images)
-            with streams.fork(vis['gri_feat'], slot=0, inputs=(vis['gri_mask'],)) as side:
-                grid = self.grid_net.last(vis['gri_feat'], vis['gri_mask'])
-            if regions is not None:
-                vis.update(regions())
-            side.join(grid)
-            vis['gri_feat'] = grid
-            return vis
         vis = images if self.cached_features else self.detector(images)
         vis = dict(vis)
         if self.config.model.use_gri_feat:

@@ -18,7 +18,6 @@ from torch.autograd.function import once_differentiable
 
 from grit_amd import lib as _lib
 from grit_amd.ops import backend
-from grit_amd.ops import streams as _streams
 from grit_amd.ops.profiling import gemm_work, timed
 
 MIN_ROWS = int(os.environ.get("GRIT_LINEAR_MIN_ROWS", "512"))  # below this the launch overhead dominates: leave it to torch
@@ -206,7 +205,6 @@ def _flush_deferred_slabs(into=None, final=False):
         group.jobs.extend(jobs)
         group.keep.extend(keep)
         group.device = keep[0].device
-        _streams.keep_for_current_stream(keep)
     if into is None:
         group.run()
 
@@ -222,7 +220,6 @@ def flush_deferred(final=False):
     _deferral["jobs"], _deferral["parked"] = [], []
     lib = _lib.load()
     dev = jobs[0][0].device
-    _streams.keep_for_current_stream([t for j in jobs for t in (j[0], j[1])])  # operands produced on forked streams of a captured step
     for dy2, x2, w, b, pw, pb, M, N, K, _rs in jobs:
         _verify(w, pw, "weight gradient [%d, %d]" % (N, K), final)
         if b is not None:

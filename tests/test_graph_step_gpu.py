@@ -76,36 +76,6 @@ def test_replayed_steps_equal_eager_steps():
             if opts[k]._steps[p]} == {5}
 
 
-def test_forked_branches_inside_the_captured_step_change_nothing(monkeypatch):
-    """grit_amd/ops/streams.py (GRIT_STEP_FORK=1; default off because the replay gets slower, profiles/r05/ab_fork.txt): the grid net beside
-    the detection module and the region cross-attention beside the grid one on forked streams of the capture -- forward AND backward
-    (autograd runs a node's backward on its forward's stream), the bucket pack ordered behind every stream.  Same losses and masters as
-    the unforked replay within the eager-vs-replay tolerance; a missing dependency shows as NaN or as a different trajectory
-    (GRIT_STEP_FORK_DEBUG=norendezvous does exactly that)."""
-    from grit_amd.engine.caption_engine import train_xe_step
-    from grit_amd.engine.graph_step import GraphedXEStep
-    from grit_amd.ops import streams
-    a, b = _batches()
-    order = [a, b, a, b, a]
-    results = []
-    for fork in (False, True):
-        monkeypatch.setattr(streams, "ENABLED", fork)
-        wrapped, opts, loss_fn = _setup()
-        first = float(train_xe_step(wrapped, order[0], opts, loss_fn))
-        step = GraphedXEStep(wrapped, opts, loss_fn, order[1], eager_steps=0)
-        losses = [first] + [float(step(x)) for x in order[1:]]
-        results.append((losses, _masters(wrapped, PICKS)))
-        del wrapped, opts, step
-        torch.cuda.empty_cache()
-    (plain, m_plain), (forked, m_forked) = results
-    assert all(np.isfinite(forked)) and forked[-1] < forked[0] - 0.02, forked
-    for e, r in zip(plain, forked):
-        assert abs(e - r) < 8e-3 * abs(e), (plain, forked)
-    for n in PICKS:
-        scale = float(torch.linalg.norm(m_plain[n]))
-        assert float(torch.linalg.norm(m_plain[n] - m_forked[n])) < 2e-3 * scale, n
-
-
 def test_replay_reads_learning_rate_and_step_count_at_replay_time():
     from grit_amd.engine.caption_engine import train_xe_step
     from grit_amd.engine.graph_step import GraphedXEStep
@@ -242,7 +212,9 @@ def _rccl_segments_worker(rank, port, steps, ret):
     from grit_amd.engine.caption_engine import train_xe_step
     a, b = _batches()
     wrapped, opts, loss_fn = _setup()
-    assert wrapped.ddp.collective and graph_step.supported(wrapped, opts)
+    assert wrapped.ddp.collective and not graph_step.supported(wrapped, opts)  # N > 1: eager launches unless asked for
+    graph_step.SEGMENTS = True  # (GRIT_STEP_GRAPH_SEGMENTS=1)
+    assert graph_step.supported(wrapped, opts)
     issued = []
 
     def spy(*args, _f=dist.all_reduce, **kw):

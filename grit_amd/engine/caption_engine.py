@@ -184,7 +184,11 @@ class _XEStepper(object):
                     # re-derived (load_state_dict, a changed live set).  The recorded launches are stale for good: drop the graph
                     # (one capture per wrapper and process) and stay on eager launches
                     g.release()
+                    model._grit_step_graph = None  # (the graph's private pool -- a full step of activations -- goes back to the allocator)
                     self.want = False
+                    import sys
+                    sys.stderr.write("train_xe: the captured step no longer fits this wrapper (optimizers rebuilt, load_state_dict or a changed "
+                                     "live parameter set); dropped -- eager launches for the rest of the process\n")
             if g is None and graph_step.supported(model, optimizers) and not getattr(model, '_grit_step_graph_taken', False):
                 # (with collectives the capture needs the bucket wrapper in steady state -- live set agreed, no late gradient in the
                 # last step: until then the steps stay eager and the capture is simply tried again at the next batch)

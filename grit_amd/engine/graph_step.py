@@ -179,6 +179,7 @@ class GraphedXEStep(object):
         # what the recorded launches depend on beyond the batch: THESE optimizer objects, each with the run layout (start / length per
         # launch, row of the device table of per-step scalars) it had at capture time -- FlatAdam._derive_runs bumps runs_version
         self._opt_state = tuple((id(o), o.runs_version) for o in self._opts)
+        model.ddp._iteration = iteration  # (the recorded pass counted itself, and it never ran: replays count in __call__)
         model._grit_step_graph_taken = True
         self.replays = 0
 

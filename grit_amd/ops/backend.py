@@ -89,3 +89,23 @@ def capturing_train_step(device):
 
 def dropout_seed(device):
     return _seeds.take(device)
+
+
+# GRIT_ROW_SKIP_CHECK=1 (debug): the row-skipping paths (Linear(row_scale=), grit_wgrad_tn_rows, grit_gemm_bf16_nt_rows, grit_winattn_bwd_bf16_rows)
+# rest on the caller's promise that the gradient rows of samples whose drop-path factor is 0 are exact zeros.  With the knob set every
+# such entry point verifies the promise on the host before it launches (one device sync per call: never in a timed or captured run).
+import os as _os
+ROW_SKIP_CHECK = _os.environ.get("GRIT_ROW_SKIP_CHECK", "0") == "1"
+
+
+def check_dropped_rows(grad, row_scale, what):
+    """grad [B * rows_per_sample, ...] or [B, ...]; row_scale [B] float32.  Raises when a sample with factor 0 has a non-zero gradient row."""
+    import torch
+    if not ROW_SKIP_CHECK or row_scale is None or grad is None or torch.cuda.is_current_stream_capturing():
+        return
+    B = row_scale.numel()
+    g = grad.reshape(B, -1)
+    bad = ((row_scale.reshape(B) == 0) & (g != 0).any(dim=1)).nonzero().flatten().tolist()
+    if bad:
+        raise RuntimeError("%s: row_scale promises zero gradient rows for samples %s, but they are not zero -- the caller does not "
+                           "multiply the branch by the same factors" % (what, bad))

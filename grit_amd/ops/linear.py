@@ -773,6 +773,8 @@ class _LinearFn(Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         dx = dw = db = None
+        if ctx.row_scale is not None:
+            backend.check_dropped_rows(dy2, ctx.row_scale[0], "Linear backward (row_scale)")
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         deferred = defer_weight_bias_grad(dy2, x2, weight, ctx.bias_param, ctx.needs_input_grad[1], need_b, ctx.single_use)
         if deferred is not None:  # short map inside a gradient-bucket scope: dW / db come from the scope's grouped launch

@@ -43,6 +43,8 @@ def _mlp_backward(d_branch, n2, w1, pre, act, w2, needs, need_b2=False, group=No
     the caller's SlabGroup -- every partial sum of the node (dW2, db1, dW1[, db2]) is then reduced by the caller's one launch
     (not combined with the side stream: the knob that enables it is an A/B diagnostic)."""
     need_x, need_w1, need_b1, need_w2 = needs
+    if row_scale is not None and rows_per_sample > 0:
+        backend.check_dropped_rows(d_branch, row_scale, "Mlp backward (drop-path factors)")
     d_n2 = d_w1 = d_b1 = d_w2 = d_b2 = None
     chain = need_x or need_w1 or need_b1
     side = fork(d_branch, act) if (chain and (need_w2 or need_b2)) else None

@@ -112,6 +112,8 @@ class _WindowAttentionFn(Function):
         rs = ctx.row_scale
         rows = (rs is not None and qkv.dtype == torch.bfloat16 and rs.is_cuda and rs.dtype == torch.float32 and rs.is_contiguous()
                 and rs.numel() == B)
+        if rows:
+            backend.check_dropped_rows(dout, rs, "window_attention backward")
         bwd = _lib.load().grit_winattn_bwd_f32 if qkv.dtype == torch.float32 else _lib.load().grit_winattn_bwd_bf16
         with _lib.device_guard(qkv.device), _Timed("bwd" if qkv.dtype == torch.bfloat16 else "bwd_f32", flops):
             if rows:

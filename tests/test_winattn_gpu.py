@@ -280,3 +280,28 @@ def test_backward_skips_the_windows_of_dropped_images(B, H, W, nH, shift, drop):
             assert not bool(skipped[3][b].any())
     for got, ref in zip(skipped[1:3], plain[1:3]):
         assert float((got.float() - ref.float()).abs().max()) <= 1e-4 * float(ref.float().abs().max()) + 1e-5
+
+
+def test_row_skip_check_knob_catches_a_caller_that_breaks_the_promise(monkeypatch):
+    """GRIT_ROW_SKIP_CHECK=1 (grit_amd/ops/backend.py check_dropped_rows): `row_scale` is the caller's promise that the gradient of the
+    dropped images is zero.  A caller that passes the factors but does not multiply the branch by them gets wrong gradients silently;
+    with the knob the backward stops with an error instead, and a caller that keeps the promise passes."""
+    from grit_amd.ops import backend
+    from grit_amd.ops.window_attention import _WindowAttentionFn
+    B, H, W, nH = 4, 20, 20, 4
+    qkv, bias, pad = _inputs(B, H, W, nH, seed=3)
+    scale = torch.tensor([1.25, 0.0, 1.25, 1.25])
+    cot = torch.randn(B, H * W, 32 * nH, generator=torch.Generator().manual_seed(5)).bfloat16()
+    monkeypatch.setattr(backend, "ROW_SKIP_CHECK", True)
+
+    def run(cotangent):
+        x = qkv.to(DEV).requires_grad_(True)
+        out = _WindowAttentionFn.apply(x, bias.to(DEV), pad.to(DEV), None, H, W, nH, 12, 6, 32**-0.5, scale.to(DEV))
+        out.backward(cotangent.to(DEV))
+        return x.grad
+
+    with pytest.raises(RuntimeError, match="promises zero gradient rows"):
+        run(cot)  # image 1 has factor 0 and a non-zero dO
+    kept = cot.clone()
+    kept[1] = 0
+    assert bool(torch.isfinite(run(kept)).all())

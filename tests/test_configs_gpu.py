@@ -38,6 +38,13 @@ GRAD_TOL = {'cap_generator.fc.weight': 0.03, 'grid_net.fc.weight': 0.12, 'cap_ge
             'detector.det_module.decoder_layers.0.cross_attn.sampling_offsets.weight': 0.55,
             'detector.backbone.layers.2.blocks.17.attn.qkv.weight': 0.12, 'detector.backbone.layers.2.blocks.0.mlp.fc1.weight': 0.12,
             'detector.input_proj.0.0.weight': 0.16}
+# two gloo ranks (half batches, bf16 sums on the wire) against one process on the whole batch: 2 x measured (profiles/r06/a14_measured.jsonl:
+# 0.0099 / 0.072 / 0.062 / 0.057 / 0.149 / 0.067 / 0.063 / 0.061 in the order of PICKS).  Until round 6: 0.15 / 0.30 for everything.
+A14_TOL = {'cap_generator.fc.weight': 0.02, 'grid_net.fc.weight': 0.145, 'cap_generator.layers.1.self_att.attention.fc_q.weight': 0.125,
+           'detector.det_module.decoder_layers.5.cross_attn.value_proj.weight': 0.115,
+           'detector.det_module.decoder_layers.0.cross_attn.sampling_offsets.weight': 0.30,
+           'detector.backbone.layers.2.blocks.17.attn.qkv.weight': 0.135, 'detector.backbone.layers.2.blocks.0.mlp.fc1.weight': 0.126,
+           'detector.input_proj.0.0.weight': 0.122}
 LOSS_TOL = 2e-4  # measured 2.1e-5 (32 images) and 3.8e-5 (16 images)
 
 
@@ -228,9 +235,9 @@ def test_a14_two_ranks_on_the_hip_path_equal_one_process_on_the_whole_batch():
         # of the partial results (2^-9 relative per tensor element) and the batch-size dependent reduction orders
         # (gradients through the deformable attention of a freshly filled decoder -- sampling_offsets starts from zero weights -- are
         # sums of cancelling terms: the same noise floor as tests/test_model_gpu.py::test_config3_*)
-        # measured: 1-7 % per tensor (the same run-to-run floor test_config3_* documents: 2-6 %); a rank whose gradient were dropped
-        # or doubled would show ~50-100 %
-        assert rel < (0.3 if 'cross_attn' in n else 0.15), (n, rel)
+        # Bound = 2 x the distance measured on MI355X (round 6, three runs, profiles/r06/a14_measured.jsonl: the runs agree to 1e-3 of
+        # the value); a rank whose gradient were dropped or doubled would show ~50-100 %
+        assert rel < A14_TOL[n], (n, rel, A14_TOL[n])
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

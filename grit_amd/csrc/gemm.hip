@@ -800,8 +800,26 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
         case 7:  // four waves, 128 x 128 wave tiles (gemm_w4.hip)
             return grit_detail::gemm_w4_launch(A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, colsum,
                                                epilogue == GRIT_GEMM_BIAS ? 0 : nt_aux, stream);
+        case 9:  // the same kernel with the tile height (256 or 224 rows) that fills the CUs better: grit_gemm_w4_tile_rows
+            return grit_detail::gemm_w4_launch(A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, colsum,
+                                               epilogue == GRIT_GEMM_BIAS ? 0 : nt_aux, stream, 0);
         default: return GRIT_ERR_BAD_ARG;
     }
+}
+
+extern "C" int grit_gemm_w4_tile_rows(int M, int N) { return grit_detail::gemm_w4_tile_rows(M, N); }
+
+// C = residual + row_scale[sample of the row] * (A B^T + bias): the output projection of a Swin branch with its residual connection
+// (persistent four-wave kernel, tile height chosen by shape).
+extern "C" int grit_gemm_bf16_nt_res(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                                     const void* bias, const void* residual, long ldres, const float* row_scale, int rows_per_sample,
+                                     void* stream) {
+    if (!A || !B || !C || !bias || !residual || M <= 0 || N <= 0 || K <= 0) return GRIT_ERR_BAD_ARG;
+    if (row_scale && rows_per_sample <= 0) return GRIT_ERR_BAD_ARG;
+    if ((lda | ldb | ldc | ldres) & 7) return GRIT_ERR_UNSUPPORTED;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias) & 15) return GRIT_ERR_UNSUPPORTED;
+    return grit_detail::gemm_w4_launch(A, lda, B, ldb, C, ldc, M, N, K, GRIT_GEMM_BIAS_RES, bias, const_cast<void*>(residual), ldres,
+                                       nullptr, 0, stream, 0, row_scale, rows_per_sample);
 }
 
 // GRIT_GEMM_DGELU / GRIT_GEMM_BIAS_GELU with the per-sample factors of the rows of A (see GemmArgs::row_scale): eight-wave variants only.

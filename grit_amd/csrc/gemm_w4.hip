@@ -37,7 +37,9 @@ struct W4Args {
     const __bf16* B; long ldb;
     __bf16* C; long ldc;
     const __bf16* bias;
-    __bf16* aux; long ldaux;   // BIAS_GELU: pre-activation out (may be NULL); DGELU: pre-activation in
+    __bf16* aux; long ldaux;   // BIAS_GELU: pre-activation out (may be NULL); DGELU: pre-activation in; BIAS_RES: the residual map in
+    const float* row_scale;    // BIAS_RES: per-sample factors of the branch (drop path) or NULL; rows_per_sample >= the tile height
+    int rows_per_sample;
     float* colsum;             // DGELU: [2 tiles_m, N] column sums of the result per 128-row wave block (rows of a shifted last tile
                                // that belong to its neighbour are left out)
     int nt;                    // non-temporal accesses, bits as GRIT_GEMM_NT_AUX
@@ -57,15 +59,26 @@ __device__ __forceinline__ void for_each_index(F&& f, std::integer_sequence<int,
 }
 
 
-template <int EPI>
+// MI = 16-row token blocks per wave: 8 (256-row tiles, the kernel as described above) or 7 (224-row tiles, round 6).  Why 7: the products
+// with N = C output columns (proj, fc2 forward, fc1 / qkv input gradients of every Swin block) have 200 x N / 256 tiles of 256 rows --
+// 400, 800, 200 at the three trainable stages: on 256 CUs the last round is 56 %, 12 %, 78 % full and the kernel runs 2, 4, 1 rounds
+// of 8 block rows.  With 224-row tiles the same maps are 458, 915, 232 tiles: 2, 4, 1 rounds of 7 block rows -- 12.5 % less time, no
+// hand-over between workgroups (the stream-K form of this kernel lost 6-84 %: tools/micro/r06_stream_k.patch).
+template <int EPI, int MI>
 __global__ __launch_bounds__(256, 1)
 void gemm_w4_bf16(const W4Args g) {
-    constexpr int BM = 256, BN = 256, BK = 64;
+    static_assert(MI == 7 || MI == 8, "wave tiles of 112 or 128 rows");
+    constexpr int BM = 32 * MI, BN = 256, BK = 64;
+    constexpr int NMFMA = 16 * MI;                   // MFMAs of one 64-deep K step of a wave
+    constexpr int NDMA = MI + 8;                     // transfers of one K step issued by a wave (MI of A, 8 of B)
     constexpr int ROWB = BK * 2;                     // 128-byte staged rows
     constexpr int A_BYTES = BM * ROWB, BUF = (BM + BN) * ROWB;  // 32 KB + 32 KB
     constexpr int IMG = 8192;                        // per wave: 32 rows x 256 B of finished bf16 output
     // stores (and compiler-visible loads) one epilogue puts between the transfers of step s + 2 and those of step s + 3
-    constexpr int EPI_OPS = EPI == GRIT_GEMM_BIAS_GELU ? 64 : (EPI == GRIT_GEMM_DGELU ? 56 : 32);
+    // (EXACT counts -- the wait behind a tile's first step allows this many younger operations: 4 MI row-segment stores per output
+    // map; the GELU' / residual epilogues also load the chunks 1.. of their second operand inside the epilogue, 4 MI - 8 pieces)
+    constexpr bool kReadsAux = EPI == GRIT_GEMM_DGELU || EPI == GRIT_GEMM_BIAS_RES;
+    constexpr int EPI_OPS = EPI == GRIT_GEMM_BIAS_GELU ? 8 * MI : (kReadsAux ? 8 * MI - 8 : 4 * MI);
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
 
@@ -91,7 +104,7 @@ void gemm_w4_bf16(const W4Args g) {
     if (g.stagger) {
         const int busiest = (band_hi - band_lo + per_xcd - 1) / per_xcd;
         if (my_tiles < busiest) {
-            const int quarter = (KT * 2900 + 9000) / 4;  // shader cycles (measured per-tile time of this kernel, K step + epilogue)
+            const int quarter = (KT * 2900 + 9000) * MI / 32;  // shader cycles (measured per-tile time of this kernel, K step + epilogue)
             const int naps = ((idx & 3) * quarter) >> 12; // s_sleep 64 = 4 096 cycles
             for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
         }
@@ -135,31 +148,33 @@ void gemm_w4_bf16(const W4Args g) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const unsigned c = (unsigned)(((4 * h + lq) ^ chunk_swizzle<BK>(l15)) * 16);
-        aoff[h] = lds0 + (wm * 128 + l15) * ROWB + c;
+        aoff[h] = lds0 + (wm * 16 * MI + l15) * ROWB + c;
         boff[h] = lds0 + A_BYTES + (wn * 128 + l15) * ROWB + c;
     }
 
-    v4f acc[8][8];
-    v8bf x0[8], w0[8], x1[8], w1[8];
+    v4f acc[MI][8];
+    v8bf x0[MI], w0[8], x1[MI], w1[8];
 #define GRIT_TIE8(f) asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]))
+#define GRIT_TIE7(f) asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]))
+#define GRIT_TIEX(f) do { if constexpr (MI == 8) GRIT_TIE8(f); else GRIT_TIE7(f); } while (0)
 
     // ---- prologue: steps 0 and 1 in flight, step 0 landed, its first half in registers
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) dmaA(q, p);
+        for (int p = 0; p < MI; ++p) dmaA(q, p);
 #pragma unroll
         for (int p = 0; p < 8; ++p) dmaB(q, p);
         advance_load();
     }
-    wait_vm<16>();
+    wait_vm<NDMA>();
     __builtin_amdgcn_s_barrier();
     for_each_index([&](auto kc) { constexpr int k = decltype(kc)::value; x0[k] = lds_read16_off<k * 2048>(aoff[0]); },
-                   std::make_integer_sequence<int, 8>{});
+                   std::make_integer_sequence<int, MI>{});
     for_each_index([&](auto kc) { constexpr int k = decltype(kc)::value; w0[k] = lds_read16_off<k * 2048>(boff[0]); },
                    std::make_integer_sequence<int, 8>{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    GRIT_TIE8(x0); GRIT_TIE8(w0);
+    GRIT_TIEX(x0); GRIT_TIE8(w0);
 
     // One 64-deep K step = 128 MFMAs (index m: k half m >> 6, token block (m >> 3) & 7, weight block m & 7), each followed by AT MOST
     // one other instruction, so that its issue hides in the 16 cycles the MFMA occupies the matrix pipe (bursts of LDS reads or
@@ -179,37 +194,45 @@ void gemm_w4_bf16(const W4Args g) {
         const unsigned a0n = aoff[0] + (unsigned)((b ^ 1) * BUF), b0n = boff[0] + (unsigned)((b ^ 1) * BUF);
         auto slot = [&](auto mc) {
             constexpr int m = decltype(mc)::value;
-            constexpr int h = m >> 6, i = (m >> 3) & 7, j = m & 7;
+            constexpr int h = m / (8 * MI), i = (m >> 3) % MI, j = m & 7;
+            // slots of the other instructions (MI = 8 as listed above; MI = 7: one token fragment and one A transfer fewer, the tail
+            // of the step closed up: the wait for step s + 1 at m 84, the 15 fragment reads of the other buffer in m 85 .. 111)
+            constexpr int M_WAIT = MI == 8 ? 92 : 84;
+            constexpr int nread = m - (M_WAIT + 1);  // position behind the wait
+            // MI = 8: every 2nd slot from 93; MI = 7: every 2nd slot 85 .. 107 (12 reads), then 109, 110, 111
+            constexpr int r_next = MI == 8 ? ((nread >= 0 && nread <= 30 && nread % 2 == 0) ? nread / 2 : -1)
+                                           : ((nread >= 0 && nread <= 22 && nread % 2 == 0) ? nread / 2
+                                              : (nread == 24 ? 12 : (nread == 25 ? 13 : (nread == 26 ? 14 : -1))));
             if constexpr (h == 0 && first) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[i][j]) : "v"(w0[j]), "v"(x0[i]));
             else if constexpr (h == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(w0[j]), "v"(x0[i]));
             else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(w1[j]), "v"(x1[i]));
-            if constexpr (m < 8) x1[m] = lds_read16_off<m * 2048>(a1);
-            else if constexpr (m < 16) w1[m - 8] = lds_read16_off<(m - 8) * 2048>(b1);
+            if constexpr (m < MI) x1[m] = lds_read16_off<m * 2048>(a1);
+            else if constexpr (m < MI + 8) w1[m - MI] = lds_read16_off<(m - MI) * 2048>(b1);
             else if constexpr (m == 20) {
                 asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                GRIT_TIE8(x1);
+                GRIT_TIEX(x1);
                 __builtin_amdgcn_s_barrier();
             } else if constexpr (m == 24) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 GRIT_TIE8(w1);
                 __builtin_amdgcn_s_barrier();
-            } else if constexpr (m >= 26 && m <= 86 && (m - 26) % 4 == 0) {
+            } else if constexpr (m >= 26 && m < 26 + 4 * NDMA && (m - 26) % 4 == 0) {
                 constexpr int d = (m - 26) / 4;
-                if constexpr (d < 8) dmaA(b, d);
-                else dmaB(b, d - 8);
-                if constexpr (d == 15) advance_load();
-            } else if constexpr (m == 92) {
-                wait_vm<first ? (16 + EPI_OPS > 63 ? 63 : 16 + EPI_OPS) : 16>();
+                if constexpr (d < MI) dmaA(b, d);
+                else dmaB(b, d - MI);
+                if constexpr (d == NDMA - 1) advance_load();
+            } else if constexpr (m == M_WAIT) {
+                wait_vm<first ? (NDMA + EPI_OPS > 63 ? 63 : NDMA + EPI_OPS) : NDMA>();
                 __builtin_amdgcn_s_barrier();
-            } else if constexpr (m >= 93 && m <= 123 && (m - 93) % 2 == 0) {
-                constexpr int r = (m - 93) / 2;
-                if constexpr (r < 8) x0[r] = lds_read16_off<r * 2048>(a0n);
-                else w0[r - 8] = lds_read16_off<(r - 8) * 2048>(b0n);
+            } else if constexpr (r_next >= 0) {
+                constexpr int r = r_next;
+                if constexpr (r < MI) x0[r] = lds_read16_off<r * 2048>(a0n);
+                else w0[r - MI] = lds_read16_off<(r - MI) * 2048>(b0n);
             }
         };
-        for_each_index(slot, std::make_integer_sequence<int, 128>{});
+        for_each_index(slot, std::make_integer_sequence<int, NMFMA>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        GRIT_TIE8(x0); GRIT_TIE8(w0);
+        GRIT_TIEX(x0); GRIT_TIE8(w0);
     };
 
     // ---- epilogue of one tile: four chunks of 32 rows through the wave's image (transposed: whole 256-byte row segments out)
@@ -239,29 +262,41 @@ void gemm_w4_bf16(const W4Args g) {
     auto h_rows = [&](int ti, auto cc, u32x4 (&dst)[8]) {
         constexpr int c = decltype(cc)::value;
         const int t = tile_of(ti), tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
-        const int mw = min(tm * BM, g.M - BM) + wm * 128, nw = tn * BN + wn * 128;
+        const int mw = min(tm * BM, g.M - BM) + wm * 16 * MI, nw = tn * BN + wn * 128;
+        constexpr int NP = 4 * (MI - 2 * c >= 2 ? 2 : 1);  // pieces of 4 rows in chunk c (MI = 7: the last chunk is one 16-row block)
 #pragma unroll
-        for (int pc = 0; pc < 8; ++pc) {
+        for (int pc = 0; pc < NP; ++pc) {
             const __bf16* hp = g.aux + (size_t)(mw + 32 * c + 4 * pc + (lane >> 4)) * g.ldaux + nw + (lane & 15) * 8;
             dst[pc] = (g.nt & 8) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(hp)) : *reinterpret_cast<const u32x4*>(hp);
         }
     };
     auto pre_epilogue = [&](int ti) {
-        if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU) {
+        if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU || EPI == GRIT_GEMM_BIAS_RES) {
             const int t = tile_of(ti), tn = t % g.tiles_n;
             const int nw = tn * BN + wn * 128;
 #pragma unroll
             for (int j = 0; j < 8; ++j) braw[j] = *reinterpret_cast<const uint2*>(g.bias + nw + 16 * j + 4 * lq);
         }
-        if constexpr (EPI == GRIT_GEMM_DGELU) h_rows(ti, std::integral_constant<int, 0>{}, hv[0]);
+        if constexpr (kReadsAux) h_rows(ti, std::integral_constant<int, 0>{}, hv[0]);
     };
     auto epilogue = [&](int ti) {
         const int t = tile_of(ti), tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
         const int m_tile = tm * BM, m0 = min(m_tile, g.M - BM);
-        const int mw = m0 + wm * 128, nw = tn * BN + wn * 128;
+        const int mw = m0 + wm * 16 * MI, nw = tn * BN + wn * 128;
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last asm MFMAs retire before their accumulators are read
+        // BIAS_RES: the factor of a row's sample.  A tile is at most rows_per_sample rows high (host-checked): two samples at most
+        float s_lo = 1.f, s_hi = 1.f;
+        int m_split = 0x7fffffff;
+        if constexpr (EPI == GRIT_GEMM_BIAS_RES) {
+            if (g.row_scale != nullptr) {
+                const int b0 = m0 / g.rows_per_sample, nb = (g.M + g.rows_per_sample - 1) / g.rows_per_sample;
+                m_split = (b0 + 1) * g.rows_per_sample;
+                s_lo = g.row_scale[b0];
+                s_hi = g.row_scale[min(b0 + 1, nb - 1)];
+            }
+        }
         v4f bias4[8];
-        if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU) {
+        if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU || EPI == GRIT_GEMM_BIAS_RES) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 bias4[j] = v4f{__builtin_bit_cast(float, braw[j].x << 16), __builtin_bit_cast(float, braw[j].x & 0xffff0000u),
@@ -275,20 +310,21 @@ void gemm_w4_bf16(const W4Args g) {
         const size_t col = (size_t)nw + (lane & 15) * 8;
         for_each_index([&](auto cc) {
             constexpr int c = decltype(cc)::value;
+            constexpr int NB = MI - 2 * c >= 2 ? 2 : 1, NP = 4 * NB;  // 16-row blocks / 4-row pieces of this chunk
             for_each_index([&](auto qc) {
                 constexpr int q = decltype(qc)::value, il = q >> 3, j = q & 7;
                 // (pins the quad to its AGPRs up to here: without it the allocator copies all 256 accumulators into VGPRs at the
                 // top of the epilogue and spills 140 of them)
                 asm volatile("" : "+a"(acc[2 * c + il][j]));
                 v4f v = acc[2 * c + il][j];
-                if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU) v += bias4[j];
+                if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU || EPI == GRIT_GEMM_BIAS_RES) v += bias4[j];
                 v4bf p;
                 p[0] = (__bf16)v[0]; p[1] = (__bf16)v[1]; p[2] = (__bf16)v[2]; p[3] = (__bf16)v[3];
                 const uint2 pk = __builtin_bit_cast(uint2, p);
                 const unsigned pb = put_base[j];  // (a variable named only in an asm operand of a nested generic lambda is not captured)
                 asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(pb), "v"(pk), "n"(il * 4096) : "memory");
-            }, std::make_integer_sequence<int, 16>{});
-            if constexpr (EPI == GRIT_GEMM_DGELU && c < 3) h_rows(ti, std::integral_constant<int, c + 1>{}, hv[(c + 1) & 1]);
+            }, std::make_integer_sequence<int, 8 * NB>{});
+            if constexpr (kReadsAux && c < 3) h_rows(ti, std::integral_constant<int, c + 1>{}, hv[(c + 1) & 1]);
             // the chunk's eight pieces come back from the image together (one wait), then leave one by one
             u32x4 pv[8];
             for_each_index([&](auto pcc) {
@@ -297,9 +333,12 @@ void gemm_w4_bf16(const W4Args g) {
                 u32x4 tv;
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tv) : "v"(go), "n"((pc >> 2) * 4096) : "memory");
                 pv[pc] = tv;
-            }, std::make_integer_sequence<int, 8>{});
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]),
-                         "+v"(pv[7]) :: "memory");
+            }, std::make_integer_sequence<int, NP>{});
+            if constexpr (NP == 8)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]),
+                             "+v"(pv[7]) :: "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]) :: "memory");
             for_each_index([&](auto pcc) {
                 constexpr int pc = decltype(pcc)::value;
                 const u32x4 v = pv[pc];
@@ -337,11 +376,31 @@ void gemm_w4_bf16(const W4Args g) {
                         cs[2 * e + 1] += own ? y[1] : 0.f;
                     }
                     store16(g.C + (size_t)m * g.ldc + col, u32x4{o[0], o[1], o[2], o[3]}, nt_c);
+                } else if constexpr (EPI == GRIT_GEMM_BIAS_RES) {
+                    // image = the branch as an unfused Linear would store it (bf16); x = shortcut + factor * branch in fp32, rounded once --
+                    // bit for bit what grit_add_layernorm_fwd computes from the stored branch
+                    const u32x4 rx = hv[c & 1][pc];
+                    const float sc = m < m_split ? s_lo : s_hi;
+                    unsigned o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float b0 = __builtin_bit_cast(float, v[e] << 16), b1 = __builtin_bit_cast(float, v[e] & 0xffff0000u);
+                        const float r0 = __builtin_bit_cast(float, rx[e] << 16), r1 = __builtin_bit_cast(float, rx[e] & 0xffff0000u);
+                        typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+                        v2bf pk;
+                        pk[0] = (__bf16)__fadd_rn(r0, __fmul_rn(b0, sc)); pk[1] = (__bf16)__fadd_rn(r1, __fmul_rn(b1, sc));  // (not fused: the add_layernorm kernel's order)
+                        o[e] = __builtin_bit_cast(unsigned, pk);
+                    }
+                    store16(g.C + (size_t)m * g.ldc + col, u32x4{o[0], o[1], o[2], o[3]}, false);
                 } else {
                     store16(g.C + (size_t)m * g.ldc + col, v, nt_c);
                 }
-            }, std::make_integer_sequence<int, 8>{});
+            }, std::make_integer_sequence<int, NP>{});
         }, std::make_integer_sequence<int, 4>{});
+        if constexpr (EPI == GRIT_GEMM_BIAS_GELU) {
+            // (no pre-activation kept: half the stores EPI_OPS counts -- drain, so that the next step's counted wait is exact)
+            if (!g.aux) wait_vm<0>();
+        }
         if constexpr (EPI == GRIT_GEMM_DGELU) {
             // lanes l, l + 16, l + 32, l + 48 hold the same 8 channels (different rows): fold them, lanes 0..15 write 8 floats each
 #pragma unroll
@@ -377,33 +436,53 @@ void gemm_w4_bf16(const W4Args g) {
 
 namespace grit_detail {
 
-int gemm_w4_launch(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K, int epilogue,
-                   const void* bias, void* aux, long ldaux, float* colsum, int nt, void* stream) {
-    if (N % 256 || K % 64 || M < 256) return GRIT_ERR_UNSUPPORTED;
-    if (epilogue < GRIT_GEMM_NONE || epilogue > GRIT_GEMM_DGELU) return GRIT_ERR_UNSUPPORTED;
-    if ((long)M * lda * 2 >= 0x7fffffffL || (long)N * ldb * 2 >= 0x7fffffffL) return GRIT_ERR_UNSUPPORTED;  // 32-bit buffer offsets
-    constexpr int LDS = 2 * (256 + 256) * 128 + 4 * 8192;  // 160 KB: the whole CU
-    W4Args g;
-    g.A = (const __bf16*)A; g.lda = lda; g.B = (const __bf16*)B; g.ldb = ldb; g.C = (__bf16*)C; g.ldc = ldc;
-    g.bias = (const __bf16*)bias; g.aux = (__bf16*)aux; g.ldaux = ldaux; g.colsum = colsum; g.nt = nt;
-    static const int stagger = [] { const char* e = getenv("GRIT_GEMM_W4_STAGGER"); return e ? atoi(e) : 1; }();
-    g.stagger = stagger;
-    g.M = M; g.N = N; g.K = K;
-    g.tiles_m = (M + 255) / 256;
-    g.tiles_n = N / 256;
+static int device_cus() {
     static grit_detail::PerDevice<int> cus_pd; int& cus = cus_pd();
     if (cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GRIT_ERR_LAUNCH;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
         cus = prop.multiProcessorCount;
     }
+    return cus;
+}
+
+// Tile height (256 or 224 rows) that needs fewer block rows per CU: rounds of one tile per CU x 16-row blocks per wave (see the kernel).
+int gemm_w4_tile_rows(int M, int N) {
+    const int cus = device_cus();
+    if (cus <= 0 || M < 256 || N % 256) return 256;
+    const long t8 = (long)((M + 255) / 256) * (N / 256), t7 = (long)((M + 223) / 224) * (N / 256);
+    const long c8 = ((t8 + cus - 1) / cus) * 8, c7 = ((t7 + cus - 1) / cus) * 7;
+    return c7 < c8 ? 224 : 256;
+}
+
+int gemm_w4_launch(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K, int epilogue,
+                   const void* bias, void* aux, long ldaux, float* colsum, int nt, void* stream, int tile_rows,
+                   const float* row_scale, int rows_per_sample) {
+    if (N % 256 || K % 64 || M < 256) return GRIT_ERR_UNSUPPORTED;
+    if (epilogue < GRIT_GEMM_NONE || epilogue > GRIT_GEMM_BIAS_RES) return GRIT_ERR_UNSUPPORTED;
+    if ((long)M * lda * 2 >= 0x7fffffffL || (long)N * ldb * 2 >= 0x7fffffffL) return GRIT_ERR_UNSUPPORTED;  // 32-bit buffer offsets
+    if (tile_rows == 0) tile_rows = gemm_w4_tile_rows(M, N);
+    if (tile_rows != 224 && tile_rows != 256) return GRIT_ERR_BAD_ARG;
+    if (epilogue == GRIT_GEMM_BIAS_RES && (!aux || (row_scale && rows_per_sample < tile_rows))) return GRIT_ERR_UNSUPPORTED;
+    constexpr int LDS = 2 * (256 + 256) * 128 + 4 * 8192;  // 160 KB: the whole CU (224-row tiles: 8 KB less, same occupancy)
+    W4Args g;
+    g.A = (const __bf16*)A; g.lda = lda; g.B = (const __bf16*)B; g.ldb = ldb; g.C = (__bf16*)C; g.ldc = ldc;
+    g.bias = (const __bf16*)bias; g.aux = (__bf16*)aux; g.ldaux = ldaux; g.colsum = colsum; g.nt = nt;
+    g.row_scale = row_scale; g.rows_per_sample = rows_per_sample;
+    static const int stagger = [] { const char* e = getenv("GRIT_GEMM_W4_STAGGER"); return e ? atoi(e) : 1; }();
+    g.stagger = stagger;
+    g.M = M; g.N = N; g.K = K;
+    g.tiles_m = (M + tile_rows - 1) / tile_rows;
+    g.tiles_n = N / 256;
+    const int cus = device_cus();
+    if (cus <= 0) return GRIT_ERR_LAUNCH;
     const int ntiles = g.tiles_m * g.tiles_n;
     const dim3 grid(ntiles < cus ? ntiles : cus), block(256);
-#define GRIT_W4_LAUNCH(E)                                                                                            \
+#define GRIT_W4_LAUNCH_MI(E, MI_)                                                                                    \
     {                                                                                                                \
-        auto kern = gemm_w4_bf16<E>;                                                                                 \
-        static grit_detail::PerDevice<bool> attr_done_pd; bool& attr_done = attr_done_pd();                                                                               \
+        auto kern = gemm_w4_bf16<E, MI_>;                                                                            \
+        static grit_detail::PerDevice<bool> attr_done_pd; bool& attr_done = attr_done_pd();                          \
         if (!attr_done) {                                                                                            \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) \
                 return GRIT_ERR_LAUNCH;                                                                              \
@@ -411,13 +490,16 @@ int gemm_w4_launch(const void* A, long lda, const void* B, long ldb, void* C, lo
         }                                                                                                            \
         hipLaunchKernelGGL(kern, grid, block, LDS, (hipStream_t)stream, g);                                          \
     }
+#define GRIT_W4_LAUNCH(E) { if (tile_rows == 224) GRIT_W4_LAUNCH_MI(E, 7) else GRIT_W4_LAUNCH_MI(E, 8) }
     switch (epilogue) {
         case GRIT_GEMM_NONE: GRIT_W4_LAUNCH(GRIT_GEMM_NONE) break;
         case GRIT_GEMM_BIAS: GRIT_W4_LAUNCH(GRIT_GEMM_BIAS) break;
         case GRIT_GEMM_BIAS_GELU: GRIT_W4_LAUNCH(GRIT_GEMM_BIAS_GELU) break;
-        default: GRIT_W4_LAUNCH(GRIT_GEMM_DGELU) break;
+        case GRIT_GEMM_DGELU: GRIT_W4_LAUNCH(GRIT_GEMM_DGELU) break;
+        default: GRIT_W4_LAUNCH(GRIT_GEMM_BIAS_RES) break;
     }
 #undef GRIT_W4_LAUNCH
+#undef GRIT_W4_LAUNCH_MI
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 

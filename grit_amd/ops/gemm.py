@@ -41,11 +41,35 @@ def gemm_nt(a, b, epilogue=NONE, bias=None, aux=None, colsum=None, out=None, var
     v = VARIANT if variant is None else variant
     work = gemm_work(M, N, K, outputs=2 if (epilogue == BIAS_GELU and aux is not None) else 1,
                      extra_in=1 if epilogue == DGELU else 0)
-    with _lib.device_guard(a.device), timed("gemm_own", epilogue=epilogue, kernel="gemm_w4" if v == 7 else "gemm_nt_bf16", **work):
+    with _lib.device_guard(a.device), timed("gemm_own", epilogue=epilogue, kernel="gemm_w4" if v in (7, 9) else "gemm_nt_bf16", **work):
         st = _lib.load().grit_gemm_bf16_nt(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0), M, N, K,
                                            epilogue, _ptr(bias), _ptr(aux), aux.stride(0) if aux is not None else 0,
                                            _ptr(colsum), VARIANT if variant is None else variant, _lib.current_stream_ptr())
     _lib.check(st, "grit_gemm_bf16_nt")
+    return out
+
+
+W4 = 9  # variant of grit_gemm_bf16_nt the long-map policy runs: the persistent four-wave kernel, tile height (256 / 224 rows) by shape
+
+
+def w4_tile_rows(M, N, device=None):
+    """Tile height variant 9 runs for an [M, N] output on the current device (sizes the GELU' column-sum partials: 2 rows per tile row)."""
+    return int(_lib.load().grit_gemm_w4_tile_rows(int(M), int(N)))
+
+
+def gemm_nt_residual(a, b, bias, residual, row_scale=None, rows_per_sample=0, out=None):
+    """out[M, N] = residual + row_scale[m // rows_per_sample] * bf16(a @ b^T + bias): the output projection of a Swin branch with its
+    residual connection in one launch (grit_gemm_bf16_nt_res); the branch map is never written.  row_scale: [B] float32 or None."""
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    work = gemm_work(M, N, K, extra_in=1)
+    with _lib.device_guard(a.device), timed("gemm_own", epilogue=4, kernel="gemm_w4", **work):
+        st = _lib.load().grit_gemm_bf16_nt_res(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0), M, N, K, _ptr(bias),
+                                               _ptr(residual), residual.stride(0), _ptr(row_scale) if row_scale is not None else None,
+                                               int(rows_per_sample), _lib.current_stream_ptr())
+    _lib.check(st, "grit_gemm_bf16_nt_res")
     return out
 
 
@@ -55,7 +79,7 @@ def _fused_variant(M, N, K):
     (stage 2: 146 / 186 against 167 / 182; profiles/r04/fused_variants.txt).  GRIT_GEMM_VARIANT overrides."""
     if VARIANT:
         return VARIANT
-    return 7 if (OWN and K >= 1024 and K % 64 == 0 and N % 256 == 0 and M >= 256 and M * K * 2 < 2 ** 31 and N * K * 2 < 2 ** 31) else 0
+    return W4 if (OWN and K >= 1024 and K % 64 == 0 and N % 256 == 0 and M >= 256 and M * K * 2 < 2 ** 31 and N * K * 2 < 2 ** 31) else 0
 
 
 def linear_bias_gelu(x2, weight, bias, row_scale=None, rows_per_sample=0):
@@ -101,8 +125,9 @@ def input_grad_dgelu(dy2, weight_t, pre, row_scale=None, rows_per_sample=0):
         _lib.check(st, "grit_gemm_bf16_nt_rows")
         return d_pre, partial
     v = _fused_variant(M, N, dy2.shape[1])
-    # (the four-wave kernel writes one row of sums per 128-row wave block of its 256-row tiles: 2 ceil(M / 256) rows, all written)
-    partial = torch.empty((2 * -(-M // 256) if v == 7 else -(-M // COLSUM_ROWS), N), dtype=torch.float32, device=dy2.device)
+    # (the four-wave kernel writes one row of sums per wave block of its 256- or 224-row tiles: 2 ceil(M / height) rows, all written)
+    w4_rows = 256 if v == 7 else (w4_tile_rows(M, N) if v == W4 else 0)
+    partial = torch.empty((2 * -(-M // w4_rows) if w4_rows else -(-M // COLSUM_ROWS), N), dtype=torch.float32, device=dy2.device)
     d_pre = gemm_nt(dy2, weight_t, DGELU, aux=pre, colsum=partial, variant=v)
     return d_pre, partial
 
@@ -117,15 +142,22 @@ OWN_MIN_ROWS = 8192
 _CUS = 256
 
 
+# GRIT_GEMM_OWN_DEEP (default 1, round 6): also the K >= 1 024 products with <= 512 output columns (fc2 forward, fc1 / qkv input
+# gradients of every Swin block) on the own kernel, now that 224-row tiles fill the CUs (profiles/r06/w4_vs_lib_224.txt: 0.91-1.14 x
+# the library's stream-K kernel stand-alone, ahead of it in the step: profiles/r06/ab_own_deep.txt).  0: the round-5 policy.
+OWN_DEEP = os.environ.get("GRIT_GEMM_OWN_DEEP", "1") != "0"
+
+
 def prefers_own(M, N, K):
-    """Shape policy, measured on MI355X against the tuned library kernels (profiles/r04/w4_vs_lib.txt): the own kernel wins or ties
-    where a tile has few K steps (K <= 512: the library pays a ring fill per tile; e.g. stage-1 proj 58 -> 42 us, stage-2 qkv 84 ->
-    77 us) and at K = 1 024 with wide outputs; the library's stream-K kernel is ahead at K >= 1 024 with <= 512 output columns (400
-    tiles on 256 CUs) and on the 12 000-tile value projection."""
+    """Shape policy, measured on MI355X against the tuned library kernels (profiles/r04/w4_vs_lib.txt, profiles/r06/w4_vs_lib_224.txt):
+    the own kernel wins or ties where a tile has few K steps (K <= 512: the library pays a ring fill per tile; e.g. stage-1 proj
+    58 -> 42 us, stage-2 qkv 84 -> 77 us), at K = 1 024 with wide outputs and -- with 224-row tiles, round 6 -- on the K >= 1 024
+    products with <= 512 output columns (400 / 800 / 200 tiles of 256 rows filled 256 CUs 1.56 / 3.1 / 0.78 times); the library stays
+    ahead on the 12 000-tile value projection."""
     if N % 256 or K % 64 or M < OWN_MIN_ROWS or M * K * 2 >= 2 ** 31 or N * K * 2 >= 2 ** 31:
         return False
     tiles = -(-M // 256) * (N // 256)
-    return tiles <= 8192 and (K <= 512 or (K <= 1024 and N >= 1024))
+    return tiles <= 8192 and (OWN_DEEP or K <= 512 or (K <= 1024 and N >= 1024))
 
 
 def prefers_own_narrow(M, N, K):
@@ -142,10 +174,28 @@ def long_linear(x2, weight, bias):
     M, K = x2.shape
     N = weight.shape[0]
     if prefers_own(M, N, K):
-        return gemm_nt(x2, weight, BIAS if bias is not None else NONE, bias=bias, variant=7)
+        return gemm_nt(x2, weight, BIAS if bias is not None else NONE, bias=bias, variant=W4)
     if prefers_own_narrow(M, N, K):
         return gemm_nt(x2, weight, BIAS if bias is not None else NONE, bias=bias, variant=0)
     return None
+
+
+def long_linear_residual(x2, weight, bias, residual2, scale, rows_per_sample):
+    """residual2 + scale[sample] * (x2 @ weight^T + bias) in ONE launch (gemm_nt_residual) where the own kernel takes the shape, or None.
+    scale: [B] float32 drop-path factors or None."""
+    if not (OWN and RESIDUAL and bias is not None and supported(x2, weight) and bias.dtype == torch.bfloat16 and bias.data_ptr() % 16 == 0
+            and residual2.dtype == torch.bfloat16 and residual2.is_contiguous() and residual2.data_ptr() % 16 == 0
+            and residual2.shape == (x2.shape[0], weight.shape[0]) and prefers_own(x2.shape[0], weight.shape[0], x2.shape[1])):
+        return None
+    if scale is not None and not (scale.is_cuda and scale.dtype == torch.float32 and scale.is_contiguous() and rows_per_sample >= 256
+                                  and scale.numel() * rows_per_sample == x2.shape[0]):
+        return None
+    return gemm_nt_residual(x2, weight, bias, residual2, scale, rows_per_sample)
+
+
+# GRIT_GEMM_RESIDUAL (default 1, round 6): proj / fc2 of a Swin block write x = shortcut + factor * branch themselves; the LayerNorm that
+# follows reads x only (grit_layernorm_fwd instead of grit_add_layernorm_fwd: one map read instead of two, one written instead of two).
+RESIDUAL = os.environ.get("GRIT_GEMM_RESIDUAL", "1") != "0"
 
 
 def long_input_grad(dy2, weight):
@@ -160,7 +210,7 @@ def long_input_grad(dy2, weight):
     if wt is None:
         return None
     if supported(dy2, wt) and prefers_own(dy2.shape[0], wt.shape[0], wt.shape[1]):
-        return gemm_nt(dy2, wt, NONE, variant=7)
+        return gemm_nt(dy2, wt, NONE, variant=W4)
     if supported(dy2, wt) and prefers_own_narrow(dy2.shape[0], wt.shape[0], wt.shape[1]):
         return gemm_nt(dy2, wt, NONE, variant=0)
     with timed("gemm_lib", **gemm_work(dy2.shape[0], wt.shape[0], wt.shape[1])):

@@ -215,6 +215,16 @@ def _add_layer_norm_backward(x2, weight, mean, rstd, scale, gx, gy, batch, branc
     return dx, d_branch, slab_sum(base, weight.dtype, slabs=nblk)
 
 
+def _residual_linear(inp, lin_w, lin_b, s2, scale, rows_per_sample):
+    """s2 + scale[sample] * (inp @ lin_w^T + lin_b) as ONE launch of the own GEMM (grit_amd/ops/gemm.py long_linear_residual), or None
+    where that does not apply (short maps, fp32, shapes the policy leaves to the library)."""
+    if not (inp.is_cuda and inp.dtype == torch.bfloat16 and s2.dtype == torch.bfloat16 and inp.numel() // inp.shape[-1] >= 8192):
+        return None
+    from grit_amd.ops import gemm as _gemm
+    x2 = inp.reshape(-1, inp.shape[-1])
+    return _gemm.long_linear_residual(x2 if x2.is_contiguous() else x2.contiguous(), lin_w, lin_b, s2, scale, rows_per_sample)
+
+
 class _LinearAddLayerNormFn(Function):
     """(inp, W, b, shortcut, scale) -> (x, LayerNorm(x)) with x = shortcut + scale * (inp @ W^T + b): the output projection
     of a Swin branch (attn.proj / mlp.fc2), the residual connection and the LayerNorm that follows, as one node -- so the
@@ -226,27 +236,34 @@ class _LinearAddLayerNormFn(Function):
         ctx.sum_params = (weight, bias, lin_b) if single_use else None  # the parameters whose gradients the node's sums are
         ctx.lin_w_param = lin_w if single_use else None
         ctx.lin_w_obj = lin_w  # the tensor object of the call: transposed copies are attached to it (grit_amd/ops/transposed.py)
-        branch = _own_linear(inp, lin_w, lin_b)  # long maps: the own four-wave kernel where it is the faster one
-        if branch is None:
-            with timed("gemm_lib", **gemm_work(inp.numel() // inp.shape[-1], lin_w.shape[0], lin_w.shape[1])):
-                branch = F.linear(inp, lin_w, lin_b)
         C = shortcut.shape[-1]
         s2 = shortcut.reshape(-1, C)
         s2 = s2 if s2.is_contiguous() else s2.contiguous()
-        b2 = branch.reshape(-1, C)
         rows = s2.shape[0]
-        x = torch.empty_like(s2)
+        x = _residual_linear(inp, lin_w, lin_b, s2, scale, rows // shortcut.shape[0]) if drop_p == 0 else None
         y = torch.empty_like(s2)
         mean = torch.empty(rows, dtype=torch.float32, device=s2.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=s2.device)
         xb, wb = int(s2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
-        with _lib.device_guard(s2.device):
-            st = _lib.load().grit_add_layernorm_fwd(_ptr(s2), _ptr(b2), _ptr(scale) if scale is not None else None,
-                                                    rows // shortcut.shape[0], float(drop_p),
-                                                    _ptr(seed_dev) if drop_p > 0 else None, _ptr(weight), _ptr(bias), rows, C,
-                                                    eps, xb, wb, _ptr(x), _ptr(y), _ptr(mean), _ptr(rstd),
+        if x is not None:  # long maps: the projection wrote x = shortcut + factor * branch itself; the LayerNorm reads x only
+            with _lib.device_guard(s2.device):
+                st = _lib.load().grit_layernorm_fwd(_ptr(x), _ptr(weight), _ptr(bias), rows, C, eps, xb, wb, _ptr(y), _ptr(mean), _ptr(rstd),
                                                     _lib.current_stream_ptr())
-        _lib.check(st, "grit_add_layernorm_fwd")
+            _lib.check(st, "grit_layernorm_fwd")
+        else:
+            branch = _own_linear(inp, lin_w, lin_b)  # long maps: the own four-wave kernel where it is the faster one
+            if branch is None:
+                with timed("gemm_lib", **gemm_work(inp.numel() // inp.shape[-1], lin_w.shape[0], lin_w.shape[1])):
+                    branch = F.linear(inp, lin_w, lin_b)
+            b2 = branch.reshape(-1, C)
+            x = torch.empty_like(s2)
+            with _lib.device_guard(s2.device):
+                st = _lib.load().grit_add_layernorm_fwd(_ptr(s2), _ptr(b2), _ptr(scale) if scale is not None else None,
+                                                        rows // shortcut.shape[0], float(drop_p),
+                                                        _ptr(seed_dev) if drop_p > 0 else None, _ptr(weight), _ptr(bias), rows, C,
+                                                        eps, xb, wb, _ptr(x), _ptr(y), _ptr(mean), _ptr(rstd),
+                                                        _lib.current_stream_ptr())
+            _lib.check(st, "grit_add_layernorm_fwd")
         ctx.save_for_backward(x, weight, mean, rstd, scale, inp, lin_w, seed_dev)
         ctx.shape, ctx.drop_p = shortcut.shape, drop_p
         ctx.set_materialize_grads(False)  # see _AddLayerNormFn

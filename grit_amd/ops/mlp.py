@@ -139,23 +139,31 @@ class _MlpAddLayerNormFn(Function):
         x2 = _rows(x_in)
         # (scale: the drop-path factors of this branch -- the fc1 tiles of samples it removes are not computed)
         pre, act = G.linear_bias_gelu(x2, w1, b1, scale, x2.shape[0] // shortcut.shape[0] if scale is not None else 0)
-        branch = G.long_linear(act, w2, b2)  # (the stage-0 map: the own narrow-output kernel; None elsewhere)
-        if branch is None:
-            with timed("gemm_lib", **gemm_work(act.numel() // act.shape[-1], w2.shape[0], w2.shape[1])):
-                branch = F.linear(act, w2, b2)
         C = shortcut.shape[-1]
         s2 = _rows(shortcut)
         rows = s2.shape[0]
-        x = torch.empty_like(s2)
         y = torch.empty_like(s2)
         mean = torch.empty(rows, dtype=torch.float32, device=s2.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=s2.device)
         xb, wb = int(s2.dtype == torch.bfloat16), int(weight.dtype == torch.bfloat16)
-        with _lib.device_guard(s2.device):
-            st = _lib.load().grit_add_layernorm_fwd(_ptr(s2), _ptr(branch), _ptr(scale), rows // shortcut.shape[0], 0.0, None,
-                                                    _ptr(weight), _ptr(bias), rows, C, eps, xb, wb, _ptr(x), _ptr(y),
-                                                    _ptr(mean), _ptr(rstd), _lib.current_stream_ptr())
-        _lib.check(st, "grit_add_layernorm_fwd")
+        # fc2 with the residual connection in its epilogue (x = shortcut + factor * branch, one launch), then the LayerNorm of x alone
+        x = G.long_linear_residual(act, w2, b2, s2, scale, rows // shortcut.shape[0])
+        if x is not None:
+            with _lib.device_guard(s2.device):
+                st = _lib.load().grit_layernorm_fwd(_ptr(x), _ptr(weight), _ptr(bias), rows, C, eps, xb, wb, _ptr(y), _ptr(mean), _ptr(rstd),
+                                                    _lib.current_stream_ptr())
+            _lib.check(st, "grit_layernorm_fwd")
+        else:
+            branch = G.long_linear(act, w2, b2)  # (the stage-0 map: the own narrow-output kernel; None elsewhere)
+            if branch is None:
+                with timed("gemm_lib", **gemm_work(act.numel() // act.shape[-1], w2.shape[0], w2.shape[1])):
+                    branch = F.linear(act, w2, b2)
+            x = torch.empty_like(s2)
+            with _lib.device_guard(s2.device):
+                st = _lib.load().grit_add_layernorm_fwd(_ptr(s2), _ptr(branch), _ptr(scale), rows // shortcut.shape[0], 0.0, None,
+                                                        _ptr(weight), _ptr(bias), rows, C, eps, xb, wb, _ptr(x), _ptr(y),
+                                                        _ptr(mean), _ptr(rstd), _lib.current_stream_ptr())
+            _lib.check(st, "grit_add_layernorm_fwd")
         ctx.save_for_backward(x, weight, mean, rstd, scale, x2, w1, pre, act, w2)
         ctx.shape, ctx.in_shape = shortcut.shape, x_in.shape
         ctx.set_materialize_grads(False)

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 38
+#define GRIT_ABI_VERSION 39
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -527,9 +527,25 @@ int grit_image_batch_fwd(const uint8_t* src, const int64_t* desc, const int32_t*
 #define GRIT_GEMM_BIAS 1
 #define GRIT_GEMM_BIAS_GELU 2
 #define GRIT_GEMM_DGELU 3
+#define GRIT_GEMM_BIAS_RES 4   /* grit_gemm_bf16_nt_res only */
 #define GRIT_GEMM_COLSUM_ROWS 128
 int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                       int epilogue, const void* bias, void* aux, long ldaux, float* colsum, int variant, void* stream);
+/* variant 9 = variant 7 with the tile height chosen by shape: 256 rows, or 224 where that needs fewer 16-row block rows per CU
+ * (the N = C products of the Swin blocks -- proj, fc2 forward, fc1 / qkv input gradients: 400 / 800 / 200 tiles of 256 rows fill the
+ * 256 CUs 1.56 / 3.1 / 0.78 times, 458 / 915 / 232 tiles of 224 rows 1.79 / 3.6 / 0.91 times: 12.5 % less time, same rounds).  Same
+ * products in the same k order: results bit-identical to variant 7.  grit_gemm_w4_tile_rows(M, N) = the height variant 9 runs for a
+ * shape on the current device; its GRIT_GEMM_DGELU column sums are 2 * ceil(M / height) rows. */
+int grit_gemm_w4_tile_rows(int M, int N);
+/* The output projection of a Swin branch WITH its residual connection (models/common/swin_model.py:289-298:
+ * x = shortcut + drop_path(proj(...)) / x = x + drop_path(mlp(...))):
+ *     C[m, n] = residual[m, n] + row_scale[m / rows_per_sample] * bf16(acc[m, n] + bias[n])
+ * -- the branch rounded to bf16 as an unfused Linear stores it, product and sum in fp32 (not fused), one rounding: bit for bit what
+ * grit_add_layernorm_fwd computes as its `sum_out` from a stored branch.  row_scale NULL = 1 (then rows_per_sample is ignored);
+ * otherwise rows_per_sample >= 256.  The branch map is never written or re-read.  Shape limits of variant 7. */
+int grit_gemm_bf16_nt_res(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                          const void* bias, const void* residual, long ldres, const float* row_scale, int rows_per_sample,
+                          void* stream);
 /* The fused Mlp GEMMs with the per-sample drop-path factors of the Swin blocks at hand (models/common/swin_model.py:289-298:
  * x = shortcut + drop_path(mlp(norm2(x))); a dropped sample's branch contributes nothing forward and receives an exactly zero
  * gradient): row_scale [ceil(M / rows_per_sample)] f32 on the device; a 256-row tile that lies inside ONE sample with factor 0 is

@@ -97,6 +97,118 @@ def test_gemm_four_wave_persistent_kernel(M, N, K):
     assert (db - ref_db).abs().max().item() <= 4e-3 * ref_db.abs().max().item() + 1e-2, (db - ref_db).abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K", [(51200, 512, 2048), (12800, 1024, 1024), (204800, 256, 768), (4096 + 17, 512, 512), (300, 256, 128),
+                                   (12800, 4096, 1024)])
+def test_gemm_four_wave_224_row_tiles(M, N, K):
+    """Variant 9 = variant 7 with the tile height chosen by shape (gemm_w4.hip, MI = 7: 224-row tiles where they need fewer block rows
+    per CU).  Same products in the same k order per accumulator: EVERY output of every epilogue bit for bit equal to variant 7; the
+    GELU' column sums (2 rows per tile row, hence a different partition of the rows) equal after the sum; nothing written outside them."""
+    from grit_amd.ops import gemm as G
+    x, w, b = _inputs(M, N, K, seed=(M + N) % 83)
+    rows = G.w4_tile_rows(M, N)
+    assert rows in (224, 256)
+    if (M, N) in ((51200, 512), (12800, 1024), (204800, 256)):
+        assert rows == 224  # the N = C products of the three trainable Swin stages on a 256-CU device
+    assert torch.equal(G.gemm_nt(x, w, G.NONE, variant=9), G.gemm_nt(x, w, G.NONE, variant=7))
+    assert torch.equal(G.gemm_nt(x, w, G.BIAS, bias=b, variant=9), G.gemm_nt(x, w, G.BIAS, bias=b, variant=7))
+    pre7 = torch.empty((M, N), device='cuda', dtype=torch.bfloat16)
+    pre9 = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
+    act7 = G.gemm_nt(x, w, G.BIAS_GELU, bias=b, aux=pre7, variant=7)
+    act9 = G.gemm_nt(x, w, G.BIAS_GELU, bias=b, aux=pre9, variant=9)
+    assert torch.equal(act7, act9) and torch.equal(pre7, pre9)
+    assert torch.equal(act7, G.gemm_nt(x, w, G.BIAS_GELU, bias=b, variant=9))  # (no pre-activation kept)
+    aux = torch.randn(M, N, device='cuda').bfloat16()
+    part7 = torch.zeros((2 * (-(-M // 256)), N), device='cuda')
+    slabs = 2 * (-(-M // rows))
+    fenced = torch.full((slabs + 2, N), float('nan'), device='cuda')
+    part9 = fenced[1:1 + slabs]
+    part9.zero_()
+    d7 = G.gemm_nt(x, w, G.DGELU, aux=aux, colsum=part7, variant=7)
+    d9 = G.gemm_nt(x, w, G.DGELU, aux=aux, colsum=part9, variant=9)
+    assert torch.equal(d7, d9)
+    assert torch.isnan(fenced[0]).all() and torch.isnan(fenced[-1]).all() and torch.isfinite(part9).all()
+    s7, s9 = part7.sum(0), part9.sum(0)
+    assert float((s7 - s9).abs().max()) <= 1e-4 * float(s7.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("M,N,K,per", [(51200, 512, 512, 1600), (51200, 512, 2048, 1600), (12800, 1024, 4096, 400), (204800, 256, 256, 6400),
+                                       (4096 + 17, 512, 512, 0), (2560, 256, 128, 256)])
+def test_gemm_residual_epilogue(M, N, K, per):
+    """grit_gemm_bf16_nt_res: x = shortcut + factor[sample] * (inp W^T + b) in one launch, against the two-launch form it replaces --
+    the branch stored in bf16 by variant 7, then grit_add_layernorm_fwd's sum -- bit for bit (same roundings in the same order), with
+    drop-path factors (zeros included: x == shortcut there, whatever the branch) and without; and against the float32 arithmetic."""
+    from grit_amd.ops import gemm as G
+    from grit_amd.ops.layer_norm import add_layer_norm
+    x, w, b = _inputs(M, N, K, seed=(M + K) % 71)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    res = torch.randn(M, N, device='cuda', generator=g).bfloat16()
+    branch = G.gemm_nt(x, w, G.BIAS, bias=b, variant=7)
+    if per:
+        B = M // per
+        scale = torch.full((B,), 1.0 / 0.9, device='cuda')
+        scale[torch.arange(B, device='cuda') % 5 == 1] = 0.0
+    else:
+        B, scale = 1, None
+    got = G.gemm_nt_residual(x, w, b, res, scale, per)
+    ln_w, ln_b = torch.ones(N, device='cuda').bfloat16(), torch.zeros(N, device='cuda').bfloat16()
+    want, _ = add_layer_norm(res.view(B, M // B, N), branch.view(B, M // B, N), scale, ln_w, ln_b)
+    assert torch.equal(got, want.reshape(M, N))
+    ref = res.float() + (1.0 if scale is None else scale.repeat_interleave(per)[:, None]) * (x.float() @ w.float().t() + b.float())
+    _close(got, ref)
+    if scale is not None:
+        dropped = (scale == 0).repeat_interleave(per)
+        assert torch.equal(got[dropped], res[dropped])
+
+
+def test_residual_epilogue_inside_the_block_tail_nodes(monkeypatch):
+    """_LinearAddLayerNormFn (attn.proj + residual + norm2) and _MlpAddLayerNormFn (Mlp + residual + next norm1) with the residual
+    connection in the GEMM epilogue (GRIT_GEMM_RESIDUAL, default) against the same nodes with the stored branch + grit_add_layernorm_fwd:
+    x, LayerNorm(x) and every gradient bit for bit (the epilogue reproduces the add kernel's roundings; the backward is the same code)."""
+    from grit_amd.ops import gemm as G
+    from grit_amd.ops import transposed
+    from grit_amd.ops.layer_norm import LayerNorm, linear_add_layer_norm
+    from grit_amd.ops.linear import Linear
+    from grit_amd.ops.mlp import mlp_add_layer_norm
+    torch.manual_seed(3)
+    B, T, C = 8, 1600, 512
+    proj = Linear(C, C).cuda().bfloat16()
+    norm = LayerNorm(C).cuda().bfloat16()
+    with torch.no_grad():
+        norm.weight.normal_(1.0, 0.2)
+        norm.bias.normal_(0.0, 0.2)
+
+    class Mlp(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1, self.act, self.fc2, self.drop = Linear(C, 4 * C), torch.nn.GELU(), Linear(4 * C, C), torch.nn.Dropout(0.0)
+    mlp = Mlp().cuda().bfloat16()
+    inp = torch.randn(B, T, C, device='cuda').bfloat16()
+    shortcut = torch.randn(B, T, C, device='cuda').bfloat16()
+    scale = torch.full((B,), 1.0 / 0.85, device='cuda')
+    scale[2] = 0.0
+    cot = [torch.randn(B, T, C, device='cuda').bfloat16() for _ in range(2)]
+    params = list(proj.parameters()) + list(norm.parameters()) + list(mlp.parameters())
+    results = []
+    for fused in (True, False):
+        monkeypatch.setattr(G, "RESIDUAL", fused)
+        transposed.refresh([proj.weight, mlp.fc1.weight, mlp.fc2.weight])
+        out = []
+        for which in ("proj", "mlp"):
+            for p in params:
+                p.grad = None
+            a, s_ = inp.clone().requires_grad_(True), shortcut.clone().requires_grad_(True)
+            if which == "proj":
+                x, y = linear_add_layer_norm(a, proj, s_, scale, norm.weight, norm.bias, norm.eps)
+            else:
+                x, y = mlp_add_layer_norm(a, mlp, s_, scale, norm)
+            (x * cot[0] * scale.view(-1, 1, 1).to(x.dtype) + y * cot[1]).sum().backward()
+            out += [x.detach(), y.detach(), a.grad, s_.grad] + [p.grad.clone() for p in params if p.grad is not None]
+        results.append(out)
+    assert len(results[0]) == len(results[1])
+    for i, (f, u) in enumerate(zip(*results)):
+        assert torch.equal(f, u), i
+
+
 def test_own_long_map_policy_and_linear_nodes():
     """grit_amd.ops.gemm.prefers_own / long_linear / long_input_grad and the Linear node on top: the own kernel takes the long-map
     shapes the policy names (values and gradients equal to the library path within bf16 rounding), everything else runs the library."""
@@ -104,7 +216,8 @@ def test_own_long_map_policy_and_linear_nodes():
     from grit_amd.ops import transposed
     from grit_amd.ops.linear import linear
     assert G.prefers_own(51200, 1536, 512) and G.prefers_own(51200, 512, 512) and G.prefers_own(12800, 3072, 1024)
-    assert not G.prefers_own(51200, 512, 2048) and not G.prefers_own(4800, 512, 512) and not G.prefers_own(51200, 384, 512)
+    assert G.prefers_own(51200, 512, 2048) and G.prefers_own(12800, 1024, 4096) and G.prefers_own(204800, 256, 1024)  # (round 6: 224-row tiles)
+    assert not G.prefers_own(4800, 512, 512) and not G.prefers_own(51200, 384, 512)
     assert not G.prefers_own(272000, 3072, 512)  # 12 756 tiles: the library's kernel is ahead there (profiles/r04/w4_vs_lib.txt)
     torch.manual_seed(0)
     M, N, K = 16384, 512, 256

@@ -46,8 +46,10 @@ def main():
             err = ((out.float() - ref.float()).abs().max() / ref.float().abs().max()).item()
             t_own = t(lambda: G.gemm_nt(x, w, G.BIAS, bias=b, out=out, variant=7))
             t_v0 = t(lambda: G.gemm_nt(x, w, G.BIAS, bias=b, out=out, variant=0))
-            print("%-26s M%-7d N%-5d K%-5d  lib NT %6.1f  lib NN %6.1f  own %6.1f us  (%.2f x NT)  err %.1e  | eight-wave v0 %6.1f" %
-                  (name, M, N, K, t_lib, t_mm, t_own, t_lib / t_own, err, t_v0), flush=True)
+            t_v9 = t(lambda: G.gemm_nt(x, w, G.BIAS, bias=b, out=out, variant=9))
+            t_lib2 = t(lambda: F.linear(x, w, b))
+            print("%-26s M%-7d N%-5d K%-5d  lib NT %6.1f / %6.1f  lib NN %6.1f  own v7 %6.1f  v9 (%d rows) %6.1f us  (%.2f x NT)  err %.1e  | eight-wave v0 %6.1f" %
+                  (name, M, N, K, t_lib, t_lib2, t_mm, t_own, G.w4_tile_rows(M, N), t_v9, min(t_lib, t_lib2) / t_v9, err, t_v0), flush=True)
         except Exception as e:
             try:
                 t_v0 = t(lambda: G.gemm_nt(x, w, G.BIAS, bias=b, out=out, variant=0))

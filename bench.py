@@ -267,21 +267,29 @@ def cpu_baseline(config, size, caption_len, steps, budget_s=60.0):
     # Thread sweep at batch 1 (1 warm-up + 2 timed steps each): torch's CPU kernels do NOT scale with the cores of these hosts --
     # measured on a 128-core / 256-cpu box: 0.55 images/s with 8 threads, 0.21 with 64, 0.10 with 128 (profiles/r03/README.md) --
     # so the headline is the BEST point of the sweep (the baseline most favourable to the CPU), with its thread count in `cores`.
+    # Round 6 (BASELINE.md section 3 asks for N = physical cores and a median of 5): the sweep takes ONE timed step per point and includes
+    # the N = physical-cores point; the headline is then re-measured at the best thread count as the median of `steps` (5) timed steps.
     matrix = []
-    for threads in sorted({min(8, logical), min(16, physical), min(32, physical), min(64, physical)}):
-        if time.perf_counter() - t_leg < 0.75 * budget_s:
-            r = sample(1, threads, min(steps, 2))
+    for threads in sorted({min(8, logical), min(16, physical), min(32, physical), min(64, physical), physical}):
+        if time.perf_counter() - t_leg < 0.6 * budget_s:
+            r = sample(1, threads, 1)
             if r is not None:
-                matrix.append(r)
-    head = max(matrix, key=lambda r: r["images_per_sec"])
-    if time.perf_counter() - t_leg < 0.85 * budget_s:
+                matrix.append(dict(r, role="sweep"))
+    best = max(matrix, key=lambda r: r["images_per_sec"])
+    head = sample(1, best["threads"], steps) if time.perf_counter() - t_leg < 0.8 * budget_s else None
+    if head is None:
+        head = best
+    else:
+        matrix.append(dict(head, role="headline"))
+    if time.perf_counter() - t_leg < 0.9 * budget_s:
         r = sample(4, head["threads"], 1)
         if r is not None:
-            matrix.append(r)
+            matrix.append(dict(r, role="batch 4"))
     return {"value": head["images_per_sec"], "unit": "images/sec", "cores": head["threads"], "kind": "port",
-            "sample": f"batch 1, {size}x{size}, T={caption_len}, fp32, best of a thread sweep (8 / 16 / 32 / 64 threads, 1 warm-up + "
-                      f"median of {head['timed_steps']} timed steps each) on a host with {physical} physical cores / {logical} cpus; "
-                      f"`matrix` holds every point plus batch 4 at the best thread count; the leg is budgeted at {budget_s:.0f} s",
+            "sample": f"batch 1, {size}x{size}, T={caption_len}, fp32: thread sweep (8 / 16 / 32 / 64 / {physical} = physical cores; 1 warm-up + "
+                      f"1 timed step each), then 1 warm-up + median of {head['timed_steps']} timed steps at the best thread count "
+                      f"({head['threads']}) on a host with {physical} physical cores / {logical} cpus; `matrix` holds every point plus "
+                      f"batch 4 at that thread count; the leg is budgeted at {budget_s:.0f} s (steps are dropped past it)",
             "matrix": matrix, "physical_cores": physical, "leg_seconds": time.perf_counter() - t_leg}
 
 

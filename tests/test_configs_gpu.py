@@ -67,8 +67,9 @@ def _free_port():
     return port
 
 
-def _config4_worker(rank, port, mode, n_images, ret):
-    """mode: 'plain' (no process group), 'rccl' (one-rank nccl group, self-collectives), 'fp32' (fp32 weights and kernels)."""
+def _config4_worker(rank, port, mode, n_images, ret, fill=False, smooth=0):
+    """mode: 'plain' (no process group), 'rccl' (one-rank nccl group, self-collectives), 'fp32' (fp32 weights and kernels).
+    fill: the name-keyed deterministic fill (tests/golden/fill.py) instead of the modules' own initialisation."""
     from grit_amd.amp import Bf16Compute
     from grit_amd.data import synthetic_batch
     torch.cuda.set_device(0)
@@ -76,11 +77,17 @@ def _config4_worker(rank, port, mode, n_images, ret):
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GRIT_DDP_SELF_COLLECTIVES="1")
         dist.init_process_group("nccl", rank=0, world_size=1)
     torch.manual_seed(0)
-    model, cfg = build_model(3, fill=False, **{'model.dropout': 0.0, 'model.detector.dropout': 0.0})
+    model, cfg = build_model(3, fill=fill, **{'model.dropout': 0.0, 'model.detector.dropout': 0.0})
     model.train().to(DEV)
     disable_drop_path(model)
     loss_fn = torch.nn.NLLLoss(ignore_index=1)
     batch = synthetic_batch(n_images, 640, 640, 20, device=DEV, seed=4)
+    if smooth:
+        # low-frequency images (white noise on a smooth x smooth grid, bicubic to 640 x 640): the feature maps then vary smoothly between
+        # neighbouring cells, and the gradient w.r.t. a sampling location -- differences of neighbouring values -- is a well-conditioned
+        # function of the location (on white-noise images a 0.1-pixel shift of a sampling point decorrelates it)
+        coarse = torch.randn(n_images, 3, smooth, smooth, generator=torch.Generator().manual_seed(11)).to(DEV)
+        batch['samples'].tensors.copy_(torch.nn.functional.interpolate(coarse, size=(640, 640), mode='bicubic', align_corners=False))
     issued = []
     if mode == 'fp32':
         out = model(batch['samples'], batch['captions'])
@@ -109,10 +116,11 @@ def _config4_worker(rank, port, mode, n_images, ret):
         dist.destroy_process_group()
 
 
-def _run(worker, *args):
+def _run(worker, *args, extra=()):
+    """worker(rank, *args, ret, *extra) in a fresh process; returns what it left in `ret`."""
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(worker, args=args + (ret,), nprocs=1, join=True)
+        mp.spawn(worker, args=args + (ret,) + tuple(extra), nprocs=1, join=True)
         return dict(ret)
 
 
@@ -143,6 +151,41 @@ def test_config3_bs16_step_against_the_fp32_kernels():
     fp32 = _run(_config4_worker, _free_port(), 'fp32', 16)
     assert plain["finite"] and fp32["finite"] and 8.0 < plain["loss"] < 10.5
     assert_close_to_fp32_step(plain, fp32)
+
+
+# measured on MI355X, round 6 (profiles/r06/filled_step_measured.jsonl, the `smooth 10` line); bound = 2 x measured
+FILLED_TOL = {'cap_generator.fc.weight': 0.022, 'grid_net.fc.weight': 0.107, 'cap_generator.layers.1.self_att.attention.fc_q.weight': 0.146,
+              'detector.det_module.decoder_layers.5.cross_attn.value_proj.weight': 0.10,
+              'detector.det_module.decoder_layers.0.cross_attn.sampling_offsets.weight': 0.70,
+              'detector.backbone.layers.2.blocks.17.attn.qkv.weight': 0.108, 'detector.backbone.layers.2.blocks.0.mlp.fc1.weight': 0.119,
+              'detector.input_proj.0.0.weight': 0.131}
+
+
+def test_filled_decoder_step_against_the_fp32_kernels():
+    """The same comparison with the name-keyed fill of the golden fixtures instead of the modules' own initialisation: MSDeformAttn's
+    `_reset_parameters` zero-initialises sampling_offsets.weight, so in the two tests above its gradient is a sum of cancelling terms and
+    is held at 0.55 only; here the sampling points spread over the maps (offsets weight ~ N(0, 1 / 512), bias ~ N(0, 1)) and the bf16
+    MSDeformAttn backward's grad_loc path is checked at model level with a non-degenerate tensor.
+
+    What the measurement showed (round 6, profiles/r06/filled_step_measured.jsonl): that tensor's bf16-vs-fp32 distance is set by the
+    CONDITIONING of d(output)/d(location) -- differences of neighbouring cells of bf16-stored value maps -- not by the kernel (which
+    matches the oracle to 1e-3 on equal inputs, tests/test_msda_gpu.py).  On white-noise images (neighbouring cells uncorrelated: a
+    0.1-pixel shift of a point, e.g. from the bf16 box-refinement MLPs, decorrelates the term) it is 0.90; on images that are smooth
+    over 16 / 32 / 64 / 128 pixels 0.57 / 0.39 / 0.35 / 0.33: the floor is the 2^-9 rounding of neighbouring values whose difference
+    is a few per cent of their size.  Zero-mean rounding noise, cosine 0.94 with the fp32 gradient; every other picked tensor is at
+    0.01-0.07.  The test runs the smooth-64 images (GRIT_TEST_SMOOTH=10 coarse cells) and bounds each tensor at 2 x measured."""
+    smooth = int(os.environ.get("GRIT_TEST_SMOOTH", "10"))
+    plain = _run(_config4_worker, _free_port(), 'plain', 8, extra=(True, smooth))
+    fp32 = _run(_config4_worker, _free_port(), 'fp32', 8, extra=(True, smooth))
+    assert plain["finite"] and fp32["finite"]
+    rels = {n: float(torch.linalg.norm(plain["grads"][n] - fp32["grads"][n]) / torch.linalg.norm(fp32["grads"][n])) for n in PICKS}
+    rel_loss = abs(plain["loss"] - fp32["loss"]) / abs(fp32["loss"])
+    if os.environ.get("GRIT_TEST_MEASURE"):
+        with open(os.environ["GRIT_TEST_MEASURE"], "a") as f:
+            f.write(json.dumps({"test": "filled_decoder_step", "rels": rels, "loss": [plain["loss"], fp32["loss"]]}) + "\n")
+    assert rel_loss < LOSS_TOL, (plain["loss"], fp32["loss"])  # measured 4e-5
+    for n, rel in rels.items():
+        assert rel < FILLED_TOL[n], rels
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

@@ -25,13 +25,14 @@ from grit_amd.models.ops.modules import MSDeformAttn
 from grit_amd.ops.attention import attention as fused_attention
 from grit_amd.ops.glue import box_refine, relu_dropout
 from grit_amd.ops.layer_norm import linear_add_layer_norm
-from grit_amd.ops.linear import Linear, linear, mark_single_use, shared_input_linears
+from grit_amd.ops.linear import Linear, linear, mark_single_use, packed_in_proj, shared_input_linears
 from grit_amd.ops.msda import StackedValueMaps
 
 _SHARED_VALUE_PROJ = os.environ.get('GRIT_SHARED_VALUE_PROJ', '1') != '0'  # A/B knobs
 _STACKED_VALUE_MAPS = os.environ.get('GRIT_STACKED_VALUE_MAPS', '1') != '0'
 from grit_amd.utils.misc import inverse_sigmoid
 
+_PACKED_IN_PROJ = os.environ.get("GRIT_DET_PACKED_IN_PROJ", "1") != "0"  # A/B knob (round 6): 0 = split weights, two Linear nodes
 _QK_LINEAR = os.environ.get("GRIT_DET_QK_LINEAR", "1") != "0"  # A/B knob: 0 = F.linear for the self-attention in-projections
 
 
@@ -99,14 +100,19 @@ class DeformableTransformerDecoderLayer(nn.Module):
         E, h = mha.embed_dim, mha.num_heads
         B, Lq, _ = tgt.shape
         qk_in = self.with_pos_embed(tgt, query_pos)
-        # split (not slices): the backward of a split is one concatenation, a slice's is a zero fill + copy + add each
-        w_qk, w_v = mha.in_proj_weight.split([2 * E, E])
-        b_qk, b_v = mha.in_proj_bias.split([2 * E, E])
-        # (ops.linear.linear, not F.linear: its backward sums the bias gradient with the column-sum kernel -- autograd's reduce kernel
-        # needs 23 us for a [4 800, 1 024] column sum, eleven of them per step)
-        lin = linear if _QK_LINEAR else F.linear
-        qk = lin(qk_in, w_qk, b_qk)  # one GEMM for q and k
-        v = lin(tgt, w_v, b_v)
+        if _PACKED_IN_PROJ and self.training and torch.is_grad_enabled() and tgt.is_cuda:
+            # ONE node over the packed parameter: both row ranges of its weight / bias gradient join the bucket's grouped launch
+            # (grit_amd/ops/linear.py _PackedInProjFn) instead of two library TN GEMMs, two column sums and three concatenations
+            qk, v = packed_in_proj(qk_in, tgt, mha.in_proj_weight, mha.in_proj_bias)
+        else:
+            # split (not slices): the backward of a split is one concatenation, a slice's is a zero fill + copy + add each
+            w_qk, w_v = mha.in_proj_weight.split([2 * E, E])
+            b_qk, b_v = mha.in_proj_bias.split([2 * E, E])
+            # (ops.linear.linear, not F.linear: its backward sums the bias gradient with the column-sum kernel -- autograd's reduce
+            # kernel needs 23 us for a [4 800, 1 024] column sum, eleven of them per step)
+            lin = linear if _QK_LINEAR else F.linear
+            qk = lin(qk_in, w_qk, b_qk)  # one GEMM for q and k
+            v = lin(tgt, w_v, b_v)
         q, k = (t.view(B, Lq, h, E // h) for t in qk.split(E, -1))
         out = fused_attention(q, k, v.view(B, Lq, h, E // h), None, scale=1.0 / math.sqrt(E // h),
                               dropout_p=mha.dropout, training=self.training)

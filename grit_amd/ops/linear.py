@@ -139,6 +139,99 @@ def defer_weight_bias_grad(dy2, x2, weight, bias, need_dw, need_db, single_use, 
     return dw, db
 
 
+def defer_packed_weight_bias_grad(parts, weight, bias):
+    """A packed projection (nn.MultiheadAttention.in_proj_weight / in_proj_bias: the rows of several Linears in one parameter) whose
+    row ranges are computed from DIFFERENT inputs: parts = [(dy2 [M, N_i], x2 [M, K]), ...] in row order.  Returns (dW [sum N_i, K],
+    db [sum N_i]) as tensors that flush_deferred() fills range by range -- each part is one more problem of the scope's grouped launch --
+    or None when the jobs must be done by the node itself (same conditions as defer_weight_bias_grad; all or nothing)."""
+    if not (WGRAD_DEFER and _deferral["active"] and weight.grad is None and bias is not None and bias.grad is None
+            and weight.dtype == torch.bfloat16 and bias.dtype == torch.bfloat16 and not backend.foreign_capture()):
+        return None
+    K = weight.shape[1]
+    for dy2, x2 in parts:
+        M, N = dy2.shape
+        if not (dy2.is_cuda and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and M < WGRAD_SMALL_MAX_ROWS and N % 64 == 0
+                and K % 64 == 0 and x2.shape == (M, K) and dy2.stride(1) == 1 and x2.stride(1) == 1 and dy2.stride(0) % 8 == 0
+                and x2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0):
+            return None
+    if sum(dy2.shape[1] for dy2, _ in parts) != weight.shape[0]:
+        return None
+    dev = parts[0][0].device
+    dw = grad_slot(weight, torch.bfloat16, dev) if DEFER_SLOT_SHORT else None
+    if dw is None:
+        dw = torch.empty(tuple(weight.shape), dtype=torch.bfloat16, device=dev)
+    db = grad_slot(bias, torch.bfloat16, dev) if DEFER_SLOT_SHORT else None
+    if db is None:
+        db = torch.empty(tuple(bias.shape), dtype=torch.bfloat16, device=dev)
+    pw0, pb0, row = dw.data_ptr(), db.data_ptr(), 0
+    for dy2, x2 in parts:
+        M, N = dy2.shape
+        _deferral["jobs"].append((dy2, x2, (weight, pw0), (bias, pb0), pw0 + row * K * 2, pb0 + row * 2, M, N, K, None))
+        row += N
+    return dw, db
+
+
+class _PackedInProjFn(Function):
+    """(qk_in, v_in, W [3E, E], b [3E]) -> (qk_in W[:2E]^T + b[:2E], v_in W[2E:]^T + b[2E:]): the in-projections of an
+    nn.MultiheadAttention whose query / key input differs from its value input (DeformableTransformerDecoderLayer: q = k = tgt + pos,
+    v = tgt; reference models/detection/det_module.py:313-326).  Taken apart with split() the weight gradient came back as two library
+    TN GEMMs (41 + 31 us at 4 800 rows), two column-sum launches and three concatenations per layer; as ONE node over the packed
+    parameter both row ranges join the gradient bucket's grouped weight-gradient launch and land in the parameter's bucket slot."""
+
+    @staticmethod
+    def forward(ctx, qk_in, v_in, weight, bias):
+        E = weight.shape[1]
+        ctx.save_for_backward(qk_in, v_in, weight)
+        ctx.bias_param, ctx.weight_param = bias, weight
+        with timed("gemm_lib", **gemm_work(qk_in.numel() // E + v_in.numel() // E, 3 * E // 2, E)):
+            return F.linear(qk_in, weight[:2 * E], bias[:2 * E]), F.linear(v_in, weight[2 * E:], bias[2 * E:])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dqk, dv):
+        qk_in, v_in, weight = ctx.saved_tensors
+        E = weight.shape[1]
+        dqk2, dv2 = dqk.reshape(-1, 2 * E), dv.reshape(-1, E)
+        dqk2 = dqk2 if dqk2.is_contiguous() else dqk2.contiguous()
+        dv2 = dv2 if dv2.is_contiguous() else dv2.contiguous()
+        q2, v2 = qk_in.reshape(-1, E), v_in.reshape(-1, E)
+        q2 = q2 if q2.is_contiguous() else q2.contiguous()
+        v2 = v2 if v2.is_contiguous() else v2.contiguous()
+        d_qk_in = d_v_in = dw = db = None
+        with timed("gemm_lib", **gemm_work(dqk2.shape[0] + dv2.shape[0], E, 3 * E // 2)):
+            if ctx.needs_input_grad[0]:
+                d_qk_in = torch.mm(dqk2, weight[:2 * E]).view(qk_in.shape)
+            if ctx.needs_input_grad[1]:
+                d_v_in = torch.mm(dv2, weight[2 * E:]).view(v_in.shape)
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            deferred = defer_packed_weight_bias_grad([(dqk2, q2), (dv2, v2)], ctx.weight_param, ctx.bias_param) \
+                if (ctx.needs_input_grad[2] and ctx.needs_input_grad[3]) else None
+            if deferred is not None:
+                dw, db = deferred
+            else:
+                group = SlabGroup() if dqk2.is_cuda else None
+                dws = [weight_grad(dqk2, q2, group), weight_grad(dv2, v2, group)]
+                dbs = [column_sum(dqk2, weight.dtype, group), column_sum(dv2, weight.dtype, group)] if dqk2.is_cuda \
+                    else [dqk2.sum(0), dv2.sum(0)]
+                if group is not None:
+                    group.run()  # (the group's outputs hold their values only now)
+                dw, db = torch.cat(dws), torch.cat(dbs)
+        return d_qk_in, d_v_in, dw, db
+
+
+def packed_in_proj(qk_in, v_in, weight, bias):
+    """(qk [.., 2E], v [.., E]) of an nn.MultiheadAttention's packed in-projection with q = k = qk_in and v = v_in; the fused node on the
+    device in training, the plain slices otherwise."""
+    E = weight.shape[1]
+    fits = (backend.override() is None and qk_in.is_cuda and torch.is_grad_enabled() and not torch.is_autocast_enabled()
+            and weight.requires_grad and bias is not None and qk_in.dtype == v_in.dtype == weight.dtype == bias.dtype
+            and qk_in.dtype in (torch.bfloat16, torch.float32) and weight.shape[0] == 3 * E and qk_in.shape == v_in.shape
+            and qk_in.numel() // E >= MIN_ROWS)
+    if not fits:
+        return F.linear(qk_in, weight[:2 * E], bias[:2 * E]), F.linear(v_in, weight[2 * E:], bias[2 * E:])
+    return _PackedInProjFn.apply(qk_in, v_in, weight, bias)
+
+
 def defer_slab_group(group, checks):
     """Leave the pending reductions of `group` (a SlabGroup whose outputs are parameter gradients of a single-use node: LayerNorm
     dgamma / dbeta, a projection's bias gradient) to flush_deferred() instead of launching them now.  checks: [(parameter, device
@@ -162,6 +255,8 @@ def _verify(p, ptr, what, final):
     hook, i.e. possibly BETWEEN the deliveries of two gradients of one node: a gradient the engine has not delivered yet (it
     holds the tensor, the memory is valid) is written anyway and checked at the next flush -- before anything can have replaced
     it, because every bucket pack starts with a flush -- and at the final flush (backward is over) it must be there."""
+    if isinstance(p, tuple):  # (parameter, address its gradient must have): a job that fills a ROW RANGE of a packed parameter's gradient
+        p, ptr = p
     if p.grad is None and not final:
         _deferral["unverified"].append((p, ptr, what))
     elif p.grad is None or p.grad.data_ptr() != ptr:

@@ -469,6 +469,59 @@ def test_deferred_grouped_weight_gradients(monkeypatch):
     assert not L._deferral["unverified"] and not L._deferral["slabs"]
 
 
+def test_packed_in_projection_node(monkeypatch):
+    """ops.linear.packed_in_proj (the decoder layers' nn.MultiheadAttention in-projection with q = k = tgt + pos, v = tgt, reference
+    models/detection/det_module.py:313-326): one node over the packed [3E, E] parameter.  Inside a gradient-bucket scope its two row
+    ranges are two problems of the scope's grouped weight-gradient launch, written into the parameter's bucket slot; outside they are
+    computed by the node.  Both against the split-weights form (two Linear nodes): outputs bit for bit, gradients within bf16
+    accumulation-order noise; nothing pending afterwards."""
+    from grit_amd.ddp import BucketedDataParallel
+    from grit_amd.ops import linear as L
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mha = torch.nn.MultiheadAttention(512, 8)
+            self.packed = True
+
+        def forward(self, t, pos):
+            w, b, E = self.mha.in_proj_weight, self.mha.in_proj_bias, 512
+            if self.packed:
+                return L.packed_in_proj(t + pos, t, w, b)
+            w_qk, w_v = w.split([2 * E, E])
+            b_qk, b_v = b.split([2 * E, E])
+            return L.linear(t + pos, w_qk, b_qk), L.linear(t, w_v, b_v)
+
+    torch.manual_seed(1)
+    net = Net().to(DEV).bfloat16()
+    with torch.no_grad():
+        net.mha.in_proj_bias.normal_(0, 0.1)
+    t = torch.randn(32, 150, 512, device=DEV).bfloat16().requires_grad_(True)
+    pos = torch.randn(32, 150, 512, device=DEV).bfloat16()
+    c_qk = torch.randn(32, 150, 1024, device=DEV).bfloat16()
+    c_v = torch.randn(32, 150, 512, device=DEV).bfloat16()
+    results = {}
+    for name, packed, wrap in (("split", False, False), ("node", True, False), ("bucket", True, True)):
+        net.packed = packed
+        for p_ in net.parameters():
+            p_.grad = None
+        t.grad = None
+        model = BucketedDataParallel(net, bucket_mb=1) if wrap else net
+        qk, v = model(t, pos)
+        ((qk.float() * c_qk.float()).sum() + (v.float() * c_v.float()).sum()).backward()
+        if wrap:
+            assert len(L._deferral["jobs"]) + sum(b.packed for b in model.buckets) > 0
+            model.finish_gradient_sync()
+        assert not L._deferral["jobs"] and not L._deferral["unverified"] and not L._deferral["active"]
+        torch.cuda.synchronize()
+        results[name] = (qk.detach(), v.detach(), t.grad.float().clone(), net.mha.in_proj_weight.grad.float().clone(),
+                         net.mha.in_proj_bias.grad.float().clone())
+    for name in ("node", "bucket"):
+        assert torch.equal(results[name][0], results["split"][0]) and torch.equal(results[name][1], results["split"][1])
+        for got, ref in zip(results[name][2:], results["split"][2:]):
+            assert (got - ref).abs().max().item() <= 2e-2 * ref.abs().max().item() + 1e-6, name
+
+
 def test_long_map_weight_gradients_are_written_into_their_bucket_slots(monkeypatch):
     """Inside a gradient-bucket scope the weight gradients of long maps (own GEMM + slab sum) are summed straight into the parameter's
     slot of the flat bucket (ops.linear.grad_slot): autograd adopts the view, the bucket pack finds the gradient in place and does

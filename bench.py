@@ -69,7 +69,7 @@ MSDA_FWD_KERNEL = {"fwd": "msda_fwd_vec4<16,4> (MSDeformAttn forward, fp32 value
                    "fwd_bf16": "msda_fwd_bf16_rows4<2> (MSDeformAttn forward, bf16 value map, fp32 sampling geometry)"}
 # HBM-side bytes per launch come from the committed PMC summary of THIS command (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), read at run time: no figure is typed in here
-PMC_SUMMARIES = ("profiles/r05/pmc_in_step.txt", "profiles/r04/pmc_in_step.txt", "profiles/r03/pmc_in_step.txt", "profiles/r02/pmc_in_step.txt")
+PMC_SUMMARIES = ("profiles/r06/pmc_in_step.txt", "profiles/r05/pmc_in_step.txt", "profiles/r04/pmc_in_step.txt", "profiles/r03/pmc_in_step.txt", "profiles/r02/pmc_in_step.txt")
 
 
 def pmc_traffic(kernel_substring):
@@ -712,7 +712,7 @@ def main():
                             "`frac_hbm` = algorithmic bytes (operands once + outputs once + fp32 split partials) / time / 8 TB/s; `bound` names "
                             "the larger one, `frac` is its value.  Per-launch HIP events on the launch stream in %d eager steps right behind "
                             "the timed region (an event pair adds ~5 us to a launch); `traffic` = PMC bytes per launch where "
-                            "profiles/r05/pmc_in_step.txt (or an earlier round.s) has the kernel" % n_an}
+                            "profiles/r06/pmc_in_step.txt (or an earlier round.s) has the kernel" % n_an}
             for name, f in families.items():
                 tt = f["t"]
                 fm, fh = f["flops"] / tt / MFMA_PEAK_BF16, f["bytes"] / tt / 1e9 / HBM_PEAK_GBPS

@@ -205,6 +205,9 @@ void gemm_nt_bf16(const GemmArgs g) {
                 for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], x0[i], acc[i][j], 0, 0, 0);
                 if (i < LOADS && kStage) dma_piece(pslot, pkt, i);
             }
+#pragma unroll
+            for (int i = MT; i < LOADS; ++i)  // (small tiles: more pieces than token blocks)
+                if (kStage) dma_piece(pslot, pkt, i);
         } else {
             v8bf w1[NTL], x1[MT];
             // k-step 0 MFMAs, with the reads of k-step 1 and the first DMA pieces in between
@@ -218,11 +221,17 @@ void gemm_nt_bf16(const GemmArgs g) {
                 if (i < LOADS / 2 && kStage) dma_piece(pslot, pkt, i);
             }
 #pragma unroll
+            for (int i = MT; i < LOADS / 2; ++i)  // (small tiles: more pieces than token blocks)
+                if (kStage) dma_piece(pslot, pkt, i);
+#pragma unroll
             for (int i = 0; i < MT; ++i) {
 #pragma unroll
                 for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j], x1[i], acc[i][j], 0, 0, 0);
                 if (i < LOADS - LOADS / 2 && kStage) dma_piece(pslot, pkt, LOADS / 2 + i);
             }
+#pragma unroll
+            for (int i = MT; i < LOADS - LOADS / 2; ++i)
+                if (kStage) dma_piece(pslot, pkt, LOADS / 2 + i);
         }
     };
 
@@ -778,7 +787,7 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
     // 16-byte DMA pieces and row stores: leading dimensions in multiples of 8 elements, 16-byte aligned bases
     if ((lda | ldb | ldc | (aux ? ldaux : 0)) & 7) return GRIT_ERR_UNSUPPORTED;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)aux | (uintptr_t)bias) & 15) return GRIT_ERR_UNSUPPORTED;
-    if (N % 128 || K % 32) return GRIT_ERR_UNSUPPORTED;
+    if ((N % 128 && !(variant == 12 && N % 64 == 0)) || K % 32) return GRIT_ERR_UNSUPPORTED;
     GemmArgs a;
     a.A = (const __bf16*)A; a.lda = lda; a.B = (const __bf16*)B; a.ldb = ldb; a.C = (__bf16*)C; a.ldc = ldc;
     a.bias = (const __bf16*)bias; a.aux = (__bf16*)aux; a.ldaux = ldaux; a.colsum = colsum;
@@ -791,12 +800,19 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
 #endif
     hipStream_t st = (hipStream_t)stream;
     if (variant == 0) variant = (N % 256 == 0 && K % 64 == 0) ? 4 : 1;  // measured: tools/bench_gemm.py
+    if (variant >= 10 && variant <= 13 && epilogue == GRIT_GEMM_DGELU) return GRIT_ERR_UNSUPPORTED;  // (column sums are laid out per 128 rows)
     switch (variant) {
         case 1: return launch<256, 128, 32, 2, 2, 3>(a, epilogue, st);
         case 2: return (K % 64) ? GRIT_ERR_UNSUPPORTED : launch<256, 128, 64, 2, 2, 2>(a, epilogue, st);  // needs 96 KB: 1 WG / CU
         case 3: return launch<256, 128, 32, 2, 2, 4>(a, epilogue, st);  // deeper ring, 96 KB
         case 4: return (K % 64 || N % 256) ? GRIT_ERR_UNSUPPORTED : launch<256, 256, 64, 2, 4, 2>(a, epilogue, st);  // 8 waves, 128 KB
         case 5: return (N % 256) ? GRIT_ERR_UNSUPPORTED : launch_pp(a, epilogue, st);  // persistent ping-pong, 160 KB
+        // short maps (the decoders' 640 .. 12 800 rows): small tiles, two or three workgroups per CU, so that a 4 800 x 512 output is 300-600
+        // workgroups instead of 38 (round 6)
+        case 10: return (K % 64) ? GRIT_ERR_UNSUPPORTED : launch<64, 128, 64, 2, 2, 3>(a, epilogue, st);   // 72 KB: two per CU
+        case 11: return (K % 64) ? GRIT_ERR_UNSUPPORTED : launch<128, 128, 64, 2, 2, 2>(a, epilogue, st);  // 64 KB: two per CU
+        case 12: return (K % 64 || N % 64) ? GRIT_ERR_UNSUPPORTED : launch<64, 64, 64, 4, 1, 3>(a, epilogue, st);  // 48 KB: three per CU
+        case 13: return launch<64, 128, 32, 2, 2, 4>(a, epilogue, st);   // 48 KB, K step 32, four slots
         case 7:  // four waves, 128 x 128 wave tiles (gemm_w4.hip)
             return grit_detail::gemm_w4_launch(A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, colsum,
                                                epilogue == GRIT_GEMM_BIAS ? 0 : nt_aux, stream);

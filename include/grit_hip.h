@@ -518,6 +518,9 @@ int grit_image_batch_fwd(const uint8_t* src, const int64_t* desc, const int32_t*
  * Needs N % 128 == 0, K % 32 == 0, 16-byte aligned bases; M is free.  variant 0 = tile configuration chosen from the
  * shape; 1..4 = explicit eight-wave configurations, 5 = persistent ping-pong, 7 = persistent FOUR-wave kernel with 128 x 128 wave tiles (gemm_w4.hip: N % 256 == 0,
  * K % 64 == 0, M >= 256, operands below 2 GiB; what the long-map forward / input-gradient GEMMs run where it beats the library).
+ * 10..13 = the eight-wave kernel's template on SHORT-map tiles (64 x 128 x 64 three slots, 128 x 128 x 64 two slots, 64 x 64 x 64 three slots (N % 64 == 0
+ * suffices), 64 x 128 x 32 four slots; two or three workgroups per CU) for maps of 640 .. 12 800 rows, NONE / BIAS / BIAS_GELU only: measured against
+ * the library in profiles/r06/small_gemm.txt (1-2.5 us ahead per call at N, K <= 512; not wired into the decoders: 0.3 ms per step at stake).
  * The NONE / BIAS results are bit-identical across variants (same products, same k order per accumulator).  The GELU epilogues of
  * variant 7 start from the bf16-ROUNDED pre-activation / gradient (what an unfused Linear -> GELU pair computes), those of variants
  * 1..5 from the fp32 values: equal up to that one rounding.  Variant 7 writes its GRIT_GEMM_DGELU column sums as 2 * ceil(M / 256) rows (one per

@@ -57,8 +57,12 @@ struct GemmArgs {
 #define GRIT_STAMP(slot)
 #endif
 
+// (waves per SIMD the register allocation must admit: two eight-wave workgroups share a CU when their stage rings fit twice)
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
+constexpr int gemm_nt_min_waves() { return (WM * WN >= 8 && NSTAGE * (BM + BN) * BK * 2 <= 80 * 1024) ? 4 : 2; }
+
 template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int EPI>
-__global__ __launch_bounds__(WM * WN * 64, 2)
+__global__ __launch_bounds__(WM * WN * 64, (gemm_nt_min_waves<BM, BN, BK, WM, WN, NSTAGE>()))
 void gemm_nt_bf16(const GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
@@ -813,6 +817,10 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
         case 11: return (K % 64) ? GRIT_ERR_UNSUPPORTED : launch<128, 128, 64, 2, 2, 2>(a, epilogue, st);  // 64 KB: two per CU
         case 12: return (K % 64 || N % 64) ? GRIT_ERR_UNSUPPORTED : launch<64, 64, 64, 4, 1, 3>(a, epilogue, st);  // 48 KB: three per CU
         case 13: return launch<64, 128, 32, 2, 2, 4>(a, epilogue, st);   // 48 KB, K step 32, four slots
+        // eight waves on 128 x 256 / 256 x 128 tiles, K step 32, three slots (72 KB), <= 128 registers: TWO eight-wave workgroups per CU --
+        // one's epilogue under the other's K loop (round 6 experiment for the fused Mlp GEMMs)
+        case 14: return (N % 256) ? GRIT_ERR_UNSUPPORTED : launch<128, 256, 32, 2, 4, 3>(a, epilogue, st);
+        case 15: return launch<256, 128, 32, 4, 2, 3>(a, epilogue, st);
         case 7:  // four waves, 128 x 128 wave tiles (gemm_w4.hip)
             return grit_detail::gemm_w4_launch(A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, colsum,
                                                epilogue == GRIT_GEMM_BIAS ? 0 : nt_aux, stream);
@@ -843,7 +851,7 @@ extern "C" int grit_gemm_bf16_nt_rows(const void* A, long lda, const void* B, lo
                                       int epilogue, const void* bias, void* aux, long ldaux, float* colsum, const float* row_scale,
                                       int rows_per_sample, int variant, void* stream) {
     if (epilogue != GRIT_GEMM_DGELU && epilogue != GRIT_GEMM_BIAS_GELU) return GRIT_ERR_BAD_ARG;
-    if (row_scale && (rows_per_sample <= 0 || variant > 4)) return GRIT_ERR_BAD_ARG;
+    if (row_scale && (rows_per_sample <= 0 || (variant > 4 && variant != 14 && variant != 15))) return GRIT_ERR_BAD_ARG;
     g_row_scale = row_scale; g_rows_per_sample = rows_per_sample;
     const int st = grit_gemm_bf16_nt(A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, colsum, variant, stream);
     g_row_scale = nullptr; g_rows_per_sample = 0;

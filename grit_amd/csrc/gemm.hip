@@ -42,6 +42,8 @@ struct GemmArgs {
                  // whole-tile outputs streamed past L2 leave the operand panels resident -- 63.4 -> 62.0 ms per training step)
     float* colsum;
     int M, N, K, tiles_m, tiles_n;
+    int stagger_lo, stagger_hi, stagger_naps;  // workgroups lo <= id < hi start `naps` x 4 096 cycles late (GRIT_GEMM_STAGGER_US, experiment)
+    int pace;                  // epilogue row stores: at most this many outstanding per wave (0: no limit).  GRIT_GEMM_PACE, experiment
     const float* row_scale;    // GRIT_GEMM_DGELU, optional: per-sample factors that were applied to the rows of A (drop path);
     int rows_per_sample;       //   a tile whose rows all belong to ONE sample with factor 0 has A = 0: its result is written as zeros
 #ifdef GRIT_GEMM_STAMPS
@@ -76,6 +78,12 @@ void gemm_nt_bf16(const GemmArgs g) {
     static_assert(WM * WN * EPI_BYTES <= NSTAGE * STAGE, "epilogue transpose must fit the stage ring");
 
     extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+    // Equal tiles keep every workgroup of the launch in lockstep: all CUs run their K loops together (HBM idle) and store together (HBM
+    // saturated, matrix pipes idle).  Starting half of the FIRST generation of workgroups half a tile time late takes the two phases apart
+    // for the rest of the launch (later workgroups inherit the phase of the slot they fill).
+    if (g.stagger_naps > 0 && (int)blockIdx.x >= g.stagger_lo && (int)blockIdx.x < g.stagger_hi)
+        for (int i = 0; i < g.stagger_naps; ++i) __builtin_amdgcn_s_sleep(64);
 
     // XCD-aware tile id: blocks with equal blockIdx % 8 share an L2; give each such group a contiguous band of tiles (bijective)
     const int nwg = g.tiles_m * g.tiles_n;
@@ -317,6 +325,7 @@ void gemm_nt_bf16(const GemmArgs g) {
                 const int row = it * 8 + (lane >> 3), chunk = lane & 7;
                 __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(eb + row * 128 + ((chunk ^ (row & 7)) * 16)),
                                             reinterpret_cast<u32x4*>(base + (size_t)it * 8 * ld));
+                if (g.pace == 1) wait_vm<1>(); else if (g.pace == 2) wait_vm<2>(); else if (g.pace == 4) wait_vm<4>();
             }
         } else if (full_rows) {
 #pragma unroll
@@ -797,6 +806,13 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
     a.bias = (const __bf16*)bias; a.aux = (__bf16*)aux; a.ldaux = ldaux; a.colsum = colsum;
     static const int nt_aux = [] { const char* e = getenv("GRIT_GEMM_NT_AUX"); return e ? atoi(e) : 15; }();
     a.nt_aux = nt_aux;
+    static const int pace = [] { const char* e = getenv("GRIT_GEMM_PACE"); return e ? atoi(e) : 0; }();
+    a.pace = pace;
+    // GRIT_GEMM_STAGGER_US=t[,mode]: mode 0 (default) = the second workgroup of every CU (ids 256 .. 511), mode 1 = odd ids below 512
+    static const float stagger_us = [] { const char* e = getenv("GRIT_GEMM_STAGGER_US"); return e ? (float)atof(e) : 0.f; }();
+    static const int stagger_mode = [] { const char* e = getenv("GRIT_GEMM_STAGGER_MODE"); return e ? atoi(e) : 0; }();
+    a.stagger_naps = (int)(stagger_us * 2100.f / 4096.f);
+    a.stagger_lo = stagger_mode == 2 ? 128 : 256; a.stagger_hi = stagger_mode == 2 ? 256 : 512;
     a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
     a.row_scale = g_row_scale; a.rows_per_sample = g_rows_per_sample;
 #ifdef GRIT_GEMM_STAMPS

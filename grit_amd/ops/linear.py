@@ -27,6 +27,9 @@ MIN_ROWS = int(os.environ.get("GRIT_LINEAR_MIN_ROWS", "512"))  # below this the 
 # one, so that the two GEMMs could fill each other's partial last wave of tiles and the small slab-sum / column-sum launches
 # run beside a GEMM instead of between two.  MEASURED SLOWER (64.4 -> 69.3 ms/step, profiles/r02/negative_results.txt): two
 # 128-KB-LDS GEMMs sharing the chip evict each other's L2 working set; the knob stays for A/B runs, default off.
+# (round 6, same-box A/B inside the captured step, profiles/r06/ab_wgrad_stream.txt: 47.5 -> 48.5 ms; with the join deferred to the bucket
+# pack -- the weight gradients beside the HBM-bound LayerNorm / window-attention kernels that follow -- 48.2 ms: matrix work and HBM
+# streaming do not overlap on this chip, they add up to ~80 % of their sum, tools/micro/overlap_probe.py)
 WGRAD_STREAM = os.environ.get("GRIT_WGRAD_STREAM", "0") == "1"
 _side_streams = {}
 

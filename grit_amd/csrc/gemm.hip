@@ -42,8 +42,6 @@ struct GemmArgs {
                  // whole-tile outputs streamed past L2 leave the operand panels resident -- 63.4 -> 62.0 ms per training step)
     float* colsum;
     int M, N, K, tiles_m, tiles_n;
-    int stagger_lo, stagger_hi, stagger_naps;  // workgroups lo <= id < hi start `naps` x 4 096 cycles late (GRIT_GEMM_STAGGER_US, experiment)
-    int pace;                  // epilogue row stores: at most this many outstanding per wave (0: no limit).  GRIT_GEMM_PACE, experiment
     const float* row_scale;    // GRIT_GEMM_DGELU, optional: per-sample factors that were applied to the rows of A (drop path);
     int rows_per_sample;       //   a tile whose rows all belong to ONE sample with factor 0 has A = 0: its result is written as zeros
 #ifdef GRIT_GEMM_STAMPS
@@ -59,12 +57,8 @@ struct GemmArgs {
 #define GRIT_STAMP(slot)
 #endif
 
-// (waves per SIMD the register allocation must admit: two eight-wave workgroups share a CU when their stage rings fit twice)
-template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
-constexpr int gemm_nt_min_waves() { return (WM * WN >= 8 && NSTAGE * (BM + BN) * BK * 2 <= 80 * 1024) ? 4 : 2; }
-
 template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int EPI>
-__global__ __launch_bounds__(WM * WN * 64, (gemm_nt_min_waves<BM, BN, BK, WM, WN, NSTAGE>()))
+__global__ __launch_bounds__(WM * WN * 64, 2)
 void gemm_nt_bf16(const GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
@@ -78,12 +72,6 @@ void gemm_nt_bf16(const GemmArgs g) {
     static_assert(WM * WN * EPI_BYTES <= NSTAGE * STAGE, "epilogue transpose must fit the stage ring");
 
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-
-    // Equal tiles keep every workgroup of the launch in lockstep: all CUs run their K loops together (HBM idle) and store together (HBM
-    // saturated, matrix pipes idle).  Starting half of the FIRST generation of workgroups half a tile time late takes the two phases apart
-    // for the rest of the launch (later workgroups inherit the phase of the slot they fill).
-    if (g.stagger_naps > 0 && (int)blockIdx.x >= g.stagger_lo && (int)blockIdx.x < g.stagger_hi)
-        for (int i = 0; i < g.stagger_naps; ++i) __builtin_amdgcn_s_sleep(64);
 
     // XCD-aware tile id: blocks with equal blockIdx % 8 share an L2; give each such group a contiguous band of tiles (bijective)
     const int nwg = g.tiles_m * g.tiles_n;
@@ -325,7 +313,6 @@ void gemm_nt_bf16(const GemmArgs g) {
                 const int row = it * 8 + (lane >> 3), chunk = lane & 7;
                 __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(eb + row * 128 + ((chunk ^ (row & 7)) * 16)),
                                             reinterpret_cast<u32x4*>(base + (size_t)it * 8 * ld));
-                if (g.pace == 1) wait_vm<1>(); else if (g.pace == 2) wait_vm<2>(); else if (g.pace == 4) wait_vm<4>();
             }
         } else if (full_rows) {
 #pragma unroll
@@ -806,13 +793,6 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
     a.bias = (const __bf16*)bias; a.aux = (__bf16*)aux; a.ldaux = ldaux; a.colsum = colsum;
     static const int nt_aux = [] { const char* e = getenv("GRIT_GEMM_NT_AUX"); return e ? atoi(e) : 15; }();
     a.nt_aux = nt_aux;
-    static const int pace = [] { const char* e = getenv("GRIT_GEMM_PACE"); return e ? atoi(e) : 0; }();
-    a.pace = pace;
-    // GRIT_GEMM_STAGGER_US=t[,mode]: mode 0 (default) = the second workgroup of every CU (ids 256 .. 511), mode 1 = odd ids below 512
-    static const float stagger_us = [] { const char* e = getenv("GRIT_GEMM_STAGGER_US"); return e ? (float)atof(e) : 0.f; }();
-    static const int stagger_mode = [] { const char* e = getenv("GRIT_GEMM_STAGGER_MODE"); return e ? atoi(e) : 0; }();
-    a.stagger_naps = (int)(stagger_us * 2100.f / 4096.f);
-    a.stagger_lo = stagger_mode == 2 ? 128 : 256; a.stagger_hi = stagger_mode == 2 ? 256 : 512;
     a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
     a.row_scale = g_row_scale; a.rows_per_sample = g_rows_per_sample;
 #ifdef GRIT_GEMM_STAMPS
@@ -833,10 +813,6 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
         case 11: return (K % 64) ? GRIT_ERR_UNSUPPORTED : launch<128, 128, 64, 2, 2, 2>(a, epilogue, st);  // 64 KB: two per CU
         case 12: return (K % 64 || N % 64) ? GRIT_ERR_UNSUPPORTED : launch<64, 64, 64, 4, 1, 3>(a, epilogue, st);  // 48 KB: three per CU
         case 13: return launch<64, 128, 32, 2, 2, 4>(a, epilogue, st);   // 48 KB, K step 32, four slots
-        // eight waves on 128 x 256 / 256 x 128 tiles, K step 32, three slots (72 KB), <= 128 registers: TWO eight-wave workgroups per CU --
-        // one's epilogue under the other's K loop (round 6 experiment for the fused Mlp GEMMs)
-        case 14: return (N % 256) ? GRIT_ERR_UNSUPPORTED : launch<128, 256, 32, 2, 4, 3>(a, epilogue, st);
-        case 15: return launch<256, 128, 32, 4, 2, 3>(a, epilogue, st);
         case 7:  // four waves, 128 x 128 wave tiles (gemm_w4.hip)
             return grit_detail::gemm_w4_launch(A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, colsum,
                                                epilogue == GRIT_GEMM_BIAS ? 0 : nt_aux, stream);
@@ -867,7 +843,7 @@ extern "C" int grit_gemm_bf16_nt_rows(const void* A, long lda, const void* B, lo
                                       int epilogue, const void* bias, void* aux, long ldaux, float* colsum, const float* row_scale,
                                       int rows_per_sample, int variant, void* stream) {
     if (epilogue != GRIT_GEMM_DGELU && epilogue != GRIT_GEMM_BIAS_GELU) return GRIT_ERR_BAD_ARG;
-    if (row_scale && (rows_per_sample <= 0 || (variant > 4 && variant != 14 && variant != 15))) return GRIT_ERR_BAD_ARG;
+    if (row_scale && (rows_per_sample <= 0 || variant > 4)) return GRIT_ERR_BAD_ARG;
     g_row_scale = row_scale; g_rows_per_sample = rows_per_sample;
     const int st = grit_gemm_bf16_nt(A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, aux, ldaux, colsum, variant, stream);
     g_row_scale = nullptr; g_rows_per_sample = 0;

@@ -24,7 +24,7 @@ def main():
         part = torch.empty((-(-M // 128), 4 * C), dtype=torch.float32, device='cuda')
         G.gemm_nt(x, w1, G.BIAS_GELU, bias=b1, aux=pre, out=act, variant=4)
         line = "M%-7d C%-5d" % (M, C)
-        for v in (4, 14, 15, 1, 7):
+        for v in (1, 2, 3, 4, 5, 7):
             try:
                 tg = t(lambda: G.gemm_nt(x, w1, G.BIAS_GELU, bias=b1, aux=pre, out=act, variant=v))
                 td = t(lambda: G.gemm_nt(dy, w2t, G.DGELU, aux=pre, colsum=part, out=dpre, variant=v))

@@ -323,10 +323,17 @@ def decode_config5(device, config, batch=64, iters=2):
                 det.append(t_det)
                 dec.append(t_dec)
     t_det, t_dec = min(det), min(dec)
+    sha1 = hashlib.sha1(tokens.cpu().numpy().tobytes()).hexdigest()
+    try:  # the recorded hash of this exact workload (tests/golden/config5_tokens.json): a changed kernel that changes a token shows here
+        with open(os.path.join(ROOT, "tests", "golden", "config5_tokens.json")) as f:
+            fixture = json.load(f)
+        match = bool(batch == 64 and fixture["tokens_sha1"] == sha1 and fixture["tokens_shape"] == list(tokens.shape))
+    except Exception:
+        match = None
     return {"workload": "beam search, beam 5, 20 steps, batch %d, synthetic 640x640, eval, bf16 weights / fp32 decoder tail" % batch,
             "captions_per_sec_sequential": batch / (t_det + t_dec), "detector_ms": t_det * 1e3, "decode_20_steps_ms": t_dec * 1e3,
             "batch": batch, "beam": 5, "iterations": iters, "n_gpus": 1,
-            "tokens_sha1": hashlib.sha1(tokens.cpu().numpy().tobytes()).hexdigest(), "tokens_shape": list(tokens.shape)}
+            "tokens_sha1": sha1, "tokens_shape": list(tokens.shape), "tokens_match_fixture": match}
 
 
 def _enable_tuned_gemms():

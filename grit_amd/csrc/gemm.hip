@@ -287,7 +287,7 @@ void gemm_nt_bf16(const GemmArgs g) {
     const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
 
     v4f bias4[NTL];
-    if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU) {
+    if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU || EPI == GRIT_GEMM_BIAS_RES) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
             const v4bf b = *reinterpret_cast<const v4bf*>(g.bias + nw + 16 * j + 4 * lq);
@@ -361,6 +361,37 @@ void gemm_nt_bf16(const GemmArgs g) {
                 put(i, j, v4f{lo[0], lo[1], hi[0], hi[1]});
             }
         flush(g.C, g.ldc, (g.nt_aux & 2) != 0);
+    } else if constexpr (EPI == GRIT_GEMM_BIAS_RES) {
+        // C = residual + factor[sample of the row] * bf16(acc + bias): the residual tile (g.aux) comes into the wave's transpose image as
+        // whole 128-byte row segments, every lane combines its 8-byte pieces in place -- the branch rounded to bf16 as an unfused Linear
+        // would store it, the sum in fp32 (multiply and add not fused) rounded once: bit for bit grit_add_layernorm_fwd's x
+        {
+            const int chunk = lane & 7;
+#pragma unroll
+            for (int it = 0; it < WTM / 8; ++it) {
+                const int row = it * 8 + (lane >> 3);
+                const int m = min(mw + row, g.M - 1);
+                const __bf16* src = g.aux + (size_t)m * g.ldaux + nw + ((chunk ^ (row & 7)) * 8);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(eb + it * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = 16 * i + l15;
+            const float sc = g.row_scale ? g.row_scale[min(mw + row, g.M - 1) / g.rows_per_sample] : 1.f;
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int chunk = (2 * j + (lq >> 1)) ^ (row & 7);
+                const v4bf r = *reinterpret_cast<const v4bf*>(eb + row * 128 + chunk * 16 + (lq & 1) * 8);
+                const v4f a = acc[i][j] + bias4[j];
+                v4f v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __fadd_rn((float)r[e], __fmul_rn((float)(__bf16)a[e], sc));
+                put(i, j, v);
+            }
+        }
+        flush(g.C, g.ldc);
     } else {  // GRIT_GEMM_DGELU
         // the pre-activation tile comes in the way the result goes out: whole 128-byte row segments (one DMA piece = 8 rows) into
         // the wave's transpose image, from where every lane picks its 8-byte pieces -- accumulator-shaped global loads (16 rows x
@@ -766,6 +797,10 @@ int launch(const GemmArgs& a, int epilogue, hipStream_t st) {
         case GRIT_GEMM_BIAS: GRIT_GEMM_LAUNCH(GRIT_GEMM_BIAS) break;
         case GRIT_GEMM_BIAS_GELU: GRIT_GEMM_LAUNCH(GRIT_GEMM_BIAS_GELU) break;
         case GRIT_GEMM_DGELU: GRIT_GEMM_LAUNCH(GRIT_GEMM_DGELU) break;
+        case GRIT_GEMM_BIAS_RES:  // (one tile shape carries it: the narrow outputs of the stage-0 map)
+            if constexpr (BM == 256 && BN == 128 && BK == 32 && NSTAGE == 3) GRIT_GEMM_LAUNCH(GRIT_GEMM_BIAS_RES)
+            else return GRIT_ERR_UNSUPPORTED;
+            break;
         default: return GRIT_ERR_BAD_ARG;
     }
 #undef GRIT_GEMM_LAUNCH
@@ -826,7 +861,8 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
 extern "C" int grit_gemm_w4_tile_rows(int M, int N) { return grit_detail::gemm_w4_tile_rows(M, N); }
 
 // C = residual + row_scale[sample of the row] * (A B^T + bias): the output projection of a Swin branch with its residual connection
-// (persistent four-wave kernel, tile height chosen by shape).
+// (persistent four-wave kernel, tile height chosen by shape; outputs that are not a multiple of 256 columns wide -- the stage-0 map's
+// 128 -- on the 256 x 128 tiles of the per-tile kernel).
 extern "C" int grit_gemm_bf16_nt_res(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                                      const void* bias, const void* residual, long ldres, const float* row_scale, int rows_per_sample,
                                      void* stream) {
@@ -834,8 +870,19 @@ extern "C" int grit_gemm_bf16_nt_res(const void* A, long lda, const void* B, lon
     if (row_scale && rows_per_sample <= 0) return GRIT_ERR_BAD_ARG;
     if ((lda | ldb | ldc | ldres) & 7) return GRIT_ERR_UNSUPPORTED;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias) & 15) return GRIT_ERR_UNSUPPORTED;
-    return grit_detail::gemm_w4_launch(A, lda, B, ldb, C, ldc, M, N, K, GRIT_GEMM_BIAS_RES, bias, const_cast<void*>(residual), ldres,
-                                       nullptr, 0, stream, 0, row_scale, rows_per_sample);
+    if (N % 256 == 0 && K % 64 == 0)
+        return grit_detail::gemm_w4_launch(A, lda, B, ldb, C, ldc, M, N, K, GRIT_GEMM_BIAS_RES, bias, const_cast<void*>(residual), ldres,
+                                           nullptr, 0, stream, 0, row_scale, rows_per_sample);
+    if (N % 128 || K % 32) return GRIT_ERR_UNSUPPORTED;
+    GemmArgs a;
+    a.A = (const __bf16*)A; a.lda = lda; a.B = (const __bf16*)B; a.ldb = ldb; a.C = (__bf16*)C; a.ldc = ldc;
+    a.bias = (const __bf16*)bias; a.aux = (__bf16*)const_cast<void*>(residual); a.ldaux = ldres; a.colsum = nullptr; a.nt_aux = 0;
+    a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
+    a.row_scale = row_scale; a.rows_per_sample = rows_per_sample;
+#ifdef GRIT_GEMM_STAMPS
+    a.stamps = nullptr;
+#endif
+    return launch<256, 128, 32, 2, 2, 3>(a, GRIT_GEMM_BIAS_RES, (hipStream_t)stream);
 }
 
 // GRIT_GEMM_DGELU / GRIT_GEMM_BIAS_GELU with the per-sample factors of the rows of A (see GemmArgs::row_scale): eight-wave variants only.

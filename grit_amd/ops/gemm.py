@@ -65,7 +65,7 @@ def gemm_nt_residual(a, b, bias, residual, row_scale=None, rows_per_sample=0, ou
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     work = gemm_work(M, N, K, extra_in=1)
-    with _lib.device_guard(a.device), timed("gemm_own", epilogue=4, kernel="gemm_w4", **work):
+    with _lib.device_guard(a.device), timed("gemm_own", epilogue=4, kernel="gemm_w4" if (N % 256 == 0 and K % 64 == 0) else "gemm_nt_bf16", **work):
         st = _lib.load().grit_gemm_bf16_nt_res(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0), M, N, K, _ptr(bias),
                                                _ptr(residual), residual.stride(0), _ptr(row_scale) if row_scale is not None else None,
                                                int(rows_per_sample), _lib.current_stream_ptr())
@@ -185,7 +185,9 @@ def long_linear_residual(x2, weight, bias, residual2, scale, rows_per_sample):
     scale: [B] float32 drop-path factors or None."""
     if not (OWN and RESIDUAL and bias is not None and supported(x2, weight) and bias.dtype == torch.bfloat16 and bias.data_ptr() % 16 == 0
             and residual2.dtype == torch.bfloat16 and residual2.is_contiguous() and residual2.data_ptr() % 16 == 0
-            and residual2.shape == (x2.shape[0], weight.shape[0]) and prefers_own(x2.shape[0], weight.shape[0], x2.shape[1])):
+            and residual2.shape == (x2.shape[0], weight.shape[0])
+            and (prefers_own(x2.shape[0], weight.shape[0], x2.shape[1])
+                 or (RESIDUAL_NARROW and prefers_own_narrow(x2.shape[0], weight.shape[0], x2.shape[1])))):
         return None
     if scale is not None and not (scale.is_cuda and scale.dtype == torch.float32 and scale.is_contiguous() and rows_per_sample >= 256
                                   and scale.numel() * rows_per_sample == x2.shape[0]):
@@ -196,6 +198,8 @@ def long_linear_residual(x2, weight, bias, residual2, scale, rows_per_sample):
 # GRIT_GEMM_RESIDUAL (default 1, round 6): proj / fc2 of a Swin block write x = shortcut + factor * branch themselves; the LayerNorm that
 # follows reads x only (grit_layernorm_fwd instead of grit_add_layernorm_fwd: one map read instead of two, one written instead of two).
 RESIDUAL = os.environ.get("GRIT_GEMM_RESIDUAL", "1") != "0"
+# GRIT_GEMM_RESIDUAL_NARROW (default 1): also proj / fc2 of the stage-0 map (128 output columns: the per-tile kernel's 256 x 128 tiles)
+RESIDUAL_NARROW = os.environ.get("GRIT_GEMM_RESIDUAL_NARROW", "1") != "0"
 
 
 def long_input_grad(dy2, weight):

@@ -337,6 +337,17 @@ def linear_add_layer_norm(inp, linear, shortcut, scale, weight, bias, eps=1e-5, 
             and (inp.requires_grad or linear.weight.requires_grad) and not torch.is_autocast_enabled()
             and shortcut.numel() // C >= MIN_ROWS_FUSED and 0.0 <= p < 1.0)
     if not fits:
+        if (p == 0 and backend.override() is None and shortcut.is_cuda and shortcut.dtype == torch.bfloat16
+                and C in SUPPORTED_C and linear.bias is not None and weight is not None and bias is not None
+                and weight.dtype == bias.dtype == torch.bfloat16 and not torch.is_autocast_enabled()
+                and not (torch.is_grad_enabled() and (inp.requires_grad or shortcut.requires_grad or linear.weight.requires_grad))):
+            # inference / a frozen stage: the projection writes x = shortcut + branch itself (same launch as in the training node),
+            # the LayerNorm reads x only
+            s2 = shortcut.reshape(-1, C)
+            x = _residual_linear(inp, linear.weight, linear.bias, s2 if s2.is_contiguous() else s2.contiguous(),
+                                 None if scale is None else scale.reshape(-1).float().contiguous(), s2.shape[0] // shortcut.shape[0])
+            if x is not None:
+                return x.view(shortcut.shape), layer_norm(x.view(shortcut.shape), weight, bias, eps)
         branch = linear(inp)
         if p > 0:
             branch = F.dropout(branch, p, True)

@@ -545,7 +545,8 @@ int grit_gemm_w4_tile_rows(int M, int N);
  *     C[m, n] = residual[m, n] + row_scale[m / rows_per_sample] * bf16(acc[m, n] + bias[n])
  * -- the branch rounded to bf16 as an unfused Linear stores it, product and sum in fp32 (not fused), one rounding: bit for bit what
  * grit_add_layernorm_fwd computes as its `sum_out` from a stored branch.  row_scale NULL = 1 (then rows_per_sample is ignored);
- * otherwise rows_per_sample >= 256.  The branch map is never written or re-read.  Shape limits of variant 7. */
+ * otherwise rows_per_sample >= 256.  The branch map is never written or re-read.  N % 256 == 0 and K % 64 == 0: variant 7's kernel and
+ * shape limits; other N % 128 == 0, K % 32 == 0 (the 128 output columns of the stage-0 map): the per-tile kernel on 256 x 128 tiles. */
 int grit_gemm_bf16_nt_res(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                           const void* bias, const void* residual, long ldres, const float* row_scale, int rows_per_sample,
                           void* stream);

@@ -137,7 +137,8 @@ def test_gemm_four_wave_224_row_tiles(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,per", [(51200, 512, 512, 1600), (51200, 512, 2048, 1600), (12800, 1024, 4096, 400), (204800, 256, 256, 6400),
-                                       (4096 + 17, 512, 512, 0), (2560, 256, 128, 256)])
+                                       (4096 + 17, 512, 512, 0), (2560, 256, 128, 256),
+                                       (102400, 128, 128, 25600), (102400, 128, 512, 25600), (1000 + 7, 128, 96, 0), (5120, 128, 64, 512)])
 def test_gemm_residual_epilogue(M, N, K, per):
     """grit_gemm_bf16_nt_res: x = shortcut + factor[sample] * (inp W^T + b) in one launch, against the two-launch form it replaces --
     the branch stored in bf16 by variant 7, then grit_add_layernorm_fwd's sum -- bit for bit (same roundings in the same order), with
@@ -147,7 +148,8 @@ def test_gemm_residual_epilogue(M, N, K, per):
     x, w, b = _inputs(M, N, K, seed=(M + K) % 71)
     g = torch.Generator(device='cuda').manual_seed(5)
     res = torch.randn(M, N, device='cuda', generator=g).bfloat16()
-    branch = G.gemm_nt(x, w, G.BIAS, bias=b, variant=7)
+    # (N = 128 / 384, the stage-0 map's narrow outputs: the per-tile kernel's 256 x 128 tiles carry the epilogue there)
+    branch = G.gemm_nt(x, w, G.BIAS, bias=b, variant=7 if N % 256 == 0 and K % 64 == 0 else 1)
     if per:
         B = M // per
         scale = torch.full((B,), 1.0 / 0.9, device='cuda')
@@ -212,6 +214,15 @@ def test_residual_epilogue_inside_the_block_tail_nodes(monkeypatch):
     assert len(results[0]) == len(results[1])
     for i, (f, u) in enumerate(zip(*results)):
         assert torch.equal(f, u), i
+    # without autograd (inference, the frozen stage 0 of a training step) the same epilogue replaces linear + grit_add_layernorm_fwd
+    nograd = []
+    for fused in (True, False):
+        monkeypatch.setattr(G, "RESIDUAL", fused)
+        with torch.no_grad():
+            nograd.append([t for sc in (None, scale) for t in linear_add_layer_norm(inp, proj, shortcut, sc, norm.weight, norm.bias, norm.eps)])
+    for i, (f, u) in enumerate(zip(*nograd)):
+        assert torch.equal(f, u), ("no_grad", i)
+    assert torch.equal(nograd[0][2], results[0][0]) and torch.equal(nograd[0][3], results[0][1])  # == the training node's x, LayerNorm(x)
 
 
 def test_own_long_map_policy_and_linear_nodes():

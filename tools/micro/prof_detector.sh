@@ -2,7 +2,7 @@
 # per-kernel time of the detector forward alone (bf16 weights, batch 64, inference)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r02
+mkdir -p $R/gpurun_out/r06
 cat > /tmp/det_only.py <<'PY'
 import os, sys, time, torch
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
@@ -22,6 +22,6 @@ with torch.no_grad():
         torch.cuda.synchronize(); print("detector ms %.2f" % ((time.perf_counter() - t0) * 1e3))
         time.sleep(0.01)
 PY
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_det -o det -- python3 /tmp/det_only.py > $R/gpurun_out/r02/det_only.log 2>&1
-grep "detector ms" $R/gpurun_out/r02/det_only.log | tail -3
-python3 $R/tools/decode_kernel_profile.py /tmp/prof_det | cut -c1-170 | tee $R/gpurun_out/r02/detector_kernel_stats.txt | head -45
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_det -o det -- python3 /tmp/det_only.py > $R/gpurun_out/r06/det_only.log 2>&1
+grep "detector ms" $R/gpurun_out/r06/det_only.log | tail -3
+python3 $R/tools/decode_kernel_profile.py /tmp/prof_det | cut -c1-170 | tee $R/gpurun_out/r06/detector_kernel_stats.txt | head -45

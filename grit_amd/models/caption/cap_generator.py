@@ -20,6 +20,7 @@ from grit_amd.ops import backend
 from grit_amd.ops import decode_inputs
 from grit_amd.ops import gate as gate_ops
 from grit_amd.ops import glue
+from grit_amd.ops import transposed as _transposed
 from grit_amd.ops import weights_epoch
 from grit_amd.ops.linear import Linear, mark_single_use
 
@@ -144,6 +145,8 @@ class CaptionGenerator(Module):
         return x, self.running_mask_x, mask_pad
 
     def forward(self, input, vis_inputs):
+        if self.training and torch.is_grad_enabled() and input.is_cuda:
+            _transposed.refresh_linears(self)  # W^T of every Linear: the short maps' input gradients as NT products (ops/gemm.py)
         fused = self._step_inputs(input)
         x, mask_x, mask_pad = fused if fused is not None else self.get_seq_inputs(input)
         mask_pad = mask_pad.to(x.dtype)

@@ -14,6 +14,7 @@ from torch import nn
 
 from grit_amd.models.common.attention import MultiHeadAttention
 from grit_amd.models.common.pos_embed import FeedForward
+from grit_amd.ops import transposed as _transposed
 from grit_amd.ops.linear import Linear, mark_single_use
 
 
@@ -49,6 +50,8 @@ class GridFeatureNetwork(nn.Module):
     def last(self, input, mask=None):
         """Output of the LAST layer only, [B, N, d_model] -- all the captioner consumes (reference transformer.py:69 takes
         out[:, -1]): the training step skips the [B, n_layers, N, d_model] collection and the slice / copy gradients behind it."""
+        if self.training and torch.is_grad_enabled() and input.is_cuda:
+            _transposed.refresh_linears(self)  # W^T of every Linear: the short maps' input gradients as NT products (ops/gemm.py)
         x = self.embed(input)
         for layer in self.layers:
             x = layer(x, x, x, mask)
@@ -56,6 +59,8 @@ class GridFeatureNetwork(nn.Module):
 
     def forward(self, input, mask=None):
         """-> (outs [B, n_layers, N, d_model], mask), outs[:, i] being the output of layer i."""
+        if self.training and torch.is_grad_enabled() and input.is_cuda:
+            _transposed.refresh_linears(self)
         x = self.embed(input)
         if len(self.layers) == 0:
             return x.new_empty(x.shape[0], 0, x.shape[1], self.d_model), mask

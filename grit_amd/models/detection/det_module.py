@@ -27,6 +27,7 @@ from grit_amd.ops.glue import box_refine, relu_dropout
 from grit_amd.ops.layer_norm import linear_add_layer_norm
 from grit_amd.ops.linear import Linear, linear, mark_single_use, packed_in_proj, shared_input_linears
 from grit_amd.ops.msda import StackedValueMaps
+from grit_amd.ops import transposed as _transposed
 
 _SHARED_VALUE_PROJ = os.environ.get('GRIT_SHARED_VALUE_PROJ', '1') != '0'  # A/B knobs
 _STACKED_VALUE_MAPS = os.environ.get('GRIT_STACKED_VALUE_MAPS', '1') != '0'
@@ -293,6 +294,8 @@ class DetectionModule(nn.Module):
         masked_fill would be a full copy of each value map that changes nothing.  `src_flatten` / `shapes`: the levels
         already flattened into one [B, S, C] map (grit_amd.ops.group_norm writes it directly), `srcs` is then unused."""
         od = self.prepare_od_inputs(srcs, masks, src_flatten, shapes, no_padding)
+        if self.training and torch.is_grad_enabled() and od['src'].is_cuda:
+            _transposed.refresh_linears(self)  # W^T of every Linear: the short maps' input gradients as NT products (ops/gemm.py)
         init_reference_out = od['reference_points']
         hs, refs = [od['tgt']], [init_reference_out]
         values = None

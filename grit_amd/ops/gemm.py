@@ -41,7 +41,7 @@ def gemm_nt(a, b, epilogue=NONE, bias=None, aux=None, colsum=None, out=None, var
     v = VARIANT if variant is None else variant
     work = gemm_work(M, N, K, outputs=2 if (epilogue == BIAS_GELU and aux is not None) else 1,
                      extra_in=1 if epilogue == DGELU else 0)
-    with _lib.device_guard(a.device), timed("gemm_own", epilogue=epilogue, kernel="gemm_w4" if v in (7, 9) else "gemm_nt_bf16", **work):
+    with _lib.device_guard(a.device), timed("gemm_own", epilogue=epilogue, kernel="gemm_w4" if v in (7, 9) else ("gemm_short" if 10 <= v <= 13 else "gemm_nt_bf16"), **work):
         st = _lib.load().grit_gemm_bf16_nt(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0), M, N, K,
                                            epilogue, _ptr(bias), _ptr(aux), aux.stride(0) if aux is not None else 0,
                                            _ptr(colsum), VARIANT if variant is None else variant, _lib.current_stream_ptr())
@@ -167,6 +167,21 @@ def prefers_own_narrow(M, N, K):
     return N in (128, 384) and K % 32 == 0 and K <= 512 and M >= 262144 and M * max(N, K) * 2 < 2 ** 31
 
 
+# GRIT_GEMM_OWN_SHORT (default 1, round 6): the Linears of the two decoders and the grid net (640 .. 4 800 rows) on the 64 x 64 x 64 tiles of
+# the per-tile kernel (grit_gemm_bf16_nt variant 12: three workgroups per CU, 600 workgroups for a 4 800 x 512 output where the
+# library launches 38-150): 1-2.5 us ahead of the tuned library kernel per call at K <= 512, level at K = 1 024 from 2 048 rows on, behind
+# it at K >= 2 048 (profiles/r06/small_gemm.txt).  Forward (+ bias) and, on the transposed copies of grit_amd.ops.transposed, input
+# gradients.  0: the library.
+OWN_SHORT = os.environ.get("GRIT_GEMM_OWN_SHORT", "1") != "0"
+SHORT = 12
+SHORT_MIN_ROWS = 512
+
+
+def prefers_own_short(M, N, K):
+    return (OWN_SHORT and SHORT_MIN_ROWS <= M < OWN_MIN_ROWS and N % 128 == 0 and K % 64 == 0
+            and (K <= 512 or (K <= 1024 and M >= 2048)))
+
+
 def long_linear(x2, weight, bias):
     """x2 [M, K] @ weight [N, K]^T (+ bias) on the own kernel, or None where the library path is to run."""
     if not (OWN and supported(x2, weight) and (bias is None or (bias.dtype == torch.bfloat16 and bias.data_ptr() % 16 == 0))):
@@ -177,6 +192,8 @@ def long_linear(x2, weight, bias):
         return gemm_nt(x2, weight, BIAS if bias is not None else NONE, bias=bias, variant=W4)
     if prefers_own_narrow(M, N, K):
         return gemm_nt(x2, weight, BIAS if bias is not None else NONE, bias=bias, variant=0)
+    if prefers_own_short(M, N, K):
+        return gemm_nt(x2, weight, BIAS if bias is not None else NONE, bias=bias, variant=SHORT)
     return None
 
 
@@ -217,5 +234,9 @@ def long_input_grad(dy2, weight):
         return gemm_nt(dy2, wt, NONE, variant=W4)
     if supported(dy2, wt) and prefers_own_narrow(dy2.shape[0], wt.shape[0], wt.shape[1]):
         return gemm_nt(dy2, wt, NONE, variant=0)
+    if supported(dy2, wt) and prefers_own_short(dy2.shape[0], wt.shape[0], wt.shape[1]):
+        return gemm_nt(dy2, wt, NONE, variant=SHORT)
+    if dy2.shape[0] < OWN_MIN_ROWS:
+        return None  # short map outside the policy: the library's NN form on the weight itself (the caller's torch.mm)
     with timed("gemm_lib", **gemm_work(dy2.shape[0], wt.shape[0], wt.shape[1])):
         return torch.nn.functional.linear(dy2, wt)

@@ -825,7 +825,7 @@ def weight_bias_grad(dy2, x2, group, need_w, need_b, weight, row_scale=None):
 
 def _own_linear(x, weight, bias):
     """F.linear on the own long-map kernel (grit_amd/ops/gemm.py long_linear) or None."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.numel() // x.shape[-1] >= 8192):
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.numel() // x.shape[-1] >= 512):
         return None
     from grit_amd.ops import gemm as _gemm
     x2 = x.reshape(-1, x.shape[-1])
@@ -834,7 +834,7 @@ def _own_linear(x, weight, bias):
 
 
 def _own_input_grad(dy2, weight, shape):
-    if not (dy2.is_cuda and dy2.dtype == torch.bfloat16 and dy2.shape[0] >= 8192):
+    if not (dy2.is_cuda and dy2.dtype == torch.bfloat16 and dy2.shape[0] >= 512):
         return None
     from grit_amd.ops import gemm as _gemm
     dx = _gemm.long_input_grad(dy2, weight)
@@ -878,8 +878,10 @@ class _LinearFn(Function):
         if deferred is not None:  # short map inside a gradient-bucket scope: dW / db come from the scope's grouped launch
             dw, db = deferred
             if ctx.needs_input_grad[0]:
-                with timed("gemm_lib", **gemm_work(dy2.shape[0], weight.shape[1], weight.shape[0])):
-                    dx = torch.mm(dy2, weight).view(x.shape)
+                dx = _own_input_grad(dy2, ctx.weight_obj, x.shape)
+                if dx is None:
+                    with timed("gemm_lib", **gemm_work(dy2.shape[0], weight.shape[1], weight.shape[0])):
+                        dx = torch.mm(dy2, weight).view(x.shape)
             return dx, dw, db, None, None
         side = fork(dy2, x2, rows=dy2.shape[0], single_use=ctx.single_use) \
             if (ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or need_b)) else None

@@ -61,3 +61,17 @@ def lookup(w):
     """The transposed copy of `w` if one exists for its current value, else None."""
     hit = getattr(w, "_grit_transposed", None) if ENABLED else None
     return hit[1] if (hit is not None and hit[0] == _tag(w)) else None
+
+
+def refresh_linears(module):
+    """refresh() for the weights of every nn.Linear inside `module` (the decoders and the grid net: the input gradients of their short
+    maps run as NT products on these copies, grit_amd/ops/gemm.py prefers_own_short).  The list of Linear modules is kept on `module`."""
+    if not ENABLED:
+        return
+    mods = getattr(module, "_grit_linear_modules", None)
+    if mods is None:
+        mods = [m for m in module.modules() if isinstance(m, torch.nn.Linear)]
+        object.__setattr__(module, "_grit_linear_modules", mods)
+    ws = [m.weight for m in mods if m.weight.requires_grad]
+    if ws and ws[0].is_cuda and ws[0].dtype == torch.bfloat16:
+        refresh(ws)

@@ -174,6 +174,20 @@ def defer_packed_weight_bias_grad(parts, weight, bias):
     return dw, db
 
 
+def _short_transposed(weight, dy2):
+    """W^T of the packed in-projection [3E, E] from grit_amd.ops.transposed when both of its column ranges fit the short-map policy of
+    grit_amd/ops/gemm.py (input gradients as NT products on the 64 x 64 x 64 tiles), else None."""
+    if weight is None or not (dy2.is_cuda and dy2.dtype == torch.bfloat16):
+        return None
+    from grit_amd.ops import gemm as _gemm
+    from grit_amd.ops import transposed
+    E = weight.shape[1]
+    if not (_gemm.OWN and _gemm.prefers_own_short(dy2.shape[0], E, 2 * E) and _gemm.prefers_own_short(dy2.shape[0], E, E)):
+        return None
+    wt = transposed.lookup(weight)
+    return wt if (wt is not None and wt.shape == (E, 3 * E)) else None
+
+
 class _PackedInProjFn(Function):
     """(qk_in, v_in, W [3E, E], b [3E]) -> (qk_in W[:2E]^T + b[:2E], v_in W[2E:]^T + b[2E:]): the in-projections of an
     nn.MultiheadAttention whose query / key input differs from its value input (DeformableTransformerDecoderLayer: q = k = tgt + pos,
@@ -186,6 +200,10 @@ class _PackedInProjFn(Function):
         E = weight.shape[1]
         ctx.save_for_backward(qk_in, v_in, weight)
         ctx.bias_param, ctx.weight_param = bias, weight
+        qk = _own_linear(qk_in, weight[:2 * E], bias[:2 * E])  # (short maps: the own 64 x 64 x 64 tiles, grit_amd/ops/gemm.py)
+        v = _own_linear(v_in, weight[2 * E:], bias[2 * E:]) if qk is not None else None
+        if v is not None:
+            return qk, v
         with timed("gemm_lib", **gemm_work(qk_in.numel() // E + v_in.numel() // E, 3 * E // 2, E)):
             return F.linear(qk_in, weight[:2 * E], bias[:2 * E]), F.linear(v_in, weight[2 * E:], bias[2 * E:])
 
@@ -201,11 +219,19 @@ class _PackedInProjFn(Function):
         q2 = q2 if q2.is_contiguous() else q2.contiguous()
         v2 = v2 if v2.is_contiguous() else v2.contiguous()
         d_qk_in = d_v_in = dw = db = None
-        with timed("gemm_lib", **gemm_work(dqk2.shape[0] + dv2.shape[0], E, 3 * E // 2)):
+        wt = _short_transposed(ctx.weight_param, dqk2)  # [E, 3E] = W^T, or None: no copy / outside the short-map policy
+        if wt is not None:
+            from grit_amd.ops import gemm as _gemm
             if ctx.needs_input_grad[0]:
-                d_qk_in = torch.mm(dqk2, weight[:2 * E]).view(qk_in.shape)
+                d_qk_in = _gemm.gemm_nt(dqk2, wt[:, :2 * E], _gemm.NONE, variant=_gemm.SHORT).view(qk_in.shape)
             if ctx.needs_input_grad[1]:
-                d_v_in = torch.mm(dv2, weight[2 * E:]).view(v_in.shape)
+                d_v_in = _gemm.gemm_nt(dv2, wt[:, 2 * E:], _gemm.NONE, variant=_gemm.SHORT).view(v_in.shape)
+        else:
+            with timed("gemm_lib", **gemm_work(dqk2.shape[0] + dv2.shape[0], E, 3 * E // 2)):
+                if ctx.needs_input_grad[0]:
+                    d_qk_in = torch.mm(dqk2, weight[:2 * E]).view(qk_in.shape)
+                if ctx.needs_input_grad[1]:
+                    d_v_in = torch.mm(dv2, weight[2 * E:]).view(v_in.shape)
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             deferred = defer_packed_weight_bias_grad([(dqk2, q2), (dv2, v2)], ctx.weight_param, ctx.bias_param) \
                 if (ctx.needs_input_grad[2] and ctx.needs_input_grad[3]) else None

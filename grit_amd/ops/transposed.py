@@ -73,5 +73,10 @@ def refresh_linears(module):
         mods = [m for m in module.modules() if isinstance(m, torch.nn.Linear)]
         object.__setattr__(module, "_grit_linear_modules", mods)
     ws = [m.weight for m in mods if m.weight.requires_grad]
+    attn = getattr(module, "_grit_mha_modules", None)
+    if attn is None:
+        attn = [m for m in module.modules() if isinstance(m, torch.nn.MultiheadAttention) and m.in_proj_weight is not None]
+        object.__setattr__(module, "_grit_mha_modules", attn)
+    ws += [m.in_proj_weight for m in attn if m.in_proj_weight.requires_grad]  # (the packed in-projection node of ops/linear.py)
     if ws and ws[0].is_cuda and ws[0].dtype == torch.bfloat16:
         refresh(ws)

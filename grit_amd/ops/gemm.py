@@ -178,6 +178,7 @@ SHORT_MIN_ROWS = 512
 
 
 def prefers_own_short(M, N, K):
+    """(K <= 1 024 at any row count or K <= 2 048 as well: within 0.03 ms per step of this rule, profiles/r06/ab_short_wide.txt)"""
     return (OWN_SHORT and SHORT_MIN_ROWS <= M < OWN_MIN_ROWS and N % 128 == 0 and K % 64 == 0
             and (K <= 512 or (K <= 1024 and M >= 2048)))
 

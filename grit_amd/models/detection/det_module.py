@@ -34,6 +34,7 @@ _STACKED_VALUE_MAPS = os.environ.get('GRIT_STACKED_VALUE_MAPS', '1') != '0'
 from grit_amd.utils.misc import inverse_sigmoid
 
 _PACKED_IN_PROJ = os.environ.get("GRIT_DET_PACKED_IN_PROJ", "1") != "0"  # A/B knob (round 6): 0 = split weights, two Linear nodes
+_VALUE_DGRAD_NT = os.environ.get("GRIT_DET_VALUE_DGRAD_NT", "1") != "0"  # A/B knob: 0 = torch.mm on the concatenated weight
 _QK_LINEAR = os.environ.get("GRIT_DET_QK_LINEAR", "1") != "0"  # A/B knob: 0 = F.linear for the self-attention in-projections
 
 
@@ -280,6 +281,8 @@ class DetectionModule(nn.Module):
                 and B * S * n * C * 2 < (1 << 32) and all(p.weight.dtype == src.dtype and p.bias is not None for p in projs):
             weight = torch.cat([p.weight for p in projs])  # [layers * C, C]: 3 MB, the split of its gradient is free
             bias = torch.cat([p.bias for p in projs])
+            if _VALUE_DGRAD_NT:
+                _transposed.refresh([weight])  # its input gradient as ONE NT product on W^T (K = layers * C) instead of the library's NN form
             stacked = linear(src, weight, bias)  # [B, S, layers * C]
             if padding_mask is not None:
                 stacked = stacked.masked_fill(padding_mask[..., None], float(0))

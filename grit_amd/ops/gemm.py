@@ -146,18 +146,22 @@ _CUS = 256
 # gradients of every Swin block) on the own kernel, now that 224-row tiles fill the CUs (profiles/r06/w4_vs_lib_224.txt: 0.91-1.14 x
 # the library's stream-K kernel stand-alone, ahead of it in the step: profiles/r06/ab_own_deep.txt).  0: the round-5 policy.
 OWN_DEEP = os.environ.get("GRIT_GEMM_OWN_DEEP", "1") != "0"
+# GRIT_GEMM_OWN_MAX_TILES (default 16 384): the stacked value projection of the deformable decoder (272 000 x 3 072 x 512: 12 756 tiles) is
+# 5 % behind the library's stream-K kernel stand-alone (profiles/r04/w4_vs_lib.txt) and level with it inside the step
+# (profiles/r06/ab_own_max_tiles.txt: 46.74 against 46.75 ms) -- level means the own kernel runs it.  8192: the library, as up to round 5.
+OWN_MAX_TILES = int(os.environ.get("GRIT_GEMM_OWN_MAX_TILES", "16384"))
 
 
 def prefers_own(M, N, K):
     """Shape policy, measured on MI355X against the tuned library kernels (profiles/r04/w4_vs_lib.txt, profiles/r06/w4_vs_lib_224.txt):
     the own kernel wins or ties where a tile has few K steps (K <= 512: the library pays a ring fill per tile; e.g. stage-1 proj
     58 -> 42 us, stage-2 qkv 84 -> 77 us), at K = 1 024 with wide outputs and -- with 224-row tiles, round 6 -- on the K >= 1 024
-    products with <= 512 output columns (400 / 800 / 200 tiles of 256 rows filled 256 CUs 1.56 / 3.1 / 0.78 times); the library stays
-    ahead on the 12 000-tile value projection."""
+    products with <= 512 output columns (400 / 800 / 200 tiles of 256 rows filled 256 CUs 1.56 / 3.1 / 0.78 times); on the 12 756-tile
+    stacked value projection the library is 5 % ahead stand-alone and level inside the step (OWN_MAX_TILES)."""
     if N % 256 or K % 64 or M < OWN_MIN_ROWS or M * K * 2 >= 2 ** 31 or N * K * 2 >= 2 ** 31:
         return False
     tiles = -(-M // 256) * (N // 256)
-    return tiles <= 8192 and (OWN_DEEP or K <= 512 or (K <= 1024 and N >= 1024))
+    return tiles <= OWN_MAX_TILES and (OWN_DEEP or K <= 512 or (K <= 1024 and N >= 1024))
 
 
 def prefers_own_narrow(M, N, K):

@@ -234,7 +234,7 @@ def test_own_long_map_policy_and_linear_nodes():
     assert G.prefers_own(51200, 1536, 512) and G.prefers_own(51200, 512, 512) and G.prefers_own(12800, 3072, 1024)
     assert G.prefers_own(51200, 512, 2048) and G.prefers_own(12800, 1024, 4096) and G.prefers_own(204800, 256, 1024)  # (round 6: 224-row tiles)
     assert not G.prefers_own(4800, 512, 512) and not G.prefers_own(51200, 384, 512)
-    assert not G.prefers_own(272000, 3072, 512)  # 12 756 tiles: the library's kernel is ahead there (profiles/r04/w4_vs_lib.txt)
+    assert G.prefers_own(272000, 3072, 512)  # 12 756 tiles: level with the library inside the step (profiles/r06/ab_own_max_tiles.txt)
     torch.manual_seed(0)
     M, N, K = 16384, 512, 256
     x = torch.randn(M, K, device='cuda').bfloat16().requires_grad_(True)

@@ -256,6 +256,66 @@ def test_own_long_map_policy_and_linear_nodes():
         _close(g_, r_)
 
 
+def test_short_map_policy_linear_and_packed_in_projection_nodes(monkeypatch):
+    """grit_amd.ops.gemm.prefers_own_short (round 6): the Linears of the decoders' 640 .. 4 800-row maps run the 64 x 64 x 64 tiles (variant 12)
+    in the forward and -- on the transposed copies -- in the input gradient; the Linear node and the packed in-projection node with the
+    policy on against the same nodes on the library (GRIT_GEMM_OWN_SHORT=0) and against float32: values and every gradient."""
+    from grit_amd.ops import gemm as G
+    from grit_amd.ops import transposed
+    from grit_amd.ops.linear import linear, packed_in_proj
+    assert G.prefers_own_short(4800, 512, 512) and G.prefers_own_short(640, 2048, 512) and G.prefers_own_short(4800, 512, 1024)
+    assert not G.prefers_own_short(640, 512, 1024) and not G.prefers_own_short(640, 512, 2048) and not G.prefers_own_short(4800, 4, 512)
+    assert not G.prefers_own_short(9600, 512, 512) and not G.prefers_own_short(320, 512, 512)  # long-map policy / decode steps: not these tiles
+    torch.manual_seed(1)
+    for M, N, K in ((4800, 512, 512), (640, 2048, 512), (4800 + 37, 256, 1024)):
+        x = torch.randn(M, K, device='cuda').bfloat16().requires_grad_(True)
+        w = (torch.randn(N, K, device='cuda') * K ** -0.5).bfloat16().requires_grad_(True)
+        b = torch.randn(N, device='cuda').bfloat16().requires_grad_(True)
+        cot = torch.randn(M, N, device='cuda').bfloat16()
+        out = []
+        for on in (True, False):
+            monkeypatch.setattr(G, "OWN_SHORT", on)
+            transposed.refresh([w])
+            assert (G.long_linear(x.detach(), w.detach(), b.detach()) is not None) == on
+            assert (G.long_input_grad(cot, w) is not None) == (on and G.prefers_own_short(M, K, N))  # (as an NT product: N and K swap)
+            for t in (x, w, b):
+                t.grad = None
+            y = linear(x, w, b)
+            (y * cot).sum().backward()
+            out.append([y.detach().float(), x.grad.float().clone(), w.grad.float().clone(), b.grad.float().clone()])
+        x32, w32, b32 = (t.detach().float().requires_grad_(True) for t in (x, w, b))
+        y32 = F.linear(x32, w32, b32)
+        (y32 * cot.float()).sum().backward()
+        for g_, l_, r_ in zip(out[0], out[1], [y32.detach(), x32.grad, w32.grad, b32.grad]):
+            _close(g_, r_)
+            _close(g_, l_)
+    # the packed in-projection: q = k from one input, v from another, two row ranges of one [3E, E] parameter
+    E, B, Lq = 256, 32, 150
+    qk_in = torch.randn(B, Lq, E, device='cuda').bfloat16().requires_grad_(True)
+    v_in = torch.randn(B, Lq, E, device='cuda').bfloat16().requires_grad_(True)
+    w = (torch.randn(3 * E, E, device='cuda') * E ** -0.5).bfloat16().requires_grad_(True)
+    b = torch.randn(3 * E, device='cuda').bfloat16().requires_grad_(True)
+    cots = torch.randn(B, Lq, 2 * E, device='cuda').bfloat16(), torch.randn(B, Lq, E, device='cuda').bfloat16()
+    out = []
+    for on in (True, False):
+        monkeypatch.setattr(G, "OWN_SHORT", on)
+        transposed.refresh([w])
+        for t in (qk_in, v_in, w, b):
+            t.grad = None
+        qk, v = packed_in_proj(qk_in, v_in, w, b)
+        ((qk * cots[0]).sum() + (v * cots[1]).sum()).backward()
+        out.append([qk.detach().float(), v.detach().float()] + [t.grad.float().clone() for t in (qk_in, v_in, w, b)])
+    for g_, l_ in zip(*out):
+        _close(g_, l_)
+    # (the two paths can agree to the bit -- same MFMA, same k order per accumulator -- so the choice of path is checked directly)
+    from grit_amd.ops.linear import _own_linear, _short_transposed
+    monkeypatch.setattr(G, "OWN_SHORT", True)
+    transposed.refresh([w])
+    assert _short_transposed(w, cots[0].reshape(-1, 2 * E)) is not None and _own_linear(qk_in.detach(), w[:2 * E].detach(), b[:2 * E].detach()) is not None
+    monkeypatch.setattr(G, "OWN_SHORT", False)
+    assert _short_transposed(w, cots[0].reshape(-1, 2 * E)) is None and _own_linear(qk_in.detach(), w[:2 * E].detach(), b[:2 * E].detach()) is None
+
+
 @pytest.mark.gpu
 def test_narrow_output_policy_for_the_stage0_maps():
     """grit_amd.ops.gemm.prefers_own_narrow: the 128- / 384-column products of the 819 200-token stage-0 map run the eight-wave own

@@ -112,7 +112,7 @@ __device__ __forceinline__ void colsum_body(const T* __restrict__ x, size_t ld, 
 // flight and an LDS fold, ran these sums at ~2 TB/s inside the training step.)
 template <typename OT>
 __device__ __forceinline__ void slab_sum_wide(const float* __restrict__ partial, long group_stride, int slabs, long n,
-                                              OT* __restrict__ out, unsigned bx, unsigned by) {
+                                              OT* __restrict__ out, unsigned bx, unsigned by, const float* __restrict__ extra) {
     const long col = ((long)bx * 256 + threadIdx.x) * 4;
     if (col >= n) return;
     const float* src = partial + (long)by * group_stride + col;
@@ -127,6 +127,7 @@ __device__ __forceinline__ void slab_sum_wide(const float* __restrict__ partial,
         for (int u = 0; u < 8; ++u) acc4 += v[u];
     }
     for (; s < slabs; ++s) acc4 += __builtin_nontemporal_load(reinterpret_cast<const f4*>(src + (long)s * n));
+    if (extra) acc4 += *reinterpret_cast<const f4*>(extra + (long)by * n + col);  // one more term, added last
     const float4 acc = make_float4(acc4[0], acc4[1], acc4[2], acc4[3]);
     OT* dst = out + (long)by * n + col;
     if constexpr (sizeof(OT) == 4) {
@@ -143,9 +144,10 @@ constexpr int kWideMark = 31;  // cw_log2 value that selects slab_sum_wide
 
 template <typename OT>
 __device__ __forceinline__ void slab_sum_body(const float* __restrict__ partial, long group_stride, int slabs, long n, int cw_log2,
-                                              OT* __restrict__ out, unsigned bx, unsigned by, float4* red) {
+                                              OT* __restrict__ out, unsigned bx, unsigned by, float4* red,
+                                              const float* __restrict__ extra = nullptr) {
     if (cw_log2 == kWideMark) {  // workgroup-uniform
-        slab_sum_wide<OT>(partial, group_stride, slabs, n, out, bx, by);
+        slab_sum_wide<OT>(partial, group_stride, slabs, n, out, bx, by, extra);
         return;
     }
     const int cw = 1 << cw_log2, sg_count = 256 >> cw_log2;
@@ -174,6 +176,10 @@ __device__ __forceinline__ void slab_sum_body(const float* __restrict__ partial,
         for (int j = 1; j < sg_count; ++j) {
             const float4 a = red[(j << cw_log2) + c];
             acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+        }
+        if (extra) {  // one more term, added last
+            const float4 e = *reinterpret_cast<const float4*>(extra + (long)by * n + col);
+            acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
         }
         OT* dst = out + (long)by * n + col;
         if constexpr (sizeof(OT) == 4) {
@@ -214,9 +220,9 @@ void slab_sum_grouped_kernel(const GroupedArgs a) {
     const unsigned by = local / a.blocks_x[j], bx = local - by * a.blocks_x[j];
     const grit_slab_job& jb = a.job[j];
     if (jb.out_is_bf16)
-        slab_sum_body<__hip_bfloat16>(jb.partial, jb.group_stride, jb.slabs, jb.n, a.cw_log2[j], (__hip_bfloat16*)jb.out, bx, by, red);
+        slab_sum_body<__hip_bfloat16>(jb.partial, jb.group_stride, jb.slabs, jb.n, a.cw_log2[j], (__hip_bfloat16*)jb.out, bx, by, red, jb.extra);
     else
-        slab_sum_body<float>(jb.partial, jb.group_stride, jb.slabs, jb.n, a.cw_log2[j], (float*)jb.out, bx, by, red);
+        slab_sum_body<float>(jb.partial, jb.group_stride, jb.slabs, jb.n, a.cw_log2[j], (float*)jb.out, bx, by, red, jb.extra);
 }
 
 // column width (log2 of float4 groups per workgroup row) for a job: see grit_slab_sum
@@ -248,6 +254,7 @@ extern "C" int grit_slab_sum_grouped(const grit_slab_job* jobs, int n_jobs, void
         if (jb.n % 4 != 0 || jb.group_stride % 4 != 0 || ((uintptr_t)jb.partial % 16) != 0 || ((uintptr_t)jb.out % 8) != 0)
             return GRIT_ERR_UNSUPPORTED;
         if (!jb.out_is_bf16 && ((uintptr_t)jb.out % 16) != 0) return GRIT_ERR_UNSUPPORTED;
+        if (((uintptr_t)jb.extra % 16) != 0) return GRIT_ERR_UNSUPPORTED;
         const long groups4 = jb.n / 4;
         a.job[j] = jb;
         a.cw_log2[j] = pick_cw_log2(groups4, jb.groups, jb.slabs);

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -99,7 +99,7 @@ WGRAD_GROUP_MAX = 32  # GRIT_WGRAD_GROUP_MAX
 class SlabJob(_c.Structure):
     """grit_slab_job of include/grit_hip.h."""
     _fields_ = [("partial", _c.c_void_p), ("group_stride", _c.c_long), ("groups", _c.c_int), ("slabs", _c.c_int),
-                ("n", _c.c_long), ("out", _c.c_void_p), ("out_is_bf16", _c.c_int)]
+                ("n", _c.c_long), ("out", _c.c_void_p), ("out_is_bf16", _c.c_int), ("extra", _c.c_void_p)]
 
 
 class WgradJob(_c.Structure):

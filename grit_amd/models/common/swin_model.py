@@ -45,6 +45,10 @@ def to_2tuple(x):
 _POOLED_DROP_PATH = os.environ.get('GRIT_POOLED_DROP_PATH', '1') != '0'  # A/B knob
 _PATCH_EMBED_FUSED = os.environ.get('GRIT_PATCH_EMBED_FUSED', '1') != '0'  # A/B knob: conv + bias + LayerNorm of PatchEmbed in one pass
 _MERGE_LN = os.environ.get('GRIT_MERGE_LN', '1') != '0'  # A/B knob: patch-merging LayerNorm on the gathering kernels
+# A/B knobs (round 6): d(pad_qkv) inside the qkv Linear's bias-gradient sum instead of a cast + an autograd add per block; one zero fill for the
+# d(bias) | d(pad) accumulators of all blocks instead of one per block
+_PAD_GRAD_VIA_BIAS = os.environ.get('GRIT_WINATTN_PAD_VIA_BIAS', '1') != '0'
+_ZERO_ARENA = os.environ.get('GRIT_WINATTN_ZERO_ARENA', '1') != '0'
 _FUSED_MLP = os.environ.get('GRIT_FUSED_MLP', '1') != '0'  # A/B knob: Mlp on the fused-epilogue GEMM (grit_amd/ops/mlp.py)
 
 
@@ -163,8 +167,15 @@ class WindowAttention(nn.Module):
         row_scale: (drop-path factors [B], rows per sample) of the attention branch, when the caller multiplies the branch by them: the
         gradient that comes back to qkv is then zero in the rows of dropped samples and its weight gradient skips them."""
         qkv = self.qkv(x, row_scale=row_scale) if row_scale is not None else self.qkv(x)
+        bias = self.qkv.bias
+        # d(pad_qkv) -- the pad rows ARE the qkv bias -- goes into the qkv Linear's own bias-gradient sum when that Linear's backward is
+        # the node of grit_amd/ops/linear.py (it tags its result); the zeroed d(bias) | d(pad) workspace comes from the backbone's one fill
+        owner = bias if (_PAD_GRAD_VIA_BIAS and bias is not None and getattr(qkv, "_grit_bias_node", None) is bias
+                         and bias.dtype == qkv.dtype) else None
+        acc = self.__dict__.pop("_grit_acc", None)
         return window_attention(qkv, self.relative_position_bias(), self.pad_qkv(qkv.dtype), H, W, self.num_heads,
-                                self.window_size[0], shift, self.scale, row_scale=None if row_scale is None else row_scale[0])
+                                self.window_size[0], shift, self.scale, row_scale=None if row_scale is None else row_scale[0],
+                                pad_owner=owner, acc=acc)
 
     def attend_map(self, x, H, W, shift):
         """x: normalised tokens [B, H*W, C] in map order -> attention output [B, H*W, C] (after proj)."""
@@ -484,6 +495,23 @@ class SwinTransformer(nn.Module):
         for j, blk in enumerate(blocks):
             blk._drop_path_ready = [scales[2 * j + 1], scales[2 * j]]  # popped from the end: attention first
 
+    def _hand_out_backward_workspaces(self, device):
+        """One zero fill for the d(relative-position bias) | d(pad_qkv) accumulators of every trainable block's window-attention backward
+        (float atomics across workgroups need zeros: 22 fills of ~5 us each inside the backward otherwise); a block's attention takes its
+        slice at its next call.  Also drops a bias-gradient term a previous, interrupted backward may have left (ops/linear.py)."""
+        blocks = [blk for stage in self.layers for blk in stage.blocks if blk.attn.qkv.weight.requires_grad]
+        for blk in blocks:
+            if blk.attn.qkv.bias is not None:
+                blk.attn.qkv.bias.__dict__.pop("_grit_bias_extra", None)
+        if not (_ZERO_ARENA and blocks):
+            return
+        sizes = [blk.attn.num_heads * blk.attn.relative_position_index.numel() + 3 * blk.attn.dim for blk in blocks]
+        arena = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+        off = 0
+        for blk, n in zip(blocks, sizes):
+            blk.attn.__dict__["_grit_acc"] = arena[off:off + n]
+            off += n
+
     def forward(self, x):
         B = x.shape[0]
         if _POOLED_DROP_PATH and self.training and x.is_cuda and torch.is_grad_enabled():
@@ -496,6 +524,7 @@ class SwinTransformer(nn.Module):
             _transposed.refresh([w for stage in self.layers for blk in stage.blocks
                                  for w in (blk.mlp.fc2.weight, blk.attn.proj.weight, blk.attn.qkv.weight, blk.mlp.fc1.weight)
                                  if w.requires_grad])
+            self._hand_out_backward_workspaces(x.device)
         x, Wh, Ww = self.patch_embed.tokens(x)  # (casts to the weights' dtype itself unless the fused pass reads the image as it is)
         if self.ape:
             pos = F.interpolate(self.absolute_pos_embed, size=(Wh, Ww), mode='bicubic')

@@ -545,11 +545,13 @@ class SlabGroup(object):
     def __init__(self):
         self.jobs, self.keep = [], []
 
-    def add(self, partial, out_dtype, slabs=None, out=None):
+    def add(self, partial, out_dtype, slabs=None, out=None, extra=None):
         """partial f32 [groups, slabs_allocated, n...] contiguous -> out [groups, n...] (sum over the first `slabs` slabs);
-        out: an existing contiguous tensor of that shape and dtype to write to."""
+        out: an existing contiguous tensor of that shape and dtype to write to; extra: f32 [groups, n...] contiguous, one more term of
+        every sum (grit_slab_job.extra)."""
         if not SlabGroup.ENABLED:
-            return slab_sum(partial, out_dtype, slabs, out)
+            res = slab_sum(partial, out_dtype, slabs, out)
+            return res if extra is None else res.add_(extra.view(res.shape).to(res.dtype))
         slabs = partial.shape[1] if slabs is None else slabs
         tail = tuple(partial.shape[2:])
         n = 1
@@ -557,8 +559,11 @@ class SlabGroup(object):
             n *= d
         if out is None:
             out = torch.empty((partial.shape[0],) + tail, dtype=out_dtype, device=partial.device)
+        if extra is not None:
+            assert extra.dtype == torch.float32 and extra.is_contiguous() and extra.numel() == partial.shape[0] * n and extra.data_ptr() % 16 == 0
+            self.keep.append(extra)
         self.jobs.append((partial.data_ptr(), partial.stride(0), partial.shape[0], slabs, n, out.data_ptr(),
-                          int(out_dtype == torch.bfloat16)))
+                          int(out_dtype == torch.bfloat16), 0 if extra is None else extra.data_ptr()))
         self.keep.append(partial)  # the partials must outlive the launch; outputs are owned by the caller
         self.device = partial.device
         return out
@@ -582,7 +587,7 @@ class SlabGroup(object):
         self.jobs, self.keep = [], []
 
 
-def column_sum(x2d, out_dtype=torch.float32, group=None):
+def column_sum(x2d, out_dtype=torch.float32, group=None, extra=None):
     """[M, N] (bf16 / f32, contiguous, N % 8 == 0) -> [N] in out_dtype (f32 accumulation).  With `group` (a SlabGroup) the
     second stage is left to the group's launch: the returned tensor is filled by group.run()."""
     M, N = x2d.shape
@@ -596,8 +601,9 @@ def column_sum(x2d, out_dtype=torch.float32, group=None):
                                      ctypes.c_void_p(partial.data_ptr()), _lib.current_stream_ptr())
     _lib.check(st, "grit_colsum")
     if group is not None:
-        return group.add(partial.unsqueeze(0), out_dtype)[0]
-    return slab_sum(partial.unsqueeze(0), out_dtype)[0]
+        return group.add(partial.unsqueeze(0), out_dtype, extra=extra)[0]
+    res = slab_sum(partial.unsqueeze(0), out_dtype)[0]
+    return res if extra is None else res.add_(extra.to(res.dtype))
 
 
 _SLAB_ROWS = int(os.environ.get("GRIT_WGRAD_SLAB_ROWS", "3200"))  # tuning knob (tools/bench_weight_grad.py)
@@ -833,7 +839,7 @@ def weight_grad(dy2, x2, group=None, param=None, row_scale=None):
     return slab_sum(part.unsqueeze(0), dy2.dtype)[0]
 
 
-def weight_bias_grad(dy2, x2, group, need_w, need_b, weight, row_scale=None):
+def weight_bias_grad(dy2, x2, group, need_w, need_b, weight, row_scale=None, bias_extra=None):
     """(dW, db) of a Linear from dy2 [M, N], x2 [M, K]; either may be None when not wanted.  Long maps with both wanted: ONE launch of
     the own kernel yields the weight-gradient slices and, as a by-product, the bias gradient's column sums (no pass over dy2 of its
     own); otherwise weight_grad / column_sum.  group: the node's SlabGroup (the sums are left to its launch)."""
@@ -843,9 +849,9 @@ def weight_bias_grad(dy2, x2, group, need_w, need_b, weight, row_scale=None):
     if pair is not None:
         slot = grad_slot(weight, dy2.dtype, dy2.device)
         dw = group.add(pair[0].unsqueeze(0), dy2.dtype, out=None if slot is None else slot.view(1, dy2.shape[1], x2.shape[1]))[0]
-        return dw, group.add(pair[1].unsqueeze(0), weight.dtype)[0]
+        return dw, group.add(pair[1].unsqueeze(0), weight.dtype, extra=bias_extra)[0]
     dw = weight_grad(dy2, x2, group, param=weight, row_scale=row_scale) if need_w else None
-    db = column_sum(dy2 if dy2.is_contiguous() else dy2.contiguous(), weight.dtype, group) if need_b else None
+    db = column_sum(dy2 if dy2.is_contiguous() else dy2.contiguous(), weight.dtype, group, extra=bias_extra) if need_b else None
     return dw, db
 
 
@@ -867,6 +873,20 @@ def _own_input_grad(dy2, weight, shape):
     return None if dx is None else dx.view(shape)
 
 
+def leave_bias_extra(bias, term):
+    """Called from the backward of a node that uses `bias` (a Linear's bias parameter, tagged by linear() on the Linear's result) a
+    second time: `term` (f32, contiguous, bias-shaped, 16-byte aligned) is its gradient contribution.  The Linear's own backward --
+    which runs later in the same pass -- adds it inside its bias-gradient reduction; the caller returns None for that input."""
+    bias._grit_bias_extra = term
+
+
+def take_bias_extra(bias):
+    term = getattr(bias, "_grit_bias_extra", None) if bias is not None else None
+    if term is not None:
+        del bias._grit_bias_extra
+    return term
+
+
 class _LinearFn(Function):
 
     @staticmethod
@@ -880,6 +900,7 @@ class _LinearFn(Function):
         ctx.bias_param = bias if single_use else None  # the parameter itself: the deferred path checks its .grad
         ctx.weight_param = weight if single_use else None
         ctx.weight_obj = weight  # the tensor object the forward was called with: transposed copies are attached to IT
+        ctx.bias_obj = bias      # ... and a gradient term another node leaves for this bias (take_bias_extra)
         own = _own_linear(x, weight, bias)
         if own is not None:
             return own
@@ -900,7 +921,11 @@ class _LinearFn(Function):
         if ctx.row_scale is not None:
             backend.check_dropped_rows(dy2, ctx.row_scale[0], "Linear backward (row_scale)")
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
-        deferred = defer_weight_bias_grad(dy2, x2, weight, ctx.bias_param, ctx.needs_input_grad[1], need_b, ctx.single_use)
+        # a second gradient term of the bias that another node of this pass left for this one (window attention: the q / k / v rows of
+        # the window-padding tokens ARE the qkv bias): it joins the bias gradient's slab sum as one more term -- no cast, no add launch
+        extra = take_bias_extra(ctx.bias_obj) if need_b else None
+        deferred = None if extra is not None else \
+            defer_weight_bias_grad(dy2, x2, weight, ctx.bias_param, ctx.needs_input_grad[1], need_b, ctx.single_use)
         if deferred is not None:  # short map inside a gradient-bucket scope: dW / db come from the scope's grouped launch
             dw, db = deferred
             if ctx.needs_input_grad[0]:
@@ -913,11 +938,12 @@ class _LinearFn(Function):
             if (ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or need_b)) else None
         group = SlabGroup() if dy2.is_cuda else None  # dW's and db's partial sums: one reduction launch
         with on_stream(side):
-            both = small_weight_bias_grad(dy2, x2, need_b, weight.dtype, group) if ctx.needs_input_grad[1] else None
+            both = small_weight_bias_grad(dy2, x2, need_b, weight.dtype, group) if (ctx.needs_input_grad[1] and extra is None) else None
             if both is not None:  # short map: dW and db partials from one launch
                 dw, db = both
             else:
-                dw, db = weight_bias_grad(dy2, x2, group, ctx.needs_input_grad[1], need_b, weight, row_scale=ctx.row_scale)
+                dw, db = weight_bias_grad(dy2, x2, group, ctx.needs_input_grad[1], need_b, weight, row_scale=ctx.row_scale,
+                                          bias_extra=extra)
             if side is None:
                 finish_group(group, ctx.single_use, [(ctx.weight_param, dw), (ctx.bias_param, db)])
             elif group is not None:
@@ -1002,7 +1028,10 @@ def linear(x, weight, bias, single_use=False, row_scale=None):
             if own is not None:
                 return own
         return F.linear(x, weight, bias)
-    return _LinearFn.apply(x, weight, bias, single_use_now(single_use), row_scale)
+    y = _LinearFn.apply(x, weight, bias, single_use_now(single_use), row_scale)
+    if bias is not None and bias.requires_grad:
+        y._grit_bias_node = bias  # (this result's backward is _LinearFn's: it honours leave_bias_extra for this bias)
+    return y
 
 
 class Linear(nn.Linear):

@@ -65,7 +65,7 @@ def _ptr(t):
 class _WindowAttentionFn(Function):
 
     @staticmethod
-    def forward(ctx, qkv, rel_bias, pad_qkv, mask, H, W, num_heads, window, shift, scale, row_scale=None):
+    def forward(ctx, qkv, rel_bias, pad_qkv, mask, H, W, num_heads, window, shift, scale, row_scale=None, pad_owner=None, acc=None):
         B, T, C3 = qkv.shape
         C = C3 // 3
         nWh, nWw = -(-H // window), -(-W // window)
@@ -93,6 +93,9 @@ class _WindowAttentionFn(Function):
         # drop path: per-image factors [B] float32 of the attention branch (the caller multiplies the branch by them): the gradient
         # that comes back is zero for images with factor 0 -- the backward kernel does not compute their windows
         ctx.row_scale = row_scale if rows else None
+        # pad_owner: the Linear bias parameter whose values pad_qkv holds, when its Linear's backward takes d(pad) into its own bias
+        # gradient (grit_amd/ops/linear.py leave_bias_extra); acc: zeroed f32 workspace for d(bias) | d(pad) (one fill per step for all blocks)
+        ctx.pad_owner, ctx.acc = pad_owner, acc
         return out
 
     @staticmethod
@@ -105,7 +108,9 @@ class _WindowAttentionFn(Function):
         dout = dout.contiguous().to(qkv.dtype)
         dqkv = torch.empty_like(qkv)
         # d(bias) and d(pad) are accumulated across workgroups with float atomics: one zero fill for both
-        acc = torch.zeros(rel_bias.numel() + C3, dtype=torch.float32, device=qkv.device)
+        acc, ctx.acc = ctx.acc, None  # (handed over once: a second backward over the same graph gets a fresh fill)
+        if acc is None or acc.numel() != rel_bias.numel() + C3 or acc.device != qkv.device or acc.dtype != torch.float32:
+            acc = torch.zeros(rel_bias.numel() + C3, dtype=torch.float32, device=qkv.device)
         dbias, dpad = acc[:rel_bias.numel()].view_as(rel_bias), acc[rel_bias.numel():]
         nWm = 0 if mask is None else mask.shape[0]
         flops = _core_flops(B, -(-H // window), -(-W // window), num_heads, window * window, 5)
@@ -125,10 +130,14 @@ class _WindowAttentionFn(Function):
                                                    _ptr(dout), _ptr(lse), B, H, W, C, num_heads, window, shift, scale,
                                                    _ptr(dqkv), _ptr(dbias), _ptr(dpad), _lib.current_stream_ptr())
         _lib.check(st, "grit_winattn_bwd")
-        return dqkv, dbias, dpad.to(pad_qkv.dtype), None, None, None, None, None, None, None, None
+        if ctx.pad_owner is not None and ctx.needs_input_grad[2]:
+            from grit_amd.ops.linear import leave_bias_extra
+            leave_bias_extra(ctx.pad_owner, dpad)  # joins the qkv Linear's bias-gradient sum: no cast, no add
+            return dqkv, dbias, None, None, None, None, None, None, None, None, None, None, None
+        return dqkv, dbias, dpad.to(pad_qkv.dtype), None, None, None, None, None, None, None, None, None, None
 
 
-def window_attention(qkv, rel_bias, pad_qkv, H, W, num_heads, window, shift, scale, mask=None, row_scale=None):
+def window_attention(qkv, rel_bias, pad_qkv, H, W, num_heads, window, shift, scale, mask=None, row_scale=None, pad_owner=None, acc=None):
     """qkv [B, H*W, 3C] (q|k|v, each head-major), rel_bias [nH, N, N] fp32, pad_qkv [3C], optional explicit
     additive mask [nW_mask, N, N] (replaces the analytic shift mask).  Returns [B, H*W, C] in qkv's dtype.
     row_scale: drop-path factors [B] of the branch this attention is part of (see _WindowAttentionFn.forward) or None."""
@@ -146,5 +155,5 @@ def window_attention(qkv, rel_bias, pad_qkv, H, W, num_heads, window, shift, sca
     cdt = torch.float32 if in_dtype in (torch.float32, torch.float64) else torch.bfloat16
     out = _WindowAttentionFn.apply(qkv.to(cdt).contiguous(), rel_bias.float().contiguous(), pad_qkv.to(cdt).contiguous(),
                                    None if mask is None else mask.float().contiguous(), H, W, num_heads, window, shift,
-                                   float(scale), row_scale)
+                                   float(scale), row_scale, pad_owner if cdt == torch.bfloat16 else None, acc)
     return out.to(in_dtype)

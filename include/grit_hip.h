@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 39
+#define GRIT_ABI_VERSION 40
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -369,6 +369,8 @@ typedef struct grit_slab_job {
     long n;
     void* out;              /* [groups, n] */
     int out_is_bf16;
+    const float* extra;     /* NULL, or [groups, n] f32 (16-byte aligned): one more term of every sum, added last (ABI 40: the q / k / v
+                             * rows of the window-padding tokens are the qkv bias -- grit_winattn_bwd's d(pad) joins the bias gradient's sum) */
 } grit_slab_job;
 int grit_slab_sum_grouped(const grit_slab_job* jobs, int n_jobs, void* stream);
 

@@ -305,3 +305,47 @@ def test_row_skip_check_knob_catches_a_caller_that_breaks_the_promise(monkeypatc
     kept = cot.clone()
     kept[1] = 0
     assert bool(torch.isfinite(run(kept)).all())
+
+
+def test_pad_gradient_inside_the_qkv_bias_sum_and_one_zero_fill(monkeypatch):
+    """Round 6: the q / k / v rows of the window-padding tokens are the qkv bias, so d(pad_qkv) is a second gradient of that bias.  With
+    GRIT_WINATTN_PAD_VIA_BIAS the attention's backward leaves its float32 d(pad) for the qkv Linear's backward, which adds it inside the
+    bias gradient's slab sum (grit_slab_job.extra) instead of a cast + an autograd add; with GRIT_WINATTN_ZERO_ARENA the d(bias) | d(pad)
+    accumulators of all blocks come zeroed from one fill.  Knobs on against knobs off: every gradient of a Swin block, the bias gradient
+    within one bf16 rounding of the float32 sum of its two terms; nothing left behind on the parameter or the module."""
+    from grit_amd.models.common import swin_model as S
+    torch.manual_seed(2)
+    C, nH, H, W, B = 256, 8, 30, 26, 3  # (30 x 26 tokens: padded to 36 x 36, so d(pad) is not zero)
+    blk = S.SwinTransformerBlock(dim=C, num_heads=nH, window_size=12, shift_size=6, drop_path=0.0).cuda().bfloat16().train()
+    blk.H, blk.W = H, W
+    x = torch.randn(B, H * W, C, device='cuda').bfloat16()
+    cot = torch.randn(B, H * W, C, device='cuda').bfloat16()
+    params = [p for p in blk.parameters()]
+
+    class Backbone(torch.nn.Module):  # (_hand_out_backward_workspaces walks self.layers[*].blocks)
+        def __init__(self):
+            super().__init__()
+            stage = torch.nn.Module()
+            stage.blocks = torch.nn.ModuleList([blk])
+            self.layers = torch.nn.ModuleList([stage])
+    bb = Backbone()
+    out = []
+    for on in (True, False):
+        monkeypatch.setattr(S, "_PAD_GRAD_VIA_BIAS", on)
+        monkeypatch.setattr(S, "_ZERO_ARENA", on)
+        for p in params:
+            p.grad = None
+        S.SwinTransformer._hand_out_backward_workspaces(bb, x.device)
+        assert ("_grit_acc" in blk.attn.__dict__) == on
+        xi = x.clone().requires_grad_(True)
+        y = blk(xi)
+        assert "_grit_acc" not in blk.attn.__dict__  # taken by the attention node
+        (y * cot).sum().backward()
+        assert not hasattr(blk.attn.qkv.bias, "_grit_bias_extra")  # taken by the qkv Linear's backward
+        out.append([y.detach().float(), xi.grad.float()] + [p.grad.float().clone() for p in params])
+    names = ["y", "dx"] + [n for n, _ in blk.named_parameters()]
+    for n, a, b in zip(names, *out):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 2.0 ** -7 * scale + 1e-6, n
+    i = names.index("attn.qkv.bias")
+    assert out[0][i].abs().max().item() > 0 and not torch.equal(out[0][i], out[1][i])  # (one rounding instead of three somewhere)

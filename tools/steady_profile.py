@@ -35,6 +35,14 @@ def main(out_dir, nwin=2):
           f"GPU busy {tot / 1e6 / nwin:.2f} ms/step, GEMM (hipBLASLt/rocBLAS) {gemm / 1e6 / nwin:.2f} ms/step")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
         print(f"{v[0] / 1e6 / nwin:8.2f} ms/step  calls/step {v[1] / nwin:7.1f}  avg {v[0] / v[1] / 1e3:9.1f} us  {k[:140]}")
+    import os
+    if os.environ.get("GRIT_PROFILE_STEP_SEQUENCE"):  # the ordered kernel list of ONE whole step (first msda_fwd to the next step's)
+        a, b = steps[-2][0], steps[-1][0]
+        with open(os.environ["GRIT_PROFILE_STEP_SEQUENCE"], "w") as fh:
+            for r in rows:
+                s0 = int(r["Start_Timestamp"])
+                if a <= s0 < b:
+                    fh.write("%9.1f us  +%7.1f  %s\n" % ((s0 - a) / 1e3, (int(r["End_Timestamp"]) - s0) / 1e3, r["Kernel_Name"][:110]))
     # the decoder phase of a step: from the first MSDeformAttn forward launch (decoder layer 0) to the end of the last MSDeformAttn
     # backward work (decoder layer 0 again): deformable decoder forward after its first sampling, grid net, caption decoder, loss,
     # and their backward passes -- thousands of small dependent kernels.  Busy time inside it, kernel count, and how much of the

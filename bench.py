@@ -676,18 +676,18 @@ def main():
             "gemm_nt_bf16": "gemm_nt_bf16<256,256,64,...> (grit_amd/csrc/gemm.hip): the Swin Mlp's fused GEMMs -- fc1 + bias + GELU "
                             "writing pre-activation and activation, fc2 input gradient x GELU' + bias-gradient column sums -- and the stage-0 map's "
                             "narrow products (128 / 384 output columns, K <= 512: HBM streams)",
-            "gemm_w4": "gemm_w4_bf16 (grit_amd/csrc/gemm_w4.hip): persistent four-wave kernel, 128 x 128 wave tiles -- qkv / proj / value "
-                       "forward GEMMs and NT input gradients of the long maps where it beats the library",
+            "gemm_w4": "gemm_w4_bf16 (grit_amd/csrc/gemm_w4.hip): persistent four-wave kernel, 128 x 128 / 112 x 128 wave tiles -- every long-map "
+                       "Linear of the step: qkv / proj / fc2 forward (proj and fc2 with the residual epilogue), the NT input gradients of the Swin "
+                       "blocks, PatchMerging, the stacked value projection of the deformable decoder and its input gradient",
             "gemm_short": "gemm_nt_bf16<64,64,64,4,1,3,E> (grit_amd/csrc/gemm.hip, variant 12): the Linears of the two decoders and the grid net "
                           "(640 .. 4 800 rows) -- forward + bias and input gradients on transposed weight copies; three workgroups per CU",
             "wgrad_tn": "wgrad_tn_256 + wgrad_tn_256_grouped (grit_amd/csrc/wgrad_tn.hip): weight gradients dW = dY^T X of the long token "
                         "maps and, grouped, of the decoders' short ones; fp32 row-slice partials",
             "wgrad_small": "wgrad_small (grit_amd/csrc/wgrad.hip): 64 x 64-tile grouped weight gradients of shapes outside 256-multiples",
-            "gemm_lib": "hipBLASLt / rocBLAS through torch (tuned table grit_amd/tunableop_gfx950.csv): K >= 1024 long-map GEMMs with <= 512 "
-                        "output columns (stream-K), the value projection, every GEMM of the two decoders",
-            "gemm_lib_long": "NOT an own kernel -- hipBLASLt through torch on the long token maps (>= 8192 rows): the stream-K "
-                             "Custom_Cijk...SK3_MT256x256x64 for K >= 1024 with <= 512 output columns (fc2 forward, fc1 / qkv input "
-                             "gradients), the stacked value projection, PatchMerging reductions, input_proj",
+            "gemm_lib": "hipBLASLt / rocBLAS through torch (tuned table grit_amd/tunableop_gfx950.csv): the sum of gemm_lib_long and "
+                        "gemm_lib_short below",
+            "gemm_lib_long": "NOT an own kernel -- hipBLASLt through torch on the long token maps (>= 8192 rows): what the policies of "
+                             "grit_amd/ops/gemm.py leave there -- the input gradients of input_proj (NN form), K >= 2 048 Linears of the grid net",
             "gemm_lib_short": "NOT an own kernel -- hipBLASLt / rocBLAS through torch on the short maps (< 8192 rows): what the short-map policy "
                               "(grit_amd/ops/gemm.py prefers_own_short) leaves of the decoders' Linears -- K >= 2 048, the gate GEMMs, the fp32 "
                               "vocabulary projection, bias + ReLU fused calls of the detached box refinement",

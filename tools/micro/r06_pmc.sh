@@ -13,7 +13,7 @@ print("HBM-side traffic of the hand-written kernels INSIDE the benchmark step (r
 print("GRIT_STEP_GRAPH=0 python3 bench.py --no-cpu-baseline --no-analysis --steps 3 --warmup 2; mean per launch; FETCH_SIZE doubled per the")
 print("gfx950 note in MI355X_MICROARCH.md; counters in KiB).  `family:` rows = all instantiations of a kernel family, launch-weighted.")
 tot, fam = {}, {}
-FAMILY = (("family:gemm_nt_bf16", "gemm_nt_bf16<"), ("family:gemm_w4", "gemm_w4_bf16<"), ("family:wgrad_tn", "wgrad_tn"), ("family:wgrad_small", "wgrad_small"), ("family:gemm_lib_long", "Custom_Cijk"))
+FAMILY = (("family:gemm_nt_bf16", "gemm_nt_bf16<256,"), ("family:gemm_short", "gemm_nt_bf16<64,"), ("family:gemm_w4", "gemm_w4_bf16<"), ("family:wgrad_tn", "wgrad_tn"), ("family:wgrad_small", "wgrad_small"), ("family:gemm_lib_long", "Custom_Cijk"))
 for name, d in (("FETCH_SIZE", "/tmp/pmc_fetch"), ("WRITE_SIZE", "/tmp/pmc_write")):
     for f in glob.glob(d + "/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):

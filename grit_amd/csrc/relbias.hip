@@ -31,6 +31,27 @@ void relbias_fwd(const T* __restrict__ table, const int64_t* __restrict__ index,
     for (int h = 0; h < nH; ++h) out[(size_t)h * n_pos + p] = to_f32(row[h]);
 }
 
+// The gathers of many window-attention modules in ONE launch (24 Swin blocks: 24 dependent ~5 us launches otherwise): blockIdx.y = job.
+struct RelbiasGroupArgs {
+    grit_relbias_job job[GRIT_RELBIAS_GROUP_MAX];
+};
+
+__global__ __launch_bounds__(256)
+void relbias_fwd_grouped(const RelbiasGroupArgs a) {
+    const grit_relbias_job& jb = a.job[blockIdx.y];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= jb.n_pos) return;
+    const int64_t r = jb.index[p];
+    if (r < 0 || r >= jb.n_rows) return;
+    if (jb.table_is_bf16) {
+        const __hip_bfloat16* row = (const __hip_bfloat16*)jb.table + (size_t)r * jb.num_heads;
+        for (int h = 0; h < jb.num_heads; ++h) jb.bias[(size_t)h * jb.n_pos + p] = to_f32(row[h]);
+    } else {
+        const float* row = (const float*)jb.table + (size_t)r * jb.num_heads;
+        for (int h = 0; h < jb.num_heads; ++h) jb.bias[(size_t)h * jb.n_pos + p] = row[h];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256)
 void relbias_bwd(const float* __restrict__ dbias, const int32_t* __restrict__ order, const int32_t* __restrict__ offsets,
@@ -60,6 +81,20 @@ int grit_relbias_fwd(const void* table, const int64_t* index, int n_rows, int nu
     else
         hipLaunchKernelGGL(relbias_fwd<float>, grid, block, 0, (hipStream_t)stream, (const float*)table, index, n_rows,
                            num_heads, n_pos, bias);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+int grit_relbias_fwd_grouped(const grit_relbias_job* jobs, int n_jobs, void* stream) {
+    if (!jobs || n_jobs <= 0 || n_jobs > GRIT_RELBIAS_GROUP_MAX) return GRIT_ERR_BAD_ARG;
+    RelbiasGroupArgs a;
+    int max_pos = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const grit_relbias_job& jb = jobs[j];
+        if (!jb.table || !jb.index || !jb.bias || jb.n_rows <= 0 || jb.num_heads <= 0 || jb.n_pos <= 0) return GRIT_ERR_BAD_ARG;
+        a.job[j] = jb;
+        if (jb.n_pos > max_pos) max_pos = jb.n_pos;
+    }
+    hipLaunchKernelGGL(relbias_fwd_grouped, dim3((max_pos + 255) / 256, n_jobs), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 

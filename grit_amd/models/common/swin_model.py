@@ -34,7 +34,7 @@ from grit_amd.ops.layer_norm import LayerNorm, add_layer_norm, linear_add_layer_
 from grit_amd.ops import transposed as _transposed
 from grit_amd.ops.linear import Linear, linear, mark_single_use, park_weight_grad_for_partner
 from grit_amd.ops.mlp import hidden as fused_hidden, mlp as fused_mlp, mlp_add_layer_norm
-from grit_amd.ops.rel_bias import relative_position_bias
+from grit_amd.ops.rel_bias import relative_position_bias, relative_position_bias_grouped
 from grit_amd.ops.window_attention import window_attention
 
 
@@ -49,6 +49,7 @@ _MERGE_LN = os.environ.get('GRIT_MERGE_LN', '1') != '0'  # A/B knob: patch-mergi
 # d(bias) | d(pad) accumulators of all blocks instead of one per block
 _PAD_GRAD_VIA_BIAS = os.environ.get('GRIT_WINATTN_PAD_VIA_BIAS', '1') != '0'
 _ZERO_ARENA = os.environ.get('GRIT_WINATTN_ZERO_ARENA', '1') != '0'
+_GROUPED_REL_BIAS = os.environ.get('GRIT_GROUPED_REL_BIAS', '1') != '0'  # one relative-position gather launch for all blocks
 _FUSED_MLP = os.environ.get('GRIT_FUSED_MLP', '1') != '0'  # A/B knob: Mlp on the fused-epilogue GEMM (grit_amd/ops/mlp.py)
 
 
@@ -155,7 +156,8 @@ class WindowAttention(nn.Module):
         """[nH, N, N] float32 = table[relative_position_index] (reference :168-171): one gather kernel forward, a
         sorted-position segment sum backward (grit_amd/ops/rel_bias.py) instead of torch's gather + permute + cast and
         its sort-based index_put gradient."""
-        return relative_position_bias(self.relative_position_bias_table, self.relative_position_index)
+        return relative_position_bias(self.relative_position_bias_table, self.relative_position_index,
+                                      given=self.__dict__.pop("_grit_rel_bias", None))  # (the backbone's one gather for all blocks)
 
     def pad_qkv(self, dtype):
         if self.qkv.bias is None:
@@ -525,6 +527,15 @@ class SwinTransformer(nn.Module):
                                  for w in (blk.mlp.fc2.weight, blk.attn.proj.weight, blk.attn.qkv.weight, blk.mlp.fc1.weight)
                                  if w.requires_grad])
             self._hand_out_backward_workspaces(x.device)
+        if _GROUPED_REL_BIAS and x.is_cuda:
+            # the relative-position gathers of all blocks in one launch (24 dependent ~5 us launches otherwise); a block's attention
+            # takes its slab at its next call
+            attns = [blk.attn for stage in self.layers for blk in stage.blocks]
+            slabs = relative_position_bias_grouped([a.relative_position_bias_table for a in attns],
+                                                   [a.relative_position_index for a in attns])
+            if slabs is not None:
+                for a, slab in zip(attns, slabs):
+                    a.__dict__["_grit_rel_bias"] = slab
         x, Wh, Ww = self.patch_embed.tokens(x)  # (casts to the weights' dtype itself unless the fused pass reads the image as it is)
         if self.ape:
             pos = F.interpolate(self.absolute_pos_embed, size=(Wh, Ww), mode='bicubic')

@@ -37,6 +37,18 @@ def _sorted_positions(index, n_rows):
     return hit
 
 
+def _table_grad(index, meta, dbias):
+    n_rows, nH, n_pos, dtype = meta
+    order, offsets = _sorted_positions(index, n_rows)
+    dbias = dbias.float().contiguous()
+    dtable = torch.empty(n_rows, nH, dtype=dtype, device=dbias.device)
+    with _lib.device_guard(dbias.device):
+        st = _lib.load().grit_relbias_bwd(_ptr(dbias), _ptr(order), _ptr(offsets), n_rows, nH, n_pos,
+                                          int(dtype == torch.bfloat16), _ptr(dtable), _lib.current_stream_ptr())
+    _lib.check(st, "grit_relbias_bwd")
+    return dtable
+
+
 class _RelBiasFn(Function):
 
     @staticmethod
@@ -54,19 +66,53 @@ class _RelBiasFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dbias):
-        n_rows, nH, n_pos, dtype = ctx.meta
-        order, offsets = _sorted_positions(ctx.index, n_rows)
-        dbias = dbias.float().contiguous()
-        dtable = torch.empty(n_rows, nH, dtype=dtype, device=dbias.device)
-        with _lib.device_guard(dbias.device):
-            st = _lib.load().grit_relbias_bwd(_ptr(dbias), _ptr(order), _ptr(offsets), n_rows, nH, n_pos,
-                                              int(dtype == torch.bfloat16), _ptr(dtable), _lib.current_stream_ptr())
-        _lib.check(st, "grit_relbias_bwd")
-        return dtable, None
+        return _table_grad(ctx.index, ctx.meta, dbias), None
 
 
-def relative_position_bias(table, index):
-    """table [n_rows, nH] (f32 / bf16), index [N, N] int64 -> [nH, N, N] float32."""
+class _RelBiasGivenFn(Function):
+    """_RelBiasFn whose forward result already exists (relative_position_bias_grouped computed it with the other modules'): no launch
+    forward, the same backward."""
+
+    @staticmethod
+    def forward(ctx, table, index, given):
+        ctx.index, ctx.meta = index, (table.shape[0], table.shape[1], index.numel(), table.dtype)
+        return given.view(given.shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dbias):
+        return _table_grad(ctx.index, ctx.meta, dbias), None, None
+
+
+def relative_position_bias_grouped(tables, indices):
+    """[relative_position_bias(t, i) values for t, i in zip(tables, indices)] from ONE launch (grit_relbias_fwd_grouped), without
+    autograd: plain float32 tensors [nH, N, N] (views of one buffer).  The caller hands each to `relative_position_bias(.., given=)`.
+    None where the kernel path does not apply."""
+    ok = (backend.override() is None and len(tables) > 0 and len(tables) <= _lib.RELBIAS_GROUP_MAX
+          and all(t.is_cuda and i.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and i.dtype == torch.int64 and t.is_contiguous()
+                  and i.is_contiguous() and t.dim() == 2 for t, i in zip(tables, indices)))
+    if not ok:
+        return None
+    sizes = [t.shape[1] * i.numel() for t, i in zip(tables, indices)]
+    with torch.no_grad():
+        buf = torch.empty(sum(sizes), dtype=torch.float32, device=tables[0].device)
+        outs, off = [], 0
+        table = (_lib.RelbiasJob * len(tables))()
+        for k, (t, i, n) in enumerate(zip(tables, indices, sizes)):
+            out = buf[off:off + n].view((t.shape[1],) + tuple(i.shape))
+            off += n
+            outs.append(out)
+            table[k] = _lib.RelbiasJob(t.data_ptr(), i.data_ptr(), out.data_ptr(), t.shape[0], t.shape[1], i.numel(),
+                                       int(t.dtype == torch.bfloat16))
+        with _lib.device_guard(tables[0].device):
+            st = _lib.load().grit_relbias_fwd_grouped(table, len(tables), _lib.current_stream_ptr())
+        _lib.check(st, "grit_relbias_fwd_grouped")
+    return outs
+
+
+def relative_position_bias(table, index, given=None):
+    """table [n_rows, nH] (f32 / bf16), index [N, N] int64 -> [nH, N, N] float32.  given: the values, already gathered by
+    relative_position_bias_grouped for this table's CURRENT contents (the caller's promise) -- only the autograd node is built."""
     ov = backend.override()
     fits = (ov is None and table.is_cuda and index.is_cuda and table.dtype in (torch.float32, torch.bfloat16)
             and index.dtype == torch.int64 and table.is_contiguous() and index.is_contiguous())
@@ -78,4 +124,6 @@ def relative_position_bias(table, index):
         return table[index.reshape(-1)].view(n, index.shape[1], -1).permute(2, 0, 1).contiguous().float()
     if torch.is_grad_enabled() and table.requires_grad:
         _sorted_positions(index, table.shape[0])  # built outside the autograd thread, before any graph capture
+    if given is not None and given.shape == (table.shape[1],) + tuple(index.shape) and given.device == table.device:
+        return _RelBiasGivenFn.apply(table, index, given) if (torch.is_grad_enabled() and table.requires_grad) else given
     return _RelBiasFn.apply(table, index)

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 40
+#define GRIT_ABI_VERSION 41
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -275,6 +275,15 @@ int grit_layernorm_bwd(const void* x, const void* weight, const void* dy, const 
  * ------------------------------------------------------------------------------------------------------ */
 int grit_relbias_fwd(const void* table, const int64_t* index, int n_rows, int num_heads, int n_pos, int table_is_bf16,
                      float* bias, void* stream);
+/* Up to GRIT_RELBIAS_GROUP_MAX forward gathers in ONE launch (the 24 Swin blocks of a step: same arithmetic per job as grit_relbias_fwd). */
+#define GRIT_RELBIAS_GROUP_MAX 32
+typedef struct grit_relbias_job {
+    const void* table;
+    const int64_t* index;
+    float* bias;
+    int n_rows, num_heads, n_pos, table_is_bf16;
+} grit_relbias_job;
+int grit_relbias_fwd_grouped(const grit_relbias_job* jobs, int n_jobs, void* stream);
 int grit_relbias_bwd(const float* dbias, const int32_t* order, const int32_t* offsets, int n_rows, int num_heads, int n_pos,
                      int table_is_bf16, void* dtable, void* stream);
 

@@ -151,6 +151,31 @@ def test_relative_position_bias_kernels(nH, dtype):
     np.testing.assert_allclose(table.grad.float().cpu().numpy(), ref_t.grad.float().cpu().numpy(), rtol=tol, atol=tol * 10)
 
 
+def test_grouped_relative_position_gather():
+    """grit_relbias_fwd_grouped (round 6: the gathers of all Swin blocks in one launch): every slab bit-equal to the per-module kernel's,
+    mixed head counts and table dtypes; handed to relative_position_bias(.., given=) the autograd node yields the same table gradient."""
+    from grit_amd.models.common.swin_model import _relative_position_index
+    from grit_amd.ops.rel_bias import relative_position_bias, relative_position_bias_grouped
+    g = torch.Generator().manual_seed(7)
+    index = _relative_position_index(12, 12).to(DEV)
+    specs = [(4, torch.bfloat16), (4, torch.bfloat16), (8, torch.float32), (16, torch.bfloat16), (32, torch.bfloat16), (3, torch.float32)]
+    tables = [torch.randn(529, nH, generator=g).to(dt).to(DEV).requires_grad_(True) for nH, dt in specs]
+    slabs = relative_position_bias_grouped(tables, [index] * len(tables))
+    assert slabs is not None and len(slabs) == len(tables)
+    for t_, slab in zip(tables, slabs):
+        one = relative_position_bias(t_, index)
+        assert not slab.requires_grad and torch.equal(slab, one.detach())
+        cot = torch.randn(slab.shape, generator=g).to(DEV)
+        one.backward(cot)
+        want, t_.grad = t_.grad.clone(), None
+        via = relative_position_bias(t_, index, given=slab)
+        assert via.requires_grad and torch.equal(via.detach(), slab)
+        via.backward(cot)
+        assert torch.equal(t_.grad, want)
+    with torch.no_grad():
+        assert relative_position_bias(tables[0], index, given=slabs[0]) is slabs[0]  # no autograd: the slab itself
+
+
 def test_backward_conservation_at_benchmark_size():
     """Stage-0 geometry of the 640x640 benchmark (160x160 map padded to 14x14 windows, 4 heads, shift 6), B = 4 -- too big
     for the oracle, checked through a size-independent property of the backward: softmax rows sum to one, so

@@ -44,6 +44,8 @@ struct GemmArgs {
     int M, N, K, tiles_m, tiles_n;
     const float* row_scale;    // GRIT_GEMM_DGELU, optional: per-sample factors that were applied to the rows of A (drop path);
     int rows_per_sample;       //   a tile whose rows all belong to ONE sample with factor 0 has A = 0: its result is written as zeros
+    const unsigned long long* seed;  // GRIT_GEMM_BIAS_RELU_DROP: device seed of the dropout hash (read when drop_p > 0)
+    float drop_p;                    // GRIT_GEMM_BIAS_RELU_DROP / GRIT_GEMM_DRELU: dropout probability
 #ifdef GRIT_GEMM_STAMPS
     unsigned long long* stamps;  // diagnostic build only (tools/micro/gemm_stamps.hip): [workgroup][wave][16] s_memtime values
 #endif
@@ -56,6 +58,15 @@ struct GemmArgs {
 #else
 #define GRIT_STAMP(slot)
 #endif
+
+// keep factor of dropout(relu(.)): the counter hash of glue.hip / layernorm.hip over the element index m * N + n
+__device__ __forceinline__ float relu_keep_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+    unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull;
+    unsigned int x = (unsigned int)(z ^ (z >> 32));
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    const float u = (float)(x >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.0f;
+}
 
 template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int EPI>
 __global__ __launch_bounds__(WM * WN * 64, 2)
@@ -287,7 +298,7 @@ void gemm_nt_bf16(const GemmArgs g) {
     const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
 
     v4f bias4[NTL];
-    if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU || EPI == GRIT_GEMM_BIAS_RES) {
+    if constexpr (EPI == GRIT_GEMM_BIAS || EPI == GRIT_GEMM_BIAS_GELU || EPI == GRIT_GEMM_BIAS_RES || EPI == GRIT_GEMM_BIAS_RELU_DROP) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
             const v4bf b = *reinterpret_cast<const v4bf*>(g.bias + nw + 16 * j + 4 * lq);
@@ -361,6 +372,59 @@ void gemm_nt_bf16(const GemmArgs g) {
                 put(i, j, v4f{lo[0], lo[1], hi[0], hi[1]});
             }
         flush(g.C, g.ldc, (g.nt_aux & 2) != 0);
+    } else if constexpr (EPI == GRIT_GEMM_BIAS_RELU_DROP) {
+        // C = dropout(relu(bf16(acc + bias))): the Linear's result rounded to bf16 as an unfused Linear stores it, then exactly what
+        // grit_relu_dropout_fwd computes from it (same hash over the element index m * N + n, same product)
+        const unsigned long long seed = g.drop_p > 0.f ? *g.seed : 0ull;
+        const float inv_keep = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const unsigned long long m = (unsigned long long)(mw + 16 * i + l15);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const v4f a = acc[i][j] + bias4[j];
+                const unsigned long long e0 = m * (unsigned long long)g.N + (unsigned long long)(nw + 16 * j + 4 * lq);
+                v4f v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = (float)(__bf16)a[e];
+                    const float k = g.drop_p > 0.f ? relu_keep_scale(seed, e0 + e, g.drop_p, inv_keep) : 1.0f;
+                    v[e] = x > 0.f ? x * k : 0.f;
+                }
+                put(i, j, v);
+            }
+        }
+        flush(g.C, g.ldc);
+    } else if constexpr (EPI == GRIT_GEMM_DRELU) {
+        // C = aux > 0 ? bf16(acc) / (1 - p) : 0 with aux = the dropout(relu(.)) OUTPUT of the forward pass (positive exactly where the
+        // unit was active and kept): the input gradient of the following Linear with the backward of ReLU + dropout in its epilogue --
+        // bit for bit grit_relu_dropout_bwd applied to the stored bf16 product
+        {
+            const int chunk = lane & 7;
+#pragma unroll
+            for (int it = 0; it < WTM / 8; ++it) {
+                const int row = it * 8 + (lane >> 3);
+                const int m = min(mw + row, g.M - 1);
+                const __bf16* src = g.aux + (size_t)m * g.ldaux + nw + ((chunk ^ (row & 7)) * 8);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(eb + it * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const float inv_keep = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = 16 * i + l15;
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int chunk = (2 * j + (lq >> 1)) ^ (row & 7);
+                const v4bf y = *reinterpret_cast<const v4bf*>(eb + row * 128 + chunk * 16 + (lq & 1) * 8);
+                v4f v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (float)y[e] > 0.f ? (float)(__bf16)acc[i][j][e] * inv_keep : 0.f;
+                put(i, j, v);
+            }
+        }
+        flush(g.C, g.ldc);
     } else if constexpr (EPI == GRIT_GEMM_BIAS_RES) {
         // C = residual + factor[sample of the row] * bf16(acc + bias): the residual tile (g.aux) comes into the wave's transpose image as
         // whole 128-byte row segments, every lane combines its 8-byte pieces in place -- the branch rounded to bf16 as an unfused Linear
@@ -801,6 +865,14 @@ int launch(const GemmArgs& a, int epilogue, hipStream_t st) {
             if constexpr (BM == 256 && BN == 128 && BK == 32 && NSTAGE == 3) GRIT_GEMM_LAUNCH(GRIT_GEMM_BIAS_RES)
             else return GRIT_ERR_UNSUPPORTED;
             break;
+        case GRIT_GEMM_BIAS_RELU_DROP:  // (the short-map tile carries the two ReLU + dropout epilogues: the decoders' FFNs)
+            if constexpr (BM == 64 && BN == 64 && BK == 64) GRIT_GEMM_LAUNCH(GRIT_GEMM_BIAS_RELU_DROP)
+            else return GRIT_ERR_UNSUPPORTED;
+            break;
+        case GRIT_GEMM_DRELU:
+            if constexpr (BM == 64 && BN == 64 && BK == 64) GRIT_GEMM_LAUNCH(GRIT_GEMM_DRELU)
+            else return GRIT_ERR_UNSUPPORTED;
+            break;
         default: return GRIT_ERR_BAD_ARG;
     }
 #undef GRIT_GEMM_LAUNCH
@@ -830,6 +902,7 @@ extern "C" int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ld
     a.nt_aux = nt_aux;
     a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
     a.row_scale = g_row_scale; a.rows_per_sample = g_rows_per_sample;
+    a.seed = nullptr; a.drop_p = 0.f;
 #ifdef GRIT_GEMM_STAMPS
     a.stamps = nullptr;  // diagnostic builds set it through launch<>() directly
 #endif
@@ -879,10 +952,35 @@ extern "C" int grit_gemm_bf16_nt_res(const void* A, long lda, const void* B, lon
     a.bias = (const __bf16*)bias; a.aux = (__bf16*)const_cast<void*>(residual); a.ldaux = ldres; a.colsum = nullptr; a.nt_aux = 0;
     a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
     a.row_scale = row_scale; a.rows_per_sample = rows_per_sample;
+    a.seed = nullptr; a.drop_p = 0.f;
 #ifdef GRIT_GEMM_STAMPS
     a.stamps = nullptr;
 #endif
     return launch<256, 128, 32, 2, 2, 3>(a, GRIT_GEMM_BIAS_RES, (hipStream_t)stream);
+}
+
+// The position-wise FFNs of the decoders (Linear -> ReLU -> dropout -> Linear) on the short-map tiles, ReLU + dropout in the epilogues:
+//   GRIT_GEMM_BIAS_RELU_DROP   C = dropout(relu(bf16(A B^T + bias)))            (forward of the first Linear; aux unused)
+//   GRIT_GEMM_DRELU            C = aux > 0 ? bf16(A B^T) / (1 - p) : 0           (input gradient of the second Linear; aux = the forward's C)
+extern "C" int grit_gemm_bf16_nt_relu(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                                      int epilogue, const void* bias, const void* aux, long ldaux, float drop_p, const uint64_t* seed_dev,
+                                      void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return GRIT_ERR_BAD_ARG;
+    if (epilogue == GRIT_GEMM_BIAS_RELU_DROP ? (!bias || (drop_p > 0.f && !seed_dev)) : (epilogue != GRIT_GEMM_DRELU || !aux)) return GRIT_ERR_BAD_ARG;
+    if ((lda | ldb | ldc | (aux ? ldaux : 0)) & 7) return GRIT_ERR_UNSUPPORTED;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)aux | (uintptr_t)bias) & 15) return GRIT_ERR_UNSUPPORTED;
+    if (N % 64 || K % 64) return GRIT_ERR_UNSUPPORTED;
+    if (epilogue == GRIT_GEMM_BIAS_RELU_DROP && ldc != N) return GRIT_ERR_UNSUPPORTED;  // (the dropout hash runs over the index m * N + n)
+    GemmArgs a;
+    a.A = (const __bf16*)A; a.lda = lda; a.B = (const __bf16*)B; a.ldb = ldb; a.C = (__bf16*)C; a.ldc = ldc;
+    a.bias = (const __bf16*)bias; a.aux = (__bf16*)const_cast<void*>(aux); a.ldaux = ldaux; a.colsum = nullptr; a.nt_aux = 0;
+    a.M = M; a.N = N; a.K = K; a.tiles_m = a.tiles_n = 0;
+    a.row_scale = nullptr; a.rows_per_sample = 0;
+    a.seed = (const unsigned long long*)seed_dev; a.drop_p = drop_p;
+#ifdef GRIT_GEMM_STAMPS
+    a.stamps = nullptr;
+#endif
+    return launch<64, 64, 64, 4, 1, 3>(a, epilogue, (hipStream_t)stream);
 }
 
 // GRIT_GEMM_DGELU / GRIT_GEMM_BIAS_GELU with the per-sample factors of the rows of A (see GemmArgs::row_scale): eight-wave variants only.

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 41
+ABI_VERSION = 42
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -90,6 +90,7 @@ SIGNATURES = {
     "grit_gemm_bf16_nt": [_ptr, _c.c_long] * 3 + [_int] * 4 + [_ptr, _ptr, _c.c_long, _ptr, _int, _ptr],
     "grit_gemm_w4_tile_rows": [_int, _int],
     "grit_gemm_bf16_nt_res": [_ptr, _c.c_long] * 3 + [_int] * 3 + [_ptr, _ptr, _c.c_long, _ptr, _int, _ptr],
+    "grit_gemm_bf16_nt_relu": [_ptr, _c.c_long] * 3 + [_int] * 4 + [_ptr, _ptr, _c.c_long, _c.c_float, _ptr, _ptr],
     "grit_gemm_bf16_nt_rows": [_ptr, _c.c_long] * 3 + [_int] * 4 + [_ptr, _ptr, _c.c_long, _ptr, _ptr, _int, _int, _ptr],
 }
 

@@ -4,7 +4,7 @@ from torch import nn
 from torch.nn import functional as F
 from grit_amd.ops.glue import relu_dropout
 from grit_amd.ops.layer_norm import add_layer_norm, linear_add_layer_norm
-from grit_amd.ops.linear import Linear
+from grit_amd.ops.linear import Linear, linear_relu_dropout
 
 
 def position_embedding(input, d_model):
@@ -37,7 +37,7 @@ class FeedForward(nn.Module):
 
     def forward(self, input):
         if self.training and torch.is_grad_enabled() and input.is_cuda:
-            hidden = relu_dropout(self.fc1(input), self.dropout_2.p, True)  # ReLU + dropout: one launch each way
+            hidden = linear_relu_dropout(input, self.fc1, self.dropout_2.p)  # ReLU + dropout in the GEMMs' epilogues (ops/linear.py)
         else:
             hidden = self.dropout_2(F.relu(self.fc1(input)))
         if self.training and torch.is_grad_enabled() and input.is_cuda:

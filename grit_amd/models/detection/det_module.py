@@ -25,7 +25,7 @@ from grit_amd.models.ops.modules import MSDeformAttn
 from grit_amd.ops.attention import attention as fused_attention
 from grit_amd.ops.glue import box_refine, relu_dropout
 from grit_amd.ops.layer_norm import linear_add_layer_norm
-from grit_amd.ops.linear import Linear, linear, mark_single_use, packed_in_proj, shared_input_linears
+from grit_amd.ops.linear import Linear, linear, linear_relu_dropout, mark_single_use, packed_in_proj, shared_input_linears
 from grit_amd.ops.msda import StackedValueMaps
 from grit_amd.ops import transposed as _transposed
 
@@ -141,7 +141,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
                                       src_level_start_index, src_padding_mask, project=False, value=value)
             tgt = tail(sampled, self.cross_attn.output_proj, tgt, self.dropout1, self.norm1)
             if self.activation is F.relu:
-                hidden = relu_dropout(self.linear1(tgt), self.dropout3.p, True)  # ReLU + dropout: one launch each way
+                hidden = linear_relu_dropout(tgt, self.linear1, self.dropout3.p)  # ReLU + dropout in the GEMMs' epilogues (ops/linear.py)
             else:
                 hidden = self.dropout3(self.activation(self.linear1(tgt)))
             return tail(hidden, self.linear2, tgt, self.dropout4, self.norm3)

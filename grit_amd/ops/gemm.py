@@ -49,6 +49,25 @@ def gemm_nt(a, b, epilogue=NONE, bias=None, aux=None, colsum=None, out=None, var
     return out
 
 
+BIAS_RELU_DROP, DRELU = 5, 6  # grit_gemm_bf16_nt_relu
+
+
+def gemm_nt_relu(a, b, epilogue, bias=None, aux=None, p=0.0, seed_dev=None):
+    """The decoders' FFN GEMMs on the short-map tiles with ReLU + dropout in the epilogue (grit_gemm_bf16_nt_relu):
+    BIAS_RELU_DROP: dropout(relu(a @ b^T + bias), p) -- bit for bit Linear + grit_relu_dropout_fwd;  DRELU: (a @ b^T) with the backward of
+    ReLU + dropout applied, aux = the forward's output -- bit for bit the product + grit_relu_dropout_bwd."""
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    with _lib.device_guard(a.device), timed("gemm_own", epilogue=epilogue, kernel="gemm_short",
+                                            **gemm_work(M, N, K, extra_in=1 if epilogue == DRELU else 0)):
+        st = _lib.load().grit_gemm_bf16_nt_relu(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0), M, N, K, epilogue,
+                                                _ptr(bias), _ptr(aux), aux.stride(0) if aux is not None else 0, float(p),
+                                                _ptr(seed_dev), _lib.current_stream_ptr())
+    _lib.check(st, "grit_gemm_bf16_nt_relu")
+    return out
+
+
 W4 = 9  # variant of grit_gemm_bf16_nt the long-map policy runs: the persistent four-wave kernel, tile height (256 / 224 rows) by shape
 
 

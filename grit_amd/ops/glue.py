@@ -124,6 +124,18 @@ class _ReluDropoutFn(Function):
         return dx, None, None
 
 
+def relu_dropout_backward(y, dy, p, seed_dev):
+    """dy with the backward of dropout(relu(.)) applied, from the forward's OUTPUT y (positive exactly where the unit was active and
+    kept): the same kernel as _ReluDropoutFn.backward, which only looks at the sign of its first operand and regenerates the keep factor."""
+    y2, dy2 = y.contiguous(), dy.contiguous()
+    dx = torch.empty_like(dy2)
+    with _lib.device_guard(y2.device):
+        st = _lib.load().grit_relu_dropout_bwd(_ptr(y2), _ptr(dy2), y2.numel(), float(p), _ptr(seed_dev) if p > 0 else None,
+                                               int(y2.dtype == torch.bfloat16), _ptr(dx), _lib.current_stream_ptr())
+    _lib.check(st, "grit_relu_dropout_bwd")
+    return dx
+
+
 def relu_dropout(x, p, training):
     """dropout(relu(x), p, training) -- one launch forward, one backward (mask regenerated from a device seed)."""
     p = float(p) if training else 0.0

@@ -225,6 +225,28 @@ def _residual_linear(inp, lin_w, lin_b, s2, scale, rows_per_sample):
     return _gemm.long_linear_residual(x2 if x2.is_contiguous() else x2.contiguous(), lin_w, lin_b, s2, scale, rows_per_sample)
 
 
+def _projection_input_grad(ctx, d_branch, inp, lin_w):
+    """d(inp) of the projection inside _LinearAddLayerNormFn: d_branch @ W on the own kernels where the policies take the shape; with the
+    backward of ReLU + dropout in the GEMM's epilogue when the node took that over from linear_relu_dropout (ctx.drelu)."""
+    h = ctx.drelu
+    if h is not None:
+        from grit_amd.ops import gemm as _gemm
+        from grit_amd.ops import transposed
+        from grit_amd.ops.glue import relu_dropout_backward
+        inp2 = inp.reshape(-1, inp.shape[-1])
+        wt = transposed.lookup(ctx.lin_w_obj)
+        if wt is not None and _gemm.supported(d_branch, wt) and inp2.data_ptr() % 16 == 0:
+            return _gemm.gemm_nt_relu(d_branch, wt, _gemm.DRELU, aux=inp2, p=h["p"]).view(inp.shape)
+        with timed("gemm_lib", **gemm_work(d_branch.shape[0], lin_w.shape[1], lin_w.shape[0])):
+            d = torch.mm(d_branch, lin_w)  # (no transposed copy of the weight at hand: the library's product, then the mask -- the contract holds)
+        return relu_dropout_backward(inp2, d, h["p"], h["seed"]).view(inp.shape)
+    d_inp = _own_input_grad(d_branch, ctx.lin_w_obj, inp.shape)
+    if d_inp is None:
+        with timed("gemm_lib", **gemm_work(d_branch.shape[0], lin_w.shape[1], lin_w.shape[0])):
+            d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
+    return d_inp
+
+
 class _LinearAddLayerNormFn(Function):
     """(inp, W, b, shortcut, scale) -> (x, LayerNorm(x)) with x = shortcut + scale * (inp @ W^T + b): the output projection
     of a Swin branch (attn.proj / mlp.fc2), the residual connection and the LayerNorm that follows, as one node -- so the
@@ -266,6 +288,16 @@ class _LinearAddLayerNormFn(Function):
             _lib.check(st, "grit_add_layernorm_fwd")
         ctx.save_for_backward(x, weight, mean, rstd, scale, inp, lin_w, seed_dev)
         ctx.shape, ctx.drop_p = shortcut.shape, drop_p
+        # `inp` = dropout(relu(.)) from linear_relu_dropout (grit_amd/ops/linear.py): this node's input-gradient GEMM applies the backward
+        # of ReLU + dropout in its epilogue, and says so in the holder -- the producer's backward then takes the gradient as it comes
+        ctx.drelu = None
+        holder = getattr(inp, "_grit_relu_holder", None)
+        if holder is not None and ctx.needs_input_grad[0] and not holder["fused"]:
+            from grit_amd.ops import gemm as _gemm
+            if (inp.dtype == torch.bfloat16 and inp.is_cuda and inp.is_contiguous()
+                    and _gemm.prefers_own_short(rows, inp.shape[-1], lin_w.shape[0])):
+                holder["fused"] = True
+                ctx.drelu = holder
         ctx.set_materialize_grads(False)  # see _AddLayerNormFn
         return x.view(shortcut.shape), y.view(shortcut.shape)
 
@@ -292,10 +324,7 @@ class _LinearAddLayerNormFn(Function):
                                                  (ctx.sum_params[2], sums.data_ptr() + 2 * esz)])):
                 group.run()  # ... and so do the node's LayerNorm / bias sums when all three gradients are wanted
             if ctx.needs_input_grad[0]:
-                d_inp = _own_input_grad(d_branch, ctx.lin_w_obj, inp.shape)
-                if d_inp is None:
-                    with timed("gemm_lib", **gemm_work(d_branch.shape[0], lin_w.shape[1], lin_w.shape[0])):
-                        d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
+                d_inp = _projection_input_grad(ctx, d_branch, inp, lin_w)
             return (d_inp, deferred[0], sums[2].to(lin_w.dtype), dx.view(ctx.shape), None, sums[0], sums[1], None, None, None,
                     None)
         # small maps inside a deferral scope: the projection's weight gradient beside the chain (grit_amd/ops/linear.py fork)
@@ -306,10 +335,7 @@ class _LinearAddLayerNormFn(Function):
             with on_stream(side):
                 d_lin_w = weight_grad(d_branch, inp2)
         if ctx.needs_input_grad[0]:
-            d_inp = _own_input_grad(d_branch, ctx.lin_w_obj, inp.shape)
-            if d_inp is None:
-                with timed("gemm_lib", **gemm_work(d_branch.shape[0], lin_w.shape[1], lin_w.shape[0])):
-                    d_inp = torch.mm(d_branch, lin_w).view(inp.shape)
+            d_inp = _projection_input_grad(ctx, d_branch, inp, lin_w)
         if d_lin_w is None:
             d_lin_w = weight_grad(d_branch, inp2, group, param=lin_w, row_scale=rs) if ctx.needs_input_grad[1] else None
             sp = ctx.sum_params

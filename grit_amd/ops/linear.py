@@ -890,9 +890,22 @@ def take_bias_extra(bias):
 class _LinearFn(Function):
 
     @staticmethod
-    def forward(ctx, x, weight, bias, single_use=False, row_scale=None):
-        ctx.save_for_backward(x, weight)
+    def forward(ctx, x, weight, bias, single_use=False, row_scale=None, relu=None):
         ctx.has_bias = bias is not None
+        ctx.relu = None
+        if relu is not None:
+            # (p, device seed, holder): dropout(relu(x W^T + b)) in the GEMM's epilogue (linear_relu_dropout checked that the short-map tile
+            # takes the shape); the backward of ReLU + dropout is applied by the consumer's input-gradient GEMM when it said so in the
+            # holder (grit_amd/ops/layer_norm.py), else here, from the saved output
+            from grit_amd.ops import gemm as _gemm
+            p, seed_dev, holder = relu
+            x2 = x.reshape(-1, x.shape[-1])
+            y = _gemm.gemm_nt_relu(x2 if x2.is_contiguous() else x2.contiguous(), weight, _gemm.BIAS_RELU_DROP, bias=bias, p=p,
+                                   seed_dev=seed_dev).view(x.shape[:-1] + (weight.shape[0],))
+            ctx.relu = (p, holder, seed_dev is not None)
+            ctx.save_for_backward(*((x, weight, y) + ((seed_dev,) if seed_dev is not None else ())))
+        else:
+            ctx.save_for_backward(x, weight)
         ctx.single_use = single_use
         # drop path: (per-sample factors [B] f32, rows per sample) of the branch this Linear feeds -- the caller's promise that the rows
         # of a sample with factor 0 come back as exact zeros in dy (wgrad_tn.hip then skips them in the weight gradient)
@@ -901,6 +914,8 @@ class _LinearFn(Function):
         ctx.weight_param = weight if single_use else None
         ctx.weight_obj = weight  # the tensor object the forward was called with: transposed copies are attached to IT
         ctx.bias_obj = bias      # ... and a gradient term another node leaves for this bias (take_bias_extra)
+        if relu is not None:
+            return y
         own = _own_linear(x, weight, bias)
         if own is not None:
             return own
@@ -910,7 +925,11 @@ class _LinearFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        x, weight = saved[0], saved[1]
+        if ctx.relu is not None and not ctx.relu[1].get("fused"):
+            from grit_amd.ops.glue import relu_dropout_backward
+            dy = relu_dropout_backward(saved[2], dy, ctx.relu[0], saved[3] if ctx.relu[2] else None)  # (no consumer took it over)
         dy2 = dy.reshape(-1, dy.shape[-1])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
@@ -933,7 +952,7 @@ class _LinearFn(Function):
                 if dx is None:
                     with timed("gemm_lib", **gemm_work(dy2.shape[0], weight.shape[1], weight.shape[0])):
                         dx = torch.mm(dy2, weight).view(x.shape)
-            return dx, dw, db, None, None
+            return dx, dw, db, None, None, None
         side = fork(dy2, x2, rows=dy2.shape[0], single_use=ctx.single_use) \
             if (ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or need_b)) else None
         group = SlabGroup() if dy2.is_cuda else None  # dW's and db's partial sums: one reduction launch
@@ -954,7 +973,35 @@ class _LinearFn(Function):
                 with timed("gemm_lib", **gemm_work(dy2.shape[0], weight.shape[1], weight.shape[0])):
                     dx = torch.mm(dy2, weight).view(x.shape)
         join(side, dw, db)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
+
+
+# GRIT_FFN_RELU_EPILOGUE (default 1, round 6): dropout(relu(fc1(x))) of the decoders' position-wise FFNs as the epilogue of fc1's GEMM, and
+# its backward as the epilogue of fc2's input-gradient GEMM (grit_gemm_bf16_nt_relu) -- a launch less each way per FFN.  0: grit_relu_dropout_*.
+RELU_EPILOGUE = os.environ.get("GRIT_FFN_RELU_EPILOGUE", "1") != "0"
+
+
+def linear_relu_dropout(x, lin, p, training=True):
+    """dropout(relu(lin(x)), p, training): one GEMM launch with the epilogue where the short-map tile takes the shape (the result carries a
+    holder through which the consuming projection node -- linear_add_layer_norm -- announces that ITS input-gradient GEMM applies the
+    backward of ReLU + dropout), else the Linear followed by grit_amd.ops.glue.relu_dropout."""
+    from grit_amd.ops import gemm as _gemm
+    from grit_amd.ops.glue import relu_dropout
+    weight, bias = lin.weight, lin.bias
+    p = float(p) if training else 0.0
+    rows = x.numel() // x.shape[-1]
+    fits = (RELU_EPILOGUE and backend.override() is None and x.is_cuda and torch.is_grad_enabled() and not torch.is_autocast_enabled()
+            and not backend.foreign_capture() and (x.requires_grad or weight.requires_grad) and bias is not None
+            and x.dtype == weight.dtype == bias.dtype == torch.bfloat16 and 0.0 <= p < 1.0 and _gemm.OWN
+            and _gemm.prefers_own_short(rows, weight.shape[0], weight.shape[1]) and weight.is_contiguous()
+            and weight.data_ptr() % 16 == 0 and bias.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
+    if not fits:
+        return relu_dropout(lin(x), p, training)
+    seed_dev = backend.dropout_seed(x.device) if p > 0 else None
+    holder = {"p": p, "seed": seed_dev, "fused": False}
+    y = _LinearFn.apply(x, weight, bias, single_use_now(getattr(lin, "single_use", False)), None, (p, seed_dev, holder))
+    y._grit_relu_holder = holder
+    return y
 
 
 class _SharedInputLinearsFn(Function):
@@ -1028,7 +1075,7 @@ def linear(x, weight, bias, single_use=False, row_scale=None):
             if own is not None:
                 return own
         return F.linear(x, weight, bias)
-    y = _LinearFn.apply(x, weight, bias, single_use_now(single_use), row_scale)
+    y = _LinearFn.apply(x, weight, bias, single_use_now(single_use), row_scale, None)
     if bias is not None and bias.requires_grad:
         y._grit_bias_node = bias  # (this result's backward is _LinearFn's: it honours leave_bias_extra for this bias)
     return y

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 41
+#define GRIT_ABI_VERSION 42
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -542,6 +542,8 @@ int grit_image_batch_fwd(const uint8_t* src, const int64_t* desc, const int32_t*
 #define GRIT_GEMM_BIAS_GELU 2
 #define GRIT_GEMM_DGELU 3
 #define GRIT_GEMM_BIAS_RES 4   /* grit_gemm_bf16_nt_res only */
+#define GRIT_GEMM_BIAS_RELU_DROP 5   /* grit_gemm_bf16_nt_relu only */
+#define GRIT_GEMM_DRELU 6            /* grit_gemm_bf16_nt_relu only */
 #define GRIT_GEMM_COLSUM_ROWS 128
 int grit_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                       int epilogue, const void* bias, void* aux, long ldaux, float* colsum, int variant, void* stream);
@@ -561,6 +563,17 @@ int grit_gemm_w4_tile_rows(int M, int N);
 int grit_gemm_bf16_nt_res(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                           const void* bias, const void* residual, long ldres, const float* row_scale, int rows_per_sample,
                           void* stream);
+/* The position-wise FFNs of the two decoders and the grid net (models/detection/det_module.py:302-304, models/common/pos_embed.py:44-48:
+ * Linear -> ReLU -> dropout -> Linear) on the short-map tiles (variant 12's 64 x 64 x 64; N % 64 == 0, K % 64 == 0), ReLU + dropout in the
+ * epilogues instead of a launch each way:
+ *   GRIT_GEMM_BIAS_RELU_DROP   C = dropout(relu(bf16(A B^T + bias)), drop_p): the first Linear's forward; keep factors from the hash of
+ *                              grit_relu_dropout_fwd over the element index m * N + n (ldc == N), seed read from seed_dev when drop_p > 0;
+ *                              bit for bit Linear (bf16 result) followed by grit_relu_dropout_fwd.  aux unused.
+ *   GRIT_GEMM_DRELU            C = aux > 0 ? bf16(A B^T) / (1 - drop_p) : 0, aux [M, N] = the forward's C (positive exactly where the unit
+ *                              was active and kept): the second Linear's input gradient with the backward of ReLU + dropout applied;
+ *                              bit for bit the stored bf16 product followed by grit_relu_dropout_bwd.  bias, seed_dev unused. */
+int grit_gemm_bf16_nt_relu(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K, int epilogue,
+                           const void* bias, const void* aux, long ldaux, float drop_p, const uint64_t* seed_dev, void* stream);
 /* The fused Mlp GEMMs with the per-sample drop-path factors of the Swin blocks at hand (models/common/swin_model.py:289-298:
  * x = shortcut + drop_path(mlp(norm2(x))); a dropped sample's branch contributes nothing forward and receives an exactly zero
  * gradient): row_scale [ceil(M / rows_per_sample)] f32 on the device; a 256-row tile that lies inside ONE sample with factor 0 is

@@ -704,3 +704,50 @@ def test_weight_gradient_skips_the_rows_of_dropped_samples(B, per, N, K, drop):
     torch.cuda.synchronize()
     assert torch.equal(gpart, part) and torch.equal(other, plain)
     assert lib.grit_wgrad_tn_rows(p(dy), dy.stride(0), p(x), x.stride(0), M, N, K, S, p(part), None, p(scale), 0, _lib.current_stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("B,T,d_model,d_ff,p", [(32, 150, 256, 1024, 0.1), (32, 20, 512, 2048, 0.1), (16, 150, 256, 1024, 0.0)])
+def test_ffn_relu_dropout_in_the_gemm_epilogues(monkeypatch, B, T, d_model, d_ff, p):
+    """Round 6: dropout(relu(fc1(x))) of the decoders' position-wise FFNs as the epilogue of fc1's GEMM (GRIT_GEMM_BIAS_RELU_DROP) and its
+    backward as the epilogue of fc2's input-gradient GEMM (GRIT_GEMM_DRELU), against the same block with grit_relu_dropout_{fwd,bwd} as
+    launches of their own (GRIT_FFN_RELU_EPILOGUE=0): output and EVERY gradient bit for bit (same hash over the same element index, same
+    roundings in the same order), with and without dropout; and without a transposed copy of fc2's weight at hand (the library's product
+    followed by the mask kernel: the contract between the two nodes holds on that path too)."""
+    from grit_amd.models.common.pos_embed import FeedForward
+    from grit_amd.ops import backend
+    from grit_amd.ops import gemm as G
+    from grit_amd.ops import linear as L
+    from grit_amd.ops import transposed
+    torch.manual_seed(11)
+    ffn = FeedForward(d_model, d_ff, dropout=p).cuda().bfloat16().train()
+    x = torch.randn(B, T, d_model, device='cuda').bfloat16()
+    cot = torch.randn(B, T, d_model, device='cuda').bfloat16()
+    calls = []
+    real = G.gemm_nt_relu
+    monkeypatch.setattr(G, "gemm_nt_relu", lambda *a, **k: (calls.append(a[2]), real(*a, **k))[1])
+
+    def run(on, with_copies=True):
+        monkeypatch.setattr(L, "RELU_EPILOGUE", on)
+        for q in ffn.parameters():
+            q.grad = None
+            q.__dict__.pop("_grit_transposed", None)
+        if with_copies:
+            transposed.refresh_linears(ffn)
+        backend._seeds.buf = None  # (the dropout seeds come in blocks from the device generator: a fresh block ...
+        torch.manual_seed(5)       #  ... from the same generator state in every arm)
+        del calls[:]
+        xi = x.clone().requires_grad_(True)
+        y = ffn(xi)
+        (y * cot).sum().backward()
+        return [y.detach(), xi.grad] + [q.grad.clone() for q in ffn.parameters()], list(calls)
+
+    fused, c_on = run(True)
+    plain, c_off = run(False)
+    assert c_on == [G.BIAS_RELU_DROP, G.DRELU] and c_off == []
+    for i, (a, b) in enumerate(zip(fused, plain)):
+        assert torch.equal(a, b), i
+    assert fused[1].abs().max().item() > 0
+    no_copy, c_nc = run(True, with_copies=False)
+    assert c_nc == [G.BIAS_RELU_DROP]  # fc2's input gradient fell back to the library + the mask kernel
+    for i, (a, b) in enumerate(zip(no_copy, plain)):
+        _close(a.float(), b.float())

@@ -67,6 +67,29 @@ void relbias_bwd(const float* __restrict__ dbias, const int32_t* __restrict__ or
     }
 }
 
+// The table gradients of many window-attention modules in ONE launch: blockIdx.y = job, blockIdx.x = table row.
+struct RelbiasBwdGroupArgs {
+    grit_relbias_bwd_job job[GRIT_RELBIAS_GROUP_MAX];
+};
+
+__global__ __launch_bounds__(256)
+void relbias_bwd_grouped(const RelbiasBwdGroupArgs a) {
+    const grit_relbias_bwd_job& jb = a.job[blockIdx.y];
+    const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (r >= jb.n_rows) return;
+    const int e0 = jb.offsets[r], e1 = jb.offsets[r + 1];
+    for (int h = wave; h < jb.num_heads; h += 4) {
+        float s = 0.f;
+        for (int e = e0 + lane; e < e1; e += 64) s += jb.dbias[(size_t)h * jb.n_pos + jb.order[e]];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) {
+            if (jb.table_is_bf16) from_f32((__hip_bfloat16*)jb.dtable + (size_t)r * jb.num_heads + h, s);
+            else from_f32((float*)jb.dtable + (size_t)r * jb.num_heads + h, s);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -95,6 +118,20 @@ int grit_relbias_fwd_grouped(const grit_relbias_job* jobs, int n_jobs, void* str
         if (jb.n_pos > max_pos) max_pos = jb.n_pos;
     }
     hipLaunchKernelGGL(relbias_fwd_grouped, dim3((max_pos + 255) / 256, n_jobs), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
+}
+
+int grit_relbias_bwd_grouped(const grit_relbias_bwd_job* jobs, int n_jobs, void* stream) {
+    if (!jobs || n_jobs <= 0 || n_jobs > GRIT_RELBIAS_GROUP_MAX) return GRIT_ERR_BAD_ARG;
+    RelbiasBwdGroupArgs a;
+    int max_rows = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const grit_relbias_bwd_job& jb = jobs[j];
+        if (!jb.dbias || !jb.order || !jb.offsets || !jb.dtable || jb.n_rows <= 0 || jb.num_heads <= 0 || jb.n_pos <= 0) return GRIT_ERR_BAD_ARG;
+        a.job[j] = jb;
+        if (jb.n_rows > max_rows) max_rows = jb.n_rows;
+    }
+    hipLaunchKernelGGL(relbias_bwd_grouped, dim3(max_rows, n_jobs), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GRIT_OK : GRIT_ERR_LAUNCH;
 }
 

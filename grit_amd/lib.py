@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrit_hip.so")
-ABI_VERSION = 42
+ABI_VERSION = 43
 
 _c = ctypes
 _ptr, _int, _i64, _f32, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -52,6 +52,7 @@ SIGNATURES = {
     "grit_merge_layernorm_bwd": [_ptr] + [_int] * 4 + [_ptr] * 4 + [_int, _int] + [_ptr] * 4,
     "grit_relbias_fwd": [_ptr, _ptr, _int, _int, _int, _int, _ptr, _ptr],
     "grit_relbias_fwd_grouped": [_ptr, _int, _ptr],
+    "grit_relbias_bwd_grouped": [_ptr, _int, _ptr],
     "grit_relbias_bwd": [_ptr, _ptr, _ptr, _int, _int, _int, _int, _ptr, _ptr],
     "grit_add_layernorm_fwd": [_ptr] * 3 + [_int, _f32, _ptr] + [_ptr] * 2 + [_int, _int, _f32, _int, _int] + [_ptr] * 5,
     "grit_add_layernorm_bwd": [_ptr] * 7 + [_int, _f32, _ptr] + [_int] * 4 + [_ptr] * 6,
@@ -120,6 +121,12 @@ class RelbiasJob(_c.Structure):
     """grit_relbias_job of include/grit_hip.h."""
     _fields_ = [("table", _c.c_void_p), ("index", _c.c_void_p), ("bias", _c.c_void_p), ("n_rows", _c.c_int), ("num_heads", _c.c_int),
                 ("n_pos", _c.c_int), ("table_is_bf16", _c.c_int)]
+
+
+class RelbiasBwdJob(_c.Structure):
+    """grit_relbias_bwd_job of include/grit_hip.h."""
+    _fields_ = [("dbias", _c.c_void_p), ("order", _c.c_void_p), ("offsets", _c.c_void_p), ("dtable", _c.c_void_p), ("n_rows", _c.c_int),
+                ("num_heads", _c.c_int), ("n_pos", _c.c_int), ("table_is_bf16", _c.c_int)]
 
 
 RELBIAS_GROUP_MAX = 32  # GRIT_RELBIAS_GROUP_MAX

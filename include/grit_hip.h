@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 42
+#define GRIT_ABI_VERSION 43
 
 #define GRIT_OK 0
 #define GRIT_ERR_BAD_ARG 1      /* null pointer, non-positive dimension, overflow of 32-bit index math      */
@@ -284,6 +284,15 @@ typedef struct grit_relbias_job {
     int n_rows, num_heads, n_pos, table_is_bf16;
 } grit_relbias_job;
 int grit_relbias_fwd_grouped(const grit_relbias_job* jobs, int n_jobs, void* stream);
+/* ... and up to GRIT_RELBIAS_GROUP_MAX table gradients in ONE launch (same arithmetic per job as grit_relbias_bwd). */
+typedef struct grit_relbias_bwd_job {
+    const float* dbias;
+    const int32_t* order;
+    const int32_t* offsets;
+    void* dtable;
+    int n_rows, num_heads, n_pos, table_is_bf16;
+} grit_relbias_bwd_job;
+int grit_relbias_bwd_grouped(const grit_relbias_bwd_job* jobs, int n_jobs, void* stream);
 int grit_relbias_bwd(const float* dbias, const int32_t* order, const int32_t* offsets, int n_rows, int num_heads, int n_pos,
                      int table_is_bf16, void* dtable, void* stream);
 

@@ -160,7 +160,8 @@ def test_grouped_relative_position_gather():
     index = _relative_position_index(12, 12).to(DEV)
     specs = [(4, torch.bfloat16), (4, torch.bfloat16), (8, torch.float32), (16, torch.bfloat16), (32, torch.bfloat16), (3, torch.float32)]
     tables = [torch.randn(529, nH, generator=g).to(dt).to(DEV).requires_grad_(True) for nH, dt in specs]
-    slabs = relative_position_bias_grouped(tables, [index] * len(tables))
+    with torch.no_grad():
+        slabs = relative_position_bias_grouped(tables, [index] * len(tables))
     assert slabs is not None and len(slabs) == len(tables)
     for t_, slab in zip(tables, slabs):
         one = relative_position_bias(t_, index)
@@ -174,6 +175,28 @@ def test_grouped_relative_position_gather():
         assert torch.equal(t_.grad, want)
     with torch.no_grad():
         assert relative_position_bias(tables[0], index, given=slabs[0]) is slabs[0]  # no autograd: the slab itself
+        plain = relative_position_bias_grouped(tables, [index] * len(tables))
+    assert all(not q.requires_grad and torch.equal(q, s_.detach()) for q, s_ in zip(plain, slabs))
+    # with autograd the slabs are the outputs of ONE node: one backward launch for all tables (grit_relbias_bwd_grouped); a frozen
+    # table's slab does not require a gradient
+    tables[1].requires_grad_(False)
+    for t_ in tables:
+        t_.grad = None
+    cots = [torch.randn(s_.shape, generator=g).to(DEV) for s_ in slabs]
+    want = []
+    for t_, c_ in zip(tables, cots):
+        if t_.requires_grad:
+            relative_position_bias(t_, index).backward(c_)
+            want.append(t_.grad.clone())
+            t_.grad = None
+        else:
+            want.append(None)
+    outs = relative_position_bias_grouped(tables, [index] * len(tables))
+    assert [o.requires_grad for o in outs] == [t_.requires_grad for t_ in tables]
+    assert all(relative_position_bias(t_, index, given=o) is o for t_, o in zip(tables, outs) if o.requires_grad)
+    torch.autograd.backward([o for o in outs if o.requires_grad], [c_ for o, c_ in zip(outs, cots) if o.requires_grad])
+    for t_, w_ in zip(tables, want):
+        assert (t_.grad is None) if w_ is None else torch.equal(t_.grad, w_)
 
 
 def test_backward_conservation_at_benchmark_size():

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r06; mkdir -p $O
 cd $R
-OFF="GRIT_GEMM_OWN_SHORT=0 GRIT_GEMM_OWN_MAX_TILES=8192 GRIT_DET_VALUE_DGRAD_NT=0 GRIT_WINATTN_PAD_VIA_BIAS=0 GRIT_WINATTN_ZERO_ARENA=0 GRIT_GEMM_RESIDUAL_NARROW=0"
+OFF="GRIT_GEMM_OWN_SHORT=0 GRIT_GEMM_OWN_MAX_TILES=8192 GRIT_DET_VALUE_DGRAD_NT=0 GRIT_WINATTN_PAD_VIA_BIAS=0 GRIT_WINATTN_ZERO_ARENA=0 GRIT_GEMM_RESIDUAL_NARROW=0 GRIT_FFN_RELU_EPILOGUE=0 GRIT_GROUPED_REL_BIAS=0 GRIT_GROUPED_REL_BIAS_BWD=0"
 run() { # name, env...
   name=$1; shift
   env "$@" timeout 600 python bench.py --steps 300 --warmup 5 --no-cpu-baseline --no-analysis > $O/soak2_$name.json 2>/dev/null

@@ -28,12 +28,15 @@ from grit_amd.ops.layer_norm import linear_add_layer_norm
 from grit_amd.ops.linear import Linear, linear, linear_relu_dropout, mark_single_use, packed_in_proj, shared_input_linears
 from grit_amd.ops.msda import StackedValueMaps
 from grit_amd.ops import transposed as _transposed
+from grit_amd.ops import backend as _backend
+from grit_amd.ops import gemm as _gemm
 
 _SHARED_VALUE_PROJ = os.environ.get('GRIT_SHARED_VALUE_PROJ', '1') != '0'  # A/B knobs
 _STACKED_VALUE_MAPS = os.environ.get('GRIT_STACKED_VALUE_MAPS', '1') != '0'
 from grit_amd.utils.misc import inverse_sigmoid
 
 _PACKED_IN_PROJ = os.environ.get("GRIT_DET_PACKED_IN_PROJ", "1") != "0"  # A/B knob (round 6): 0 = split weights, two Linear nodes
+_MLP_OWN = os.environ.get("GRIT_DET_MLP_OWN", "1") != "0"  # A/B knob: 0 = torch._addmm_activation for the detached box-refinement MLP
 _VALUE_DGRAD_NT = os.environ.get("GRIT_DET_VALUE_DGRAD_NT", "1") != "0"  # A/B knob: 0 = torch.mm on the concatenated weight
 _QK_LINEAR = os.environ.get("GRIT_DET_QK_LINEAR", "1") != "0"  # A/B knob: 0 = F.linear for the self-attention in-projections
 
@@ -50,8 +53,17 @@ class MLP(nn.Module):
     def forward(self, x):
         for layer in self.layers[:-1]:
             if x.is_cuda and not torch.is_grad_enabled() and x.dim() >= 2 and x.dtype == layer.weight.dtype and layer.bias is not None:
-                # no autograd (box refinement is detached, evaluation): bias + ReLU in the GEMM's epilogue, one launch
-                x = torch._addmm_activation(layer.bias, x.reshape(-1, x.shape[-1]), layer.weight.t()).view(*x.shape[:-1], -1)
+                # no autograd (box refinement is detached, evaluation): bias + ReLU in the GEMM's epilogue, one launch -- the own short-map
+                # tile where its policy takes the shape (grit_gemm_bf16_nt_relu with p = 0), else the library's fused call
+                x2 = x.reshape(-1, x.shape[-1])
+                if (_MLP_OWN and x.dtype == torch.bfloat16 and layer.bias.dtype == torch.bfloat16 and _gemm.OWN
+                        and _gemm.prefers_own_short(x2.shape[0], layer.weight.shape[0], layer.weight.shape[1])
+                        and _gemm.supported(x2 if x2.is_contiguous() else x2.contiguous(), layer.weight) and layer.bias.data_ptr() % 16 == 0
+                        and _backend.override() is None):
+                    x = _gemm.gemm_nt_relu(x2 if x2.is_contiguous() else x2.contiguous(), layer.weight, _gemm.BIAS_RELU_DROP,
+                                           bias=layer.bias, p=0.0).view(*x.shape[:-1], -1)
+                    continue
+                x = torch._addmm_activation(layer.bias, x2, layer.weight.t()).view(*x.shape[:-1], -1)
             else:
                 x = F.relu(layer(x))
         return self.layers[-1](x)

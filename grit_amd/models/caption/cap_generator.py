@@ -22,7 +22,7 @@ from grit_amd.ops import gate as gate_ops
 from grit_amd.ops import glue
 from grit_amd.ops import transposed as _transposed
 from grit_amd.ops import weights_epoch
-from grit_amd.ops.linear import Linear, mark_single_use
+from grit_amd.ops.linear import Linear, mark_single_use, own_or_library_linear
 
 
 # GRIT_FUSED_STEP_INPUTS=0: masks, step counter and embedding sum of a decoding step as the reference's separate torch ops
@@ -75,7 +75,7 @@ class ParallelAttentionLayer(GeneratorLayer):
         if gate_ops.supported(self_att, self_att, self_att, mask_pad, self.fc_alpha1):
             # inference on the device: the gate arithmetic below as pack -> ONE fc_alpha1 GEMM -> fuse (grit_amd/ops/gate.py)
             d = self_att.shape[-1]
-            q12 = F.linear(self_att, *self._cross_query_weights())  # fc_q of both cross-attentions: one GEMM
+            q12 = own_or_library_linear(self_att, *self._cross_query_weights())  # fc_q of both cross-attentions: one GEMM (inference)
             enc1 = self.vis_att1(self_att, y1, y1, mask_y1, q_proj=q12[..., :d])
             enc2 = self.vis_att2(self_att, y2, y2, mask_y2, q_proj=q12[..., d:])
             return self.pwff(gate_ops.gated_merge(self_att, enc1, enc2, mask_pad, self.fc_alpha1)) * mask_pad

@@ -19,7 +19,7 @@ from grit_amd.ops import kv_cache
 from grit_amd.ops import weights_epoch
 from grit_amd.ops.attention import attention as fused_attention
 from grit_amd.ops.layer_norm import add_layer_norm, linear_add_layer_norm
-from grit_amd.ops.linear import Linear
+from grit_amd.ops.linear import Linear, own_or_library_linear
 
 
 # GRIT_DECODE_KV_CACHE=0: step-wise decoding re-projects the raw key / value history on every step, as the reference does
@@ -138,7 +138,7 @@ class MultiHeadAttention(Module):
                 # weights -- equal up to the GEMM kernel the library picks for t times the rows.
                 w, b = self.attention.fused_weights(('fc_q', 'fc_k', 'fc_v'))
                 d = queries.shape[-1]
-                qkv = F.linear(queries, w, b)
+                qkv = own_or_library_linear(queries, w, b)  # (inference only: no autograd here)
                 q_proj, keys, values = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
             self._kv_deferred = bool(cached and _KV_FUSED_APPEND)
             if self._kv_deferred:

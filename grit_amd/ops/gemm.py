@@ -197,7 +197,9 @@ def prefers_own_narrow(M, N, K):
 # gradients.  0: the library.
 OWN_SHORT = os.environ.get("GRIT_GEMM_OWN_SHORT", "1") != "0"
 SHORT = 12
-SHORT_MIN_ROWS = 512
+# (64: the beam-search steps' 64 .. 320-row Linears too -- config 5's 20 decode steps 11.75 -> 11.08 ms with the same tokens,
+# profiles/r06/decode_short_min_rows.txt; 512: the training step's maps only)
+SHORT_MIN_ROWS = int(os.environ.get("GRIT_GEMM_SHORT_MIN_ROWS", "64"))
 
 
 def prefers_own_short(M, N, K):

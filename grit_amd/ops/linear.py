@@ -857,12 +857,18 @@ def weight_bias_grad(dy2, x2, group, need_w, need_b, weight, row_scale=None, bia
 
 def _own_linear(x, weight, bias):
     """F.linear on the own long-map kernel (grit_amd/ops/gemm.py long_linear) or None."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.numel() // x.shape[-1] >= 512):
-        return None
     from grit_amd.ops import gemm as _gemm
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.numel() // x.shape[-1] >= min(512, _gemm.SHORT_MIN_ROWS)):
+        return None
     x2 = x.reshape(-1, x.shape[-1])
     y = _gemm.long_linear(x2 if x2.is_contiguous() else x2.contiguous(), weight, bias)
     return None if y is None else y.view(x.shape[:-1] + (weight.shape[0],))
+
+
+def own_or_library_linear(x, weight, bias):
+    """F.linear without autograd bookkeeping of its own: the own kernels where the policies take the shape, else the library."""
+    y = _own_linear(x, weight, bias) if (backend.override() is None and not torch.is_autocast_enabled()) else None
+    return y if y is not None else F.linear(x, weight, bias)
 
 
 def _own_input_grad(dy2, weight, shape):

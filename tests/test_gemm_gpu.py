@@ -265,7 +265,8 @@ def test_short_map_policy_linear_and_packed_in_projection_nodes(monkeypatch):
     from grit_amd.ops.linear import linear, packed_in_proj
     assert G.prefers_own_short(4800, 512, 512) and G.prefers_own_short(640, 2048, 512) and G.prefers_own_short(4800, 512, 1024)
     assert not G.prefers_own_short(640, 512, 1024) and not G.prefers_own_short(640, 512, 2048) and not G.prefers_own_short(4800, 4, 512)
-    assert not G.prefers_own_short(9600, 512, 512) and not G.prefers_own_short(320, 512, 512)  # long-map policy / decode steps: not these tiles
+    assert not G.prefers_own_short(9600, 512, 512) and not G.prefers_own_short(32, 512, 512)  # long-map policy / a handful of rows: not these tiles
+    assert G.prefers_own_short(320, 512, 512)  # the beam-search steps' 64 .. 320 rows (profiles/r06/decode_short_min_rows.txt)
     torch.manual_seed(1)
     for M, N, K in ((4800, 512, 512), (640, 2048, 512), (4800 + 37, 256, 1024)):
         x = torch.randn(M, K, device='cuda').bfloat16().requires_grad_(True)

@@ -4,7 +4,7 @@ from torch import nn
 from torch.nn import functional as F
 from grit_amd.ops.glue import relu_dropout
 from grit_amd.ops.layer_norm import add_layer_norm, linear_add_layer_norm
-from grit_amd.ops.linear import Linear, linear_relu_dropout
+from grit_amd.ops.linear import Linear, linear_relu_dropout, own_or_library_linear
 
 
 def position_embedding(input, d_model):
@@ -44,4 +44,5 @@ class FeedForward(nn.Module):
             ln = self.layer_norm  # fc2 + dropout + residual + LayerNorm as one autograd node
             return linear_add_layer_norm(hidden, self.fc2, input, None, ln.weight, ln.bias, ln.eps, self.dropout.p, True)[1]
         ln = self.layer_norm
-        return add_layer_norm(input, self.dropout(self.fc2(hidden)), None, ln.weight, ln.bias, ln.eps)[1]
+        branch = own_or_library_linear(hidden, self.fc2.weight, self.fc2.bias) if not torch.is_grad_enabled() else self.fc2(hidden)
+        return add_layer_norm(input, self.dropout(branch), None, ln.weight, ln.bias, ln.eps)[1]

@@ -62,4 +62,5 @@ def fuse(enc1_raw, enc2_raw, gates, mask_pad):
 def gated_merge(self_att, enc1_raw, enc2_raw, mask_pad, fc):
     """((enc1 * sigmoid(fc(cat[self_att, enc1])) + enc2 * sigmoid(fc(cat[self_att, enc2]))) / sqrt(2)) * mask_pad with
     enc_i = enc_i_raw * mask_pad; self_att already masked."""
-    return fuse(enc1_raw, enc2_raw, F.linear(pack(self_att, enc1_raw, enc2_raw, mask_pad), fc.weight, fc.bias), mask_pad)
+    from grit_amd.ops.linear import own_or_library_linear
+    return fuse(enc1_raw, enc2_raw, own_or_library_linear(pack(self_att, enc1_raw, enc2_raw, mask_pad), fc.weight, fc.bias), mask_pad)

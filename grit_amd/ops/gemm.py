@@ -202,10 +202,15 @@ SHORT = 12
 SHORT_MIN_ROWS = int(os.environ.get("GRIT_GEMM_SHORT_MIN_ROWS", "64"))
 
 
+# (A/B: the K = 1 024 gate GEMM and the K = 2 048 FFN product of the beam-search steps on the tile too -- 11.03 against 10.77 ms per decode,
+# profiles/r06/decode_short_decode_max_k.txt: they stay with the library)
+SHORT_DECODE_MAX_K = int(os.environ.get("GRIT_GEMM_SHORT_DECODE_MAX_K", "512"))
+
+
 def prefers_own_short(M, N, K):
     """(K <= 1 024 at any row count or K <= 2 048 as well: within 0.03 ms per step of this rule, profiles/r06/ab_short_wide.txt)"""
     return (OWN_SHORT and SHORT_MIN_ROWS <= M < OWN_MIN_ROWS and N % 128 == 0 and K % 64 == 0
-            and (K <= 512 or (K <= 1024 and M >= 2048)))
+            and (K <= 512 or (K <= 1024 and M >= 2048) or (M < 512 and K <= SHORT_DECODE_MAX_K)))
 
 
 def long_linear(x2, weight, bias):
